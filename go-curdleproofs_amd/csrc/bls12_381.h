@@ -1,0 +1,495 @@
+// BLS12-381 base-field / scalar-field / G1 arithmetic on 32-bit limbs.
+//
+// One header, two consumers: the gfx950 kernels (msm_kernels.hip) and the host
+// side of libcurdlemsm.so (window combine, Jacobian normalisation, the
+// msmaccumulator mirror).  It replaces what the reference gets from the
+// un-vendored gnark-crypto v0.11.0 (/root/reference/go.mod:6): fp.Element,
+// fr.Element, G1Affine, G1Jac and the bucket arithmetic inside
+// (*G1Jac).MultiExp (called at msmaccumulator/msmaccumulator.go:59).
+//
+// Memory layout is gnark's: fp.Element = [6]uint64 and fr.Element = [4]uint64,
+// little-endian limbs, Montgomery form (R = 2^384 resp. 2^256).  On a
+// little-endian machine that is bit-identical to 12 resp. 8 uint32 limbs, which
+// is what the CDNA4 integer multiplier (v_mad_u64_u32: 32x32+64) wants.
+//
+// This is product code.  It never includes or links anything under oracle/.
+#pragma once
+#include <stdint.h>
+#include <type_traits>
+
+#if defined(__HIPCC__)
+#define CURDLE_HD __host__ __device__ __forceinline__
+#define CURDLE_HD_NOINLINE __host__ __device__ __noinline__ inline
+#else
+#define CURDLE_HD inline
+#define CURDLE_HD_NOINLINE inline
+#endif
+
+namespace curdle {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------
+// Parameters (32-bit little-endian limbs)
+// ---------------------------------------------------------------------------
+struct FpParams {
+  static constexpr int N = 12;
+  // p = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+  static CURDLE_HD u32 mod(int i) {
+    constexpr u32 m[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                           0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+    return m[i];
+  }
+  // R = 2^384 mod p (Montgomery one)
+  static CURDLE_HD u32 one(int i) {
+    constexpr u32 m[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u,
+                           0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+    return m[i];
+  }
+  static constexpr u32 n0inv = 0xfffcfffdu;  // -p^-1 mod 2^32
+};
+
+struct FrParams {
+  static constexpr int N = 8;
+  // r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+  static CURDLE_HD u32 mod(int i) {
+    constexpr u32 m[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
+                          0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+    return m[i];
+  }
+  // 2^256 mod r
+  static CURDLE_HD u32 one(int i) {
+    constexpr u32 m[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
+                          0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+    return m[i];
+  }
+  static constexpr u32 n0inv = 0xffffffffu;  // -r^-1 mod 2^32
+};
+
+// ---------------------------------------------------------------------------
+// Generic Montgomery field element on N 32-bit limbs, always fully reduced.
+// ---------------------------------------------------------------------------
+template <class PR>
+struct Mont {
+  static constexpr int N = PR::N;
+  u32 l[N];
+};
+typedef Mont<FpParams> Fp;
+typedef Mont<FrParams> Fr;
+
+template <class PR>
+CURDLE_HD void f_zero(Mont<PR>& r) {
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) r.l[i] = 0;
+}
+template <class PR>
+CURDLE_HD void f_one(Mont<PR>& r) {
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) r.l[i] = PR::one(i);
+}
+template <class PR>
+CURDLE_HD bool f_is_zero(const Mont<PR>& a) {
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) acc |= a.l[i];
+  return acc == 0;
+}
+template <class PR>
+CURDLE_HD bool f_eq(const Mont<PR>& a, const Mont<PR>& b) {
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) acc |= a.l[i] ^ b.l[i];
+  return acc == 0;
+}
+
+// r = a - p if a >= p else a   (a < 2p, carry = extra top bit of a)
+template <class PR>
+CURDLE_HD void f_cond_sub(Mont<PR>& r, const u32* a, u32 top) {
+  u32 d[PR::N];
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) {
+    u64 t = (u64)a[i] - PR::mod(i) - borrow;
+    d[i] = (u32)t;
+    borrow = (t >> 32) & 1;
+  }
+  // a >= p  <=>  top set or no final borrow
+  bool ge = (top != 0) | (borrow == 0);
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) r.l[i] = ge ? d[i] : a[i];
+}
+
+template <class PR>
+CURDLE_HD void f_add(Mont<PR>& r, const Mont<PR>& a, const Mont<PR>& b) {
+  u32 s[PR::N];
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) {
+    u64 t = (u64)a.l[i] + b.l[i] + c;
+    s[i] = (u32)t;
+    c = t >> 32;
+  }
+  f_cond_sub<PR>(r, s, (u32)c);
+}
+
+template <class PR>
+CURDLE_HD void f_sub(Mont<PR>& r, const Mont<PR>& a, const Mont<PR>& b) {
+  u32 d[PR::N];
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) {
+    u64 t = (u64)a.l[i] - b.l[i] - borrow;
+    d[i] = (u32)t;
+    borrow = (t >> 32) & 1;
+  }
+  u32 mask = (u32)0 - (u32)borrow;  // all ones if a < b
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) {
+    u64 t = (u64)d[i] + (PR::mod(i) & mask) + c;
+    r.l[i] = (u32)t;
+    c = t >> 32;
+  }
+}
+
+template <class PR>
+CURDLE_HD void f_neg(Mont<PR>& r, const Mont<PR>& a) {
+  // r = (a == 0) ? 0 : p - a
+  u32 nz = 0;
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) nz |= a.l[i];
+  u32 mask = nz ? 0xffffffffu : 0u;
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) {
+    u64 t = (u64)PR::mod(i) - a.l[i] - borrow;
+    r.l[i] = (u32)t & mask;
+    borrow = (t >> 32) & 1;
+  }
+}
+
+template <class PR>
+CURDLE_HD void f_dbl(Mont<PR>& r, const Mont<PR>& a) {
+  f_add<PR>(r, a, a);
+}
+
+// ---------------------------------------------------------------------------
+// Column accumulator for product-scanning multiplication: a 96-bit value
+// {hi:lo}.  On gfx950 one product costs one v_mad_u64_u32 (quarter-rate
+// 32x32+64 multiply-add, carry-out in VCC) plus one v_addc_co_u32, with no
+// zero-extension moves; hipcc cannot be coaxed into using the multiply-add's
+// carry-out from C, hence the generated asm blocks in mac_gfx950.inc.
+// ---------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "mac_gfx950.inc"
+#endif
+
+template <int I, int E, class F>
+CURDLE_HD void static_for(F&& f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, E>(f);
+  }
+}
+
+// acc += sum_{i<K} a[i] * b[-i]   (b walks downwards)
+template <int K>
+CURDLE_HD void col_mac_vv(u64& lo, u32& hi, const u32* a, const u32* b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  macv<K>(lo, hi, a, b);
+#else
+  for (int i = 0; i < K; i++) {
+    u64 p = (u64)a[i] * b[-i];
+    lo += p;
+    hi += (lo < p);
+  }
+#endif
+}
+// Same, second factor known at compile time (modulus limbs; SGPRs on gfx950).
+template <int K>
+CURDLE_HD void col_mac_vs(u64& lo, u32& hi, const u32* a, const u32* b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  macs<K>(lo, hi, a, b);
+#else
+  col_mac_vv<K>(lo, hi, a, b);
+#endif
+}
+CURDLE_HD void col_shift(u64& lo, u32& hi) {
+  lo = (lo >> 32) | ((u64)hi << 32);
+  hi = 0;
+}
+
+template <class PR>
+struct ModTable {
+  u32 v[PR::N];
+  CURDLE_HD ModTable() {
+#pragma unroll
+    for (int i = 0; i < PR::N; i++) v[i] = PR::mod(i);
+  }
+};
+
+// Product-scanning (FIPS) Montgomery product, r = a*b*R^-1 mod p, fully reduced.
+// 2*N^2 + N multiplies.  p < 2^(32N-2) for both fields, so the result before
+// the conditional subtraction is < 2p and fits N limbs.
+template <class PR>
+CURDLE_HD void f_mul_inl(Mont<PR>& r, const Mont<PR>& a, const Mont<PR>& b) {
+  constexpr int N = PR::N;
+  const ModTable<PR> P;
+  u32 m[N];
+  u32 t[N];
+  u64 lo = 0;
+  u32 hi = 0;
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    col_mac_vv<k + 1>(lo, hi, &a.l[0], &b.l[k]);
+    if constexpr (k > 0) col_mac_vs<k>(lo, hi, &m[0], &P.v[k]);
+    m[k] = (u32)lo * PR::n0inv;
+    col_mac_vs<1>(lo, hi, &m[k], &P.v[0]);
+    col_shift(lo, hi);
+  });
+  static_for<N, 2 * N - 1>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int i0 = k - N + 1;
+    col_mac_vv<N - i0>(lo, hi, &a.l[i0], &b.l[N - 1]);
+    col_mac_vs<N - i0>(lo, hi, &m[i0], &P.v[N - 1]);
+    t[k - N] = (u32)lo;
+    col_shift(lo, hi);
+  });
+  t[N - 1] = (u32)lo;
+  f_cond_sub<PR>(r, t, 0);
+}
+
+// Montgomery reduction of a single element: r = a * R^-1 (Montgomery -> canonical)
+template <class PR>
+CURDLE_HD void f_from_mont(Mont<PR>& r, const Mont<PR>& a) {
+  constexpr int N = PR::N;
+  const ModTable<PR> P;
+  u32 m[N];
+  u32 t[N];
+  u64 lo = 0;
+  u32 hi = 0;
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    u64 s = lo + a.l[k];
+    hi += (s < lo);
+    lo = s;
+    if constexpr (k > 0) col_mac_vs<k>(lo, hi, &m[0], &P.v[k]);
+    m[k] = (u32)lo * PR::n0inv;
+    col_mac_vs<1>(lo, hi, &m[k], &P.v[0]);
+    col_shift(lo, hi);
+  });
+  static_for<N, 2 * N - 1>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int i0 = k - N + 1;
+    col_mac_vs<N - i0>(lo, hi, &m[i0], &P.v[N - 1]);
+    t[k - N] = (u32)lo;
+    col_shift(lo, hi);
+  });
+  t[N - 1] = (u32)lo;
+  f_cond_sub<PR>(r, t, 0);
+}
+
+// Fp multiply entry points.  In device code the 700-instruction body is kept
+// out of line (one copy per kernel image, operands and result passed in VGPRs
+// as 12-lane vectors so nothing touches scratch): a G1 mixed add holds ten of
+// them and would otherwise overflow the instruction cache.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CURDLE_INLINE_MUL)
+typedef u32 u32x12 __attribute__((ext_vector_type(12)));
+__device__ __noinline__ inline u32x12 fp_mul_call(u32x12 a, u32x12 b) {
+  Fp x, y, r;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    x.l[i] = a[i];
+    y.l[i] = b[i];
+  }
+  f_mul_inl<FpParams>(r, x, y);
+  u32x12 o;
+#pragma unroll
+  for (int i = 0; i < 12; i++) o[i] = r.l[i];
+  return o;
+}
+CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) {
+  u32x12 x, y;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    x[i] = a.l[i];
+    y[i] = b.l[i];
+  }
+  u32x12 o = fp_mul_call(x, y);
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = o[i];
+}
+#else
+CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) { f_mul_inl<FpParams>(r, a, b); }
+#endif
+CURDLE_HD void fp_sqr(Fp& r, const Fp& a) { fp_mul(r, a, a); }
+CURDLE_HD void fp_add(Fp& r, const Fp& a, const Fp& b) { f_add<FpParams>(r, a, b); }
+CURDLE_HD void fp_sub(Fp& r, const Fp& a, const Fp& b) { f_sub<FpParams>(r, a, b); }
+CURDLE_HD void fp_neg(Fp& r, const Fp& a) { f_neg<FpParams>(r, a); }
+CURDLE_HD void fp_dbl(Fp& r, const Fp& a) { f_dbl<FpParams>(r, a); }
+CURDLE_HD void fr_mul(Fr& r, const Fr& a, const Fr& b) { f_mul_inl<FrParams>(r, a, b); }
+CURDLE_HD void fr_add(Fr& r, const Fr& a, const Fr& b) { f_add<FrParams>(r, a, b); }
+CURDLE_HD void fr_sub(Fr& r, const Fr& a, const Fr& b) { f_sub<FrParams>(r, a, b); }
+
+// ---------------------------------------------------------------------------
+// G1: y^2 = x^3 + 4
+// ---------------------------------------------------------------------------
+// gnark G1Affine: (0,0) is the point at infinity (curdleproof.go:23 zeroPoint).
+struct G1Affine {
+  Fp x, y;
+};
+// Extended Jacobian ("XYZZ"): x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; infinity <=> ZZ = 0.
+struct G1XYZZ {
+  Fp x, y, zz, zzz;
+};
+// gnark G1Jac: x = X/Z^2, y = Y/Z^3; infinity <=> Z = 0.
+struct G1Jac {
+  Fp x, y, z;
+};
+
+CURDLE_HD bool g1_affine_is_inf(const G1Affine& p) { return f_is_zero(p.x) & f_is_zero(p.y); }
+CURDLE_HD bool g1_is_inf(const G1XYZZ& p) { return f_is_zero(p.zz); }
+CURDLE_HD void g1_set_inf(G1XYZZ& p) {
+  f_one(p.x);
+  f_one(p.y);
+  f_zero(p.zz);
+  f_zero(p.zzz);
+}
+CURDLE_HD void g1_from_affine(G1XYZZ& r, const G1Affine& a) {
+  if (g1_affine_is_inf(a)) {
+    g1_set_inf(r);
+    return;
+  }
+  r.x = a.x;
+  r.y = a.y;
+  f_one(r.zz);
+  f_one(r.zzz);
+}
+
+// r = 2*(x,y) for an affine, non-infinity input.  EFD mdbl-2008-s-1 (a = 0).
+CURDLE_HD void g1_dbl_affine(G1XYZZ& r, const Fp& x1, const Fp& y1) {
+  Fp u, v, w, s, m, t;
+  fp_dbl(u, y1);
+  fp_sqr(v, u);
+  fp_mul(w, u, v);
+  fp_mul(s, x1, v);
+  fp_sqr(t, x1);
+  fp_dbl(m, t);
+  fp_add(m, m, t);  // 3*x1^2
+  fp_sqr(r.x, m);
+  fp_sub(r.x, r.x, s);
+  fp_sub(r.x, r.x, s);
+  fp_sub(t, s, r.x);
+  fp_mul(t, m, t);
+  fp_mul(u, w, y1);
+  fp_sub(r.y, t, u);
+  r.zz = v;
+  r.zzz = w;
+}
+
+// p = 2*p.  EFD dbl-2008-s-1 (a = 0).  y = 0 cannot occur on a prime-order
+// curve, so the only special case is infinity (ZZ = 0 stays 0).
+CURDLE_HD void g1_dbl(G1XYZZ& p) {
+  Fp u, v, w, s, m, t;
+  fp_dbl(u, p.y);
+  fp_sqr(v, u);
+  fp_mul(w, u, v);
+  fp_mul(s, p.x, v);
+  fp_sqr(t, p.x);
+  fp_dbl(m, t);
+  fp_add(m, m, t);
+  Fp x3;
+  fp_sqr(x3, m);
+  fp_sub(x3, x3, s);
+  fp_sub(x3, x3, s);
+  fp_sub(t, s, x3);
+  fp_mul(t, m, t);
+  fp_mul(u, w, p.y);
+  fp_sub(p.y, t, u);
+  p.x = x3;
+  fp_mul(p.zz, v, p.zz);
+  fp_mul(p.zzz, w, p.zzz);
+}
+
+// acc += (x2, +-y2) with (x2,y2) affine.  EFD madd-2008-s plus the exceptional
+// cases (acc infinity, equal points -> doubling, opposite points -> infinity).
+// The caller filters an infinity (0,0) base.
+CURDLE_HD void g1_madd(G1XYZZ& acc, const Fp& x2, const Fp& y2) {
+  if (g1_is_inf(acc)) {
+    acc.x = x2;
+    acc.y = y2;
+    f_one(acc.zz);
+    f_one(acc.zzz);
+    return;
+  }
+  Fp pp, r, t, q, ppp;
+  fp_mul(pp, x2, acc.zz);
+  fp_sub(pp, pp, acc.x);  // P = U2 - X1
+  fp_mul(r, y2, acc.zzz);
+  fp_sub(r, r, acc.y);  // R = S2 - Y1
+  if (f_is_zero(pp)) {
+    if (f_is_zero(r))
+      g1_dbl_affine(acc, x2, y2);
+    else
+      g1_set_inf(acc);
+    return;
+  }
+  fp_sqr(t, pp);         // PP
+  fp_mul(ppp, pp, t);    // PPP
+  fp_mul(q, acc.x, t);   // Q = X1*PP
+  fp_mul(acc.zz, acc.zz, t);
+  fp_mul(acc.zzz, acc.zzz, ppp);
+  fp_sqr(t, r);
+  fp_sub(t, t, ppp);
+  fp_sub(t, t, q);
+  fp_sub(t, t, q);  // X3
+  fp_sub(q, q, t);
+  fp_mul(q, r, q);  // R*(Q - X3)
+  fp_mul(ppp, acc.y, ppp);
+  fp_sub(acc.y, q, ppp);
+  acc.x = t;
+}
+
+// acc += b.  EFD add-2008-s plus exceptional cases.
+CURDLE_HD void g1_add(G1XYZZ& acc, const G1XYZZ& b) {
+  if (g1_is_inf(b)) return;
+  if (g1_is_inf(acc)) {
+    acc = b;
+    return;
+  }
+  Fp u1, u2, s1, s2, pp, r, t, q, ppp;
+  fp_mul(u1, acc.x, b.zz);
+  fp_mul(u2, b.x, acc.zz);
+  fp_mul(s1, acc.y, b.zzz);
+  fp_mul(s2, b.y, acc.zzz);
+  fp_sub(pp, u2, u1);
+  fp_sub(r, s2, s1);
+  if (f_is_zero(pp)) {
+    if (f_is_zero(r))
+      g1_dbl(acc);
+    else
+      g1_set_inf(acc);
+    return;
+  }
+  fp_sqr(t, pp);
+  fp_mul(ppp, pp, t);
+  fp_mul(q, u1, t);
+  fp_mul(acc.zz, acc.zz, b.zz);
+  fp_mul(acc.zz, acc.zz, t);
+  fp_mul(acc.zzz, acc.zzz, b.zzz);
+  fp_mul(acc.zzz, acc.zzz, ppp);
+  fp_sqr(t, r);
+  fp_sub(t, t, ppp);
+  fp_sub(t, t, q);
+  fp_sub(t, t, q);
+  fp_sub(q, q, t);
+  fp_mul(q, r, q);
+  fp_mul(s1, s1, ppp);
+  fp_sub(acc.y, q, s1);
+  acc.x = t;
+}
+
+CURDLE_HD void g1_neg(G1XYZZ& p) { fp_neg(p.y, p.y); }
+
+}  // namespace curdle

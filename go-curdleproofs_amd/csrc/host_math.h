@@ -1,0 +1,125 @@
+// Host-side G1 / Fr helpers of libcurdlemsm.so, built on the same limb
+// arithmetic as the kernels (bls12_381.h).  Used for the O(256)-doubling window
+// combine after the GPU phases, the canonical Jacobian output, and the
+// msmaccumulator mirror (one 255-bit scalar multiplication per
+// AccumulateCheck, msmaccumulator/msmaccumulator.go:44).
+//
+// Product code: nothing here touches oracle/.
+#pragma once
+#include <string.h>
+
+#include "bls12_381.h"
+
+namespace curdle {
+
+// a^e for a multi-limb exponent e (little-endian 32-bit limbs), Montgomery in/out.
+inline void fp_pow(Fp& r, const Fp& a, const u32* e, int nlimbs) {
+  Fp acc;
+  f_one(acc);
+  for (int i = nlimbs * 32 - 1; i >= 0; i--) {
+    fp_sqr(acc, acc);
+    if ((e[i / 32] >> (i % 32)) & 1) fp_mul(acc, acc, a);
+  }
+  r = acc;
+}
+
+// r = a^-1 (a != 0) by Fermat: a^(p-2).
+inline void fp_inv(Fp& r, const Fp& a) {
+  u32 e[12];
+  for (int i = 0; i < 12; i++) e[i] = FpParams::mod(i);
+  e[0] -= 2;  // p ends in ...aaab, no borrow
+  fp_pow(r, a, e, 12);
+}
+
+// XYZZ -> affine; returns false for infinity (out set to (0,0), gnark's encoding).
+inline bool g1_to_affine(G1Affine& out, const G1XYZZ& p) {
+  if (g1_is_inf(p)) {
+    f_zero(out.x);
+    f_zero(out.y);
+    return false;
+  }
+  // 1/ZZZ, then 1/ZZ = ZZ^2 / ZZZ^2 * ... cheaper: invert ZZ*ZZZ once.
+  Fp t, ti, izz, izzz;
+  fp_mul(t, p.zz, p.zzz);
+  fp_inv(ti, t);
+  fp_mul(izz, ti, p.zzz);
+  fp_mul(izzz, ti, p.zz);
+  fp_mul(out.x, p.x, izz);
+  fp_mul(out.y, p.y, izzz);
+  return true;
+}
+
+// gnark G1Jac (X, Y, Z), any representative -> XYZZ.
+inline void g1_from_jac(G1XYZZ& r, const G1Jac& j) {
+  if (f_is_zero(j.z)) {
+    g1_set_inf(r);
+    return;
+  }
+  r.x = j.x;
+  r.y = j.y;
+  fp_sqr(r.zz, j.z);
+  fp_mul(r.zzz, r.zz, j.z);
+}
+
+// Canonical Jacobian the C ABI returns: (x, y, 1), or (1, 1, 0) for infinity.
+inline void g1_to_canonical_jac(u64 out[18], const G1XYZZ& p) {
+  G1Affine a;
+  G1Jac j;
+  if (g1_to_affine(a, p)) {
+    j.x = a.x;
+    j.y = a.y;
+    f_one(j.z);
+  } else {
+    f_one(j.x);
+    f_one(j.y);
+    f_zero(j.z);
+  }
+  memcpy(out, &j, sizeof(j));
+}
+
+// r = k * p, k canonical (not Montgomery) little-endian limbs; left-to-right
+// double-and-add.  Host only (used O(1) times per call).
+inline void g1_scalar_mul(G1XYZZ& r, const G1XYZZ& p, const u32* k, int nlimbs) {
+  G1XYZZ acc;
+  g1_set_inf(acc);
+  for (int i = nlimbs * 32 - 1; i >= 0; i--) {
+    g1_dbl(acc);
+    if ((k[i / 32] >> (i % 32)) & 1) g1_add(acc, p);
+  }
+  r = acc;
+}
+
+// Projective equality of two XYZZ points (gnark G1Jac.Equal, msmaccumulator.go:63).
+inline bool g1_equal(const G1XYZZ& a, const G1XYZZ& b) {
+  bool ia = g1_is_inf(a), ib = g1_is_inf(b);
+  if (ia || ib) return ia && ib;
+  Fp l, r;
+  fp_mul(l, a.x, b.zz);
+  fp_mul(r, b.x, a.zz);
+  if (!f_eq(l, r)) return false;
+  fp_mul(l, a.y, b.zzz);
+  fp_mul(r, b.y, a.zzz);
+  return f_eq(l, r);
+}
+
+// The G1 generator (bls12381.Generators(), used by common/rand.go:27).
+inline void g1_generator(G1Affine& g) {
+  static const u64 gx[6] = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull,
+                            0xf0ae6acdf3d0e747ull, 0xedce6ecc21dbf440ull, 0x120177419e0bfb75ull};
+  static const u64 gy[6] = {0xbaac93d50ce72271ull, 0x8c22631a7918fd8eull, 0xdd595f13570725ceull,
+                            0x51ac582950405194ull, 0x0e1c8c3fad0059c0ull, 0x0bbc3efc5008a26aull};
+  memcpy(&g.x, gx, 48);
+  memcpy(&g.y, gy, 48);
+}
+
+// canonical integer (little-endian limbs, < r) -> Montgomery fr.Element
+inline void fr_to_mont(Fr& r, const Fr& canonical) {
+  // multiply by R^2 mod r
+  static const u32 r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
+                            0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+  Fr rr;
+  for (int i = 0; i < 8; i++) rr.l[i] = r2[i];
+  fr_mul(r, canonical, rr);
+}
+
+}  // namespace curdle

@@ -1,0 +1,543 @@
+// C ABI of libcurdlemsm.so (include/curdle_msm.h): context, workspace, phase
+// sequencing, the host-side window combine and the accumulator / rand handles.
+//
+// There is deliberately no CPU implementation of the MSM behind these entry
+// points: if the HIP runtime has no device, they fail with CURDLE_ENODEV.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/curdle_msm.h"
+#include "../host/common_rand.h"
+#include "../host/msmaccumulator.h"
+#include "host_math.h"
+#include "msm_kernels.h"
+
+using namespace curdle;
+
+// ---------------------------------------------------------------------------
+// Errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(e_ == hipErrorOutOfMemory ? CURDLE_ENOMEM : CURDLE_EHIP, "%s: %s", #expr, \
+                  hipGetErrorString(e_));                                                  \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// Context: one device per process, one stream, a grow-only workspace.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct Ctx {
+  std::mutex mu;
+  bool inited = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Buf points, scalars, counts, starts, cursor, sorted, buckets, partials, winsums;
+  G1XYZZ* h_winsums = nullptr;  // pinned
+  size_t h_winsums_cap = 0;
+  // profiling
+  bool profile = false;
+  hipEvent_t ev[CURDLE_PROF_MAX_KERNELS + 1];
+  bool ev_made = false;
+  curdle_profile last = {};
+};
+
+Ctx g_ctx;
+
+int ensure(Buf& b, size_t bytes) {
+  if (bytes <= b.cap) return CURDLE_OK;
+  if (b.p) {
+    HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  HIP_TRY(hipMalloc(&b.p, want));
+  b.cap = want;
+  return CURDLE_OK;
+}
+
+int init_locked(int device) {
+  if (g_ctx.inited) {
+    if (device != g_ctx.device) return fail(CURDLE_EINVAL, "already initialised on device %d", g_ctx.device);
+    return CURDLE_OK;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(CURDLE_ENODEV, "no HIP device visible (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(CURDLE_EINVAL, "device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  g_ctx.device = device;
+  g_ctx.inited = true;
+  return CURDLE_OK;
+}
+
+// r as four 64-bit limbs, for the top-window check below.
+const u64 kR64[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+
+// Number of signed c-bit windows that cover every scalar < r: ceil(255 / c),
+// plus one when the top window's largest value (+ carry) could exceed 2^(c-1)
+// and would have to borrow from a window that does not exist (c = 3, 5, 15).
+int num_windows(int c) {
+  int W = (255 + c - 1) / c;
+  int sh = c * (W - 1);
+  u64 top = kR64[sh / 64] >> (sh % 64);
+  if (sh % 64 && sh / 64 + 1 < 4) top |= kR64[sh / 64 + 1] << (64 - sh % 64);
+  if (c < 64) top &= ((u64)1 << c) - 1;
+  if (top + 1 > ((u64)1 << (c - 1))) W += 1;
+  return W;
+}
+
+int choose_window_bits(size_t n) {
+  const char* env = getenv("CURDLE_WINDOW_BITS");
+  if (env) {
+    int c = atoi(env);
+    if (c >= 2 && c <= 16) return c;
+  }
+  int lg = 0;
+  while (((size_t)1 << (lg + 1)) <= n) lg++;
+  int c = lg - 4;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  return c;
+}
+
+int make_plan(MsmPlan& p, size_t n, int c, int win_begin, int win_end) {
+  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
+  if (c == 0) c = choose_window_bits(n);
+  if (c < 2 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [2, 16]", c);
+  p.n = (uint32_t)n;
+  p.c = c;
+  p.W = num_windows(c);
+  p.B = 1u << (c - 1);
+  if (win_end < 0) win_end = p.W;
+  if (win_begin < 0 || win_begin > win_end || win_end > p.W)
+    return fail(CURDLE_EINVAL, "window range [%d, %d) outside [0, %d)", win_begin, win_end, p.W);
+  p.win_begin = win_begin;
+  p.win_end = win_end;
+  p.seg = p.B < 8 ? p.B : 8;
+  p.nseg = p.B / p.seg;
+  return CURDLE_OK;
+}
+
+struct Prof {
+  Ctx& c;
+  hipStream_t s;
+  int k = 0;
+  bool on;
+  explicit Prof(Ctx& ctx, hipStream_t st) : c(ctx), s(st), on(ctx.profile) {
+    if (on && !c.ev_made) {
+      for (auto& e : c.ev) hipEventCreate(&e);
+      c.ev_made = true;
+    }
+    if (on) hipEventRecord(c.ev[0], s);
+  }
+  void mark(const char* name) {
+    if (!on || k >= CURDLE_PROF_MAX_KERNELS) return;
+    c.last.name[k] = name;
+    k++;
+    hipEventRecord(c.ev[k], s);
+  }
+  void finish(const MsmPlan& p) {
+    if (!on) return;
+    c.last.n_kernels = k;
+    for (int i = 0; i < k; i++) hipEventElapsedTime(&c.last.ms[i], c.ev[i], c.ev[i + 1]);
+    c.last.window_bits = p.c;
+    c.last.num_windows = p.W;
+  }
+};
+
+void set_out_infinity(uint64_t out[18]) {
+  G1XYZZ inf;
+  g1_set_inf(inf);
+  g1_to_canonical_jac(out, inf);
+}
+
+// The GPU phases + host combine.  Caller holds g_ctx.mu; d_points / d_scalars are device pointers.
+int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int c, int win_begin, int win_end,
+                      uint64_t out[18], hipStream_t stream) {
+  MsmPlan p;
+  int rc = make_plan(p, n, c, win_begin, win_end);
+  if (rc) return rc;
+  const uint32_t nw = p.win_end - p.win_begin;
+  if (n == 0 || nw == 0) {
+    set_out_infinity(out);
+    return CURDLE_OK;
+  }
+  Ctx& C = g_ctx;
+  const size_t nb = (size_t)nw * p.B;
+  if ((rc = ensure(C.counts, nb * 4))) return rc;
+  if ((rc = ensure(C.starts, nb * 4))) return rc;
+  if ((rc = ensure(C.cursor, nb * 4))) return rc;
+  if ((rc = ensure(C.sorted, (size_t)nw * n * 4))) return rc;
+  if ((rc = ensure(C.buckets, nb * sizeof(G1XYZZ)))) return rc;
+  if ((rc = ensure(C.partials, (size_t)nw * p.nseg * sizeof(G1XYZZ)))) return rc;
+  if ((rc = ensure(C.winsums, (size_t)nw * sizeof(G1XYZZ)))) return rc;
+  if (C.h_winsums_cap < nw) {
+    if (C.h_winsums) HIP_TRY(hipHostFree(C.h_winsums));
+    C.h_winsums = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&C.h_winsums, 64 * sizeof(G1XYZZ) + (size_t)nw * sizeof(G1XYZZ), hipHostMallocDefault));
+    C.h_winsums_cap = nw + 64;
+  }
+  MsmWorkspace ws;
+  ws.counts = (uint32_t*)C.counts.p;
+  ws.starts = (uint32_t*)C.starts.p;
+  ws.cursor = (uint32_t*)C.cursor.p;
+  ws.sorted = (uint32_t*)C.sorted.p;
+  ws.buckets = (G1XYZZ*)C.buckets.p;
+  ws.partials = (G1XYZZ*)C.partials.p;
+  ws.winsums = (G1XYZZ*)C.winsums.p;
+
+  HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, stream));
+  Prof prof(C, stream);
+  HIP_TRY(launch_hist(p, ws, d_scalars, stream));
+  prof.mark("hist");
+  HIP_TRY(launch_scan(p, ws, stream));
+  prof.mark("scan");
+  HIP_TRY(launch_scatter(p, ws, d_scalars, stream));
+  prof.mark("scatter");
+  HIP_TRY(launch_accumulate(p, ws, d_points, stream));
+  prof.mark("accumulate");
+  HIP_TRY(launch_bucket_reduce(p, ws, stream));
+  prof.mark("bucket_reduce");
+  HIP_TRY(launch_window_sum(p, ws, stream));
+  prof.mark("window_sum");
+  HIP_TRY(hipMemcpyAsync(C.h_winsums, ws.winsums, (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  prof.finish(p);
+
+  // Window combine: sum_w 2^(c*w) * winsum[w], Horner from the top window down,
+  // then the 2^(c*win_begin) scaling of a partial.
+  G1XYZZ acc;
+  g1_set_inf(acc);
+  for (int lw = (int)nw - 1; lw >= 0; lw--) {
+    if (!g1_is_inf(acc))
+      for (int k = 0; k < p.c; k++) g1_dbl(acc);
+    g1_add(acc, C.h_winsums[lw]);
+  }
+  if (!g1_is_inf(acc))
+    for (int k = 0; k < p.c * p.win_begin; k++) g1_dbl(acc);
+  g1_to_canonical_jac(out, acc);
+  return CURDLE_OK;
+}
+
+int upload_locked(const uint64_t* points, const uint64_t* scalars, size_t n, hipStream_t stream) {
+  Ctx& C = g_ctx;
+  int rc;
+  if ((rc = ensure(C.points, n * 96))) return rc;
+  if ((rc = ensure(C.scalars, n * 32))) return rc;
+  HIP_TRY(hipMemcpyAsync(C.points.p, points, n * 96, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(C.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, stream));
+  return CURDLE_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Life cycle
+// ---------------------------------------------------------------------------
+extern "C" int curdle_init(int device) {
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  return init_locked(device);
+}
+
+extern "C" int curdle_shutdown(void) {
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  Ctx& C = g_ctx;
+  if (!C.inited) return CURDLE_OK;
+  hipSetDevice(C.device);
+  hipStreamSynchronize(C.stream);
+  for (Buf* b : {&C.points, &C.scalars, &C.counts, &C.starts, &C.cursor, &C.sorted, &C.buckets, &C.partials, &C.winsums}) {
+    if (b->p) hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  if (C.h_winsums) hipHostFree(C.h_winsums);
+  C.h_winsums = nullptr;
+  C.h_winsums_cap = 0;
+  if (C.ev_made)
+    for (auto& e : C.ev) hipEventDestroy(e);
+  C.ev_made = false;
+  hipStreamDestroy(C.stream);
+  C.stream = nullptr;
+  C.inited = false;
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_last_error(char* buf, size_t len) {
+  if (!buf || len == 0) return CURDLE_EINVAL;
+  snprintf(buf, len, "%s", g_err);
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_device_available(void) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+  return ndev > 0 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// MSM
+// ---------------------------------------------------------------------------
+extern "C" int curdle_msm_window_bits(size_t n) { return choose_window_bits(n); }
+
+extern "C" int curdle_msm_num_windows(size_t n, int window_bits) {
+  int c = window_bits ? window_bits : choose_window_bits(n);
+  if (c < 2 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [2, 16]", c);
+  return num_windows(c);
+}
+
+extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
+  if (!out_jac) return fail(CURDLE_EINVAL, "out_jac is null");
+  if (n == 0) {
+    set_out_infinity(out_jac);
+    return CURDLE_OK;
+  }
+  if (!points || !scalars) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if ((rc = upload_locked(points, scalars, n, g_ctx.stream))) return rc;
+  return msm_device_locked(g_ctx.points.p, g_ctx.scalars.p, n, 0, 0, -1, out_jac, g_ctx.stream);
+}
+
+extern "C" int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, size_t n, int window_bits,
+                                            int win_begin, int win_end, uint64_t out_jac[18], void* stream) {
+  if (!out_jac) return fail(CURDLE_EINVAL, "out_jac is null");
+  if (n && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
+  return msm_device_locked(d_points, d_scalars, n, window_bits, win_begin, win_end, out_jac, s);
+}
+
+extern "C" int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n, uint64_t out_jac[18],
+                                    void* stream) {
+  return curdle_msm_g1_device_windows(d_points, d_scalars, n, 0, 0, -1, out_jac, stream);
+}
+
+extern "C" int curdle_g1_sum(const uint64_t* jac_points, size_t k, uint64_t out_jac[18]) {
+  if (!out_jac || (k && !jac_points)) return fail(CURDLE_EINVAL, "null argument");
+  G1XYZZ acc;
+  g1_set_inf(acc);
+  for (size_t i = 0; i < k; i++) {
+    G1Jac j;
+    memcpy(&j, jac_points + 18 * i, sizeof(j));
+    G1XYZZ t;
+    g1_from_jac(t, j);
+    g1_add(acc, t);
+  }
+  g1_to_canonical_jac(out_jac, acc);
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scalars, const size_t* offsets, size_t k,
+                                   uint64_t* out_jac) {
+  if (!offsets || !out_jac) return fail(CURDLE_EINVAL, "null argument");
+  for (size_t j = 0; j < k; j++) {
+    if (offsets[j + 1] < offsets[j]) return fail(CURDLE_EINVAL, "offsets not monotone at %zu", j);
+    size_t lo = offsets[j], n = offsets[j + 1] - offsets[j];
+    int rc = curdle_msm_g1(points ? points + 12 * lo : nullptr, scalars ? scalars + 4 * lo : nullptr, n,
+                           out_jac + 18 * j);
+    if (rc) return rc;
+  }
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k, const uint64_t* scalars, size_t n,
+                                   uint64_t* out_jac) {
+  if (!out_jac || (k && !points_sets)) return fail(CURDLE_EINVAL, "null argument");
+  for (size_t j = 0; j < k; j++) {
+    int rc = curdle_msm_g1(points_sets[j], scalars, n, out_jac + 18 * j);
+    if (rc) return rc;
+  }
+  return CURDLE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Profiling / self-test
+// ---------------------------------------------------------------------------
+extern "C" int curdle_profile_enable(int on) {
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  g_ctx.profile = on != 0;
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_profile_last(curdle_profile* out) {
+  if (!out) return fail(CURDLE_EINVAL, "null argument");
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  *out = g_ctx.last;
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64_t* out64, int on_device) {
+  if (op < 0 || op > 7 || !in64 || !out64) return fail(CURDLE_EINVAL, "bad selftest arguments");
+  const uint32_t* in = reinterpret_cast<const uint32_t*>(in64);
+  uint32_t* out = reinterpret_cast<uint32_t*>(out64);
+  const size_t in_w = op <= 3 ? 24 : (op == 4 ? 16 : 96);
+  const size_t out_w = op <= 3 ? 12 : (op == 4 ? 8 : 48);
+  if (!on_device) {
+    for (size_t i = 0; i < n; i++) {
+      const uint32_t* s = in + i * in_w;
+      uint32_t* d = out + i * out_w;
+      if (op <= 3) {
+        Fp a, b, r;
+        memcpy(&a, s, 48);
+        memcpy(&b, s + 12, 48);
+        if (op == 0) fp_mul(r, a, b);
+        else if (op == 1) fp_add(r, a, b);
+        else if (op == 2) fp_sub(r, a, b);
+        else fp_sqr(r, a);
+        memcpy(d, &r, 48);
+      } else if (op == 4) {
+        Fr a, r;
+        memcpy(&a, s, 32);
+        f_from_mont<FrParams>(r, a);
+        memcpy(d, &r, 32);
+      } else {
+        G1XYZZ acc, b;
+        memcpy(&acc, s, 192);
+        memcpy(&b, s + 48, 192);
+        if (op == 5) {
+          if (!(f_is_zero(b.x) & f_is_zero(b.y))) g1_madd(acc, b.x, b.y);
+        } else if (op == 6) {
+          g1_add(acc, b);
+        } else {
+          g1_dbl(acc);
+        }
+        memcpy(d, &acc, 192);
+      }
+    }
+    return CURDLE_OK;
+  }
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  void *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_in, n * in_w * 4));
+  HIP_TRY(hipMalloc(&d_out, n * out_w * 4));
+  HIP_TRY(hipMemcpyAsync(d_in, in, n * in_w * 4, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(launch_selftest(op, (const uint32_t*)d_in, n, (uint32_t*)d_out, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(out, d_out, n * out_w * 4, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  hipFree(d_in);
+  hipFree(d_out);
+  return CURDLE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// common.Rand and msmaccumulator handles
+// ---------------------------------------------------------------------------
+struct curdle_rand {
+  common::Rand r;
+  explicit curdle_rand(uint64_t seed) : r(seed) {}
+};
+struct curdle_acc {
+  msmaccumulator::MsmAccumulator a;
+};
+
+extern "C" curdle_rand* curdle_rand_new(uint64_t seed) { return new (std::nothrow) curdle_rand(seed); }
+extern "C" void curdle_rand_free(curdle_rand* r) { delete r; }
+
+extern "C" int curdle_rand_get_fr(curdle_rand* r, uint64_t out_fr[4]) {
+  if (!r || !out_fr) return fail(CURDLE_EINVAL, "null argument");
+  Fr f;
+  r->r.GetFr(f);
+  memcpy(out_fr, &f, 32);
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_rand_get_g1_affine(curdle_rand* r, uint64_t out_aff[12]) {
+  if (!r || !out_aff) return fail(CURDLE_EINVAL, "null argument");
+  G1Affine p;
+  r->r.GetG1Affine(p);
+  memcpy(out_aff, &p, 96);
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_rand_permutation(curdle_rand* r, size_t n, uint32_t* out) {
+  if (!r || (n && !out)) return fail(CURDLE_EINVAL, "null argument");
+  std::vector<uint32_t> perm;
+  r->r.GeneratePermutation(n, perm);
+  if (n) memcpy(out, perm.data(), n * 4);
+  return CURDLE_OK;
+}
+
+extern "C" curdle_acc* curdle_acc_new(void) { return new (std::nothrow) curdle_acc(); }
+extern "C" void curdle_acc_free(curdle_acc* a) { delete a; }
+
+extern "C" int curdle_acc_accumulate_check(curdle_acc* a, const uint64_t C_jac[18], const uint64_t* x, size_t x_len,
+                                           const uint64_t* v, size_t v_len, curdle_rand* rand) {
+  if (!a || !C_jac || !rand || (x_len && !x) || (v_len && !v)) return fail(CURDLE_EINVAL, "null argument");
+  G1Jac C;
+  memcpy(&C, C_jac, sizeof(C));
+  std::vector<Fr> xs(x_len);
+  std::vector<G1Affine> vs(v_len);
+  if (x_len) memcpy(xs.data(), x, x_len * 32);
+  if (v_len) memcpy(vs.data(), v, v_len * 96);
+  msmaccumulator::Status st = a->a.AccumulateCheck(C, xs, vs, &rand->r);
+  if (!st.ok) return fail(CURDLE_EINVAL, "%s", st.err.c_str());
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_acc_verify(curdle_acc* a, int* ok) {
+  if (!a || !ok) return fail(CURDLE_EINVAL, "null argument");
+  bool b = false;
+  char saved[256];
+  msmaccumulator::Status st = a->a.Verify(&b);
+  *ok = b ? 1 : 0;
+  if (!st.ok) {
+    snprintf(saved, sizeof(saved), "%s", st.err.c_str());
+    // keep the class of the underlying failure (no device vs HIP error) visible to the caller
+    return fail(strstr(saved, "no HIP device") ? CURDLE_ENODEV : CURDLE_EHIP, "%s", saved);
+  }
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_acc_get_A_c(const curdle_acc* a, uint64_t out_jac[18]) {
+  if (!a || !out_jac) return fail(CURDLE_EINVAL, "null argument");
+  g1_to_canonical_jac(out_jac, a->a.A_c);
+  return CURDLE_OK;
+}
+
+extern "C" size_t curdle_acc_num_bases(const curdle_acc* a) { return a ? a->a.NumBases() : 0; }
+
+extern "C" int curdle_acc_export(const curdle_acc* a, uint64_t* points, uint64_t* scalars) {
+  if (!a || !points || !scalars) return fail(CURDLE_EINVAL, "null argument");
+  size_t n = a->a.NumBases();
+  if (n) {
+    memcpy(points, a->a.Bases().data(), n * 96);
+    memcpy(scalars, a->a.Scalars().data(), n * 32);
+  }
+  return CURDLE_OK;
+}

@@ -1,0 +1,47 @@
+// Host-callable launchers of the gfx950 MSM kernels (msm_kernels.hip).
+// Internal to libcurdlemsm.so; the public surface is include/curdle_msm.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bls12_381.h"
+
+namespace curdle {
+
+// Pippenger decomposition of one MSM.  Scalars are recoded into W signed c-bit
+// digits d_w in [-2^(c-1), 2^(c-1)], so a window has B = 2^(c-1) buckets
+// (bucket b holds the points whose |digit| is b+1).
+struct MsmPlan {
+  uint32_t n;       // pairs
+  int c;            // window bits
+  int W;            // windows in the full decomposition
+  uint32_t B;       // buckets per window = 2^(c-1)
+  int win_begin;    // windows [win_begin, win_end) are computed by this call
+  int win_end;
+  uint32_t seg;     // buckets per running-sum segment in the bucket reduce
+  uint32_t nseg;    // segments per window = B / seg
+};
+
+// Device workspace, laid out by msm_api.hip.
+struct MsmWorkspace {
+  uint32_t* counts;   // [W][B]   points per bucket
+  uint32_t* starts;   // [W][B]   exclusive prefix of counts inside the window, + window base
+  uint32_t* cursor;   // [W][B]   scatter cursors (copy of starts)
+  uint32_t* sorted;   // [nw][n]  point index | sign<<31, grouped by bucket
+  G1XYZZ* buckets;    // [nw][B]
+  G1XYZZ* partials;   // [nw][nseg]
+  G1XYZZ* winsums;    // [nw]
+};
+
+// Every launcher enqueues on `stream` and returns the launch status.
+hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);
+hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
+hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);
+hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream);
+hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
+hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
+
+// Element-wise primitive test (curdle_selftest_op); all pointers are device memory.
+hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream);
+
+}  // namespace curdle

@@ -1,0 +1,299 @@
+"""ctypes binding of libcurdlemsm.so (include/curdle_msm.h).
+
+Thin plumbing only: every function below forwards to one C-ABI entry point of
+the HIP library; there is no Python or CPU implementation of the MSM here.  If
+the shared library is missing, importing this package raises -- the product
+path must fail loudly rather than fall back.
+
+Layouts are gnark-crypto's (see the header): points are uint64[n, 12]
+(G1Affine, Montgomery), scalars uint64[n, 4] (fr.Element, Montgomery), results
+uint64[18] (G1Jac, canonical representative).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("CURDLE_MSM_LIB", os.path.join(os.path.dirname(_HERE), "libcurdlemsm.so"))
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C go-curdleproofs_amd` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+
+_lib = C.CDLL(LIB_PATH)
+
+OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
+
+# Every symbol include/curdle_msm.h declares (tests check they are all exported).
+SYMBOLS = [
+    "curdle_init", "curdle_shutdown", "curdle_last_error", "curdle_device_available",
+    "curdle_msm_g1", "curdle_msm_g1_device", "curdle_msm_g1_device_windows",
+    "curdle_msm_window_bits", "curdle_msm_num_windows", "curdle_g1_sum",
+    "curdle_msm_g1_batch", "curdle_msm_g1_multi",
+    "curdle_rand_new", "curdle_rand_free", "curdle_rand_get_fr", "curdle_rand_get_g1_affine",
+    "curdle_rand_permutation",
+    "curdle_acc_new", "curdle_acc_free", "curdle_acc_accumulate_check", "curdle_acc_verify",
+    "curdle_acc_get_A_c", "curdle_acc_num_bases", "curdle_acc_export",
+    "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op",
+]
+
+_u64p = C.POINTER(C.c_uint64)
+_vp = C.c_void_p
+
+
+class _Profile(C.Structure):
+    _fields_ = [("n_kernels", C.c_int), ("name", C.c_char_p * 16), ("ms", C.c_float * 16),
+                ("window_bits", C.c_int), ("num_windows", C.c_int)]
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(_lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_init = _sig("curdle_init", C.c_int, C.c_int)
+_shutdown = _sig("curdle_shutdown", C.c_int)
+_last_error = _sig("curdle_last_error", C.c_int, C.c_char_p, C.c_size_t)
+_device_available = _sig("curdle_device_available", C.c_int)
+_msm_g1 = _sig("curdle_msm_g1", C.c_int, _vp, _vp, C.c_size_t, _vp)
+_msm_g1_device = _sig("curdle_msm_g1_device", C.c_int, _vp, _vp, C.c_size_t, _vp, _vp)
+_msm_g1_device_windows = _sig("curdle_msm_g1_device_windows", C.c_int, _vp, _vp, C.c_size_t, C.c_int, C.c_int,
+                              C.c_int, _vp, _vp)
+_window_bits = _sig("curdle_msm_window_bits", C.c_int, C.c_size_t)
+_num_windows = _sig("curdle_msm_num_windows", C.c_int, C.c_size_t, C.c_int)
+_g1_sum = _sig("curdle_g1_sum", C.c_int, _vp, C.c_size_t, _vp)
+_msm_batch = _sig("curdle_msm_g1_batch", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
+_msm_multi = _sig("curdle_msm_g1_multi", C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp)
+_rand_new = _sig("curdle_rand_new", _vp, C.c_uint64)
+_rand_free = _sig("curdle_rand_free", None, _vp)
+_rand_get_fr = _sig("curdle_rand_get_fr", C.c_int, _vp, _vp)
+_rand_get_g1 = _sig("curdle_rand_get_g1_affine", C.c_int, _vp, _vp)
+_rand_perm = _sig("curdle_rand_permutation", C.c_int, _vp, C.c_size_t, _vp)
+_acc_new = _sig("curdle_acc_new", _vp)
+_acc_free = _sig("curdle_acc_free", None, _vp)
+_acc_check = _sig("curdle_acc_accumulate_check", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp)
+_acc_verify = _sig("curdle_acc_verify", C.c_int, _vp, C.POINTER(C.c_int))
+_acc_get_A_c = _sig("curdle_acc_get_A_c", C.c_int, _vp, _vp)
+_acc_num_bases = _sig("curdle_acc_num_bases", C.c_size_t, _vp)
+_acc_export = _sig("curdle_acc_export", C.c_int, _vp, _vp, _vp)
+_profile_enable = _sig("curdle_profile_enable", C.c_int, C.c_int)
+_profile_last = _sig("curdle_profile_last", C.c_int, C.POINTER(_Profile))
+_selftest_op = _sig("curdle_selftest_op", C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_int)
+
+
+class CurdleError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"curdle error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(256)
+    _last_error(buf, 256)
+    return buf.value.decode()
+
+
+def _check(rc: int) -> None:
+    if rc != OK:
+        raise CurdleError(rc, last_error())
+
+
+def _as_u64(a, cols=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if cols is not None and a.size and a.shape[-1] != cols:
+        raise ValueError(f"expected last dimension {cols}, got {a.shape}")
+    return a
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_vp)
+
+
+def init(device: int = 0) -> None:
+    _check(_init(device))
+
+
+def shutdown() -> None:
+    _check(_shutdown())
+
+
+def device_available() -> bool:
+    return bool(_device_available())
+
+
+def msm_g1(points, scalars) -> np.ndarray:
+    """(*G1Jac).MultiExp on host arrays: points uint64[n,12], scalars uint64[n,4] -> uint64[18]."""
+    points = _as_u64(points, 12)
+    scalars = _as_u64(scalars, 4)
+    n = points.shape[0] if points.size else 0
+    ns = scalars.shape[0] if scalars.size else 0
+    if n != ns:
+        # gnark MultiExp: "len(points) != len(scalars)"
+        raise CurdleError(EINVAL, "len(points) != len(scalars)")
+    out = np.zeros(18, dtype=np.uint64)
+    _check(_msm_g1(_ptr(points), _ptr(scalars), n, _ptr(out)))
+    return out
+
+
+def msm_g1_device(d_points: int, d_scalars: int, n: int, stream: int = 0, window_bits: int = 0,
+                  win_begin: int = 0, win_end: int = -1) -> np.ndarray:
+    """MSM on device-resident inputs (raw device pointers, e.g. torch_tensor.data_ptr())."""
+    out = np.zeros(18, dtype=np.uint64)
+    _check(_msm_g1_device_windows(d_points, d_scalars, n, window_bits, win_begin, win_end, _ptr(out),
+                                  stream or None))
+    return out
+
+
+def window_bits(n: int) -> int:
+    return _window_bits(n)
+
+
+def num_windows(n: int, c: int = 0) -> int:
+    rc = _num_windows(n, c)
+    if rc < 0:
+        _check(rc)
+    return rc
+
+
+def g1_sum(jac_points) -> np.ndarray:
+    jac_points = _as_u64(jac_points, 18)
+    k = jac_points.shape[0] if jac_points.size else 0
+    out = np.zeros(18, dtype=np.uint64)
+    _check(_g1_sum(_ptr(jac_points), k, _ptr(out)))
+    return out
+
+
+def msm_g1_batch(points, scalars, offsets) -> np.ndarray:
+    points = _as_u64(points, 12)
+    scalars = _as_u64(scalars, 4)
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)  # size_t
+    k = len(offs) - 1
+    out = np.zeros((k, 18), dtype=np.uint64)
+    _check(_msm_batch(_ptr(points), _ptr(scalars), _ptr(offs), k, _ptr(out)))
+    return out
+
+
+def msm_g1_multi(points_sets, scalars) -> np.ndarray:
+    sets = [_as_u64(p, 12) for p in points_sets]
+    scalars = _as_u64(scalars, 4)
+    n = scalars.shape[0] if scalars.size else 0
+    for s in sets:
+        if (s.shape[0] if s.size else 0) != n:
+            raise CurdleError(EINVAL, "len(points) != len(scalars)")
+    arr = (_vp * len(sets))(*[s.ctypes.data for s in sets])
+    out = np.zeros((len(sets), 18), dtype=np.uint64)
+    _check(_msm_multi(C.cast(arr, _vp), len(sets), _ptr(scalars), n, _ptr(out)))
+    return out
+
+
+class Rand:
+    """common.Rand (common/rand.go) through the library's host mirror."""
+
+    def __init__(self, seed: int):
+        self._h = _rand_new(seed)
+        if not self._h:
+            raise MemoryError("curdle_rand_new")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _rand_free(h)
+
+    def get_fr(self) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint64)
+        _check(_rand_get_fr(self._h, _ptr(out)))
+        return out
+
+    def get_frs(self, n: int) -> np.ndarray:
+        return np.array([self.get_fr() for _ in range(n)], dtype=np.uint64).reshape(n, 4)
+
+    def get_g1_affine(self) -> np.ndarray:
+        out = np.zeros(12, dtype=np.uint64)
+        _check(_rand_get_g1(self._h, _ptr(out)))
+        return out
+
+    def get_g1_affines(self, n: int) -> np.ndarray:
+        return np.array([self.get_g1_affine() for _ in range(n)], dtype=np.uint64).reshape(n, 12)
+
+    def generate_permutation(self, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.uint32)
+        _check(_rand_perm(self._h, n, _ptr(out)))
+        return out
+
+
+class MsmAccumulator:
+    """msmaccumulator.MsmAccumulator (msmaccumulator/msmaccumulator.go:11-64)."""
+
+    def __init__(self):
+        self._h = _acc_new()
+        if not self._h:
+            raise MemoryError("curdle_acc_new")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _acc_free(h)
+
+    def accumulate_check(self, C_jac, x, v, rand: Rand) -> None:
+        C_jac = _as_u64(C_jac)
+        x = _as_u64(x, 4)
+        v = _as_u64(v, 12)
+        nx = x.shape[0] if x.size else 0
+        nv = v.shape[0] if v.size else 0
+        _check(_acc_check(self._h, _ptr(C_jac), _ptr(x), nx, _ptr(v), nv, rand._h))
+
+    def verify(self) -> bool:
+        ok = C.c_int(0)
+        _check(_acc_verify(self._h, C.byref(ok)))
+        return bool(ok.value)
+
+    @property
+    def A_c(self) -> np.ndarray:
+        out = np.zeros(18, dtype=np.uint64)
+        _check(_acc_get_A_c(self._h, _ptr(out)))
+        return out
+
+    def num_bases(self) -> int:
+        return _acc_num_bases(self._h)
+
+    def export(self):
+        n = self.num_bases()
+        pts = np.zeros((n, 12), dtype=np.uint64)
+        sc = np.zeros((n, 4), dtype=np.uint64)
+        if n:
+            _check(_acc_export(self._h, _ptr(pts), _ptr(sc)))
+        return pts, sc
+
+
+def profile_enable(on: bool = True) -> None:
+    _check(_profile_enable(1 if on else 0))
+
+
+def profile_last() -> dict:
+    p = _Profile()
+    _check(_profile_last(C.byref(p)))
+    return {
+        "kernels": {p.name[i].decode(): float(p.ms[i]) for i in range(p.n_kernels)},
+        "window_bits": p.window_bits,
+        "num_windows": p.num_windows,
+    }
+
+
+_SELFTEST_W = {0: (24, 12), 1: (24, 12), 2: (24, 12), 3: (24, 12), 4: (16, 8), 5: (96, 48), 6: (96, 48), 7: (96, 48)}
+
+
+def selftest_op(op: int, inp: np.ndarray, on_device: bool) -> np.ndarray:
+    """inp: uint32[n, in_width] -> uint32[n, out_width] (see curdle_selftest_op)."""
+    iw, ow = _SELFTEST_W[op]
+    inp = np.ascontiguousarray(inp, dtype=np.uint32)
+    assert inp.ndim == 2 and inp.shape[1] == iw, inp.shape
+    out = np.zeros((inp.shape[0], ow), dtype=np.uint32)
+    _check(_selftest_op(op, _ptr(inp), inp.shape[0], _ptr(out), 1 if on_device else 0))
+    return out

@@ -1,0 +1,65 @@
+// msmaccumulator mirror -- see msmaccumulator.h.
+// Reference: /root/reference/msmaccumulator/msmaccumulator.go.
+#include "msmaccumulator.h"
+
+#include <string.h>
+
+#include "../../include/curdle_msm.h"
+#include "../csrc/host_math.h"
+
+namespace curdle {
+namespace msmaccumulator {
+
+MsmAccumulator::MsmAccumulator() { g1_set_inf(A_c); }
+
+Status MsmAccumulator::AccumulateCheck(const G1Jac& C, const std::vector<Fr>& x, const std::vector<G1Affine>& v,
+                                       common::Rand* rand) {
+  if (v.size() != x.size()) return Status::Error("x and v must have the same length");  // :28-30
+
+  Fr alpha;
+  rand->GetFr(alpha);  // :32
+
+  Fr tmp;
+  for (size_t i = 0; i < v.size(); i++) {  // :38-43
+    fr_mul(tmp, alpha, x[i]);
+    std::string key(reinterpret_cast<const char*>(&v[i]), sizeof(G1Affine));
+    auto it = index_.find(key);
+    if (it == index_.end()) {
+      index_.emplace(std::move(key), bases_.size());
+      bases_.push_back(v[i]);
+      scalars_.push_back(tmp);
+    } else {
+      fr_add(scalars_[it->second], scalars_[it->second], tmp);
+    }
+  }
+
+  // A_c += alpha * C  (:44, ScalarMultiplication with the canonical big.Int of alpha)
+  Fr alpha_c;
+  f_from_mont<FrParams>(alpha_c, alpha);
+  G1XYZZ Cx, t;
+  g1_from_jac(Cx, C);
+  g1_scalar_mul(t, Cx, alpha_c.l, 8);
+  g1_add(A_c, t);
+  return Status::OK();
+}
+
+Status MsmAccumulator::Verify(bool* ok) {
+  *ok = false;
+  uint64_t out[CURDLE_G1_JAC_U64];
+  int rc = curdle_msm_g1(reinterpret_cast<const uint64_t*>(bases_.data()),
+                         reinterpret_cast<const uint64_t*>(scalars_.data()), bases_.size(), out);  // :59
+  if (rc != CURDLE_OK) {
+    char buf[256];
+    curdle_last_error(buf, sizeof(buf));
+    return Status::Error(std::string("computing msm: ") + buf);  // :60
+  }
+  G1Jac j;
+  memcpy(&j, out, sizeof(j));
+  G1XYZZ res;
+  g1_from_jac(res, j);
+  *ok = g1_equal(res, A_c);  // :63
+  return Status::OK();
+}
+
+}  // namespace msmaccumulator
+}  // namespace curdle

@@ -1,0 +1,56 @@
+// Host mirror of the reference's `msmaccumulator` package
+// (/root/reference/msmaccumulator/msmaccumulator.go:11-64): same names,
+// argument order and error behaviour, with the final MultiExp (:59) running on
+// the GPU through the C ABI (curdle_msm_g1).  Go's (value, error) pairs become
+// a Status return + out-params.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../csrc/bls12_381.h"
+#include "common_rand.h"
+
+namespace curdle {
+namespace msmaccumulator {
+
+struct Status {
+  bool ok;
+  std::string err;  // text of the Go error ("x and v must have the same length", "computing msm: ...")
+  static Status OK() { return Status{true, ""}; }
+  static Status Error(const std::string& e) { return Status{false, e}; }
+};
+
+class MsmAccumulator {
+ public:
+  // New(), msmaccumulator.go:16-21
+  MsmAccumulator();
+
+  // AccumulateCheck(C, x, v, rand), msmaccumulator.go:23-47.
+  // C is a gnark G1Jac (any representative), x Montgomery scalars, v affine bases.
+  Status AccumulateCheck(const G1Jac& C, const std::vector<Fr>& x, const std::vector<G1Affine>& v,
+                         common::Rand* rand);
+
+  // Verify(), msmaccumulator.go:49-64: flatten the map, one MultiExp, Equal(A_c).
+  Status Verify(bool* ok);
+
+  // Exported field A_c (msmaccumulator.go:12), kept as XYZZ internally.
+  G1XYZZ A_c;
+
+  size_t NumBases() const { return bases_.size(); }
+  const std::vector<G1Affine>& Bases() const { return bases_; }
+  const std::vector<Fr>& Scalars() const { return scalars_; }
+
+ private:
+  // baseScalarMap map[G1Affine]fr.Element (:13): keyed by the 96 key bytes, so
+  // a base shared by several checks merges; kept in insertion order (Go's map
+  // order is random per run, :53-56, so only the group element is defined).
+  std::unordered_map<std::string, size_t> index_;
+  std::vector<G1Affine> bases_;
+  std::vector<Fr> scalars_;
+};
+
+}  // namespace msmaccumulator
+}  // namespace curdle

@@ -1,0 +1,176 @@
+/*
+ * curdle_msm.h -- C ABI of libcurdlemsm.so: BLS12-381 G1 multi-scalar
+ * multiplication on MI355X (gfx950), the drop-in for the MSM path of
+ * jsign/go-curdleproofs.
+ *
+ * Every entry point replaces one reference interface (paths relative to
+ * /root/reference); INTEGRATION.md shows the cgo binding for each.
+ *
+ * Data layouts are gnark-crypto v0.11.0's in-memory layouts (go.mod:6), so Go
+ * slices can be handed over with unsafe.Pointer(&s[0]) and no copy:
+ *   fr.Element            = 4 x uint64, little-endian limbs, Montgomery (R = 2^256)
+ *   fp.Element            = 6 x uint64, little-endian limbs, Montgomery (R = 2^384)
+ *   bls12381.G1Affine     = {X, Y fp.Element}   = 12 x uint64; (0,0) is infinity
+ *   bls12381.G1Jac        = {X, Y, Z fp.Element} = 18 x uint64; Z = 0 is infinity
+ *
+ * Results are returned as the canonical Jacobian representative: (x, y, 1) of
+ * the affine result (Z = Montgomery one), or (1, 1, 0) for infinity.  The
+ * reference never inspects Jacobian limbs (only Equal / AddAssign / to-affine,
+ * e.g. msmaccumulator/msmaccumulator.go:63), so any representative is valid;
+ * a canonical one makes results byte-comparable.
+ *
+ * All functions return CURDLE_OK (0) or a negative CURDLE_E* code; the text of
+ * the last error on the calling thread is available from curdle_last_error().
+ * No C++ exception crosses this boundary.  Calls are synchronous (no pointer
+ * is retained after return -- the cgo rule) and thread-safe.  There is no CPU
+ * fallback: if no gfx950 device is usable the MSM entry points fail with
+ * CURDLE_ENODEV.
+ */
+#ifndef CURDLE_MSM_H
+#define CURDLE_MSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CURDLE_OK 0
+#define CURDLE_EINVAL (-1) /* bad argument (null pointer, length mismatch)      */
+#define CURDLE_ENODEV (-2) /* no usable HIP device / library not initialised    */
+#define CURDLE_EHIP (-3)   /* a HIP runtime call failed                         */
+#define CURDLE_ENOMEM (-4) /* device or host allocation failed                  */
+#define CURDLE_EFALSE (-5) /* reserved                                          */
+
+#define CURDLE_G1_AFFINE_U64 12
+#define CURDLE_G1_JAC_U64 18
+#define CURDLE_FR_U64 4
+
+/* ------------------------------------------------------------------------- *
+ * Library life cycle
+ * ------------------------------------------------------------------------- */
+
+/* Selects the HIP device this process computes on (one process per GPU) and
+ * creates the stream + workspace.  Called implicitly with device 0 by the
+ * first MSM call.  Replaces: common.MultiExpConf (common/util.go:14), the
+ * reference's only configuration knob. */
+int curdle_init(int device);
+int curdle_shutdown(void);
+/* Copies the calling thread's last error text (NUL-terminated) into buf. */
+int curdle_last_error(char* buf, size_t len);
+/* 1 if a HIP device is visible to the library, else 0 (never fails). */
+int curdle_device_available(void);
+
+/* ------------------------------------------------------------------------- *
+ * The hot path: (*G1Jac).MultiExp(points []G1Affine, scalars []fr.Element, cfg)
+ *   gnark-crypto v0.11.0, called at msmaccumulator/msmaccumulator.go:59 and
+ *   the 38 other sites listed in SURVEY.md section 8(a).
+ * out_jac = sum_i scalars[i] * points[i].  n = 0 gives infinity and CURDLE_OK
+ * (msmaccumulator_test.go:14 runs sizes 0..3).  Inputs are host memory and
+ * are copied to the device on every call: the prover mutates bases in place
+ * between calls (innerproductargument.go:155-166), so nothing is cached by
+ * pointer.
+ * ------------------------------------------------------------------------- */
+int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n,
+                  uint64_t out_jac[CURDLE_G1_JAC_U64]);
+
+/* Same MSM with inputs already resident in device memory (HIP device
+ * pointers, same layouts).  `stream` is a hipStream_t or NULL for the
+ * library's own stream.  This is what bench.py times. */
+int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n,
+                         uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
+
+/* Partial MSM over Pippenger windows [win_begin, win_end) of the
+ * decomposition the library would use for (n, window_bits); the partial is
+ * already scaled by 2^(window_bits*win_begin).  Summing the partials of a
+ * partition of [0, curdle_msm_num_windows()) with curdle_g1_sum() gives the
+ * full MSM.  This is the multi-GPU split of north_star: one rank per GPU, each
+ * taking a window range, 144-byte partials all-gathered over RCCL.
+ * window_bits = 0 lets the library choose. */
+int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, size_t n,
+                                 int window_bits, int win_begin, int win_end,
+                                 uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
+int curdle_msm_window_bits(size_t n);              /* the library's choice of c for n   */
+int curdle_msm_num_windows(size_t n, int window_bits); /* ceil(256 / c) for that choice */
+
+/* out = sum of k Jacobian points (host memory, any representatives).
+ * Replaces the chain of G1Jac.AddAssign a caller would do on partials. */
+int curdle_g1_sum(const uint64_t* jac_points, size_t k, uint64_t out_jac[CURDLE_G1_JAC_U64]);
+
+/* k independent MSMs in one call (many
+ * concurrent msmaccumulator.Verify calls).  MSM j covers pairs
+ * [offsets[j], offsets[j+1]) of the concatenated points/scalars arrays;
+ * offsets has k+1 entries.  out_jac holds k results. */
+int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scalars,
+                        const size_t* offsets, size_t k, uint64_t* out_jac);
+
+/* k MSMs that share ONE scalar vector against k base sets of n points each
+ * (samemultiscalarargument.go:64-70 and :206,218,231; curdleproof.go:110,114).
+ * points_sets[j] points at n affine points. */
+int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k,
+                        const uint64_t* scalars, size_t n, uint64_t* out_jac);
+
+/* ------------------------------------------------------------------------- *
+ * msmaccumulator (msmaccumulator/msmaccumulator.go:11-64), host-side mirror.
+ * The Go package keeps its own map; these entry points exist so that the
+ * C++/Python side of this repository can run the reference's accumulator
+ * tests through the same library.  `rand` is a curdle_rand handle
+ * (common/rand.go).
+ * ------------------------------------------------------------------------- */
+typedef struct curdle_acc curdle_acc;
+typedef struct curdle_rand curdle_rand;
+
+curdle_rand* curdle_rand_new(uint64_t seed);                  /* common.NewRand, rand.go:19        */
+void curdle_rand_free(curdle_rand* r);
+int curdle_rand_get_fr(curdle_rand* r, uint64_t out_fr[4]);   /* GetFr, rand.go:35 (Montgomery)    */
+int curdle_rand_get_g1_affine(curdle_rand* r, uint64_t out_aff[12]); /* GetG1Affine, rand.go:72    */
+int curdle_rand_permutation(curdle_rand* r, size_t n, uint32_t* out); /* GeneratePermutation :97   */
+
+curdle_acc* curdle_acc_new(void);                             /* New, msmaccumulator.go:16         */
+void curdle_acc_free(curdle_acc* a);
+/* AccumulateCheck(C, x, v, rand), msmaccumulator.go:23.  len(x) != len(v) is
+ * CURDLE_EINVAL ("x and v must have the same length"). */
+int curdle_acc_accumulate_check(curdle_acc* a, const uint64_t C_jac[18],
+                                const uint64_t* x, size_t x_len,
+                                const uint64_t* v, size_t v_len, curdle_rand* rand);
+/* Verify(), msmaccumulator.go:49: *ok = 1 iff MSM(bases, scalars) == A_c.  The
+ * MSM runs on the GPU through curdle_msm_g1. */
+int curdle_acc_verify(curdle_acc* a, int* ok);
+int curdle_acc_get_A_c(const curdle_acc* a, uint64_t out_jac[18]); /* exported field A_c, :12     */
+size_t curdle_acc_num_bases(const curdle_acc* a);
+/* Flattened map (bases then scalars), in insertion order. */
+int curdle_acc_export(const curdle_acc* a, uint64_t* points, uint64_t* scalars);
+
+/* ------------------------------------------------------------------------- *
+ * Profiling and diagnostics (used by bench.py and tests; not part of the
+ * reference's surface).
+ * ------------------------------------------------------------------------- */
+#define CURDLE_PROF_MAX_KERNELS 16
+typedef struct {
+  int n_kernels;
+  const char* name[CURDLE_PROF_MAX_KERNELS];
+  float ms[CURDLE_PROF_MAX_KERNELS]; /* HIP-event time of each kernel, last MSM call */
+  int window_bits;
+  int num_windows;
+} curdle_profile;
+/* When enabled, every MSM call brackets each kernel with hipEvents on the
+ * stream it launches on and keeps the durations of the last call. */
+int curdle_profile_enable(int on);
+int curdle_profile_last(curdle_profile* out);
+
+/* Element-wise device self-test of the field / curve primitives, so tests can
+ * compare the gfx950 arithmetic with the oracle operation by operation.
+ *   op 0: fp_mul(a,b)      in: n x (12+12) u32-limbed Fp pairs, out: n x Fp
+ *   op 1: fp_add  2: fp_sub  3: fp_sqr(a)
+ *   op 4: fr_from_mont(a)  in: n x Fr pairs (b ignored), out: n x Fr
+ *   op 5: xyzz madd: in: n x (XYZZ acc | affine), out: n x XYZZ
+ *   op 6: xyzz add : in: n x (XYZZ | XYZZ),       out: n x XYZZ
+ *   op 7: xyzz dbl : in: n x (XYZZ | XYZZ ignored) out: n x XYZZ
+ * on_device = 0 runs the same header code on the host CPU. */
+int curdle_selftest_op(int op, const uint64_t* in, size_t n, uint64_t* out, int on_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURDLE_MSM_H */
