@@ -348,7 +348,7 @@ struct G1Jac {
   Fp x, y, z;
 };
 
-CURDLE_HD bool g1_affine_is_inf(const G1Affine& p) { return f_is_zero(p.x) & f_is_zero(p.y); }
+CURDLE_HD bool g1_affine_is_inf(const G1Affine& p) { return f_is_zero(p.x) && f_is_zero(p.y); }
 CURDLE_HD bool g1_is_inf(const G1XYZZ& p) { return f_is_zero(p.zz); }
 CURDLE_HD void g1_set_inf(G1XYZZ& p) {
   f_one(p.x);

@@ -56,7 +56,7 @@ struct Ctx {
   bool inited = false;
   int device = 0;
   hipStream_t stream = nullptr;
-  Buf points, scalars, counts, starts, cursor, sorted, buckets, partials, winsums;
+  Buf points, scalars, counts, starts, cursor, fragcnt, foff, small, sorted, frags, partials, winsums;
   G1XYZZ* h_winsums = nullptr;  // pinned
   size_t h_winsums_cap = 0;
   // profiling
@@ -143,6 +143,20 @@ int make_plan(MsmPlan& p, size_t n, int c, int win_begin, int win_end) {
   p.win_end = win_end;
   p.seg = p.B < 8 ? p.B : 8;
   p.nseg = p.B / p.seg;
+  // Sorted positions per accumulate lane: about two full-chip rounds of lanes
+  // (256 CUs x 4 SIMDs x 2 waves x 64 lanes) for large inputs, never below 8.
+  const uint64_t entries = (uint64_t)(p.win_end - p.win_begin) * n;
+  uint64_t L = (entries + 2 * 131072 - 1) / (2 * 131072);
+  if (const char* env = getenv("CURDLE_SEG_LEN")) L = (uint64_t)atoi(env);
+  if (L < 8) L = 8;
+  if (L > 128) L = 128;
+  p.L = (uint32_t)L;
+  p.max_small = 16;
+  // a bucket with more than max_small fragments holds more than (max_small - 1) * L entries
+  uint64_t ml = entries / ((uint64_t)(p.max_small - 1) * p.L) + 1;
+  uint64_t nbk = (uint64_t)(p.win_end - p.win_begin) * p.B;
+  p.max_large = (uint32_t)(ml < nbk ? ml : nbk);
+  if (p.max_large == 0) p.max_large = 1;
   return CURDLE_OK;
 }
 
@@ -153,21 +167,21 @@ struct Prof {
   bool on;
   explicit Prof(Ctx& ctx, hipStream_t st) : c(ctx), s(st), on(ctx.profile) {
     if (on && !c.ev_made) {
-      for (auto& e : c.ev) hipEventCreate(&e);
+      for (auto& e : c.ev) (void)hipEventCreate(&e);
       c.ev_made = true;
     }
-    if (on) hipEventRecord(c.ev[0], s);
+    if (on) (void)hipEventRecord(c.ev[0], s);
   }
   void mark(const char* name) {
     if (!on || k >= CURDLE_PROF_MAX_KERNELS) return;
     c.last.name[k] = name;
     k++;
-    hipEventRecord(c.ev[k], s);
+    (void)hipEventRecord(c.ev[k], s);
   }
   void finish(const MsmPlan& p) {
     if (!on) return;
     c.last.n_kernels = k;
-    for (int i = 0; i < k; i++) hipEventElapsedTime(&c.last.ms[i], c.ev[i], c.ev[i + 1]);
+    for (int i = 0; i < k; i++) (void)hipEventElapsedTime(&c.last.ms[i], c.ev[i], c.ev[i + 1]);
     c.last.window_bits = p.c;
     c.last.num_windows = p.W;
   }
@@ -192,11 +206,16 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   }
   Ctx& C = g_ctx;
   const size_t nb = (size_t)nw * p.B;
+  if (nb > (size_t)1024 * 4096) return fail(CURDLE_EINVAL, "%zu bucket slots exceed the scan capacity", nb);
+  const size_t nlanes = ((size_t)nw * n + p.L - 1) / p.L;
   if ((rc = ensure(C.counts, nb * 4))) return rc;
-  if ((rc = ensure(C.starts, nb * 4))) return rc;
+  if ((rc = ensure(C.starts, (nb + 1) * 4))) return rc;
   if ((rc = ensure(C.cursor, nb * 4))) return rc;
+  if ((rc = ensure(C.fragcnt, nb * 4))) return rc;
+  if ((rc = ensure(C.foff, (nb + 1) * 4))) return rc;
+  if ((rc = ensure(C.small, (1024 + 1 + (size_t)p.max_large) * 4))) return rc;
   if ((rc = ensure(C.sorted, (size_t)nw * n * 4))) return rc;
-  if ((rc = ensure(C.buckets, nb * sizeof(G1XYZZ)))) return rc;
+  if ((rc = ensure(C.frags, (nb + nlanes + 1) * sizeof(G1XYZZ)))) return rc;
   if ((rc = ensure(C.partials, (size_t)nw * p.nseg * sizeof(G1XYZZ)))) return rc;
   if ((rc = ensure(C.winsums, (size_t)nw * sizeof(G1XYZZ)))) return rc;
   if (C.h_winsums_cap < nw) {
@@ -209,12 +228,18 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   ws.counts = (uint32_t*)C.counts.p;
   ws.starts = (uint32_t*)C.starts.p;
   ws.cursor = (uint32_t*)C.cursor.p;
+  ws.fragcnt = (uint32_t*)C.fragcnt.p;
+  ws.foff = (uint32_t*)C.foff.p;
+  ws.blocksum = (uint32_t*)C.small.p;
+  ws.nlarge = ws.blocksum + 1024;
+  ws.large = ws.blocksum + 1025;
   ws.sorted = (uint32_t*)C.sorted.p;
-  ws.buckets = (G1XYZZ*)C.buckets.p;
+  ws.frags = (G1XYZZ*)C.frags.p;
   ws.partials = (G1XYZZ*)C.partials.p;
   ws.winsums = (G1XYZZ*)C.winsums.p;
 
   HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, stream));
+  HIP_TRY(hipMemsetAsync(ws.nlarge, 0, 4, stream));
   Prof prof(C, stream);
   HIP_TRY(launch_hist(p, ws, d_scalars, stream));
   prof.mark("hist");
@@ -224,6 +249,8 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   prof.mark("scatter");
   HIP_TRY(launch_accumulate(p, ws, d_points, stream));
   prof.mark("accumulate");
+  HIP_TRY(launch_merge_large(p, ws, stream));
+  prof.mark("merge_large");
   HIP_TRY(launch_bucket_reduce(p, ws, stream));
   prof.mark("bucket_reduce");
   HIP_TRY(launch_window_sum(p, ws, stream));
@@ -271,20 +298,21 @@ extern "C" int curdle_shutdown(void) {
   std::lock_guard<std::mutex> g(g_ctx.mu);
   Ctx& C = g_ctx;
   if (!C.inited) return CURDLE_OK;
-  hipSetDevice(C.device);
-  hipStreamSynchronize(C.stream);
-  for (Buf* b : {&C.points, &C.scalars, &C.counts, &C.starts, &C.cursor, &C.sorted, &C.buckets, &C.partials, &C.winsums}) {
-    if (b->p) hipFree(b->p);
+  (void)hipSetDevice(C.device);
+  (void)hipStreamSynchronize(C.stream);
+  for (Buf* b : {&C.points, &C.scalars, &C.counts, &C.starts, &C.cursor, &C.fragcnt, &C.foff, &C.small, &C.sorted, &C.frags,
+                 &C.partials, &C.winsums}) {
+    if (b->p) (void)hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
   }
-  if (C.h_winsums) hipHostFree(C.h_winsums);
+  if (C.h_winsums) (void)hipHostFree(C.h_winsums);
   C.h_winsums = nullptr;
   C.h_winsums_cap = 0;
   if (C.ev_made)
-    for (auto& e : C.ev) hipEventDestroy(e);
+    for (auto& e : C.ev) (void)hipEventDestroy(e);
   C.ev_made = false;
-  hipStreamDestroy(C.stream);
+  (void)hipStreamDestroy(C.stream);
   C.stream = nullptr;
   C.inited = false;
   return CURDLE_OK;
@@ -384,6 +412,38 @@ extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k,
 }
 
 // ---------------------------------------------------------------------------
+// Synthetic inputs
+// ---------------------------------------------------------------------------
+extern "C" int curdle_synth_points_walk_device(const uint64_t k[4], const uint64_t q[4], size_t n, void* d_out) {
+  if (!k || !q || (n && !d_out)) return fail(CURDLE_EINVAL, "null argument");
+  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 points", n);
+  if (n == 0) return CURDLE_OK;
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  G1Affine gen;
+  g1_generator(gen);
+  G1XYZZ gx, t;
+  g1_from_affine(gx, gen);
+  G1Affine p0, table[27];
+  g1_scalar_mul(t, gx, reinterpret_cast<const u32*>(k), 8);
+  g1_to_affine(p0, t);
+  g1_scalar_mul(t, gx, reinterpret_cast<const u32*>(q), 8);
+  for (int j = 0; j < 27; j++) {
+    g1_to_affine(table[j], t);
+    g1_dbl(t);
+  }
+  void* d_table = nullptr;
+  HIP_TRY(hipMalloc(&d_table, sizeof(table)));
+  HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(launch_synth_walk((const G1Affine*)d_table, p0, (uint32_t)n, d_out, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipFree(d_table));
+  return CURDLE_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Profiling / self-test
 // ---------------------------------------------------------------------------
 extern "C" int curdle_profile_enable(int on) {
@@ -428,7 +488,7 @@ extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64
         memcpy(&acc, s, 192);
         memcpy(&b, s + 48, 192);
         if (op == 5) {
-          if (!(f_is_zero(b.x) & f_is_zero(b.y))) g1_madd(acc, b.x, b.y);
+          if (!(f_is_zero(b.x) && f_is_zero(b.y))) g1_madd(acc, b.x, b.y);
         } else if (op == 6) {
           g1_add(acc, b);
         } else {
@@ -450,8 +510,8 @@ extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64
   HIP_TRY(launch_selftest(op, (const uint32_t*)d_in, n, (uint32_t*)d_out, g_ctx.stream));
   HIP_TRY(hipMemcpyAsync(out, d_out, n * out_w * 4, hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-  hipFree(d_in);
-  hipFree(d_out);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
   return CURDLE_OK;
 }
 

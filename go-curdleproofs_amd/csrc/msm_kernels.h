@@ -20,15 +20,23 @@ struct MsmPlan {
   int win_end;
   uint32_t seg;     // buckets per running-sum segment in the bucket reduce
   uint32_t nseg;    // segments per window = B / seg
+  uint32_t L;       // sorted positions per accumulate lane
+  uint32_t max_small;  // buckets with more fragments than this are pre-merged by a block
+  uint32_t max_large;  // capacity of the large-bucket queue (= grid of merge_large)
 };
 
 // Device workspace, laid out by msm_api.hip.
 struct MsmWorkspace {
-  uint32_t* counts;   // [W][B]   points per bucket
-  uint32_t* starts;   // [W][B]   exclusive prefix of counts inside the window, + window base
-  uint32_t* cursor;   // [W][B]   scatter cursors (copy of starts)
-  uint32_t* sorted;   // [nw][n]  point index | sign<<31, grouped by bucket
-  G1XYZZ* buckets;    // [nw][B]
+  uint32_t* counts;   // [nb]      points per bucket, nb = nw * B slots (window-major)
+  uint32_t* starts;   // [nb + 1]  exclusive prefix of counts; [nb] = number of sorted entries
+  uint32_t* cursor;   // [nb]      scatter cursors (copy of starts)
+  uint32_t* fragcnt;  // [nb]      accumulation fragments per bucket
+  uint32_t* foff;     // [nb + 1]  exclusive prefix of fragcnt
+  uint32_t* blocksum; // [1024]    scan scratch
+  uint32_t* large;    // [max_large] buckets queued for merge_large
+  uint32_t* nlarge;   // [1]
+  uint32_t* sorted;   // [nw * n]  point index | sign<<31, grouped by bucket
+  G1XYZZ* frags;      // [nb + lanes + 1]
   G1XYZZ* partials;   // [nw][nseg]
   G1XYZZ* winsums;    // [nw]
 };
@@ -38,8 +46,12 @@ hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, const void* d_s
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);
 hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream);
+hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
+
+// P_i = p0 + i*Q for i < n (n <= 2^27); d_table holds 27 affine points 2^j * Q.
+hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32_t n, void* d_out, hipStream_t stream);
 
 // Element-wise primitive test (curdle_selftest_op); all pointers are device memory.
 hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream);

@@ -4,13 +4,17 @@
 // (/root/reference/msmaccumulator/msmaccumulator.go:59 and the call sites in
 // SURVEY.md section 8a).  Phases, one kernel each:
 //   hist        scalar Montgomery->canonical, signed c-bit digits, bucket sizes
-//   scan        per-window exclusive prefix of the bucket sizes
+//   scan        exclusive prefix of the bucket sizes over all (window, bucket)
+//               slots, then of the per-bucket fragment counts
 //   scatter     point indices grouped by (window, bucket)
-//   accumulate  one lane per bucket: gathers its affine points (96 B each, AoS as
-//               gnark stores them) and sums them with XYZZ mixed additions
+//   accumulate  one lane per L consecutive sorted positions: gathers the affine
+//               points (96 B each, AoS as gnark stores them), sums them with XYZZ
+//               mixed additions and emits one fragment per bucket it touches, so
+//               the work per lane is the same however skewed the scalars are
+//   merge_large block-per-bucket tree sum for buckets with many fragments
 //   reduce      sum_b (b+1)*bucket[b] per window, as running sums over short
 //               segments (the serial chain is what matters: one G1 addition is
-//               ~10 us of dependent 32-bit multiply-adds on one lane)
+//               ~10-25 us of dependent 32-bit multiply-adds on one lane)
 //   window_sum  per-window tree sum of the segment results
 // The last 255 doublings (combining the <= 64 window sums) are O(1) work with a
 // serial dependency chain and are done by the host side of the library.
@@ -74,34 +78,87 @@ __global__ void __launch_bounds__(kBlock) k_hist(const uint4* __restrict__ scala
   });
 }
 
-// One block per window: starts[b] = window base + sum_{b' < b} counts[b'].
-__global__ void __launch_bounds__(1024) k_scan(const u32* __restrict__ counts, u32* __restrict__ starts,
-                                               u32* __restrict__ cursor, MsmPlan p) {
-  __shared__ u32 part[1024];
-  const u32 lw = blockIdx.x;
+// ---------------------------------------------------------------------------
+// Exclusive prefix sums over all (window, bucket) slots, three small kernels:
+// block-local scan (4096 slots per block), scan of the block totals, fix-up.
+// out has len + 1 entries; out[len] = grand total.
+// ---------------------------------------------------------------------------
+static constexpr int kScanThreads = 1024;
+static constexpr int kScanItems = 4;
+static constexpr int kScanTile = kScanThreads * kScanItems;
+
+__device__ __forceinline__ u32 block_exclusive_scan_1024(u32 v, u32* sh, u32& total) {
   const u32 tid = threadIdx.x;
-  const u32 per = (p.B + 1023u) / 1024u;
-  const u32 lo = tid * per;
-  const u32* cw = counts + (size_t)lw * p.B;
-  u32 sum = 0;
-  for (u32 k = 0; k < per; k++)
-    if (lo + k < p.B) sum += cw[lo + k];
-  part[tid] = sum;
+  sh[tid] = v;
   __syncthreads();
-  for (u32 off = 1; off < 1024; off <<= 1) {
-    u32 v = tid >= off ? part[tid - off] : 0;
+  for (u32 off = 1; off < kScanThreads; off <<= 1) {
+    u32 t = tid >= off ? sh[tid - off] : 0;
     __syncthreads();
-    part[tid] += v;
+    sh[tid] += t;
     __syncthreads();
   }
-  u32 run = part[tid] - sum + lw * p.n;  // exclusive prefix + base of this window's slice of `sorted`
-  for (u32 k = 0; k < per; k++) {
-    if (lo + k < p.B) {
-      size_t o = (size_t)lw * p.B + lo + k;
-      starts[o] = run;
-      cursor[o] = run;
-      run += cw[lo + k];
-    }
+  total = sh[kScanThreads - 1];
+  return sh[tid] - v;
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_scan_local(const u32* __restrict__ in, u32 len, u32* __restrict__ out,
+                                                            u32* __restrict__ blocksum) {
+  __shared__ u32 sh[kScanThreads];
+  const u32 base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  u32 v[kScanItems], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    v[k] = base + k < len ? in[base + k] : 0;
+    sum += v[k];
+  }
+  u32 total;
+  u32 run = block_exclusive_scan_1024(sum, sh, total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    if (base + k < len) out[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+}
+
+// Single block: exclusive scan of the (<= 1024) block totals in place; grand total to out[len].
+__global__ void __launch_bounds__(kScanThreads) k_scan_top(u32* __restrict__ blocksum, u32 nblocks, u32* __restrict__ out,
+                                                          u32 len) {
+  __shared__ u32 sh[kScanThreads];
+  u32 v = threadIdx.x < nblocks ? blocksum[threadIdx.x] : 0;
+  u32 total;
+  u32 ex = block_exclusive_scan_1024(v, sh, total);
+  if (threadIdx.x < nblocks) blocksum[threadIdx.x] = ex;
+  if (threadIdx.x == 0) out[len] = total;
+}
+
+// Fix-up after the scan of the bucket sizes: global start of every bucket, the
+// scatter cursor, and the number of accumulation fragments the bucket will have.
+// Lane t of the accumulate kernel owns sorted positions [t*L, (t+1)*L); a bucket
+// spanning [s, s+cnt) is touched by lanes s/L .. (s+cnt-1)/L, one fragment each.
+__global__ void __launch_bounds__(kBlock) k_fix_starts(u32* __restrict__ starts, const u32* __restrict__ blocksum,
+                                                       const u32* __restrict__ counts, u32* __restrict__ cursor,
+                                                       u32* __restrict__ fragcnt, u32 len, u32 L) {
+  u32 i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= len) return;
+  u32 s = starts[i] + blocksum[i / kScanTile];
+  starts[i] = s;
+  cursor[i] = s;
+  u32 cnt = counts[i];
+  fragcnt[i] = cnt ? ((s + cnt - 1) / L - s / L + 1) : 0;
+}
+
+// Fix-up after the scan of the fragment counts; buckets with more than
+// `max_small` fragments are queued for the block-per-bucket pre-reduction.
+__global__ void __launch_bounds__(kBlock) k_fix_foff(u32* __restrict__ foff, const u32* __restrict__ blocksum,
+                                                     const u32* __restrict__ fragcnt, u32* __restrict__ large,
+                                                     u32* __restrict__ nlarge, u32 len, u32 max_small, u32 max_large) {
+  u32 i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= len) return;
+  foff[i] += blocksum[i / kScanTile];
+  if (fragcnt[i] > max_small) {
+    u32 k = atomicAdd(nlarge, 1u);
+    if (k < max_large) large[k] = i;
   }
 }
 
@@ -145,28 +202,87 @@ __device__ __forceinline__ void store_xyzz(G1XYZZ* dst, const G1XYZZ& r) {
   store_fp(d + 9, r.zzz);
 }
 
-// One lane per (window, bucket): sum of the bucket's points.
+// Balanced bucket accumulation.  Lane t owns L consecutive positions of the
+// bucket-sorted point list, whatever buckets they belong to, so every lane of
+// every wave does the same number of mixed additions however skewed the scalars
+// are (all-equal scalars, short top window).  When the list moves on to the
+// next bucket the lane stores its running sum as a fragment of the finished
+// bucket and starts again from infinity.  Fragments of one bucket are
+// contiguous: slot = foff[bucket] + (t - start[bucket] / L).
 __global__ void __launch_bounds__(kBlock, 2)
     k_accumulate(const uint4* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ starts,
-                 const u32* __restrict__ counts, G1XYZZ* __restrict__ buckets, u32 ntasks) {
-  u32 t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= ntasks) return;
-  const u32 start = starts[t];
-  const u32 cnt = counts[t];
+                 const u32* __restrict__ foff, G1XYZZ* __restrict__ frags, u32 nb, u32 L) {
+  const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  const u32 total = starts[nb];
+  u32 pos = t * L;
+  if (pos >= total) return;
+  const u32 end = min(pos + L, total);
+  // bucket containing `pos`: first index with starts[idx] > pos, minus one
+  u32 lo = 0, hi = nb;
+  while (lo < hi) {
+    u32 mid = (lo + hi) >> 1;
+    if (starts[mid] > pos) hi = mid;
+    else lo = mid + 1;
+  }
+  u32 g = lo - 1;
+  u32 gend = starts[lo];
   G1XYZZ acc;
   g1_set_inf(acc);
-  for (u32 k = 0; k < cnt; k++) {
-    const u32 e = sorted[start + k];
-    const u32 idx = e & 0x7fffffffu;
-    const uint4* src = points + (size_t)idx * 6;
+  for (; pos < end; pos++) {
+    if (pos == gend) {
+      store_xyzz(&frags[foff[g] + (t - starts[g] / L)], acc);
+      g1_set_inf(acc);
+      do {
+        g++;
+        gend = starts[g + 1];
+      } while (gend == pos);
+    }
+    const u32 e = sorted[pos];
+    const uint4* src = points + (size_t)(e & 0x7fffffffu) * 6;
     Fp x, y;
     load_fp(x, src);
     load_fp(y, src + 3);
-    if (f_is_zero(x) & f_is_zero(y)) continue;  // (0,0) = infinity (curdleproof.go:23)
+    if (f_is_zero(x) && f_is_zero(y)) continue;  // (0,0) = infinity (curdleproof.go:23)
     if (e >> 31) fp_neg(y, y);
     g1_madd(acc, x, y);
   }
-  store_xyzz(&buckets[t], acc);
+  store_xyzz(&frags[foff[g] + (t - starts[g] / L)], acc);
+}
+
+// One block per queued bucket (more than max_small fragments): tree-sum of the
+// fragments into the bucket's first fragment slot, fragcnt := 1.
+__global__ void __launch_bounds__(kBlock, 2)
+    k_merge_large(const u32* __restrict__ large, const u32* __restrict__ nlarge, const u32* __restrict__ foff,
+                  u32* __restrict__ fragcnt, G1XYZZ* __restrict__ frags, u32 max_large) {
+  __shared__ G1XYZZ sh[kBlock];
+  const u32 nl = min(*nlarge, max_large);
+  const u32 tid = threadIdx.x;
+  for (u32 q = blockIdx.x; q < nl; q += gridDim.x) {  // block-uniform trip count
+    const u32 g = large[q];
+    const u32 m = fragcnt[g];
+    G1XYZZ* f = frags + foff[g];
+    G1XYZZ acc, b;
+    g1_set_inf(acc);
+    for (u32 k = tid; k < m; k += kBlock) {
+      load_xyzz(b, &f[k]);
+      g1_add(acc, b);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (u32 off = kBlock / 2; off > 0; off >>= 1) {
+      if (tid < off) {
+        b = sh[tid + off];
+        g1_add(acc, b);
+        sh[tid] = acc;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      store_xyzz(&f[0], acc);
+      fragcnt[g] = 1;
+    }
+    __syncthreads();
+  }
 }
 
 // r = k * p for a small k (k < 2^16): left-to-right double-and-add.
@@ -182,21 +298,27 @@ __device__ __forceinline__ void g1_mul_small(G1XYZZ& r, const G1XYZZ& p, u32 k) 
 
 // One lane per segment of `seg` consecutive buckets of one window:
 //   out = sum_{u < seg} (lo + u + 1) * bucket[lo + u]
-// as the classic running sum over the segment plus lo * (segment total).
+// as the classic running sum over the segment plus lo * (segment total).  A
+// bucket's value is the sum of its fragments, folded into the running sum here.
 __global__ void __launch_bounds__(kBlock, 2)
-    k_bucket_reduce(const G1XYZZ* __restrict__ buckets, G1XYZZ* __restrict__ partials, MsmPlan p, u32 nw) {
+    k_bucket_reduce(const G1XYZZ* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
+                    G1XYZZ* __restrict__ partials, MsmPlan p, u32 nw) {
   u32 t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= nw * p.nseg) return;
   const u32 lw = t / p.nseg;
   const u32 j = t - lw * p.nseg;
   const u32 lo = j * p.seg;
-  const G1XYZZ* bw = buckets + (size_t)lw * p.B + lo;
+  const u32 g0 = lw * p.B + lo;
   G1XYZZ run, acc, b;
   g1_set_inf(run);
   g1_set_inf(acc);
   for (int u = (int)p.seg - 1; u >= 0; u--) {
-    load_xyzz(b, &bw[u]);
-    g1_add(run, b);
+    const u32 m = fragcnt[g0 + u];
+    const G1XYZZ* f = frags + foff[g0 + u];
+    for (u32 k = 0; k < m; k++) {
+      load_xyzz(b, &f[k]);
+      g1_add(run, b);
+    }
     g1_add(acc, run);
   }
   if (lo != 0) {
@@ -244,9 +366,24 @@ hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, const void* d_s
   return hipGetLastError();
 }
 
+static hipError_t scan_u32(const u32* in, u32 len, u32* out, u32* blocksum, hipStream_t stream) {
+  const u32 nblocks = cdiv(len, kScanTile);
+  if (nblocks > (u32)kScanThreads) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(kScanThreads), 0, stream, in, len, out, blocksum);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanThreads), 0, stream, blocksum, nblocks, out, len);
+  return hipGetLastError();
+}
+
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  hipLaunchKernelGGL(k_scan, dim3(p.win_end - p.win_begin), dim3(1024), 0, stream, ws.counts, ws.starts,
-                     ws.cursor, p);
+  const u32 nb = (p.win_end - p.win_begin) * p.B;
+  hipError_t e = scan_u32(ws.counts, nb, ws.starts, ws.blocksum, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_fix_starts, dim3(cdiv(nb, kBlock)), dim3(kBlock), 0, stream, ws.starts, ws.blocksum, ws.counts,
+                     ws.cursor, ws.fragcnt, nb, p.L);
+  e = scan_u32(ws.fragcnt, nb, ws.foff, ws.blocksum, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_fix_foff, dim3(cdiv(nb, kBlock)), dim3(kBlock), 0, stream, ws.foff, ws.blocksum, ws.fragcnt,
+                     ws.large, ws.nlarge, nb, p.max_small, p.max_large);
   return hipGetLastError();
 }
 
@@ -258,22 +395,77 @@ hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, const void* 
 
 hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  const u32 ntasks = nw * p.B;
-  hipLaunchKernelGGL(k_accumulate, dim3(cdiv(ntasks, kBlock)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const uint4*>(d_points), ws.sorted, ws.starts, ws.counts, ws.buckets, ntasks);
+  const u32 nb = nw * p.B;
+  const u32 nlanes = cdiv((u64)nw * p.n, p.L);
+  hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nlanes, kBlock)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const uint4*>(d_points), ws.sorted, ws.starts, ws.foff, ws.frags, nb, p.L);
+  return hipGetLastError();
+}
+
+hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
+  hipLaunchKernelGGL(k_merge_large, dim3(p.max_large < 1024u ? p.max_large : 1024u), dim3(kBlock), 0, stream, ws.large, ws.nlarge, ws.foff,
+                     ws.fragcnt, ws.frags, p.max_large);
   return hipGetLastError();
 }
 
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv((u64)nw * p.nseg, kBlock)), dim3(kBlock), 0, stream, ws.buckets,
-                     ws.partials, p, nw);
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv((u64)nw * p.nseg, kBlock)), dim3(kBlock), 0, stream, ws.frags, ws.foff,
+                     ws.fragcnt, ws.partials, p, nw);
   return hipGetLastError();
 }
 
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
   hipLaunchKernelGGL(k_window_sum, dim3(nw), dim3(kBlock), 0, stream, ws.partials, ws.winsums, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic bases of SURVEY.md section 8(d): P_i = P_0 + i*Q, affine, gnark
+// layout.  table[j] = 2^j * Q (affine).  One lane per point: <= 27 mixed adds,
+// then one Fermat inversion of ZZ*ZZZ to normalise.
+// ---------------------------------------------------------------------------
+__constant__ u32 kPminus2[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                                 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+
+__global__ void __launch_bounds__(kBlock, 2)
+    k_synth_walk(const G1Affine* __restrict__ table, G1Affine p0, u32 n, uint4* __restrict__ out) {
+  u32 i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  G1XYZZ acc;
+  g1_from_affine(acc, p0);
+  for (int j = 0; j < 27; j++) {
+    if ((i >> j) & 1u) {
+      G1Affine t = table[j];
+      g1_madd(acc, t.x, t.y);
+    }
+  }
+  Fp x, y;
+  if (g1_is_inf(acc)) {
+    f_zero(x);
+    f_zero(y);
+  } else {
+    Fp t, inv, izz, izzz;
+    fp_mul(t, acc.zz, acc.zzz);
+    f_one(inv);
+    for (int b = 383; b >= 0; b--) {
+      fp_sqr(inv, inv);
+      if ((kPminus2[b >> 5] >> (b & 31)) & 1u) fp_mul(inv, inv, t);
+    }
+    fp_mul(izz, inv, acc.zzz);
+    fp_mul(izzz, inv, acc.zz);
+    fp_mul(x, acc.x, izz);
+    fp_mul(y, acc.y, izzz);
+  }
+  store_fp(out + (size_t)i * 6, x);
+  store_fp(out + (size_t)i * 6 + 3, y);
+}
+
+hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32_t n, void* d_out,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(k_synth_walk, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, d_table, p0, n,
+                     reinterpret_cast<uint4*>(d_out));
   return hipGetLastError();
 }
 
@@ -309,7 +501,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __res
       b32[k] = src[48 + k];
     }
     if (op == 5) {
-      if (!(f_is_zero(b.x) & f_is_zero(b.y))) g1_madd(acc, b.x, b.y);
+      if (!(f_is_zero(b.x) && f_is_zero(b.y))) g1_madd(acc, b.x, b.y);
     } else if (op == 6) {
       g1_add(acc, b);
     } else {

@@ -24,6 +24,15 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `make -C go-curdleproofs_amd` "
         "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
 
+# PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process do not
+# both see the GPU.  When torch is present (it provides device memory, streams and
+# torch.distributed to callers of this binding) load it first so that
+# libcurdlemsm.so binds to the runtime already in the process.
+try:  # pragma: no cover - depends on the environment
+    import torch  # noqa: F401
+except Exception:  # torch absent: the system ROCm runtime is used
+    torch = None
+
 _lib = C.CDLL(LIB_PATH)
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
@@ -39,6 +48,7 @@ SYMBOLS = [
     "curdle_acc_new", "curdle_acc_free", "curdle_acc_accumulate_check", "curdle_acc_verify",
     "curdle_acc_get_A_c", "curdle_acc_num_bases", "curdle_acc_export",
     "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op",
+    "curdle_synth_points_walk_device",
 ]
 
 _u64p = C.POINTER(C.c_uint64)
@@ -84,6 +94,7 @@ _acc_num_bases = _sig("curdle_acc_num_bases", C.c_size_t, _vp)
 _acc_export = _sig("curdle_acc_export", C.c_int, _vp, _vp, _vp)
 _profile_enable = _sig("curdle_profile_enable", C.c_int, C.c_int)
 _profile_last = _sig("curdle_profile_last", C.c_int, C.POINTER(_Profile))
+_synth_walk = _sig("curdle_synth_points_walk_device", C.c_int, _vp, _vp, C.c_size_t, _vp)
 _selftest_op = _sig("curdle_selftest_op", C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_int)
 
 
@@ -297,3 +308,14 @@ def selftest_op(op: int, inp: np.ndarray, on_device: bool) -> np.ndarray:
     out = np.zeros((inp.shape[0], ow), dtype=np.uint32)
     _check(_selftest_op(op, _ptr(inp), inp.shape[0], _ptr(out), 1 if on_device else 0))
     return out
+
+
+def int_to_limbs(v: int, n: int = 4) -> np.ndarray:
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
+
+
+def synth_points_walk_device(k: int, q: int, n: int, d_out: int) -> None:
+    """P_i = (k + i*q) * G for i < n, written as gnark G1Affine into device memory at d_out
+    (n * 96 bytes).  k, q are canonical integers < r."""
+    ka, qa = int_to_limbs(k), int_to_limbs(q)
+    _check(_synth_walk(_ptr(ka), _ptr(qa), n, d_out))

@@ -1,0 +1,68 @@
+"""Multi-GPU MSM: one process per GPU, Pippenger windows split across ranks.
+
+north_star: "partitioned across the 8 GPUs of one node by splitting Pippenger
+windows with an RCCL reduce of 8 partial G1 points over xGMI".  Every rank
+holds all n pairs and computes the partial sum over its window range
+(curdle_msm_g1_device_windows); the 144-byte partials are exchanged with one
+all_gather (RCCL has no user-defined reduction and G1 addition is not an
+element-wise sum, so "reduce" = gather + 7 additions) and
+summed on every rank by curdle_g1_sum.  The exchange is latency-only
+(world_size x 144 B); xGMI bandwidth is irrelevant to it.
+
+torch.distributed is plumbing here: the process group and the all_gather.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+from . import g1_sum, msm_g1_device, num_windows, window_bits
+
+
+def window_partition(n_windows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, as-even-as-possible split of [0, n_windows) over the ranks.
+    Ranks beyond n_windows get an empty range."""
+    base, extra = divmod(n_windows, world_size)
+    begin = rank * base + min(rank, extra)
+    end = begin + base + (1 if rank < extra else 0)
+    return begin, end
+
+
+def gather_partials(partial: np.ndarray, group=None, device=None) -> np.ndarray:
+    """all_gather of one uint64[18] Jacobian point per rank -> uint64[world, 18]."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    # torch has no uint64 collectives on every backend; int64 carries the same bits
+    t = torch.from_numpy(partial.view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return np.stack([o.cpu().numpy().view(np.uint64) for o in out])
+
+
+def msm_g1_distributed(d_points: int, d_scalars: int, n: int, group=None, device=None, stream: int = 0,
+                       c: int = 0,
+                       partial_fn: Optional[Callable[[int, int, int], np.ndarray]] = None) -> np.ndarray:
+    """Full MSM result (uint64[18]) on every rank.
+
+    partial_fn(c, win_begin, win_end) -> uint64[18] replaces the GPU partial; it
+    exists so the collective plumbing can be exercised by the world_size-2 gloo
+    tests on a machine without a GPU.  The product default is the HIP path.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    c = c or window_bits(n)
+    W = num_windows(n, c)
+    begin, end = window_partition(W, world, rank)
+    if partial_fn is not None:
+        partial = partial_fn(c, begin, end)
+    else:
+        partial = msm_g1_device(d_points, d_scalars, n, stream=stream, window_bits=c, win_begin=begin, win_end=end)
+    allp = gather_partials(np.ascontiguousarray(partial, dtype=np.uint64), group=group, device=device)
+    return g1_sum(allp)

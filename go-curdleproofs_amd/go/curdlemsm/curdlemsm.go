@@ -1,0 +1,116 @@
+// Package curdlemsm binds libcurdlemsm.so (include/curdle_msm.h) for the Go
+// reference: it is what `common.MultiExp` forwards to once the reference's 39
+// `X.MultiExp(points, scalars, common.MultiExpConf)` call sites are routed
+// through one function (INTEGRATION.md).
+//
+// UNVERIFIED: there is no Go toolchain in the build image, so this file has
+// never been compiled.  It is deliberately small: one cgo call per entry point,
+// zero-copy (gnark's fp.Element / fr.Element / G1Affine / G1Jac are
+// pointer-free [k]uint64 arrays, so &s[0] can be handed to C directly and the
+// cgo pointer rules hold: the library keeps no pointer after returning).
+package curdlemsm
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -L${SRCDIR}/../.. -lcurdlemsm -Wl,-rpath,${SRCDIR}/../..
+#include <stdlib.h>
+#include "curdle_msm.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"unsafe"
+
+	bls12381 "github.com/consensys/gnark-crypto/ecc/bls12-381"
+	"github.com/consensys/gnark-crypto/ecc/bls12-381/fr"
+)
+
+func lastError(rc C.int) error {
+	var buf [256]C.char
+	C.curdle_last_error(&buf[0], C.size_t(len(buf)))
+	return fmt.Errorf("curdlemsm: rc=%d: %s", int(rc), C.GoString(&buf[0]))
+}
+
+// Init selects the HIP device of this process (one process per GPU).
+func Init(device int) error {
+	if rc := C.curdle_init(C.int(device)); rc != 0 {
+		return lastError(rc)
+	}
+	return nil
+}
+
+// MultiExp is the drop-in for (*bls12381.G1Jac).MultiExp(points, scalars, cfg):
+// dst = sum_i scalars[i] * points[i].  Same contract as gnark: the receiver is
+// overwritten, a length mismatch is an error, an empty input gives infinity.
+func MultiExp(dst *bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Element) (*bls12381.G1Jac, error) {
+	if len(points) != len(scalars) {
+		return nil, errors.New("len(points) != len(scalars)")
+	}
+	var pp, sp unsafe.Pointer
+	if len(points) > 0 {
+		pp = unsafe.Pointer(&points[0])
+		sp = unsafe.Pointer(&scalars[0])
+	}
+	rc := C.curdle_msm_g1((*C.uint64_t)(pp), (*C.uint64_t)(sp), C.size_t(len(points)),
+		(*C.uint64_t)(unsafe.Pointer(dst)))
+	if rc != 0 {
+		return nil, lastError(rc)
+	}
+	return dst, nil
+}
+
+// MultiExpShared computes len(sets) MSMs that share one scalar vector
+// (samemultiscalarargument.go:64-70, :206/:218/:231; curdleproof.go:110,:114).
+func MultiExpShared(dst []bls12381.G1Jac, sets [][]bls12381.G1Affine, scalars []fr.Element) error {
+	if len(dst) != len(sets) {
+		return errors.New("len(dst) != len(sets)")
+	}
+	if len(sets) == 0 {
+		return nil
+	}
+	// C array of base-set pointers, allocated in C memory (cgo forbids Go pointers to Go pointers)
+	arr := (*[1 << 20]*C.uint64_t)(C.malloc(C.size_t(len(sets)) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(arr))
+	for i, s := range sets {
+		if len(s) != len(scalars) {
+			return errors.New("len(points) != len(scalars)")
+		}
+		if len(s) > 0 {
+			arr[i] = (*C.uint64_t)(unsafe.Pointer(&s[0]))
+		}
+	}
+	var sp unsafe.Pointer
+	if len(scalars) > 0 {
+		sp = unsafe.Pointer(&scalars[0])
+	}
+	rc := C.curdle_msm_g1_multi((**C.uint64_t)(unsafe.Pointer(arr)), C.size_t(len(sets)),
+		(*C.uint64_t)(sp), C.size_t(len(scalars)), (*C.uint64_t)(unsafe.Pointer(&dst[0])))
+	if rc != 0 {
+		return lastError(rc)
+	}
+	return nil
+}
+
+// MultiExpBatch runs independent MSMs in one call (many concurrent
+// msmaccumulator.Verify calls, BASELINE config 5).  offsets has len(dst)+1 entries.
+func MultiExpBatch(dst []bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Element, offsets []uint64) error {
+	if len(offsets) != len(dst)+1 || len(points) != len(scalars) {
+		return errors.New("bad batch shape")
+	}
+	if len(dst) == 0 {
+		return nil
+	}
+	var pp, sp unsafe.Pointer
+	if len(points) > 0 {
+		pp = unsafe.Pointer(&points[0])
+		sp = unsafe.Pointer(&scalars[0])
+	}
+	rc := C.curdle_msm_g1_batch((*C.uint64_t)(pp), (*C.uint64_t)(sp),
+		(*C.size_t)(unsafe.Pointer(&offsets[0])), C.size_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&dst[0])))
+	if rc != 0 {
+		return lastError(rc)
+	}
+	return nil
+}

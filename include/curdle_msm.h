@@ -159,14 +159,22 @@ typedef struct {
 int curdle_profile_enable(int on);
 int curdle_profile_last(curdle_profile* out);
 
+/* Synthetic MSM bases of SURVEY.md section 8(d), generated on the GPU into
+ * device memory: P_i = (k + i*q) * G for i < n, gnark G1Affine layout.  k and
+ * q are canonical (non-Montgomery) 256-bit integers, little-endian limbs.
+ * Because every P_i has a known discrete log, the exact MSM result at any n is
+ * (k*sum(s_i) + q*sum(i*s_i)) * G, which is how full-size runs are checked. */
+int curdle_synth_points_walk_device(const uint64_t k[4], const uint64_t q[4], size_t n, void* d_out);
+
 /* Element-wise device self-test of the field / curve primitives, so tests can
  * compare the gfx950 arithmetic with the oracle operation by operation.
  *   op 0: fp_mul(a,b)      in: n x (12+12) u32-limbed Fp pairs, out: n x Fp
  *   op 1: fp_add  2: fp_sub  3: fp_sqr(a)
  *   op 4: fr_from_mont(a)  in: n x Fr pairs (b ignored), out: n x Fr
- *   op 5: xyzz madd: in: n x (XYZZ acc | affine), out: n x XYZZ
- *   op 6: xyzz add : in: n x (XYZZ | XYZZ),       out: n x XYZZ
- *   op 7: xyzz dbl : in: n x (XYZZ | XYZZ ignored) out: n x XYZZ
+ *   op 5: xyzz madd: in: n x (XYZZ acc | XYZZ whose X,Y hold the affine addend), out: n x XYZZ
+ *   op 6: xyzz add : in: n x (XYZZ | XYZZ),            out: n x XYZZ
+ *   op 7: xyzz dbl : in: n x (XYZZ | XYZZ ignored),    out: n x XYZZ
+ * (limbs are passed as uint32 little-endian; 24/16/96 in and 12/8/48 out per item)
  * on_device = 0 runs the same header code on the host CPU. */
 int curdle_selftest_op(int op, const uint64_t* in, size_t n, uint64_t* out, int on_device);
 

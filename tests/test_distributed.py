@@ -1,0 +1,92 @@
+"""The N > 1 path on CPU: two processes, gloo backend, the same window split,
+all_gather and g1_sum the GPU ranks use (curdlemsm.distributed).  There is no GPU
+in this container, so each rank's partial MSM comes from the oracle (the partial
+over windows [a, b) is the MSM with every scalar replaced by the value of its
+signed digits in that range); on the GPU box the partials come from the HIP path
+(tests/test_msm_gpu.py::test_window_partials_sum_to_full_msm)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def signed_digit_partial_scalars(scalars, c, W, begin, end, R):
+    """Value of digits [begin, end) of the signed c-bit recoding (what a rank covers)."""
+    half = 1 << (c - 1)
+    out = []
+    for s in scalars:
+        carry, acc, v = 0, 0, s
+        for w in range(W):
+            raw = (v & ((1 << c) - 1)) + carry
+            v >>= c
+            if raw > half:
+                d, carry = raw - (1 << c), 1
+            else:
+                d, carry = raw, 0
+            if begin <= w < end:
+                acc += d << (c * w)
+        out.append(acc % R)
+    return out
+
+
+def _worker(rank, world, port, n, result_dir):
+    sys.path[:0] = [os.path.join(ROOT, "oracle", "py"), PKG]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import bls12381_ref as o
+    import coracle as co
+    import curdlemsm as cm
+    from curdlemsm.distributed import msm_g1_distributed
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, q = o.Rand(1).get_frs(2)
+        pts = co.points_walk(k, q, n)
+        sc_int = o.Rand(2).get_frs(n)
+        sc = np.array([o.fr_to_mont_limbs(s) for s in sc_int], dtype=np.uint64)
+
+        def partial_fn(c, begin, end):
+            W = cm.num_windows(n, c)
+            ps = signed_digit_partial_scalars(sc_int, c, W, begin, end, o.R)
+            return co.msm_pippenger(pts, np.array([o.fr_to_mont_limbs(s) for s in ps], dtype=np.uint64), threads=2)
+
+        res = {}
+        for c in (16, 15, 7):
+            res[c] = msm_g1_distributed(0, 0, n, c=c, partial_fn=partial_fn)
+        full = co.msm_pippenger(pts, sc, threads=2)
+        ok = all((res[c] == full).all() for c in res)
+        np.save(os.path.join(result_dir, f"rank{rank}.npy"), np.array([int(ok)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_window_split_allgather_sum_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, 48, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(tmp_path / f"rank{r}.npy")[0] == 1
+
+
+def test_window_partition_properties():
+    sys.path.insert(0, PKG)
+    from curdlemsm.distributed import window_partition
+    for W in (1, 16, 18, 32, 52, 64):
+        for world in (1, 2, 3, 4, 8, 64, 100):
+            ranges = [window_partition(W, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == W
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [e - b for b, e in ranges]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,299 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the
+oracle -- golden vectors, seeded random inputs at sizes the C oracle finishes in
+seconds, and size-independent properties at BASELINE.json's full sizes.
+Bit-exact throughout (integer arithmetic; results compared as the canonical
+Jacobian representative)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_case_names
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_scalars(rng, n, oracle):
+    """n uniform Montgomery-form fr.Elements (any value < r is a valid one)."""
+    out = np.zeros((n, 4), dtype=np.uint64)
+    have = 0
+    top = oracle.R >> 192
+    while have < n:
+        cand = rng.integers(0, 1 << 64, size=(n - have + 16, 4), dtype=np.uint64)
+        cand[:, 3] &= np.uint64((1 << 63) - 1)
+        ok = cand[:, 3] < np.uint64(top)          # strictly below r's top limb: < r for sure
+        cand = cand[ok][: n - have]
+        out[have:have + len(cand)] = cand
+        have += len(cand)
+    return out
+
+
+def canonical_ints(sc, oracle):
+    return [oracle.fr_from_mont_limbs([int(v) for v in row]) for row in sc]
+
+
+# ------------------------------------------------------------------ primitives ---
+def test_device_primitives_match_host(gpu, oracle):
+    """Same limb code on the GPU and on the host (host checked against the oracle in
+    tests/test_host_mirror.py), operation by operation, exceptional cases included."""
+    from test_host_mirror import fp32, group_cases, group_inputs
+    rng = np.random.default_rng(5)
+    n = 4096
+    A = [int.from_bytes(rng.bytes(48), "big") % oracle.P for _ in range(n)]
+    B = [int.from_bytes(rng.bytes(48), "big") % oracle.P for _ in range(n)]
+    A[0], B[1], A[2], B[2], A[3], B[3] = 0, 0, oracle.P - 1, oracle.P - 1, 1, oracle.P - 1
+    inp = np.array([fp32(a) + fp32(b) for a, b in zip(A, B)], dtype=np.uint32)
+    for op in (0, 1, 2, 3):
+        assert (gpu.selftest_op(op, inp, True) == gpu.selftest_op(op, inp, False)).all(), op
+    # spot-check the device result against big-integer arithmetic directly
+    out = gpu.selftest_op(0, inp[:64], True)
+    for i in range(64):
+        assert sum(int(x) << (32 * k) for k, x in enumerate(out[i])) == A[i] * B[i] * oracle.R_FP_INV % oracle.P
+    S = rng.integers(0, 1 << 32, size=(n, 16), dtype=np.uint32)
+    S[:, 7] &= 0x3FFFFFFF
+    assert (gpu.selftest_op(4, S, True) == gpu.selftest_op(4, S, False)).all()
+    cases = group_cases(oracle)
+    for op in (5, 6, 7):
+        arr = group_inputs(oracle, op, cases)
+        assert (gpu.selftest_op(op, arr, True) == gpu.selftest_op(op, arr, False)).all(), op
+
+
+# -------------------------------------------------------------- golden vectors ---
+def test_golden_vectors_bit_exact(gpu, golden):
+    names = golden_case_names(golden)
+    assert len(names) >= 17
+    for name in names:
+        got = gpu.msm_g1(golden[name + "_points"], golden[name + "_scalars"])
+        assert (got == golden[name + "_expected"]).all(), name
+
+
+def test_golden_vectors_every_window_size(gpu, golden):
+    """Each supported window width c (2..16), including the widths that need an
+    extra top window, on vectors that exercise carries and exceptional additions."""
+    try:
+        for c in range(2, 17):
+            os.environ["CURDLE_WINDOW_BITS"] = str(c)
+            for name in ("rand0_n16", "rand0_n257", "edge_window_boundaries", "edge_extreme_scalars",
+                         "edge_duplicate_bases", "edge_opposite_points", "edge_infinity_bases"):
+                got = gpu.msm_g1(golden[name + "_points"], golden[name + "_scalars"])
+                assert (got == golden[name + "_expected"]).all(), (name, c)
+    finally:
+        os.environ.pop("CURDLE_WINDOW_BITS", None)
+
+
+def test_segment_lengths(gpu, golden):
+    """The accumulate kernel's lane segment length must not change results (fragment
+    bookkeeping at every alignment)."""
+    try:
+        for L in (8, 9, 13, 32, 128):
+            os.environ["CURDLE_SEG_LEN"] = str(L)
+            for name in ("rand0_n257", "rand0_n1024", "edge_all_equal_scalars", "edge_small_scalars"):
+                got = gpu.msm_g1(golden[name + "_points"], golden[name + "_scalars"])
+                assert (got == golden[name + "_expected"]).all(), (name, L)
+    finally:
+        os.environ.pop("CURDLE_SEG_LEN", None)
+
+
+# ------------------------------------------------------- seeded random vs C oracle ---
+@pytest.mark.parametrize("n", [5, 6, 7, 8, 9, 60, 64, 124, 128, 252, 256, 308, 628, 1268, 2548, 1 << 12, 1 << 14])
+def test_random_inputs_match_c_oracle(gpu, oracle, coracle, n):
+    # protocol sizes of SURVEY.md 8(d): m = 6..9, ell, n = ell+4, 5*ell+8
+    k, q = oracle.Rand(1).get_frs(2)
+    pts = coracle.points_walk(k, q + n, n)
+    sc = rand_scalars(np.random.default_rng(n), n, oracle)
+    got = gpu.msm_g1(pts, sc)
+    exp = coracle.msm_pippenger(pts, sc, threads=8)
+    assert (got == exp).all()
+    assert (gpu.msm_g1(pts, sc) == got).all()   # run-to-run identical (scatter order is not)
+
+
+def test_skewed_scalar_sets_match_c_oracle(gpu, oracle, coracle):
+    """All-equal scalars (a11), <= 9-bit scalars (a13), 1 % infinity bases, one hot bucket."""
+    n = 4096
+    k, q = oracle.Rand(2).get_frs(2)
+    pts = coracle.points_walk(k, q, n)
+    rng = np.random.default_rng(77)
+    beta = np.array(oracle.fr_to_mont_limbs(oracle.Rand(4).get_fr()), dtype=np.uint64)
+    sets = {
+        "all_equal": np.tile(beta, (n, 1)),
+        "small": np.array([oracle.fr_to_mont_limbs(int(v)) for v in rng.integers(0, 508, n)], dtype=np.uint64),
+        "one_hot_window": np.array([oracle.fr_to_mont_limbs((int(v) << 64) | 0x1234) for v in rng.integers(0, 1 << 60, n)], dtype=np.uint64),
+    }
+    for name, sc in sets.items():
+        assert (gpu.msm_g1(pts, sc) == coracle.msm_pippenger(pts, sc, threads=8)).all(), name
+    p2 = pts.copy()
+    p2[rng.random(n) < 0.01] = 0
+    sc = rand_scalars(rng, n, oracle)
+    assert (gpu.msm_g1(p2, sc) == coracle.msm_pippenger(p2, sc, threads=8)).all()
+
+
+# ---------------------------------------------------- full sizes via properties ---
+def _walk_expected(oracle, coracle, k, q, sc):
+    """P_i = (k + i q) G  =>  MSM = (k * sum s_i + q * sum i s_i) G  (SURVEY.md 8d)."""
+    s = canonical_ints(sc, oracle)
+    s0 = sum(s) % oracle.R
+    s1 = sum(i * v for i, v in enumerate(s)) % oracle.R
+    e = (k * s0 + q * s1) % oracle.R
+    aff = coracle.scalar_mul_gen(e)
+    pt = oracle.affine_from_mont_limbs([int(v) for v in aff])
+    return np.array(oracle.jac_to_mont_limbs(pt), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("logn", [10, 16, 20])
+def test_full_size_known_discrete_log(gpu, oracle, coracle, logn):
+    """BASELINE configs[1] (N = 2^16) and the headline N = 2^20, bit-exact without a
+    2^20-point oracle.  Inputs generated on the GPU and resident in HBM."""
+    import torch
+    n = 1 << logn
+    k, q = oracle.Rand(1).get_frs(2)
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    head = d_pts[:64].cpu().numpy().view(np.uint64)
+    assert (head == coracle.points_walk(k, q, 64)).all()      # generator itself vs the oracle
+    sc = rand_scalars(np.random.default_rng(logn), n, oracle)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    got = gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
+    assert (got == _walk_expected(oracle, coracle, k, q, sc)).all()
+    # host-buffer entry point, same inputs
+    if logn <= 16:
+        assert (gpu.msm_g1(d_pts.cpu().numpy().view(np.uint64), sc) == got).all()
+
+
+def test_linearity_at_full_size(gpu, oracle):
+    """MSM(P, a) + MSM(P, b) == MSM(P, a + b) at N = 2^18 (size-independent property)."""
+    import torch
+    n = 1 << 18
+    k, q = oracle.Rand(6).get_frs(2)
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    rng = np.random.default_rng(1)
+    # canonical small-ish integers in Montgomery form are not needed: linearity holds
+    # on the Montgomery values too because x -> x*R^-1 is linear mod r.
+    a = rand_scalars(rng, n, oracle)
+    b = rand_scalars(rng, n, oracle)
+    R = oracle.R
+    ab = np.array([oracle._limbs((oracle._from_limbs(x) + oracle._from_limbs(y)) % R, 4) for x, y in zip(a, b)], dtype=np.uint64)
+    res = []
+    for sc in (a, b, ab):
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        res.append(gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n))
+    assert (gpu.g1_sum(np.stack(res[:2])) == res[2]).all()
+
+
+# ------------------------------------------------------------- window partition ---
+def test_window_partials_sum_to_full_msm(gpu, oracle, coracle):
+    """The multi-GPU split: partials over a partition of the windows, summed, equal
+    the full MSM -- for 1, 2, 4, 8 ranks and for a window count that does not divide."""
+    import torch
+    from curdlemsm.distributed import window_partition
+    n = 1 << 12
+    k, q = oracle.Rand(8).get_frs(2)
+    pts = coracle.points_walk(k, q, n)
+    sc = rand_scalars(np.random.default_rng(8), n, oracle)
+    d_pts = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    exp = coracle.msm_pippenger(pts, sc, threads=8)
+    for c in (16, 15, 8):
+        W = gpu.num_windows(n, c)
+        assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c) == exp).all()
+        for world in (2, 4, 8):
+            parts = []
+            for rank in range(world):
+                b, e = window_partition(W, world, rank)
+                parts.append(gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c, win_begin=b, win_end=e))
+            assert (gpu.g1_sum(np.stack(parts)) == exp).all(), (c, world)
+
+
+# ------------------------------------------------------------------ batch / multi ---
+def test_batch_and_multi_entry_points(gpu, oracle, coracle):
+    k, q = oracle.Rand(9).get_frs(2)
+    sizes = [0, 1, 628, 3, 308]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    pts = coracle.points_walk(k, q, int(offs[-1]))
+    sc = rand_scalars(np.random.default_rng(9), int(offs[-1]), oracle)
+    out = gpu.msm_g1_batch(pts, sc, offs)
+    for j, (lo, hi) in enumerate(zip(offs[:-1], offs[1:])):
+        assert (out[j] == coracle.msm_pippenger(pts[lo:hi], sc[lo:hi], threads=4)).all(), j
+    # one scalar vector against three base sets (samemultiscalarargument.go:64-70)
+    n = 256
+    sets = [coracle.points_walk(k + j, q, n) for j in range(3)]
+    s = rand_scalars(np.random.default_rng(10), n, oracle)
+    out = gpu.msm_g1_multi(sets, s)
+    for j in range(3):
+        assert (out[j] == coracle.msm_pippenger(sets[j], s, threads=4)).all()
+
+
+# ----------------------------------------------------- msmaccumulator (reference tests) ---
+def test_msm_accumulator_reference_test(gpu):
+    """msmaccumulator/msmaccumulator_test.go:12-50, sizes 0..3 (the Go loop ranges
+    over indices), MultiExp and Verify on the GPU."""
+    for n in (0, 1, 2, 3):
+        rand = gpu.Rand(0)
+        A = rand.get_g1_affines(n)
+        x = rand.get_frs(n)
+        C1 = gpu.msm_g1(A, x)
+        B = rand.get_g1_affines(n)
+        y = rand.get_frs(n)
+        C2 = gpu.msm_g1(B, y)
+        ma = gpu.MsmAccumulator()
+        ma.accumulate_check(C1, x, A, rand)
+        ma.accumulate_check(C2, y, B, rand)
+        assert ma.verify() is True
+
+
+def test_msm_accumulator_matches_golden_and_rejects_wrong_instance(gpu, golden_acc):
+    for n in (1, 2, 3):
+        rand = gpu.Rand(0)
+        A = rand.get_g1_affines(n); x = rand.get_frs(n)
+        B = rand.get_g1_affines(n); y = rand.get_frs(n)
+        assert (A == golden_acc[f"n{n}_A"]).all() and (y == golden_acc[f"n{n}_y"]).all()
+        C1, C2 = gpu.msm_g1(A, x), gpu.msm_g1(B, y)
+        assert (C1 == golden_acc[f"n{n}_C1"]).all() and (C2 == golden_acc[f"n{n}_C2"]).all()
+        ma = gpu.MsmAccumulator()
+        ma.accumulate_check(C1, x, A, rand)
+        ma.accumulate_check(C2, y, B, rand)
+        assert (ma.A_c == golden_acc[f"n{n}_A_c"]).all()
+        assert ma.verify()
+        # soundness: a wrong claimed result flips only the final batched check
+        # (grandproductargument_test.go:107-111)
+        bad = gpu.MsmAccumulator()
+        r2 = gpu.Rand(1)
+        bad.accumulate_check(C2, x, A, r2)      # C2 is not MSM(A, x)
+        bad.accumulate_check(C2, y, B, r2)
+        assert bad.verify() is False
+
+
+def test_verifier_shaped_accumulation(gpu, oracle, coracle):
+    """Config 3's final MSM shape: ell = 252 -> 5*ell + 8 = 1,268 distinct bases with
+    shared CRS bases merged across 8 checks and one infinity base."""
+    ell, nbl = 252, 4
+    n = ell + nbl
+    k, q = oracle.Rand(11).get_frs(2)
+    allp = coracle.points_walk(k, q, 5 * ell + 8)
+    Gs, Hs, H = allp[:ell], allp[ell:ell + nbl], allp[ell + nbl:ell + nbl + 1]
+    Gt, Gu = allp[n + 1:n + 2], allp[n + 2:n + 3]
+    Rs, Ss, Ts, Us = (allp[n + 3 + i * ell:n + 3 + (i + 1) * ell] for i in range(4))
+    zero = np.zeros((1, 12), dtype=np.uint64)
+    checks = [
+        Gs,                                             # sameperm :140 (all-equal scalars beta)
+        np.concatenate([Gs, Hs, H]),                    # ipa :269  (n + 1 terms)
+        np.concatenate([Gs, Hs]),                       # ipa :292
+        np.concatenate([Gs, Hs[:2], Gt, Gu]),           # samemsm :206  G
+        np.concatenate([Ts, zero, zero, H, zero]),      # samemsm :218  T' (infinity bases)
+        np.concatenate([Us, zero, zero, zero, H]),      # samemsm :231  U'
+        Rs, Ss,                                         # curdleproof.go:306, :309
+    ]
+    rng = np.random.default_rng(12)
+    rand = gpu.Rand(43)
+    ma = gpu.MsmAccumulator()
+    for i, v in enumerate(checks):
+        x = rand_scalars(rng, len(v), oracle)
+        if i == 0:
+            x[:] = x[0]
+        C = coracle.msm_pippenger(v, x, threads=8)
+        ma.accumulate_check(C, x, v, rand)
+    assert ma.num_bases() == 5 * ell + 8
+    assert ma.verify() is True
+    pts, sc = ma.export()
+    assert (gpu.msm_g1(pts, sc) == ma.A_c).all()
+    assert (coracle.msm_pippenger(pts, sc, threads=8) == ma.A_c).all()

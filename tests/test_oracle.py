@@ -1,0 +1,123 @@
+"""The oracle against its anchors: published curve parameters, the derived
+common.Rand known answers, the committed golden vectors
+and the behavioural invariants of the reference's own tests."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_case_names
+
+
+def test_curve_parameters_and_montgomery_constants(oracle):
+    oracle.self_check()
+
+
+def test_rand_known_answers(oracle):
+    # SURVEY.md 8(c) "Derived known-answers for common.Rand"
+    assert oracle.Rand(0).get_fr() == 0x119141DCE89807096095D9729B0DA80481A492498E235346EFC58AA73335A351
+    assert oracle.Rand(42).get_fr() == 0x3FD883DC9CAF077F278639C4414A377ADD5EF1794C25B3BAF279DFC872AF0CB7
+    assert oracle.Rand(43).get_fr() == 0x0217F70B7CC47702219E2879BC1E5D29CDECC751F5EF4C0AC59FF0C99CA9F209
+    assert oracle.compress(oracle.Rand(0).get_g1_affine()).hex() == (
+        "b058e2c67ce70d724988ddfb90b744d65d03df778ecf68eeb0a0d5713e34fe51a53fa09820b7068cf427c2ae3ba25305")
+    with open(os.path.join(ROOT, "tests", "golden", "rand_known_answers.json")) as f:
+        ka = json.load(f)
+    assert [hex(v) for v in oracle.Rand(0).get_frs(8)] == ka["seed0_frs_8"]
+    assert oracle.Rand(42).generate_permutation(10) == ka["seed42_permutation_10"]
+    assert oracle.Rand(0).generate_permutation(124) == ka["seed0_permutation_124"]
+
+
+def test_rand_rejection_sampling_is_exercised(oracle):
+    # rand.go:36-46: the second 32-byte block of seed 0 is >= r and must be skipped
+    import hashlib, struct
+    raw = hashlib.shake_256(struct.pack(">Q", 0)).digest(96)
+    blocks = [int.from_bytes(raw[i:i + 32], "big") for i in (0, 32, 64)]
+    assert blocks[0] < oracle.R and blocks[1] >= oracle.R
+    r = oracle.Rand(0)
+    assert r.get_fr() == blocks[0] and r.get_fr() == blocks[2]
+
+
+def test_permutations_differ_across_draws(oracle):
+    # common/rand_test.go:11-27
+    r = oracle.Rand(42)
+    perm = r.generate_permutation(10)
+    for _ in range(100):
+        new = r.generate_permutation(10)
+        assert sorted(new) == list(range(10))
+        assert new != perm
+        perm = new
+
+
+def test_python_oracle_reproduces_golden(oracle, golden):
+    # small cases only (pure-Python loops); the big ones are covered through the C oracle below
+    for name in golden_case_names(golden):
+        pts, sc = golden[name + "_points"], golden[name + "_scalars"]
+        if len(pts) > 64:
+            continue
+        P = [oracle.affine_from_mont_limbs([int(v) for v in row]) for row in pts]
+        S = [oracle.fr_from_mont_limbs([int(v) for v in row]) for row in sc]
+        exp = oracle.jac_from_mont_limbs([int(v) for v in golden[name + "_expected"]])
+        assert oracle.msm(P, S) == exp, name
+
+
+def test_c_oracle_matches_golden_bit_exact(coracle, golden):
+    names = golden_case_names(golden)
+    assert "rand0_n1024" in names and "rand0_n0" in names
+    for name in names:
+        pts, sc, exp = golden[name + "_points"], golden[name + "_scalars"], golden[name + "_expected"]
+        assert (coracle.msm_naive(pts, sc) == exp).all(), name
+        for c in (0, 5, 16):
+            assert (coracle.msm_pippenger(pts, sc, threads=2, c=c) == exp).all(), (name, c)
+
+
+def test_c_oracle_primitives(oracle, coracle):
+    rng = np.random.default_rng(11)
+    for _ in range(50):
+        a = int.from_bytes(rng.bytes(48), "big") % oracle.P
+        b = int.from_bytes(rng.bytes(48), "big") % oracle.P
+        got = oracle._from_limbs(coracle.fp_mul(oracle._limbs(a, 6), oracle._limbs(b, 6)))
+        assert got == a * b * oracle.R_FP_INV % oracle.P
+        s = int.from_bytes(rng.bytes(32), "big") % oracle.R
+        assert oracle._from_limbs(coracle.fr_from_mont(oracle._limbs(s, 4))) == s * oracle.R_FR_INV % oracle.R
+
+
+def test_c_oracle_walk_has_known_discrete_logs(oracle, coracle):
+    k, q = oracle.Rand(1).get_frs(2)
+    W = coracle.points_walk(k, q, 40)
+    for i in (0, 1, 2, 17, 39):
+        assert oracle.affine_from_mont_limbs([int(v) for v in W[i]]) == oracle.scalar_mul((k + i * q) % oracle.R, oracle.G1)
+
+
+def test_accumulator_restatement_completeness_and_soundness(oracle, golden_acc):
+    # msmaccumulator_test.go:12-50 (sizes 0..3 because the Go loop ranges over indices)
+    for n in (0, 1, 2, 3):
+        r = oracle.Rand(0)
+        A = r.get_g1_affines(n); x = r.get_frs(n); C1 = oracle.msm(A, x)
+        B = r.get_g1_affines(n); y = r.get_frs(n); C2 = oracle.msm(B, y)
+        ma = oracle.MsmAccumulator()
+        ma.accumulate_check(C1, x, A, r)
+        ma.accumulate_check(C2, y, B, r)
+        assert ma.verify()
+        assert oracle.jac_to_mont_limbs(ma.A_c) == [int(v) for v in golden_acc[f"n{n}_A_c"]]
+        if n:
+            # a wrong instance must flip the batched check (grandproductargument_test.go:107-111)
+            bad = oracle.MsmAccumulator()
+            r2 = oracle.Rand(0)
+            for _ in range(4 * n):
+                r2.get_fr()
+            bad.accumulate_check(oracle.add(C1, oracle.G1), x, A, r2)
+            bad.accumulate_check(C2, y, B, r2)
+            assert not bad.verify()
+    with pytest.raises(ValueError):
+        oracle.MsmAccumulator().accumulate_check(oracle.G1, [1, 2], [oracle.G1], oracle.Rand(0))
+
+
+def test_accumulator_merges_shared_bases(oracle):
+    # msmaccumulator.go:40-42: the same base in two checks is one map entry
+    r = oracle.Rand(5)
+    A = r.get_g1_affines(3); x = r.get_frs(3); y = r.get_frs(3)
+    ma = oracle.MsmAccumulator()
+    ma.accumulate_check(oracle.msm(A, x), x, A, r)
+    ma.accumulate_check(oracle.msm(A, y), y, A, r)
+    assert len(ma.base_scalar_map) == 3 and ma.verify()
