@@ -56,7 +56,7 @@ struct Ctx {
   bool inited = false;
   int device = 0;
   hipStream_t stream = nullptr;
-  Buf points, scalars, counts, starts, cursor, fragcnt, foff, small, sorted, frags, partials, winsums;
+  Buf points, scalars, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials, winsums;
   G1XYZZ* h_winsums = nullptr;  // pinned
   size_t h_winsums_cap = 0;
   // profiling
@@ -157,6 +157,11 @@ int make_plan(MsmPlan& p, size_t n, int c, int win_begin, int win_end) {
   uint64_t nbk = (uint64_t)(p.win_end - p.win_begin) * p.B;
   p.max_large = (uint32_t)(ml < nbk ? ml : nbk);
   if (p.max_large == 0) p.max_large = 1;
+  // Scalars per sort block: about 512 blocks over all windows, at least 4096 each.
+  uint64_t ch = (entries + 511) / 512;
+  if (ch < 4096) ch = 4096;
+  if (ch > n) ch = n;
+  p.chunk = (uint32_t)ch;
   return CURDLE_OK;
 }
 
@@ -214,6 +219,7 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   if ((rc = ensure(C.fragcnt, nb * 4))) return rc;
   if ((rc = ensure(C.foff, (nb + 1) * 4))) return rc;
   if ((rc = ensure(C.small, (1024 + 1 + (size_t)p.max_large) * 4))) return rc;
+  if ((rc = ensure(C.digits, (size_t)nw * n * 4))) return rc;
   if ((rc = ensure(C.sorted, (size_t)nw * n * 4))) return rc;
   if ((rc = ensure(C.frags, (nb + nlanes + 1) * sizeof(G1XYZZ)))) return rc;
   if ((rc = ensure(C.partials, (size_t)nw * p.nseg * sizeof(G1XYZZ)))) return rc;
@@ -233,6 +239,7 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   ws.blocksum = (uint32_t*)C.small.p;
   ws.nlarge = ws.blocksum + 1024;
   ws.large = ws.blocksum + 1025;
+  ws.digits = (uint32_t*)C.digits.p;
   ws.sorted = (uint32_t*)C.sorted.p;
   ws.frags = (G1XYZZ*)C.frags.p;
   ws.partials = (G1XYZZ*)C.partials.p;
@@ -241,11 +248,13 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, stream));
   HIP_TRY(hipMemsetAsync(ws.nlarge, 0, 4, stream));
   Prof prof(C, stream);
-  HIP_TRY(launch_hist(p, ws, d_scalars, stream));
+  HIP_TRY(launch_digits(p, ws, d_scalars, stream));
+  prof.mark("digits");
+  HIP_TRY(launch_hist(p, ws, stream));
   prof.mark("hist");
   HIP_TRY(launch_scan(p, ws, stream));
   prof.mark("scan");
-  HIP_TRY(launch_scatter(p, ws, d_scalars, stream));
+  HIP_TRY(launch_scatter(p, ws, stream));
   prof.mark("scatter");
   HIP_TRY(launch_accumulate(p, ws, d_points, stream));
   prof.mark("accumulate");
@@ -300,7 +309,7 @@ extern "C" int curdle_shutdown(void) {
   if (!C.inited) return CURDLE_OK;
   (void)hipSetDevice(C.device);
   (void)hipStreamSynchronize(C.stream);
-  for (Buf* b : {&C.points, &C.scalars, &C.counts, &C.starts, &C.cursor, &C.fragcnt, &C.foff, &C.small, &C.sorted, &C.frags,
+  for (Buf* b : {&C.points, &C.scalars, &C.counts, &C.starts, &C.cursor, &C.fragcnt, &C.foff, &C.small, &C.digits, &C.sorted, &C.frags,
                  &C.partials, &C.winsums}) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;

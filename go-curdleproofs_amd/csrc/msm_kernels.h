@@ -23,6 +23,7 @@ struct MsmPlan {
   uint32_t L;       // sorted positions per accumulate lane
   uint32_t max_small;  // buckets with more fragments than this are pre-merged by a block
   uint32_t max_large;  // capacity of the large-bucket queue (= grid of merge_large)
+  uint32_t chunk;      // scalars per sort block
 };
 
 // Device workspace, laid out by msm_api.hip.
@@ -35,6 +36,7 @@ struct MsmWorkspace {
   uint32_t* blocksum; // [1024]    scan scratch
   uint32_t* large;    // [max_large] buckets queued for merge_large
   uint32_t* nlarge;   // [1]
+  uint32_t* digits;   // [nw][n]   |digit| | sign<<31, window-major
   uint32_t* sorted;   // [nw * n]  point index | sign<<31, grouped by bucket
   G1XYZZ* frags;      // [nb + lanes + 1]
   G1XYZZ* partials;   // [nw][nseg]
@@ -42,9 +44,10 @@ struct MsmWorkspace {
 };
 
 // Every launcher enqueues on `stream` and returns the launch status.
-hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);
+hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);
+hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
-hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);
+hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream);
 hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);

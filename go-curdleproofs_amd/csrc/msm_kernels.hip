@@ -3,10 +3,12 @@
 // Replaces the body of gnark-crypto's (*G1Jac).MultiExp as the reference uses it
 // (/root/reference/msmaccumulator/msmaccumulator.go:59 and the call sites in
 // SURVEY.md section 8a).  Phases, one kernel each:
-//   hist        scalar Montgomery->canonical, signed c-bit digits, bucket sizes
+//   digits      scalar Montgomery->canonical, signed c-bit digits (window-major)
+//   hist        bucket sizes, per-window histogram staged in LDS
 //   scan        exclusive prefix of the bucket sizes over all (window, bucket)
 //               slots, then of the per-bucket fragment counts
-//   scatter     point indices grouped by (window, bucket)
+//   scatter     point indices grouped by (window, bucket): LDS histogram again,
+//               one coalesced returning atomic per (block, bucket) reserves the range
 //   accumulate  one lane per L consecutive sorted positions: gathers the affine
 //               points (96 B each, AoS as gnark stores them), sums them with XYZZ
 //               mixed additions and emits one fragment per bucket it touches, so
@@ -65,17 +67,80 @@ __device__ __forceinline__ Fr load_scalar_canonical(const uint4* scalars, u32 i)
   return s;
 }
 
-__global__ void __launch_bounds__(kBlock) k_hist(const uint4* __restrict__ scalars, MsmPlan p,
-                                                 u32* __restrict__ counts) {
+// Phase 1: recode every scalar once.  digits[lw][i] = |d| | sign << 31 (0 = no
+// contribution), window-major so the sort passes below read them coalesced.
+__global__ void __launch_bounds__(kBlock) k_digits(const uint4* __restrict__ scalars, MsmPlan p,
+                                                   u32* __restrict__ digits) {
   u32 i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= p.n) return;
   Fr s = load_scalar_canonical(scalars, i);
   for_each_digit(s, p.c, p.W, [&](int w, int d) {
-    if (d != 0 && w >= p.win_begin && w < p.win_end) {
+    if (w >= p.win_begin && w < p.win_end) {
       u32 mag = d < 0 ? (u32)(-d) : (u32)d;
-      atomicAdd(&counts[(size_t)(w - p.win_begin) * p.B + (mag - 1)], 1u);
+      digits[(size_t)(w - p.win_begin) * p.n + i] = mag | (d < 0 ? 0x80000000u : 0u);
     }
   });
+}
+
+// Bucket sort of the point indices, per-window histogram staged in LDS
+// (B <= 32768 counters = 128 KiB of the CU's 160 KiB).  Block (chunk, window)
+// owns `chunk` consecutive scalars of one window.
+static constexpr int kSortThreads = 1024;
+
+// Phase 2: bucket sizes.  LDS atomics absorb the 16.7 M increments; one coalesced
+// global atomic per (block, non-empty bucket) publishes them.
+__global__ void __launch_bounds__(kSortThreads) k_hist(const u32* __restrict__ digits, MsmPlan p, u32 chunk,
+                                                      u32* __restrict__ counts) {
+  extern __shared__ u32 lds_cnt[];
+  const u32 lw = blockIdx.y;
+  const u32 i0 = blockIdx.x * chunk;
+  const u32 i1 = min(i0 + chunk, p.n);
+  for (u32 b = threadIdx.x; b < p.B; b += kSortThreads) lds_cnt[b] = 0;
+  __syncthreads();
+  const u32* dw = digits + (size_t)lw * p.n;
+  for (u32 i = i0 + threadIdx.x; i < i1; i += kSortThreads) {
+    u32 mag = dw[i] & 0x7fffffffu;
+    if (mag) atomicAdd(&lds_cnt[mag - 1], 1u);
+  }
+  __syncthreads();
+  u32* cw = counts + (size_t)lw * p.B;
+  for (u32 b = threadIdx.x; b < p.B; b += kSortThreads) {
+    u32 v = lds_cnt[b];
+    if (v) atomicAdd(&cw[b], v);
+  }
+}
+
+// Phase 4: scatter.  The block rebuilds its local histogram, reserves a range per
+// bucket with one returning global atomic (wavefront-coalesced), then hands out
+// positions inside the ranges with LDS atomics.
+__global__ void __launch_bounds__(kSortThreads) k_scatter(const u32* __restrict__ digits, MsmPlan p, u32 chunk,
+                                                         u32* __restrict__ cursor, u32* __restrict__ sorted) {
+  extern __shared__ u32 lds_cnt[];
+  const u32 lw = blockIdx.y;
+  const u32 i0 = blockIdx.x * chunk;
+  const u32 i1 = min(i0 + chunk, p.n);
+  for (u32 b = threadIdx.x; b < p.B; b += kSortThreads) lds_cnt[b] = 0;
+  __syncthreads();
+  const u32* dw = digits + (size_t)lw * p.n;
+  for (u32 i = i0 + threadIdx.x; i < i1; i += kSortThreads) {
+    u32 mag = dw[i] & 0x7fffffffu;
+    if (mag) atomicAdd(&lds_cnt[mag - 1], 1u);
+  }
+  __syncthreads();
+  u32* cw = cursor + (size_t)lw * p.B;
+  for (u32 b = threadIdx.x; b < p.B; b += kSortThreads) {
+    u32 v = lds_cnt[b];
+    if (v) lds_cnt[b] = atomicAdd(&cw[b], v);
+  }
+  __syncthreads();
+  for (u32 i = i0 + threadIdx.x; i < i1; i += kSortThreads) {
+    u32 d = dw[i];
+    u32 mag = d & 0x7fffffffu;
+    if (mag) {
+      u32 pos = atomicAdd(&lds_cnt[mag - 1], 1u);
+      sorted[pos] = i | (d & 0x80000000u);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -160,20 +225,6 @@ __global__ void __launch_bounds__(kBlock) k_fix_foff(u32* __restrict__ foff, con
     u32 k = atomicAdd(nlarge, 1u);
     if (k < max_large) large[k] = i;
   }
-}
-
-__global__ void __launch_bounds__(kBlock) k_scatter(const uint4* __restrict__ scalars, MsmPlan p,
-                                                    u32* __restrict__ cursor, u32* __restrict__ sorted) {
-  u32 i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= p.n) return;
-  Fr s = load_scalar_canonical(scalars, i);
-  for_each_digit(s, p.c, p.W, [&](int w, int d) {
-    if (d != 0 && w >= p.win_begin && w < p.win_end) {
-      u32 mag = d < 0 ? (u32)(-d) : (u32)d;
-      u32 pos = atomicAdd(&cursor[(size_t)(w - p.win_begin) * p.B + (mag - 1)], 1u);
-      sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
-    }
-  });
 }
 
 __device__ __forceinline__ void load_fp(Fp& r, const uint4* src) {
@@ -360,9 +411,30 @@ __global__ void __launch_bounds__(kBlock, 2)
 // ---------------------------------------------------------------------------
 static inline u32 cdiv(u64 a, u32 b) { return (u32)((a + b - 1) / b); }
 
-hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream) {
-  hipLaunchKernelGGL(k_hist, dim3(cdiv(p.n, kBlock)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const uint4*>(d_scalars), p, ws.counts);
+// LDS histograms larger than the default 64 KiB need the opt-in once per process.
+static hipError_t sort_lds_optin() {
+  static hipError_t st = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       32768 * 4);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               32768 * 4);
+  }();
+  return st;
+}
+
+hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream) {
+  hipLaunchKernelGGL(k_digits, dim3(cdiv(p.n, kBlock)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const uint4*>(d_scalars), p, ws.digits);
+  return hipGetLastError();
+}
+
+hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
+  hipError_t e = sort_lds_optin();
+  if (e != hipSuccess) return e;
+  const u32 nw = p.win_end - p.win_begin;
+  hipLaunchKernelGGL(k_hist, dim3(cdiv(p.n, p.chunk), nw), dim3(kSortThreads), p.B * 4, stream, ws.digits, p, p.chunk,
+                     ws.counts);
   return hipGetLastError();
 }
 
@@ -387,9 +459,12 @@ hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t str
   return hipGetLastError();
 }
 
-hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream) {
-  hipLaunchKernelGGL(k_scatter, dim3(cdiv(p.n, kBlock)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const uint4*>(d_scalars), p, ws.cursor, ws.sorted);
+hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
+  hipError_t e = sort_lds_optin();
+  if (e != hipSuccess) return e;
+  const u32 nw = p.win_end - p.win_begin;
+  hipLaunchKernelGGL(k_scatter, dim3(cdiv(p.n, p.chunk), nw), dim3(kSortThreads), p.B * 4, stream, ws.digits, p,
+                     p.chunk, ws.cursor, ws.sorted);
   return hipGetLastError();
 }
 
