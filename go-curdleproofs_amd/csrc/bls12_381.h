@@ -320,8 +320,56 @@ CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) {
 #pragma unroll
   for (int i = 0; i < 12; i++) r.l[i] = o[i];
 }
-#else
+#elif defined(__HIP_DEVICE_COMPILE__)
 CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) { f_mul_inl<FpParams>(r, a, b); }
+#else
+// Host: the window combine after the GPU phases is a serial chain of ~2,400
+// field multiplications, so the host path uses 64-bit limbs (mulx-friendly)
+// instead of the kernels' 32-bit columns.  Same Montgomery form, same results.
+CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) {
+  typedef unsigned __int128 u128;
+  static const u64 P64[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
+                             0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+  static const u64 N0 = 0x89f3fffcfffcfffdull;
+  u64 x[6], y[6], t[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 6; i++) {
+    x[i] = (u64)a.l[2 * i] | ((u64)a.l[2 * i + 1] << 32);
+    y[i] = (u64)b.l[2 * i] | ((u64)b.l[2 * i + 1] << 32);
+  }
+  for (int i = 0; i < 6; i++) {
+    u64 c = 0;
+    for (int j = 0; j < 6; j++) {
+      u128 s = (u128)x[j] * y[i] + t[j] + c;
+      t[j] = (u64)s;
+      c = (u64)(s >> 64);
+    }
+    u64 top = t[6] + c;  // value < 2p: no overflow past limb 6
+    const u64 m = t[0] * N0;
+    u128 s = (u128)m * P64[0] + t[0];
+    c = (u64)(s >> 64);
+    for (int j = 1; j < 6; j++) {
+      s = (u128)m * P64[j] + t[j] + c;
+      t[j - 1] = (u64)s;
+      c = (u64)(s >> 64);
+    }
+    s = (u128)top + c;
+    t[5] = (u64)s;
+    t[6] = (u64)(s >> 64);
+  }
+  // conditional subtraction
+  u64 d[6], borrow = 0;
+  for (int i = 0; i < 6; i++) {
+    u128 s = (u128)t[i] - P64[i] - borrow;
+    d[i] = (u64)s;
+    borrow = (u64)(s >> 64) & 1;
+  }
+  const bool ge = t[6] != 0 || borrow == 0;
+  for (int i = 0; i < 6; i++) {
+    u64 v = ge ? d[i] : t[i];
+    r.l[2 * i] = (u32)v;
+    r.l[2 * i + 1] = (u32)(v >> 32);
+  }
+}
 #endif
 CURDLE_HD void fp_sqr(Fp& r, const Fp& a) { fp_mul(r, a, a); }
 CURDLE_HD void fp_add(Fp& r, const Fp& a, const Fp& b) { f_add<FpParams>(r, a, b); }

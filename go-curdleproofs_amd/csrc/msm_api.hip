@@ -20,6 +20,8 @@
 
 using namespace curdle;
 
+extern "C" void curdle_window_combine(const void* winsums_xyzz, int nw, int c, int win_begin, uint64_t out[18]);
+
 // ---------------------------------------------------------------------------
 // Errors
 // ---------------------------------------------------------------------------
@@ -268,18 +270,9 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   HIP_TRY(hipStreamSynchronize(stream));
   prof.finish(p);
 
-  // Window combine: sum_w 2^(c*w) * winsum[w], Horner from the top window down,
-  // then the 2^(c*win_begin) scaling of a partial.
-  G1XYZZ acc;
-  g1_set_inf(acc);
-  for (int lw = (int)nw - 1; lw >= 0; lw--) {
-    if (!g1_is_inf(acc))
-      for (int k = 0; k < p.c; k++) g1_dbl(acc);
-    g1_add(acc, C.h_winsums[lw]);
-  }
-  if (!g1_is_inf(acc))
-    for (int k = 0; k < p.c * p.win_begin; k++) g1_dbl(acc);
-  g1_to_canonical_jac(out, acc);
+  // Window combine: sum_w 2^(c*w) * winsum[w], Horner from the top window down, then
+  // the 2^(c*win_begin) scaling of a partial (host/window_combine.cpp).
+  curdle_window_combine(C.h_winsums, (int)nw, p.c, p.win_begin, out);
   return CURDLE_OK;
 }
 
