@@ -1,0 +1,499 @@
+// Device-internal BLS12-381 base field and G1 arithmetic for gfx950:
+// 14 limbs of 28 bits, Montgomery radix R' = 2^392, lazily reduced.
+//
+// Why not the 12 x 32-bit limbs gnark stores (bls12_381.h)?  On gfx950 the only
+// wide multiplier is v_mad_u64_u32 (32x32+64).  With saturated 32-bit limbs every
+// product needs its carry captured (v_addc_co_u32), and the pair issues every
+// 9.25-10.4 cycles per SIMD; the multiply alone issues every 4.9
+// (profiles/r01_ubench_valu.txt).  With 28-bit limbs a 64-bit column accumulator
+// holds all <= 29 products of a column without overflow, so a field product is
+// 406 bare multiply-adds (315 for a square) plus a shift and a mask per column:
+// measured 1.33x the throughput of the 32-bit form.  R' = 2^392 leaves 11 spare
+// bits over p (381 bits), which buys lazy reduction: products come out below 2p
+// with NO conditional subtraction as long as the operands are below 32p, and
+// additions / subtractions only propagate carries.
+//
+// Value bounds (multiples of p) are part of every function's contract below.
+// Limbs 0..12 are always < 2^28 after `norm`; limb 13 carries the excess.
+//
+// External (gnark, R = 2^384, 12 x u32 saturated, canonical) <-> internal
+// conversions are one Montgomery product by a constant each way; the MSM converts
+// every input point once (k_convert_points) and every window sum once.
+//
+// Device-only header.  Replaces, on the GPU, the fp.Element arithmetic the
+// reference gets from gnark-crypto (go.mod:6) inside (*G1Jac).MultiExp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bls12_381.h"
+
+namespace curdle {
+namespace d28 {
+
+static constexpr int N = 14;
+static constexpr u32 MASK = 0x0fffffffu;
+static constexpr u32 N0 = 0x0ffcfffdu;  // -p^-1 mod 2^28
+
+struct F28 {
+  u32 l[N];
+};
+// XYZZ point, x = X/ZZ, y = Y/ZZZ; infinity <=> ZZ == 0 (all limbs zero).
+// Invariant for stored points: X, Y < 10p; ZZ, ZZZ < 2p; limbs normalised.
+struct X28 {
+  F28 x, y, zz, zzz;
+};
+// Affine point in internal form, x, y < 2p; (0,0) = infinity.
+struct A28 {
+  F28 x, y;
+};
+
+#define CURDLE_D28_TABLE(name, ...)                      \
+  __device__ __forceinline__ u32 name(int i) {           \
+    constexpr u32 t[N] = {__VA_ARGS__};                  \
+    return t[i];                                         \
+  }
+// p
+CURDLE_D28_TABLE(kP, 0xfffaaabu, 0xfefffffu, 0x3ffffb9u, 0xfffeb15u, 0x6241eabu, 0xa0f6b0fu, 0xf6730d2u, 0xf38512bu,
+                 0x4774b84u, 0x4bacd76u, 0xba7b643u, 0xe69a4b1u, 0x1ea397fu, 0x001a011u)
+// 2^392 mod p  (one)
+CURDLE_D28_TABLE(kOne, 0x347fcb8u, 0xd800000u, 0x002b119u, 0x0cde6d2u, 0xc7212e0u, 0x83a2090u, 0x037669fu, 0xda0f73eu,
+                 0x9b09b42u, 0x1297bb0u, 0x515d98fu, 0x012ca7cu, 0x659fcfau, 0x000577au)
+// 2^400 mod p: mul by it maps gnark form (x*2^384) to internal form (x*2^392)
+CURDLE_D28_TABLE(kToInt, 0x80e6299u, 0x3500034u, 0xeb12856u, 0xdeb2699u, 0xc988670u, 0x4ef6697u, 0x70983e8u, 0xa4e6fe9u,
+                 0x3e8a053u, 0xecf271eu, 0xc20d323u, 0x6eb6385u, 0x47f1286u, 0x00156dau)
+// 2^384 mod p: mul by it maps internal form back to gnark form
+CURDLE_D28_TABLE(kToExt, 0x002fffdu, 0x0900000u, 0xc000276u, 0x000bc40u, 0x8baebf4u, 0x5753c75u, 0x55f4898u, 0x7052574u,
+                 0x7ce5853u, 0x56ec6d7u, 0x71a97a2u, 0xe4935c0u, 0xec3fa80u, 0x0015f65u)
+// K*p in borrow-proof limb form: limbs 0..12 >= 2^28 - 1, limb 13 = top(K*p) - 1,
+// so (a + K - b) is non-negative limb by limb for normalised b < (K-1)p.
+CURDLE_D28_TABLE(kK4, 0x1ffeaaacu, 0x1fbffffeu, 0x1ffffee6u, 0x1fffac53u, 0x18907aaeu, 0x183dac3cu, 0x1d9cc349u,
+                 0x1ce144aeu, 0x11dd2e12u, 0x12eb35d8u, 0x1e9ed90cu, 0x19a692c5u, 0x17a8e5feu, 0x0068043u)
+CURDLE_D28_TABLE(kK8, 0x1ffd5558u, 0x1f7ffffeu, 0x1ffffdceu, 0x1fff58a8u, 0x1120f55eu, 0x107b587au, 0x1b398694u,
+                 0x19c2895eu, 0x13ba5c26u, 0x15d66bb1u, 0x1d3db219u, 0x134d258cu, 0x1f51cbfeu, 0x00d0087u)
+CURDLE_D28_TABLE(kK16, 0x1ffaaab0u, 0x1efffffeu, 0x1ffffb9eu, 0x1ffeb152u, 0x1241eabeu, 0x10f6b0f5u, 0x16730d29u,
+                 0x138512beu, 0x1774b84eu, 0x1bacd763u, 0x1a7b6433u, 0x169a4b1au, 0x1ea397fdu, 0x01a0110u)
+#undef CURDLE_D28_TABLE
+
+#include "mac28_gfx950.inc"
+
+struct PTable {
+  u32 v[N];
+  __device__ __forceinline__ PTable() {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = kP(i);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Montgomery product, r = a*b / 2^392 mod p (not canonical).
+// Requires limbs(a), limbs(b) < 2^30 and a*b < 2^392 * p (e.g. a, b < 32p).
+// Ensures r < 2p, limbs normalised.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void mul_inl(F28& r, const F28& a, const F28& b) {
+  const PTable P;
+  u32 m[N];
+  u32 t[N];
+  u64 acc = 0;
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    m28v<k + 1>(acc, &a.l[0], &b.l[k]);
+    if constexpr (k > 0) m28s<k>(acc, &m[0], &P.v[k]);
+    m[k] = ((u32)acc * N0) & MASK;
+    m28s<1>(acc, &m[k], &P.v[0]);
+    acc >>= 28;
+  });
+  static_for<N, 2 * N - 1>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int i0 = k - N + 1;
+    m28v<N - i0>(acc, &a.l[i0], &b.l[N - 1]);
+    m28s<N - i0>(acc, &m[i0], &P.v[N - 1]);
+    t[k - N] = (u32)acc & MASK;
+    acc >>= 28;
+  });
+  t[N - 1] = (u32)acc;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = t[i];
+}
+
+// Square: cross products once, doubled by a 64-bit shift-add (v_lshl_add_u64).
+// Same contract as mul_inl(r, a, a).
+__device__ __forceinline__ void sqr_inl(F28& r, const F28& a) {
+  const PTable P;
+  u32 m[N];
+  u32 t[N];
+  u64 acc = 0;
+  static_for<0, 2 * N - 1>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int lo = k < N ? 0 : k - N + 1;   // smallest i with k - i <= N-1
+    constexpr int pairs = (k + 1) / 2 - lo;     // i in [lo, k/2) with i < k - i
+    if constexpr (pairs > 0) {
+      u64 cross = 0;
+      m28v<pairs>(cross, &a.l[lo], &a.l[k - lo]);
+      acc += cross << 1;
+    }
+    if constexpr (k % 2 == 0) m28v<1>(acc, &a.l[k / 2], &a.l[k / 2]);
+    if constexpr (k < N) {
+      if constexpr (k > 0) m28s<k>(acc, &m[0], &P.v[k]);
+      m[k] = ((u32)acc * N0) & MASK;
+      m28s<1>(acc, &m[k], &P.v[0]);
+    } else {
+      constexpr int i0 = k - N + 1;
+      m28s<N - i0>(acc, &m[i0], &P.v[N - 1]);
+      t[k - N] = (u32)acc & MASK;
+    }
+    acc >>= 28;
+  });
+  t[N - 1] = (u32)acc;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = t[i];
+}
+
+// Out-of-line entry points (one copy per code object, operands in VGPRs): a mixed
+// addition holds ten products and would overflow the instruction cache inlined.
+typedef u32 u32x14 __attribute__((ext_vector_type(14)));
+__device__ __noinline__ inline u32x14 mul_call(u32x14 a, u32x14 b) {
+  F28 x, y, r;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    x.l[i] = a[i];
+    y.l[i] = b[i];
+  }
+  mul_inl(r, x, y);
+  u32x14 o;
+#pragma unroll
+  for (int i = 0; i < N; i++) o[i] = r.l[i];
+  return o;
+}
+__device__ __noinline__ inline u32x14 sqr_call(u32x14 a) {
+  F28 x, r;
+#pragma unroll
+  for (int i = 0; i < N; i++) x.l[i] = a[i];
+  sqr_inl(r, x);
+  u32x14 o;
+#pragma unroll
+  for (int i = 0; i < N; i++) o[i] = r.l[i];
+  return o;
+}
+__device__ __forceinline__ void mul(F28& r, const F28& a, const F28& b) {
+  u32x14 x, y;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    x[i] = a.l[i];
+    y[i] = b.l[i];
+  }
+  u32x14 o = mul_call(x, y);
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = o[i];
+}
+__device__ __forceinline__ void sqr(F28& r, const F28& a) {
+  u32x14 x;
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] = a.l[i];
+  u32x14 o = sqr_call(x);
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = o[i];
+}
+
+// ---------------------------------------------------------------------------
+// Linear operations: limb-wise, then one carry pass.  No reduction mod p.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void norm(F28& a) {
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < N - 1; i++) {
+    u32 t = a.l[i] + c;
+    a.l[i] = t & MASK;
+    c = t >> 28;
+  }
+  a.l[N - 1] += c;
+}
+__device__ __forceinline__ void set_zero(F28& a) {
+#pragma unroll
+  for (int i = 0; i < N; i++) a.l[i] = 0;
+}
+__device__ __forceinline__ void set_one(F28& a) {
+#pragma unroll
+  for (int i = 0; i < N; i++) a.l[i] = kOne(i);
+}
+__device__ __forceinline__ bool all_zero(const F28& a) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) o |= a.l[i];
+  return o == 0;
+}
+// a == 0 mod p for a normalised a < 2p (a product): a is 0 or p.
+__device__ __forceinline__ bool is_zero_lt2p(const F28& a) {
+  u32 o0 = 0, op = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    o0 |= a.l[i];
+    op |= a.l[i] ^ kP(i);
+  }
+  return (o0 == 0) | (op == 0);
+}
+// r = a + b.  value(r) = a + b.
+__device__ __forceinline__ void add(F28& r, const F28& a, const F28& b) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = a.l[i] + b.l[i];
+  norm(r);
+}
+// r = a - b + K*p, K in {4, 8, 16}.  Requires b normalised and b < (K-1)p.
+template <int K>
+__device__ __forceinline__ void sub(F28& r, const F28& a, const F28& b) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const u32 k = K == 4 ? kK4(i) : (K == 8 ? kK8(i) : kK16(i));
+    r.l[i] = a.l[i] + k - b.l[i];
+  }
+  norm(r);
+}
+
+// ---------------------------------------------------------------------------
+// External <-> internal
+// ---------------------------------------------------------------------------
+// 12 saturated 32-bit limbs -> 14 limbs of 28 bits (same integer).
+__device__ __forceinline__ void unpack(F28& r, const u32* w) {
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const int bit = 28 * j;
+    const int lo = bit >> 5, sh = bit & 31;
+    u32 v = w[lo] >> sh;
+    if (sh > 4 && lo + 1 < 12) v |= w[lo + 1] << (32 - sh);
+    r.l[j] = v & MASK;
+  }
+}
+// 14 x 28-bit limbs (value < 2^384) -> 12 saturated limbs.
+__device__ __forceinline__ void pack(u32* w, const F28& a) {
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const int bit = 32 * k;
+    const int j = bit / 28, sh = bit % 28;
+    u32 v = a.l[j] >> sh;
+    if (j + 1 < N) v |= a.l[j + 1] << (28 - sh);
+    if (28 - sh + 28 < 32 && j + 2 < N) v |= a.l[j + 2] << (56 - sh);
+    w[k] = v;
+  }
+}
+// Canonical representative of a normalised a < 2p.
+__device__ __forceinline__ void canonical_lt2p(F28& a) {
+  u32 d[N];
+  int borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    int t = (int)a.l[i] - (int)kP(i) - borrow;
+    borrow = t < 0;
+    d[i] = (u32)t & (i < N - 1 ? MASK : 0xffffffffu);
+  }
+  if (!borrow) {
+#pragma unroll
+    for (int i = 0; i < N; i++) a.l[i] = d[i];
+  }
+}
+// gnark fp.Element (12 x u32, Montgomery 2^384, canonical) -> internal, < 2p.
+__device__ __forceinline__ void from_gnark(F28& r, const u32* w) {
+  F28 t, c;
+  unpack(t, w);
+#pragma unroll
+  for (int i = 0; i < N; i++) c.l[i] = kToInt(i);
+  mul(r, t, c);
+}
+// internal (< 32p) -> gnark fp.Element, canonical.
+__device__ __forceinline__ void to_gnark(u32* w, const F28& a) {
+  F28 t, c;
+#pragma unroll
+  for (int i = 0; i < N; i++) c.l[i] = kToExt(i);
+  mul(t, a, c);
+  canonical_lt2p(t);
+  pack(w, t);
+}
+
+// ---------------------------------------------------------------------------
+// G1 on XYZZ coordinates (EFD "xyzz" formulas for a = 0), lazily reduced.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool is_inf(const X28& p) { return all_zero(p.zz); }
+__device__ __forceinline__ bool affine_is_inf(const A28& p) { return all_zero(p.x) && all_zero(p.y); }
+__device__ __forceinline__ void set_inf(X28& p) {
+  set_one(p.x);
+  set_one(p.y);
+  set_zero(p.zz);
+  set_zero(p.zzz);
+}
+
+// r = 2 * (x1, y1), affine input with x1, y1 < 4p, not infinity.  mdbl-2008-s-1.
+__device__ __forceinline__ void dbl_affine(X28& r, const F28& x1, const F28& y1) {
+  F28 u, v, w, s, m, t;
+  add(u, y1, y1);        // < 8p
+  sqr(v, u);             // V
+  mul(w, u, v);          // W
+  mul(s, x1, v);         // S
+  sqr(t, x1);
+  add(m, t, t);
+  add(m, m, t);          // M = 3 x1^2 < 6p
+  sqr(r.x, m);
+  add(t, s, s);          // 2S < 4p
+  sub<8>(r.x, r.x, t);   // X3 < 10p
+  sub<16>(t, s, r.x);    // S - X3 < 18p
+  mul(t, m, t);
+  mul(u, w, y1);
+  sub<4>(r.y, t, u);     // Y3 < 6p
+  r.zz = v;
+  r.zzz = w;
+}
+
+// p = 2p.  dbl-2008-s-1.  Infinity stays infinity (ZZ = 0 => ZZ3 = 0).
+__device__ __forceinline__ void dbl(X28& p) {
+  F28 u, v, w, s, m, t, x3;
+  add(u, p.y, p.y);      // < 20p
+  sqr(v, u);
+  mul(w, u, v);
+  mul(s, p.x, v);
+  sqr(t, p.x);
+  add(m, t, t);
+  add(m, m, t);          // < 6p
+  sqr(x3, m);
+  add(t, s, s);
+  sub<8>(x3, x3, t);     // < 10p
+  sub<16>(t, s, x3);     // < 18p
+  mul(t, m, t);
+  mul(u, w, p.y);
+  sub<4>(p.y, t, u);     // < 6p
+  p.x = x3;
+  mul(p.zz, v, p.zz);
+  mul(p.zzz, w, p.zzz);
+}
+
+// acc += (x2, y2), affine with x2 < 2p, y2 < 4p (a negated y is 4p - y), not
+// infinity.  madd-2008-s with the exceptional cases.
+__device__ __forceinline__ void madd(X28& acc, const F28& x2, const F28& y2) {
+  if (is_inf(acc)) {
+    acc.x = x2;
+    acc.y = y2;
+    set_one(acc.zz);
+    set_one(acc.zzz);
+    return;
+  }
+  F28 pp, r, t, q, ppp, p;
+  mul(p, x2, acc.zz);
+  sub<16>(p, p, acc.x);   // P = U2 - X1 < 18p
+  mul(r, y2, acc.zzz);
+  sub<16>(r, r, acc.y);   // R = S2 - Y1 < 18p
+  sqr(pp, p);             // PP < 2p
+  if (is_zero_lt2p(pp)) {  // P == 0 mod p: same x
+    sqr(t, r);
+    if (is_zero_lt2p(t))
+      dbl_affine(acc, x2, y2);
+    else
+      set_inf(acc);
+    return;
+  }
+  mul(ppp, p, pp);        // PPP
+  mul(q, acc.x, pp);      // Q
+  mul(acc.zz, acc.zz, pp);
+  mul(acc.zzz, acc.zzz, ppp);
+  sqr(t, r);
+  add(p, ppp, q);
+  add(p, p, q);           // PPP + 2Q < 6p
+  sub<8>(t, t, p);        // X3 < 10p
+  sub<16>(q, q, t);       // Q - X3 < 18p
+  mul(q, r, q);
+  mul(ppp, acc.y, ppp);
+  sub<4>(acc.y, q, ppp);  // Y3 < 6p
+  acc.x = t;
+}
+
+// acc += b.  add-2008-s with the exceptional cases.
+__device__ __forceinline__ void add(X28& acc, const X28& b) {
+  if (is_inf(b)) return;
+  if (is_inf(acc)) {
+    acc = b;
+    return;
+  }
+  F28 u1, u2, s1, s2, p, r, pp, ppp, q, t;
+  mul(u1, acc.x, b.zz);
+  mul(u2, b.x, acc.zz);
+  mul(s1, acc.y, b.zzz);
+  mul(s2, b.y, acc.zzz);
+  sub<4>(p, u2, u1);      // < 6p
+  sub<4>(r, s2, s1);      // < 6p
+  sqr(pp, p);
+  if (is_zero_lt2p(pp)) {
+    sqr(t, r);
+    if (is_zero_lt2p(t))
+      dbl(acc);
+    else
+      set_inf(acc);
+    return;
+  }
+  mul(ppp, p, pp);
+  mul(q, u1, pp);
+  mul(t, acc.zz, b.zz);
+  mul(acc.zz, t, pp);
+  mul(t, acc.zzz, b.zzz);
+  mul(acc.zzz, t, ppp);
+  sqr(t, r);
+  add(p, ppp, q);
+  add(p, p, q);           // < 6p
+  sub<8>(t, t, p);        // X3 < 10p
+  sub<16>(q, q, t);       // < 18p
+  mul(q, r, q);
+  mul(s1, s1, ppp);
+  sub<4>(acc.y, q, s1);   // < 6p
+  acc.x = t;
+}
+
+// r = k * p, small k: left-to-right double-and-add.
+__device__ __forceinline__ void mul_small(X28& r, const X28& p, u32 k) {
+  set_inf(r);
+  if (k == 0) return;
+  const int top = 31 - __clz(k);
+  for (int bit = top; bit >= 0; bit--) {
+    dbl(r);
+    if ((k >> bit) & 1u) add(r, p);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Memory: 16-byte vector accesses (an F28 is 56 B, X28 224 B, A28 112 B; arrays
+// of X28 / A28 are 16-B aligned).
+// ---------------------------------------------------------------------------
+template <int WORDS>
+__device__ __forceinline__ void load_words(u32* dst, const void* src) {
+  static_assert(WORDS % 4 == 0, "");
+  const uint4* s = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+  for (int i = 0; i < WORDS / 4; i++) {
+    uint4 v = s[i];
+    dst[4 * i] = v.x;
+    dst[4 * i + 1] = v.y;
+    dst[4 * i + 2] = v.z;
+    dst[4 * i + 3] = v.w;
+  }
+}
+template <int WORDS>
+__device__ __forceinline__ void store_words(void* dst, const u32* src) {
+  static_assert(WORDS % 4 == 0, "");
+  uint4* d = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+  for (int i = 0; i < WORDS / 4; i++) d[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+}
+__device__ __forceinline__ void load(X28& r, const X28* src) { load_words<56>(reinterpret_cast<u32*>(&r), src); }
+__device__ __forceinline__ void store(X28* dst, const X28& r) { store_words<56>(dst, reinterpret_cast<const u32*>(&r)); }
+__device__ __forceinline__ void load(A28& r, const A28* src) { load_words<28>(reinterpret_cast<u32*>(&r), src); }
+__device__ __forceinline__ void store(A28* dst, const A28& r) { store_words<28>(dst, reinterpret_cast<const u32*>(&r)); }
+
+// X28 -> gnark-form XYZZ (G1XYZZ of bls12_381.h), canonical coordinates.
+__device__ __forceinline__ void to_gnark(G1XYZZ& o, const X28& p) {
+  to_gnark(o.x.l, p.x);
+  to_gnark(o.y.l, p.y);
+  to_gnark(o.zz.l, p.zz);
+  to_gnark(o.zzz.l, p.zzz);
+}
+__device__ __forceinline__ void from_gnark(X28& o, const G1XYZZ& p) {
+  from_gnark(o.x, p.x.l);
+  from_gnark(o.y, p.y.l);
+  from_gnark(o.zz, p.zz.l);
+  from_gnark(o.zzz, p.zzz.l);
+}
+
+}  // namespace d28
+}  // namespace curdle

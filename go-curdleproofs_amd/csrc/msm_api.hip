@@ -58,7 +58,7 @@ struct Ctx {
   bool inited = false;
   int device = 0;
   hipStream_t stream = nullptr;
-  Buf points, scalars, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials, winsums;
+  Buf points, scalars, points28, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials, winsums;
   G1XYZZ* h_winsums = nullptr;  // pinned
   size_t h_winsums_cap = 0;
   // profiling
@@ -223,8 +223,9 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   if ((rc = ensure(C.small, (1024 + 1 + (size_t)p.max_large) * 4))) return rc;
   if ((rc = ensure(C.digits, (size_t)nw * n * 4))) return rc;
   if ((rc = ensure(C.sorted, (size_t)nw * n * 4))) return rc;
-  if ((rc = ensure(C.frags, (nb + nlanes + 1) * sizeof(G1XYZZ)))) return rc;
-  if ((rc = ensure(C.partials, (size_t)nw * p.nseg * sizeof(G1XYZZ)))) return rc;
+  if ((rc = ensure(C.points28, n * kA28Bytes))) return rc;
+  if ((rc = ensure(C.frags, (nb + nlanes + 1) * kX28Bytes))) return rc;
+  if ((rc = ensure(C.partials, (size_t)nw * p.nseg * kX28Bytes))) return rc;
   if ((rc = ensure(C.winsums, (size_t)nw * sizeof(G1XYZZ)))) return rc;
   if (C.h_winsums_cap < nw) {
     if (C.h_winsums) HIP_TRY(hipHostFree(C.h_winsums));
@@ -243,13 +244,16 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   ws.large = ws.blocksum + 1025;
   ws.digits = (uint32_t*)C.digits.p;
   ws.sorted = (uint32_t*)C.sorted.p;
-  ws.frags = (G1XYZZ*)C.frags.p;
-  ws.partials = (G1XYZZ*)C.partials.p;
+  ws.points28 = C.points28.p;
+  ws.frags = C.frags.p;
+  ws.partials = C.partials.p;
   ws.winsums = (G1XYZZ*)C.winsums.p;
 
   HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, stream));
   HIP_TRY(hipMemsetAsync(ws.nlarge, 0, 4, stream));
   Prof prof(C, stream);
+  HIP_TRY(launch_convert_points(p, ws, d_points, stream));
+  prof.mark("convert_points");
   HIP_TRY(launch_digits(p, ws, d_scalars, stream));
   prof.mark("digits");
   HIP_TRY(launch_hist(p, ws, stream));
@@ -258,7 +262,7 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   prof.mark("scan");
   HIP_TRY(launch_scatter(p, ws, stream));
   prof.mark("scatter");
-  HIP_TRY(launch_accumulate(p, ws, d_points, stream));
+  HIP_TRY(launch_accumulate(p, ws, stream));
   prof.mark("accumulate");
   HIP_TRY(launch_merge_large(p, ws, stream));
   prof.mark("merge_large");
@@ -302,7 +306,7 @@ extern "C" int curdle_shutdown(void) {
   if (!C.inited) return CURDLE_OK;
   (void)hipSetDevice(C.device);
   (void)hipStreamSynchronize(C.stream);
-  for (Buf* b : {&C.points, &C.scalars, &C.counts, &C.starts, &C.cursor, &C.fragcnt, &C.foff, &C.small, &C.digits, &C.sorted, &C.frags,
+  for (Buf* b : {&C.points, &C.scalars, &C.points28, &C.counts, &C.starts, &C.cursor, &C.fragcnt, &C.foff, &C.small, &C.digits, &C.sorted, &C.frags,
                  &C.partials, &C.winsums}) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;

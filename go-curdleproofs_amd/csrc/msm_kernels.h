@@ -26,6 +26,10 @@ struct MsmPlan {
   uint32_t chunk;      // scalars per sort block
 };
 
+// Sizes of the internal (fp28.h) point formats, for workspace allocation.
+static constexpr size_t kX28Bytes = 224;
+static constexpr size_t kA28Bytes = 112;
+
 // Device workspace, laid out by msm_api.hip.
 struct MsmWorkspace {
   uint32_t* counts;   // [nb]      points per bucket, nb = nw * B slots (window-major)
@@ -38,9 +42,10 @@ struct MsmWorkspace {
   uint32_t* nlarge;   // [1]
   uint32_t* digits;   // [nw][n]   |digit| | sign<<31, window-major
   uint32_t* sorted;   // [nw * n]  point index | sign<<31, grouped by bucket
-  G1XYZZ* frags;      // [nb + lanes + 1]
-  G1XYZZ* partials;   // [nw][nseg]
-  G1XYZZ* winsums;    // [nw]
+  void* points28;     // [n]       input points in internal form (d28::A28, 112 B)
+  void* frags;        // [nb + lanes + 1]  d28::X28 (224 B)
+  void* partials;     // [nw][nseg]        d28::X28
+  G1XYZZ* winsums;    // [nw]      gnark-form XYZZ, canonical coordinates
 };
 
 // Every launcher enqueues on `stream` and returns the launch status.
@@ -48,7 +53,8 @@ hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d
 hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
-hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream);
+hipError_t launch_convert_points(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream);
+hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);

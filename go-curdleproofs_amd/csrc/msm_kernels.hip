@@ -26,7 +26,13 @@
 
 #include "msm_kernels.h"
 
+#include "fp28.h"
+
 namespace curdle {
+
+using d28::A28;
+using d28::F28;
+using d28::X28;
 
 static constexpr int kBlock = 256;
 
@@ -227,30 +233,18 @@ __global__ void __launch_bounds__(kBlock) k_fix_foff(u32* __restrict__ foff, con
   }
 }
 
-__device__ __forceinline__ void load_fp(Fp& r, const uint4* src) {
-  uint4 a = src[0], b = src[1], c = src[2];
-  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-  r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
-}
-__device__ __forceinline__ void store_fp(uint4* dst, const Fp& r) {
-  dst[0] = make_uint4(r.l[0], r.l[1], r.l[2], r.l[3]);
-  dst[1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
-  dst[2] = make_uint4(r.l[8], r.l[9], r.l[10], r.l[11]);
-}
-__device__ __forceinline__ void load_xyzz(G1XYZZ& r, const G1XYZZ* src) {
-  const uint4* s = reinterpret_cast<const uint4*>(src);
-  load_fp(r.x, s);
-  load_fp(r.y, s + 3);
-  load_fp(r.zz, s + 6);
-  load_fp(r.zzz, s + 9);
-}
-__device__ __forceinline__ void store_xyzz(G1XYZZ* dst, const G1XYZZ& r) {
-  uint4* d = reinterpret_cast<uint4*>(dst);
-  store_fp(d, r.x);
-  store_fp(d + 3, r.y);
-  store_fp(d + 6, r.zz);
-  store_fp(d + 9, r.zzz);
+// Phase 0: gnark points (R = 2^384, saturated limbs) -> internal form (fp28.h),
+// once per MSM: one Montgomery product per coordinate.  (0,0) stays (0,0).
+__global__ void __launch_bounds__(kBlock, 2)
+    k_convert_points(const uint4* __restrict__ points, u32 n, A28* __restrict__ out) {
+  u32 i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  u32 w[24];
+  d28::load_words<24>(w, points + (size_t)i * 6);
+  A28 a;
+  d28::from_gnark(a.x, w);
+  d28::from_gnark(a.y, w + 12);
+  d28::store(&out[i], a);
 }
 
 // Balanced bucket accumulation.  Lane t owns L consecutive positions of the
@@ -261,8 +255,8 @@ __device__ __forceinline__ void store_xyzz(G1XYZZ* dst, const G1XYZZ& r) {
 // bucket and starts again from infinity.  Fragments of one bucket are
 // contiguous: slot = foff[bucket] + (t - start[bucket] / L).
 __global__ void __launch_bounds__(kBlock, 2)
-    k_accumulate(const uint4* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ starts,
-                 const u32* __restrict__ foff, G1XYZZ* __restrict__ frags, u32 nb, u32 L) {
+    k_accumulate(const A28* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ starts,
+                 const u32* __restrict__ foff, X28* __restrict__ frags, u32 nb, u32 L) {
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
   const u32 total = starts[nb];
   u32 pos = t * L;
@@ -277,73 +271,64 @@ __global__ void __launch_bounds__(kBlock, 2)
   }
   u32 g = lo - 1;
   u32 gend = starts[lo];
-  G1XYZZ acc;
-  g1_set_inf(acc);
+  X28 acc;
+  d28::set_inf(acc);
   for (; pos < end; pos++) {
     if (pos == gend) {
-      store_xyzz(&frags[foff[g] + (t - starts[g] / L)], acc);
-      g1_set_inf(acc);
+      d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
+      d28::set_inf(acc);
       do {
         g++;
         gend = starts[g + 1];
       } while (gend == pos);
     }
     const u32 e = sorted[pos];
-    const uint4* src = points + (size_t)(e & 0x7fffffffu) * 6;
-    Fp x, y;
-    load_fp(x, src);
-    load_fp(y, src + 3);
-    if (f_is_zero(x) && f_is_zero(y)) continue;  // (0,0) = infinity (curdleproof.go:23)
-    if (e >> 31) fp_neg(y, y);
-    g1_madd(acc, x, y);
+    A28 pt;
+    d28::load(pt, &points[e & 0x7fffffffu]);
+    if (d28::affine_is_inf(pt)) continue;  // (0,0) = infinity (curdleproof.go:23)
+    if (e >> 31) {
+      F28 z;
+      d28::set_zero(z);
+      d28::sub<4>(pt.y, z, pt.y);  // 4p - y
+    }
+    d28::madd(acc, pt.x, pt.y);
   }
-  store_xyzz(&frags[foff[g] + (t - starts[g] / L)], acc);
+  d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
 }
 
 // One block per queued bucket (more than max_small fragments): tree-sum of the
 // fragments into the bucket's first fragment slot, fragcnt := 1.
 __global__ void __launch_bounds__(kBlock, 2)
     k_merge_large(const u32* __restrict__ large, const u32* __restrict__ nlarge, const u32* __restrict__ foff,
-                  u32* __restrict__ fragcnt, G1XYZZ* __restrict__ frags, u32 max_large) {
-  __shared__ G1XYZZ sh[kBlock];
+                  u32* __restrict__ fragcnt, X28* __restrict__ frags, u32 max_large) {
+  __shared__ X28 sh[kBlock];
   const u32 nl = min(*nlarge, max_large);
   const u32 tid = threadIdx.x;
   for (u32 q = blockIdx.x; q < nl; q += gridDim.x) {  // block-uniform trip count
     const u32 g = large[q];
     const u32 m = fragcnt[g];
-    G1XYZZ* f = frags + foff[g];
-    G1XYZZ acc, b;
-    g1_set_inf(acc);
+    X28* f = frags + foff[g];
+    X28 acc, b;
+    d28::set_inf(acc);
     for (u32 k = tid; k < m; k += kBlock) {
-      load_xyzz(b, &f[k]);
-      g1_add(acc, b);
+      d28::load(b, &f[k]);
+      d28::add(acc, b);
     }
     sh[tid] = acc;
     __syncthreads();
     for (u32 off = kBlock / 2; off > 0; off >>= 1) {
       if (tid < off) {
         b = sh[tid + off];
-        g1_add(acc, b);
+        d28::add(acc, b);
         sh[tid] = acc;
       }
       __syncthreads();
     }
     if (tid == 0) {
-      store_xyzz(&f[0], acc);
+      d28::store(&f[0], acc);
       fragcnt[g] = 1;
     }
     __syncthreads();
-  }
-}
-
-// r = k * p for a small k (k < 2^16): left-to-right double-and-add.
-__device__ __forceinline__ void g1_mul_small(G1XYZZ& r, const G1XYZZ& p, u32 k) {
-  g1_set_inf(r);
-  if (k == 0) return;
-  int top = 31 - __clz(k);
-  for (int bit = top; bit >= 0; bit--) {
-    g1_dbl(r);
-    if ((k >> bit) & 1u) g1_add(r, p);
   }
 }
 
@@ -352,58 +337,65 @@ __device__ __forceinline__ void g1_mul_small(G1XYZZ& r, const G1XYZZ& p, u32 k) 
 // as the classic running sum over the segment plus lo * (segment total).  A
 // bucket's value is the sum of its fragments, folded into the running sum here.
 __global__ void __launch_bounds__(kBlock, 2)
-    k_bucket_reduce(const G1XYZZ* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
-                    G1XYZZ* __restrict__ partials, MsmPlan p, u32 nw) {
+    k_bucket_reduce(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
+                    X28* __restrict__ partials, MsmPlan p, u32 nw) {
   u32 t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= nw * p.nseg) return;
   const u32 lw = t / p.nseg;
   const u32 j = t - lw * p.nseg;
   const u32 lo = j * p.seg;
   const u32 g0 = lw * p.B + lo;
-  G1XYZZ run, acc, b;
-  g1_set_inf(run);
-  g1_set_inf(acc);
+  X28 run, acc, b;
+  d28::set_inf(run);
+  d28::set_inf(acc);
   for (int u = (int)p.seg - 1; u >= 0; u--) {
     const u32 m = fragcnt[g0 + u];
-    const G1XYZZ* f = frags + foff[g0 + u];
+    const X28* f = frags + foff[g0 + u];
     for (u32 k = 0; k < m; k++) {
-      load_xyzz(b, &f[k]);
-      g1_add(run, b);
+      d28::load(b, &f[k]);
+      d28::add(run, b);
     }
-    g1_add(acc, run);
+    d28::add(acc, run);
   }
   if (lo != 0) {
-    G1XYZZ s;
-    g1_mul_small(s, run, lo);
-    g1_add(acc, s);
+    X28 s;
+    d28::mul_small(s, run, lo);
+    d28::add(acc, s);
   }
-  store_xyzz(&partials[t], acc);
+  d28::store(&partials[t], acc);
 }
 
-// One block per window: winsums[w] = sum of the window's segment results.
+// One block per window: winsums[w] = sum of the window's segment results,
+// converted back to gnark form (canonical XYZZ coordinates) for the host combine.
 __global__ void __launch_bounds__(kBlock, 2)
-    k_window_sum(const G1XYZZ* __restrict__ partials, G1XYZZ* __restrict__ winsums, MsmPlan p) {
-  __shared__ G1XYZZ sh[kBlock];
+    k_window_sum(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, MsmPlan p) {
+  __shared__ X28 sh[kBlock];
   const u32 lw = blockIdx.x;
   const u32 tid = threadIdx.x;
-  const G1XYZZ* pw = partials + (size_t)lw * p.nseg;
-  G1XYZZ acc, b;
-  g1_set_inf(acc);
+  const X28* pw = partials + (size_t)lw * p.nseg;
+  X28 acc, b;
+  d28::set_inf(acc);
   for (u32 k = tid; k < p.nseg; k += kBlock) {
-    load_xyzz(b, &pw[k]);
-    g1_add(acc, b);
+    d28::load(b, &pw[k]);
+    d28::add(acc, b);
   }
   sh[tid] = acc;
   __syncthreads();
   for (u32 off = kBlock / 2; off > 0; off >>= 1) {
     if (tid < off) {
       b = sh[tid + off];
-      g1_add(acc, b);
+      d28::add(acc, b);
       sh[tid] = acc;
     }
     __syncthreads();
   }
-  if (tid == 0) store_xyzz(&winsums[lw], acc);
+  if (tid == 0) {
+    G1XYZZ o;
+    d28::to_gnark(o, acc);
+    u32* dst = reinterpret_cast<u32*>(&winsums[lw]);
+    const u32* src = reinterpret_cast<const u32*>(&o);
+    for (int k = 0; k < 48; k++) dst[k] = src[k];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -468,31 +460,40 @@ hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t 
   return hipGetLastError();
 }
 
-hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream) {
+hipError_t launch_convert_points(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream) {
+  hipLaunchKernelGGL(k_convert_points, dim3(cdiv(p.n, kBlock)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const uint4*>(d_points), p.n, reinterpret_cast<A28*>(ws.points28));
+  return hipGetLastError();
+}
+
+hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
   const u32 nb = nw * p.B;
   const u32 nlanes = cdiv((u64)nw * p.n, p.L);
   hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nlanes, kBlock)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const uint4*>(d_points), ws.sorted, ws.starts, ws.foff, ws.frags, nb, p.L);
+                     reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
+                     reinterpret_cast<X28*>(ws.frags), nb, p.L);
   return hipGetLastError();
 }
 
 hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   hipLaunchKernelGGL(k_merge_large, dim3(p.max_large < 1024u ? p.max_large : 1024u), dim3(kBlock), 0, stream, ws.large, ws.nlarge, ws.foff,
-                     ws.fragcnt, ws.frags, p.max_large);
+                     ws.fragcnt, reinterpret_cast<X28*>(ws.frags), p.max_large);
   return hipGetLastError();
 }
 
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv((u64)nw * p.nseg, kBlock)), dim3(kBlock), 0, stream, ws.frags, ws.foff,
-                     ws.fragcnt, ws.partials, p, nw);
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv((u64)nw * p.nseg, kBlock)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p,
+                     nw);
   return hipGetLastError();
 }
 
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  hipLaunchKernelGGL(k_window_sum, dim3(nw), dim3(kBlock), 0, stream, ws.partials, ws.winsums, p);
+  hipLaunchKernelGGL(k_window_sum, dim3(nw), dim3(kBlock), 0, stream, reinterpret_cast<const X28*>(ws.partials),
+                     ws.winsums, p);
   return hipGetLastError();
 }
 
@@ -508,33 +509,43 @@ __global__ void __launch_bounds__(kBlock, 2)
     k_synth_walk(const G1Affine* __restrict__ table, G1Affine p0, u32 n, uint4* __restrict__ out) {
   u32 i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  G1XYZZ acc;
-  g1_from_affine(acc, p0);
+  X28 acc;
+  if (g1_affine_is_inf(p0)) {
+    d28::set_inf(acc);
+  } else {
+    d28::from_gnark(acc.x, p0.x.l);
+    d28::from_gnark(acc.y, p0.y.l);
+    d28::set_one(acc.zz);
+    d28::set_one(acc.zzz);
+  }
   for (int j = 0; j < 27; j++) {
     if ((i >> j) & 1u) {
       G1Affine t = table[j];
-      g1_madd(acc, t.x, t.y);
+      F28 x, y;
+      d28::from_gnark(x, t.x.l);
+      d28::from_gnark(y, t.y.l);
+      d28::madd(acc, x, y);
     }
   }
-  Fp x, y;
-  if (g1_is_inf(acc)) {
-    f_zero(x);
-    f_zero(y);
+  u32 w[24];
+  if (d28::is_inf(acc)) {
+    for (int k = 0; k < 24; k++) w[k] = 0;
   } else {
-    Fp t, inv, izz, izzz;
-    fp_mul(t, acc.zz, acc.zzz);
-    f_one(inv);
+    F28 t, inv, izz, izzz, x, y;
+    d28::mul(t, acc.zz, acc.zzz);
+    d28::set_one(inv);
     for (int b = 383; b >= 0; b--) {
-      fp_sqr(inv, inv);
-      if ((kPminus2[b >> 5] >> (b & 31)) & 1u) fp_mul(inv, inv, t);
+      d28::sqr(inv, inv);
+      if ((kPminus2[b >> 5] >> (b & 31)) & 1u) d28::mul(inv, inv, t);
     }
-    fp_mul(izz, inv, acc.zzz);
-    fp_mul(izzz, inv, acc.zz);
-    fp_mul(x, acc.x, izz);
-    fp_mul(y, acc.y, izzz);
+    d28::mul(izz, inv, acc.zzz);
+    d28::mul(izzz, inv, acc.zz);
+    d28::mul(x, acc.x, izz);
+    d28::mul(y, acc.y, izzz);
+    d28::to_gnark(w, x);
+    d28::to_gnark(w + 12, y);
   }
-  store_fp(out + (size_t)i * 6, x);
-  store_fp(out + (size_t)i * 6 + 3, y);
+  d28::store_words<24>(out + (size_t)i * 6, w);
 }
 
 hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32_t n, void* d_out,
@@ -547,42 +558,53 @@ hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32
 // ---------------------------------------------------------------------------
 // Primitive self-test (curdle_selftest_op)
 // ---------------------------------------------------------------------------
+// All operands and results cross this kernel in gnark form; the operation itself
+// runs in the internal radix-2^28 form the MSM kernels use.
 __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __restrict__ in, size_t n, u32* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   if (op <= 3) {
-    Fp a, b, r;
-    for (int k = 0; k < 12; k++) {
-      a.l[k] = in[i * 24 + k];
-      b.l[k] = in[i * 24 + 12 + k];
-    }
-    if (op == 0) fp_mul(r, a, b);
-    else if (op == 1) fp_add(r, a, b);
-    else if (op == 2) fp_sub(r, a, b);
-    else fp_sqr(r, a);
-    for (int k = 0; k < 12; k++) out[i * 12 + k] = r.l[k];
+    u32 w[24];
+    for (int k = 0; k < 24; k++) w[k] = in[i * 24 + k];
+    F28 a, b, r;
+    d28::from_gnark(a, w);
+    d28::from_gnark(b, w + 12);
+    if (op == 0) d28::mul(r, a, b);
+    else if (op == 1) d28::add(r, a, b);
+    else if (op == 2) d28::sub<4>(r, a, b);
+    else d28::sqr(r, a);
+    u32 o[12];
+    d28::to_gnark(o, r);
+    for (int k = 0; k < 12; k++) out[i * 12 + k] = o[k];
   } else if (op == 4) {
     Fr a, r;
     for (int k = 0; k < 8; k++) a.l[k] = in[i * 16 + k];
     f_from_mont<FrParams>(r, a);
     for (int k = 0; k < 8; k++) out[i * 8 + k] = r.l[k];
   } else {
-    G1XYZZ acc, b;
+    G1XYZZ ga, gb;
     const u32* src = in + i * 96;
-    u32* a32 = reinterpret_cast<u32*>(&acc);
-    u32* b32 = reinterpret_cast<u32*>(&b);
+    u32* a32 = reinterpret_cast<u32*>(&ga);
+    u32* b32 = reinterpret_cast<u32*>(&gb);
     for (int k = 0; k < 48; k++) {
       a32[k] = src[k];
       b32[k] = src[48 + k];
     }
+    X28 acc, b;
+    d28::from_gnark(acc, ga);
+    d28::from_gnark(b, gb);
+    // gnark-form infinity is ZZ = 0 (X = Y = one): from_gnark maps 0 -> 0
     if (op == 5) {
-      if (!(f_is_zero(b.x) && f_is_zero(b.y))) g1_madd(acc, b.x, b.y);
+      if (!(f_is_zero(gb.x) && f_is_zero(gb.y))) d28::madd(acc, b.x, b.y);
     } else if (op == 6) {
-      g1_add(acc, b);
+      d28::add(acc, b);
     } else {
-      g1_dbl(acc);
+      d28::dbl(acc);
     }
-    for (int k = 0; k < 48; k++) out[i * 48 + k] = a32[k];
+    G1XYZZ o;
+    d28::to_gnark(o, acc);
+    const u32* o32 = reinterpret_cast<const u32*>(&o);
+    for (int k = 0; k < 48; k++) out[i * 48 + k] = o32[k];
   }
 }
 

@@ -1,0 +1,43 @@
+"""Size sweep on the GPU box: per-kernel HIP-event times and wall time per MSM for
+N = 2^10..2^20 and the protocol sizes, inputs resident in HBM.
+    python tools/sweep.py [c=<window bits>] > gpurun_out/sweep.log
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "go-curdleproofs_amd"))
+import numpy as np
+import torch
+import curdlemsm as cm
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+sizes = [8, 308, 628, 1268, 2548] + [1 << k for k in range(10, 21, 2)]
+if len(sys.argv) > 1:
+    sizes = [int(x) for x in sys.argv[1].split(",")]
+cs = [0]
+if len(sys.argv) > 2:
+    cs = [int(x) for x in sys.argv[2].split(",")]
+cm.init(0)
+cm.profile_enable(True)
+nmax = max(sizes)
+d_pts = torch.empty((nmax, 12), dtype=torch.int64, device="cuda:0")
+cm.synth_points_walk_device(12345678901234567890 % R_MOD, 98765432109876543210 % R_MOD, nmax, d_pts.data_ptr())
+rng = np.random.default_rng(1)
+sc = rng.integers(0, 1 << 64, size=(nmax, 4), dtype=np.uint64)
+sc[:, 3] &= np.uint64((1 << 62) - 1)
+d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+for n in sizes:
+    for c in cs:
+        reps = 5 if n >= (1 << 16) else 10
+        for _ in range(2):
+            cm.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ks = {}
+        for _ in range(reps):
+            cm.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c)
+            pr = cm.profile_last()
+            for k, v in pr["kernels"].items():
+                ks[k] = ks.get(k, 0) + v / reps
+        dt = (time.perf_counter() - t0) / reps
+        print(f"n={n:8d} c={pr['window_bits']:2d} W={pr['num_windows']:2d} wall {dt*1e3:8.3f} ms  {n/dt/1e6:8.2f} Mpairs/s  kernels {sum(ks.values()):7.3f} ms :: "
+              + " ".join(f"{k}={v:.3f}" for k, v in ks.items()), flush=True)
