@@ -20,7 +20,7 @@
 
 using namespace curdle;
 
-extern "C" void curdle_window_combine(const void* winsums_xyzz, int nw, int c, int win_begin, uint64_t out[18]);
+extern "C" void curdle_window_combine(const void* winsums_xyzz, int nw, const int* dbls, uint64_t out[18]);
 
 // ---------------------------------------------------------------------------
 // Errors
@@ -58,9 +58,10 @@ struct Ctx {
   bool inited = false;
   int device = 0;
   hipStream_t stream = nullptr;
-  Buf points, scalars, points28, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials, winsums;
-  G1XYZZ* h_winsums = nullptr;  // pinned
-  size_t h_winsums_cap = 0;
+  Buf points, scalars, offsets, points28, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials,
+      winsums, winsums28, results;
+  void* h_buf = nullptr;  // pinned: window sums (k = 1) or results (batch)
+  size_t h_buf_cap = 0;
   // profiling
   bool profile = false;
   hipEvent_t ev[CURDLE_PROF_MAX_KERNELS + 1];
@@ -100,54 +101,70 @@ int init_locked(int device) {
   return CURDLE_OK;
 }
 
-// r as four 64-bit limbs, for the top-window check below.
-const u64 kR64[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
-
-// Number of signed c-bit windows that cover every scalar < r: ceil(255 / c),
-// plus one when the top window's largest value (+ carry) could exceed 2^(c-1)
-// and would have to borrow from a window that does not exist (c = 3, 5, 15).
-int num_windows(int c) {
-  int W = (255 + c - 1) / c;
-  int sh = c * (W - 1);
-  u64 top = kR64[sh / 64] >> (sh % 64);
-  if (sh % 64 && sh / 64 + 1 < 4) top |= kR64[sh / 64 + 1] << (64 - sh % 64);
-  if (c < 64) top &= ((u64)1 << c) - 1;
-  if (top + 1 > ((u64)1 << (c - 1))) W += 1;
-  return W;
-}
-
 int choose_window_bits(size_t n) {
   const char* env = getenv("CURDLE_WINDOW_BITS");
   if (env) {
     int c = atoi(env);
-    if (c >= 2 && c <= 16) return c;
+    if (c >= 4 && c <= 16) return c;
   }
   int lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
-  int c = lg - 4;
+  int c = lg - 2;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
   return c;
 }
 
-int make_plan(MsmPlan& p, size_t n, int c, int win_begin, int win_end) {
-  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
-  if (c == 0) c = choose_window_bits(n);
-  if (c < 2 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [2, 16]", c);
-  p.n = (uint32_t)n;
+// Window widths for a maximum width c: W = ceil(255 / c) windows, the 255 scalar
+// bits spread as evenly as possible (the wider windows lowest), the top window
+// unsigned.  For c = 16 that is 15 windows of 16 bits and a 15-bit top window.
+int window_widths(int c, uint8_t bits[kMaxWindows]) {
+  const int W = (255 + c - 1) / c;
+  const int base = 255 / W, extra = 255 % W;
+  for (int w = 0; w < W; w++) bits[w] = (uint8_t)(base + (w < extra ? 1 : 0));
+  return W;
+}
+
+// Plan for k MSMs of n_total pairs in all, the largest having n_max pairs.
+int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end) {
+  if (n_total > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n_total);
+  if (c == 0) c = choose_window_bits(n_max);
+  if (c < 4 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", c);
+  memset(&p, 0, sizeof(p));
+  p.n = (uint32_t)n_total;
+  p.k = (uint32_t)k;
+  p.n_max = (uint32_t)n_max;
   p.c = c;
-  p.W = num_windows(c);
-  p.B = 1u << (c - 1);
+  p.W = window_widths(c, p.bits);
   if (win_end < 0) win_end = p.W;
   if (win_begin < 0 || win_begin > win_end || win_end > p.W)
     return fail(CURDLE_EINVAL, "window range [%d, %d) outside [0, %d)", win_begin, win_end, p.W);
   p.win_begin = win_begin;
   p.win_end = win_end;
-  p.seg = p.B < 8 ? p.B : 8;
-  p.nseg = p.B / p.seg;
+  uint32_t sh = 0, min_nbkt = 0xffffffffu;
+  for (int w = 0; w < p.W; w++) {
+    p.shift[w] = (uint16_t)sh;
+    sh += p.bits[w];
+    p.nbkt[w] = w == p.W - 1 ? (1u << p.bits[w]) : (1u << (p.bits[w] - 1));
+  }
+  for (int w = win_begin; w < win_end; w++) {
+    p.base[w] = p.NB;
+    p.NB += p.nbkt[w];
+    if (p.nbkt[w] > p.max_nbkt) p.max_nbkt = p.nbkt[w];
+    if (p.nbkt[w] < min_nbkt) min_nbkt = p.nbkt[w];
+  }
+  if (p.max_nbkt > 32768) return fail(CURDLE_EINVAL, "window of %u buckets exceeds the LDS histogram", p.max_nbkt);
+  const uint64_t nbk = (uint64_t)k * p.NB;
+  // Buckets per running-sum segment: long segments amortise the per-segment scalar
+  // multiple, short ones keep the serial chain short when there are few buckets.
+  p.seg = nbk >= (1u << 19) ? 8 : (nbk >= (1u << 14) ? 4 : 2);
+  if (const char* env = getenv("CURDLE_REDUCE_SEG")) p.seg = (uint32_t)atoi(env);
+  if (p.seg < 1) p.seg = 1;
+  while (p.seg > min_nbkt || (p.seg & (p.seg - 1))) p.seg >>= 1;
+  p.NS = p.NB / p.seg;
   // Sorted positions per accumulate lane: about two full-chip rounds of lanes
   // (256 CUs x 4 SIMDs x 2 waves x 64 lanes) for large inputs, never below 8.
-  const uint64_t entries = (uint64_t)(p.win_end - p.win_begin) * n;
+  const uint64_t entries = (uint64_t)(win_end - win_begin) * n_total;
   uint64_t L = (entries + 2 * 131072 - 1) / (2 * 131072);
   if (const char* env = getenv("CURDLE_SEG_LEN")) L = (uint64_t)atoi(env);
   if (L < 8) L = 8;
@@ -156,13 +173,13 @@ int make_plan(MsmPlan& p, size_t n, int c, int win_begin, int win_end) {
   p.max_small = 16;
   // a bucket with more than max_small fragments holds more than (max_small - 1) * L entries
   uint64_t ml = entries / ((uint64_t)(p.max_small - 1) * p.L) + 1;
-  uint64_t nbk = (uint64_t)(p.win_end - p.win_begin) * p.B;
   p.max_large = (uint32_t)(ml < nbk ? ml : nbk);
   if (p.max_large == 0) p.max_large = 1;
-  // Scalars per sort block: about 512 blocks over all windows, at least 4096 each.
+  // Pairs per sort block: about 512 blocks over all windows, at least 4096 pairs each
+  // (an MSM of a batch is never split below that).
   uint64_t ch = (entries + 511) / 512;
   if (ch < 4096) ch = 4096;
-  if (ch > n) ch = n;
+  if (ch > n_max) ch = n_max ? n_max : 1;
   p.chunk = (uint32_t)ch;
   return CURDLE_OK;
 }
@@ -200,21 +217,30 @@ void set_out_infinity(uint64_t out[18]) {
   g1_to_canonical_jac(out, inf);
 }
 
-// The GPU phases + host combine.  Caller holds g_ctx.mu; d_points / d_scalars are device pointers.
-int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int c, int win_begin, int win_end,
-                      uint64_t out[18], hipStream_t stream) {
+// The GPU phases + combine for k MSMs (k = 1: host combine; k > 1: GPU combine).
+// Caller holds g_ctx.mu; d_points / d_scalars are device pointers holding the pairs
+// of all MSMs back to back; h_off has k + 1 entries.
+int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
+                      int win_begin, int win_end, uint64_t* out, hipStream_t stream) {
+  const size_t n = h_off[k];
+  size_t n_max = 0;
+  for (size_t j = 0; j < k; j++) {
+    if (h_off[j + 1] < h_off[j]) return fail(CURDLE_EINVAL, "offsets not monotone at %zu", j);
+    if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
+  }
   MsmPlan p;
-  int rc = make_plan(p, n, c, win_begin, win_end);
+  int rc = make_plan(p, n, k, n_max, c, win_begin, win_end);
   if (rc) return rc;
   const uint32_t nw = p.win_end - p.win_begin;
   if (n == 0 || nw == 0) {
-    set_out_infinity(out);
+    for (size_t j = 0; j < k; j++) set_out_infinity(out + 18 * j);
     return CURDLE_OK;
   }
   Ctx& C = g_ctx;
-  const size_t nb = (size_t)nw * p.B;
+  const size_t nb = k * (size_t)p.NB;
   if (nb > (size_t)1024 * 4096) return fail(CURDLE_EINVAL, "%zu bucket slots exceed the scan capacity", nb);
   const size_t nlanes = ((size_t)nw * n + p.L - 1) / p.L;
+  if ((rc = ensure(C.offsets, (k + 1) * 4))) return rc;
   if ((rc = ensure(C.counts, nb * 4))) return rc;
   if ((rc = ensure(C.starts, (nb + 1) * 4))) return rc;
   if ((rc = ensure(C.cursor, nb * 4))) return rc;
@@ -225,15 +251,22 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   if ((rc = ensure(C.sorted, (size_t)nw * n * 4))) return rc;
   if ((rc = ensure(C.points28, n * kA28Bytes))) return rc;
   if ((rc = ensure(C.frags, (nb + nlanes + 1) * kX28Bytes))) return rc;
-  if ((rc = ensure(C.partials, (size_t)nw * p.nseg * kX28Bytes))) return rc;
+  if ((rc = ensure(C.partials, k * (size_t)p.NS * kX28Bytes))) return rc;
   if ((rc = ensure(C.winsums, (size_t)nw * sizeof(G1XYZZ)))) return rc;
-  if (C.h_winsums_cap < nw) {
-    if (C.h_winsums) HIP_TRY(hipHostFree(C.h_winsums));
-    C.h_winsums = nullptr;
-    HIP_TRY(hipHostMalloc((void**)&C.h_winsums, 64 * sizeof(G1XYZZ) + (size_t)nw * sizeof(G1XYZZ), hipHostMallocDefault));
-    C.h_winsums_cap = nw + 64;
+  if (k > 1) {
+    if ((rc = ensure(C.winsums28, k * (size_t)nw * kX28Bytes))) return rc;
+    if ((rc = ensure(C.results, k * 144))) return rc;
+  }
+  const size_t host_need = k > 1 ? k * 144 : (size_t)nw * sizeof(G1XYZZ);
+  if (C.h_buf_cap < host_need) {
+    if (C.h_buf) HIP_TRY(hipHostFree(C.h_buf));
+    C.h_buf = nullptr;
+    C.h_buf_cap = 0;
+    HIP_TRY(hipHostMalloc(&C.h_buf, host_need + 4096, hipHostMallocDefault));
+    C.h_buf_cap = host_need + 4096;
   }
   MsmWorkspace ws;
+  ws.offsets = (const uint32_t*)C.offsets.p;
   ws.counts = (uint32_t*)C.counts.p;
   ws.starts = (uint32_t*)C.starts.p;
   ws.cursor = (uint32_t*)C.cursor.p;
@@ -247,8 +280,11 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   ws.points28 = C.points28.p;
   ws.frags = C.frags.p;
   ws.partials = C.partials.p;
+  ws.winsums28 = C.winsums28.p;
   ws.winsums = (G1XYZZ*)C.winsums.p;
+  ws.results = (uint64_t*)C.results.p;
 
+  HIP_TRY(hipMemcpyAsync(C.offsets.p, h_off, (k + 1) * 4, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, stream));
   HIP_TRY(hipMemsetAsync(ws.nlarge, 0, 4, stream));
   Prof prof(C, stream);
@@ -270,13 +306,25 @@ int msm_device_locked(const void* d_points, const void* d_scalars, size_t n, int
   prof.mark("bucket_reduce");
   HIP_TRY(launch_window_sum(p, ws, stream));
   prof.mark("window_sum");
-  HIP_TRY(hipMemcpyAsync(C.h_winsums, ws.winsums, (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
+  if (k > 1) {
+    HIP_TRY(launch_combine(p, ws, stream));
+    prof.mark("combine");
+    HIP_TRY(hipMemcpyAsync(C.h_buf, ws.results, k * 144, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    prof.finish(p);
+    memcpy(out, C.h_buf, k * 144);
+    return CURDLE_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(C.h_buf, ws.winsums, (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof.finish(p);
 
-  // Window combine: sum_w 2^(c*w) * winsum[w], Horner from the top window down, then
-  // the 2^(c*win_begin) scaling of a partial (host/window_combine.cpp).
-  curdle_window_combine(C.h_winsums, (int)nw, p.c, p.win_begin, out);
+  // Window combine on the host: Horner from the top window down, each step shifting
+  // by the width of the window below, then the 2^shift scaling of a partial
+  // (host/window_combine.cpp).
+  int dbls[kMaxWindows];
+  for (uint32_t lw = 0; lw < nw; lw++) dbls[lw] = lw > 0 ? p.bits[p.win_begin + lw - 1] : p.shift[p.win_begin];
+  curdle_window_combine(C.h_buf, (int)nw, dbls, out);
   return CURDLE_OK;
 }
 
@@ -306,15 +354,15 @@ extern "C" int curdle_shutdown(void) {
   if (!C.inited) return CURDLE_OK;
   (void)hipSetDevice(C.device);
   (void)hipStreamSynchronize(C.stream);
-  for (Buf* b : {&C.points, &C.scalars, &C.points28, &C.counts, &C.starts, &C.cursor, &C.fragcnt, &C.foff, &C.small, &C.digits, &C.sorted, &C.frags,
-                 &C.partials, &C.winsums}) {
+  for (Buf* b : {&C.points, &C.scalars, &C.offsets, &C.points28, &C.counts, &C.starts, &C.cursor, &C.fragcnt, &C.foff,
+                 &C.small, &C.digits, &C.sorted, &C.frags, &C.partials, &C.winsums, &C.winsums28, &C.results}) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
   }
-  if (C.h_winsums) (void)hipHostFree(C.h_winsums);
-  C.h_winsums = nullptr;
-  C.h_winsums_cap = 0;
+  if (C.h_buf) (void)hipHostFree(C.h_buf);
+  C.h_buf = nullptr;
+  C.h_buf_cap = 0;
   if (C.ev_made)
     for (auto& e : C.ev) (void)hipEventDestroy(e);
   C.ev_made = false;
@@ -341,11 +389,17 @@ extern "C" int curdle_device_available(void) {
 // ---------------------------------------------------------------------------
 extern "C" int curdle_msm_window_bits(size_t n) { return choose_window_bits(n); }
 
-extern "C" int curdle_msm_num_windows(size_t n, int window_bits) {
+extern "C" int curdle_msm_window_widths(size_t n, int window_bits, int widths[64]) {
   int c = window_bits ? window_bits : choose_window_bits(n);
-  if (c < 2 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [2, 16]", c);
-  return num_windows(c);
+  if (c < 4 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", c);
+  uint8_t bits[kMaxWindows];
+  int W = window_widths(c, bits);
+  if (widths)
+    for (int w = 0; w < W; w++) widths[w] = bits[w];
+  return W;
 }
+
+extern "C" int curdle_msm_num_windows(size_t n, int window_bits) { return curdle_msm_window_widths(n, window_bits, nullptr); }
 
 extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
   if (!out_jac) return fail(CURDLE_EINVAL, "out_jac is null");
@@ -354,29 +408,55 @@ extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, si
     return CURDLE_OK;
   }
   if (!points || !scalars) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
+  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
   std::lock_guard<std::mutex> g(g_ctx.mu);
   int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(g_ctx.device));
   if ((rc = upload_locked(points, scalars, n, g_ctx.stream))) return rc;
-  return msm_device_locked(g_ctx.points.p, g_ctx.scalars.p, n, 0, 0, -1, out_jac, g_ctx.stream);
+  const uint32_t off[2] = {0, (uint32_t)n};
+  return msm_device_locked(g_ctx.points.p, g_ctx.scalars.p, off, 1, 0, 0, -1, out_jac, g_ctx.stream);
 }
 
 extern "C" int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, size_t n, int window_bits,
                                             int win_begin, int win_end, uint64_t out_jac[18], void* stream) {
   if (!out_jac) return fail(CURDLE_EINVAL, "out_jac is null");
   if (n && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
+  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
   std::lock_guard<std::mutex> g(g_ctx.mu);
   int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(g_ctx.device));
   hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
-  return msm_device_locked(d_points, d_scalars, n, window_bits, win_begin, win_end, out_jac, s);
+  const uint32_t off[2] = {0, (uint32_t)n};
+  return msm_device_locked(d_points, d_scalars, off, 1, window_bits, win_begin, win_end, out_jac, s);
 }
 
 extern "C" int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n, uint64_t out_jac[18],
                                     void* stream) {
   return curdle_msm_g1_device_windows(d_points, d_scalars, n, 0, 0, -1, out_jac, stream);
+}
+
+// k MSMs in one pass of the pipeline; inputs resident on the device.
+extern "C" int curdle_msm_g1_batch_device(const void* d_points, const void* d_scalars, const size_t* offsets, size_t k,
+                                          uint64_t* out_jac, void* stream) {
+  if (!offsets || (k && !out_jac)) return fail(CURDLE_EINVAL, "null argument");
+  if (k == 0) return CURDLE_OK;
+  if (offsets[k] > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", offsets[k]);
+  if (offsets[k] && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null");
+  std::vector<uint32_t> off(k + 1);
+  for (size_t j = 0; j <= k; j++) {
+    if (j && offsets[j] < offsets[j - 1]) return fail(CURDLE_EINVAL, "offsets not monotone at %zu", j - 1);
+    off[j] = (uint32_t)(offsets[j] - offsets[0]);
+  }
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
+  const char* dp = (const char*)d_points + offsets[0] * 96;
+  const char* ds = (const char*)d_scalars + offsets[0] * 32;
+  return msm_device_locked(dp, ds, off.data(), k, 0, 0, -1, out_jac, s);
 }
 
 extern "C" int curdle_g1_sum(const uint64_t* jac_points, size_t k, uint64_t out_jac[18]) {
@@ -396,25 +476,60 @@ extern "C" int curdle_g1_sum(const uint64_t* jac_points, size_t k, uint64_t out_
 
 extern "C" int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scalars, const size_t* offsets, size_t k,
                                    uint64_t* out_jac) {
-  if (!offsets || !out_jac) return fail(CURDLE_EINVAL, "null argument");
-  for (size_t j = 0; j < k; j++) {
+  if (!offsets || (k && !out_jac)) return fail(CURDLE_EINVAL, "null argument");
+  if (k == 0) return CURDLE_OK;
+  for (size_t j = 0; j < k; j++)
     if (offsets[j + 1] < offsets[j]) return fail(CURDLE_EINVAL, "offsets not monotone at %zu", j);
-    size_t lo = offsets[j], n = offsets[j + 1] - offsets[j];
-    int rc = curdle_msm_g1(points ? points + 12 * lo : nullptr, scalars ? scalars + 4 * lo : nullptr, n,
-                           out_jac + 18 * j);
-    if (rc) return rc;
+  const size_t lo = offsets[0], n = offsets[k] - offsets[0];
+  if (n == 0) {
+    for (size_t j = 0; j < k; j++) set_out_infinity(out_jac + 18 * j);
+    return CURDLE_OK;
   }
-  return CURDLE_OK;
+  if (!points || !scalars) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
+  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
+  std::vector<uint32_t> off(k + 1);
+  for (size_t j = 0; j <= k; j++) off[j] = (uint32_t)(offsets[j] - lo);
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  if ((rc = upload_locked(points + 12 * lo, scalars + 4 * lo, n, g_ctx.stream))) return rc;
+  return msm_device_locked(g_ctx.points.p, g_ctx.scalars.p, off.data(), k, 0, 0, -1, out_jac, g_ctx.stream);
 }
 
+// k base sets against one scalar vector: run as a batch of k MSMs whose scalar
+// segments are k device copies of the same n scalars (the recoding is a few
+// percent of an MSM; sharing it is a later refinement).
 extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k, const uint64_t* scalars, size_t n,
                                    uint64_t* out_jac) {
-  if (!out_jac || (k && !points_sets)) return fail(CURDLE_EINVAL, "null argument");
-  for (size_t j = 0; j < k; j++) {
-    int rc = curdle_msm_g1(points_sets[j], scalars, n, out_jac + 18 * j);
-    if (rc) return rc;
+  if ((k && !out_jac) || (k && !points_sets)) return fail(CURDLE_EINVAL, "null argument");
+  if (k == 0) return CURDLE_OK;
+  if (n == 0) {
+    for (size_t j = 0; j < k; j++) set_out_infinity(out_jac + 18 * j);
+    return CURDLE_OK;
   }
-  return CURDLE_OK;
+  if (!scalars) return fail(CURDLE_EINVAL, "scalars null with n = %zu", n);
+  if (k * n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "k*n = %zu exceeds the supported 2^27 pairs", k * n);
+  for (size_t j = 0; j < k; j++)
+    if (!points_sets[j]) return fail(CURDLE_EINVAL, "points_sets[%zu] is null", j);
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  Ctx& C = g_ctx;
+  if ((rc = ensure(C.points, k * n * 96))) return rc;
+  if ((rc = ensure(C.scalars, k * n * 32))) return rc;
+  std::vector<uint32_t> off(k + 1);
+  for (size_t j = 0; j < k; j++) {
+    off[j] = (uint32_t)(j * n);
+    HIP_TRY(hipMemcpyAsync((char*)C.points.p + j * n * 96, points_sets[j], n * 96, hipMemcpyHostToDevice, C.stream));
+    if (j == 0)
+      HIP_TRY(hipMemcpyAsync(C.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, C.stream));
+    else
+      HIP_TRY(hipMemcpyAsync((char*)C.scalars.p + j * n * 32, C.scalars.p, n * 32, hipMemcpyDeviceToDevice, C.stream));
+  }
+  off[k] = (uint32_t)(k * n);
+  return msm_device_locked(C.points.p, C.scalars.p, off.data(), k, 0, 0, -1, out_jac, C.stream);
 }
 
 // ---------------------------------------------------------------------------

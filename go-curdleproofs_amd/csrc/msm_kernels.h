@@ -8,31 +8,46 @@
 
 namespace curdle {
 
-// Pippenger decomposition of one MSM.  Scalars are recoded into W signed c-bit
-// digits d_w in [-2^(c-1), 2^(c-1)], so a window has B = 2^(c-1) buckets
-// (bucket b holds the points whose |digit| is b+1).
+static constexpr int kMaxWindows = 64;
+
+// Pippenger decomposition shared by the k MSMs of one call (k = 1 for a single
+// MSM).  The 255 scalar bits are cut into W windows of bits[w] bits each, as
+// even as possible.  Windows below the top one are recoded into signed digits
+// d in [-2^(b-1), 2^(b-1)] (2^(b-1) buckets: negating an affine point is free);
+// the top window keeps its unsigned digit (2^b buckets), so no carry can leave
+// it and no window is left with a handful of heavily loaded buckets.  Bucket
+// slot `base[w] + m - 1` of an MSM holds the points whose |digit| in window w
+// is m; the MSMs' slot ranges follow each other (NB slots each).
 struct MsmPlan {
-  uint32_t n;       // pairs
-  int c;            // window bits
-  int W;            // windows in the full decomposition
-  uint32_t B;       // buckets per window = 2^(c-1)
-  int win_begin;    // windows [win_begin, win_end) are computed by this call
+  uint32_t n;          // pairs of all MSMs of the call
+  uint32_t k;          // MSMs in the call
+  uint32_t n_max;      // pairs of the largest MSM
+  int c;               // requested maximum window width
+  int W;               // windows of the full decomposition
+  int win_begin;       // windows [win_begin, win_end) are computed by this call
   int win_end;
-  uint32_t seg;     // buckets per running-sum segment in the bucket reduce
-  uint32_t nseg;    // segments per window = B / seg
-  uint32_t L;       // sorted positions per accumulate lane
+  uint32_t NB;         // bucket slots per MSM over [win_begin, win_end)
+  uint32_t NS;         // bucket-reduce segments per MSM = NB / seg
+  uint32_t seg;        // buckets per running-sum segment
+  uint32_t max_nbkt;   // largest nbkt[] in range
+  uint32_t L;          // sorted positions per accumulate lane
   uint32_t max_small;  // buckets with more fragments than this are pre-merged by a block
-  uint32_t max_large;  // capacity of the large-bucket queue (= grid of merge_large)
-  uint32_t chunk;      // scalars per sort block
+  uint32_t max_large;  // capacity of the large-bucket queue
+  uint32_t chunk;      // pairs per sort block
+  uint8_t bits[kMaxWindows];    // width of window w
+  uint16_t shift[kMaxWindows];  // bit offset of window w
+  uint32_t nbkt[kMaxWindows];   // bucket slots of window w
+  uint32_t base[kMaxWindows];   // first slot of window w inside an MSM's NB slots
 };
 
 // Sizes of the internal (fp28.h) point formats, for workspace allocation.
 static constexpr size_t kX28Bytes = 224;
 static constexpr size_t kA28Bytes = 112;
 
-// Device workspace, laid out by msm_api.hip.
+// Device workspace, laid out by msm_api.hip.  nb = k * NB bucket slots.
 struct MsmWorkspace {
-  uint32_t* counts;   // [nb]      points per bucket, nb = nw * B slots (window-major)
+  const uint32_t* offsets;  // [k + 1]   first pair of each MSM (device)
+  uint32_t* counts;   // [nb]      points per bucket
   uint32_t* starts;   // [nb + 1]  exclusive prefix of counts; [nb] = number of sorted entries
   uint32_t* cursor;   // [nb]      scatter cursors (copy of starts)
   uint32_t* fragcnt;  // [nb]      accumulation fragments per bucket
@@ -41,23 +56,27 @@ struct MsmWorkspace {
   uint32_t* large;    // [max_large] buckets queued for merge_large
   uint32_t* nlarge;   // [1]
   uint32_t* digits;   // [nw][n]   |digit| | sign<<31, window-major
-  uint32_t* sorted;   // [nw * n]  point index | sign<<31, grouped by bucket
+  uint32_t* sorted;   // [nw * n]  pair index | sign<<31, grouped by bucket
   void* points28;     // [n]       input points in internal form (d28::A28, 112 B)
   void* frags;        // [nb + lanes + 1]  d28::X28 (224 B)
-  void* partials;     // [nw][nseg]        d28::X28
-  G1XYZZ* winsums;    // [nw]      gnark-form XYZZ, canonical coordinates
+  void* partials;     // [k * NS]          d28::X28
+  void* winsums28;    // [k][nw]           d28::X28 (batched calls: combined on the GPU)
+  G1XYZZ* winsums;    // [nw]      gnark-form XYZZ, canonical coordinates (k = 1: combined on the host)
+  uint64_t* results;  // [k][18]   canonical Jacobian results of a batched call
 };
 
 // Every launcher enqueues on `stream` and returns the launch status.
+hipError_t launch_convert_points(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream);
 hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);
 hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
-hipError_t launch_convert_points(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream);
 hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
+// Batched calls only: Horner over each MSM's window sums + normalisation, one lane per MSM.
+hipError_t launch_combine(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 
 // P_i = p0 + i*Q for i < n (n <= 2^27); d_table holds 27 affine points 2^j * Q.
 hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32_t n, void* d_out, hipStream_t stream);

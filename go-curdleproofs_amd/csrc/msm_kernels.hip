@@ -36,31 +36,34 @@ using d28::X28;
 
 static constexpr int kBlock = 256;
 
+// p - 2 (Fermat inversion exponent), 32-bit words
+__constant__ u32 kPminus2[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                                 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+
 // ---------------------------------------------------------------------------
-// Signed-digit recoding shared by hist and scatter.
-// f(w, d): d in [-2^(c-1), 2^(c-1)], called for w = 0..W-1 in order.
-// The scalar is shifted down c bits per window so every limb index is static
-// (runtime-indexed register arrays would go to scratch).
+// Digit recoding.  f(w, mag, neg) is called for w = 0..W-1 in order; windows
+// below the top are signed (a raw digit above half the window range becomes its
+// negative complement and carries one into the next window), the top window is
+// unsigned.  The scalar is shifted down window by window so every limb index is
+// static (runtime-indexed register arrays would go to scratch).
 // ---------------------------------------------------------------------------
 template <class F>
-__device__ __forceinline__ void for_each_digit(Fr s, int c, int W, F&& f) {
-  const u32 mask = (1u << c) - 1u;
-  const u32 half = 1u << (c - 1);
+__device__ __forceinline__ void for_each_digit(Fr s, const MsmPlan& p, F&& f) {
   u32 carry = 0;
-  for (int w = 0; w < W; w++) {
-    u32 raw = (s.l[0] & mask) + carry;
+  for (int w = 0; w < p.W; w++) {
+    const u32 c = p.bits[w];
+    const u32 raw = (s.l[0] & ((1u << c) - 1u)) + carry;
 #pragma unroll
     for (int i = 0; i < 7; i++) s.l[i] = (s.l[i] >> c) | (s.l[i + 1] << (32 - c));
     s.l[7] >>= c;
-    int d;
-    if (raw > half) {
-      d = (int)raw - (int)(1u << c);
+    u32 mag = raw, neg = 0;
+    carry = 0;
+    if (w != p.W - 1 && raw > (1u << (c - 1))) {
+      mag = (1u << c) - raw;
+      neg = 0x80000000u;
       carry = 1;
-    } else {
-      d = (int)raw;
-      carry = 0;
     }
-    f(w, d);
+    f(w, mag, neg);
   }
 }
 
@@ -80,28 +83,27 @@ __global__ void __launch_bounds__(kBlock) k_digits(const uint4* __restrict__ sca
   u32 i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= p.n) return;
   Fr s = load_scalar_canonical(scalars, i);
-  for_each_digit(s, p.c, p.W, [&](int w, int d) {
-    if (w >= p.win_begin && w < p.win_end) {
-      u32 mag = d < 0 ? (u32)(-d) : (u32)d;
-      digits[(size_t)(w - p.win_begin) * p.n + i] = mag | (d < 0 ? 0x80000000u : 0u);
-    }
+  for_each_digit(s, p, [&](int w, u32 mag, u32 neg) {
+    if (w >= p.win_begin && w < p.win_end) digits[(size_t)(w - p.win_begin) * p.n + i] = mag ? (mag | neg) : 0u;
   });
 }
 
-// Bucket sort of the point indices, per-window histogram staged in LDS
-// (B <= 32768 counters = 128 KiB of the CU's 160 KiB).  Block (chunk, window)
-// owns `chunk` consecutive scalars of one window.
+// Bucket sort of the pair indices, per-window histogram staged in LDS (at most
+// 32768 counters = 128 KiB of the CU's 160 KiB).  Block (x, lw, j) owns pairs
+// [off[j] + x*chunk, ...) of MSM j for local window lw.
 static constexpr int kSortThreads = 1024;
 
-// Phase 2: bucket sizes.  LDS atomics absorb the 16.7 M increments; one coalesced
+// Phase 2: bucket sizes.  LDS atomics absorb the increments; one coalesced
 // global atomic per (block, non-empty bucket) publishes them.
-__global__ void __launch_bounds__(kSortThreads) k_hist(const u32* __restrict__ digits, MsmPlan p, u32 chunk,
-                                                      u32* __restrict__ counts) {
+__global__ void __launch_bounds__(kSortThreads) k_hist(const u32* __restrict__ digits, MsmPlan p,
+                                                      const u32* __restrict__ offsets, u32* __restrict__ counts) {
   extern __shared__ u32 lds_cnt[];
-  const u32 lw = blockIdx.y;
-  const u32 i0 = blockIdx.x * chunk;
-  const u32 i1 = min(i0 + chunk, p.n);
-  for (u32 b = threadIdx.x; b < p.B; b += kSortThreads) lds_cnt[b] = 0;
+  const u32 lw = blockIdx.y, j = blockIdx.z;
+  const u32 i0 = offsets[j] + blockIdx.x * p.chunk;
+  const u32 i1 = min(i0 + p.chunk, offsets[j + 1]);
+  if (i0 >= i1) return;  // block-uniform
+  const u32 nb = p.nbkt[p.win_begin + lw];
+  for (u32 b = threadIdx.x; b < nb; b += kSortThreads) lds_cnt[b] = 0;
   __syncthreads();
   const u32* dw = digits + (size_t)lw * p.n;
   for (u32 i = i0 + threadIdx.x; i < i1; i += kSortThreads) {
@@ -109,8 +111,8 @@ __global__ void __launch_bounds__(kSortThreads) k_hist(const u32* __restrict__ d
     if (mag) atomicAdd(&lds_cnt[mag - 1], 1u);
   }
   __syncthreads();
-  u32* cw = counts + (size_t)lw * p.B;
-  for (u32 b = threadIdx.x; b < p.B; b += kSortThreads) {
+  u32* cw = counts + (size_t)j * p.NB + p.base[p.win_begin + lw];
+  for (u32 b = threadIdx.x; b < nb; b += kSortThreads) {
     u32 v = lds_cnt[b];
     if (v) atomicAdd(&cw[b], v);
   }
@@ -119,13 +121,16 @@ __global__ void __launch_bounds__(kSortThreads) k_hist(const u32* __restrict__ d
 // Phase 4: scatter.  The block rebuilds its local histogram, reserves a range per
 // bucket with one returning global atomic (wavefront-coalesced), then hands out
 // positions inside the ranges with LDS atomics.
-__global__ void __launch_bounds__(kSortThreads) k_scatter(const u32* __restrict__ digits, MsmPlan p, u32 chunk,
-                                                         u32* __restrict__ cursor, u32* __restrict__ sorted) {
+__global__ void __launch_bounds__(kSortThreads) k_scatter(const u32* __restrict__ digits, MsmPlan p,
+                                                         const u32* __restrict__ offsets, u32* __restrict__ cursor,
+                                                         u32* __restrict__ sorted) {
   extern __shared__ u32 lds_cnt[];
-  const u32 lw = blockIdx.y;
-  const u32 i0 = blockIdx.x * chunk;
-  const u32 i1 = min(i0 + chunk, p.n);
-  for (u32 b = threadIdx.x; b < p.B; b += kSortThreads) lds_cnt[b] = 0;
+  const u32 lw = blockIdx.y, j = blockIdx.z;
+  const u32 i0 = offsets[j] + blockIdx.x * p.chunk;
+  const u32 i1 = min(i0 + p.chunk, offsets[j + 1]);
+  if (i0 >= i1) return;  // block-uniform
+  const u32 nb = p.nbkt[p.win_begin + lw];
+  for (u32 b = threadIdx.x; b < nb; b += kSortThreads) lds_cnt[b] = 0;
   __syncthreads();
   const u32* dw = digits + (size_t)lw * p.n;
   for (u32 i = i0 + threadIdx.x; i < i1; i += kSortThreads) {
@@ -133,8 +138,8 @@ __global__ void __launch_bounds__(kSortThreads) k_scatter(const u32* __restrict_
     if (mag) atomicAdd(&lds_cnt[mag - 1], 1u);
   }
   __syncthreads();
-  u32* cw = cursor + (size_t)lw * p.B;
-  for (u32 b = threadIdx.x; b < p.B; b += kSortThreads) {
+  u32* cw = cursor + (size_t)j * p.NB + p.base[p.win_begin + lw];
+  for (u32 b = threadIdx.x; b < nb; b += kSortThreads) {
     u32 v = lds_cnt[b];
     if (v) lds_cnt[b] = atomicAdd(&cw[b], v);
   }
@@ -332,19 +337,19 @@ __global__ void __launch_bounds__(kBlock, 2)
   }
 }
 
-// One lane per segment of `seg` consecutive buckets of one window:
+// One lane per segment of `seg` consecutive buckets of one window of one MSM
+// (grid: x = segment blocks, y = local window, z = MSM):
 //   out = sum_{u < seg} (lo + u + 1) * bucket[lo + u]
 // as the classic running sum over the segment plus lo * (segment total).  A
 // bucket's value is the sum of its fragments, folded into the running sum here.
 __global__ void __launch_bounds__(kBlock, 2)
     k_bucket_reduce(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
-                    X28* __restrict__ partials, MsmPlan p, u32 nw) {
-  u32 t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= nw * p.nseg) return;
-  const u32 lw = t / p.nseg;
-  const u32 j = t - lw * p.nseg;
-  const u32 lo = j * p.seg;
-  const u32 g0 = lw * p.B + lo;
+                    X28* __restrict__ partials, MsmPlan p) {
+  const u32 w = p.win_begin + blockIdx.y, j = blockIdx.z;
+  const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= p.nbkt[w] / p.seg) return;
+  const u32 lo = t * p.seg;
+  const u32 g0 = j * p.NB + p.base[w] + lo;
   X28 run, acc, b;
   d28::set_inf(run);
   d28::set_inf(acc);
@@ -362,20 +367,23 @@ __global__ void __launch_bounds__(kBlock, 2)
     d28::mul_small(s, run, lo);
     d28::add(acc, s);
   }
-  d28::store(&partials[t], acc);
+  d28::store(&partials[(size_t)j * p.NS + p.base[w] / p.seg + t], acc);
 }
 
-// One block per window: winsums[w] = sum of the window's segment results,
-// converted back to gnark form (canonical XYZZ coordinates) for the host combine.
+// One block per (local window, MSM): sum of the window's segment results.  A
+// single MSM gets its window sums in gnark form (canonical XYZZ coordinates) for
+// the host combine; a batch keeps them in internal form for k_combine.
 __global__ void __launch_bounds__(kBlock, 2)
-    k_window_sum(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, MsmPlan p) {
+    k_window_sum(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28, MsmPlan p) {
   __shared__ X28 sh[kBlock];
-  const u32 lw = blockIdx.x;
+  const u32 lw = blockIdx.x, j = blockIdx.y;
+  const u32 w = p.win_begin + lw;
   const u32 tid = threadIdx.x;
-  const X28* pw = partials + (size_t)lw * p.nseg;
+  const u32 nseg = p.nbkt[w] / p.seg;
+  const X28* pw = partials + (size_t)j * p.NS + p.base[w] / p.seg;
   X28 acc, b;
   d28::set_inf(acc);
-  for (u32 k = tid; k < p.nseg; k += kBlock) {
+  for (u32 k = tid; k < nseg; k += kBlock) {
     d28::load(b, &pw[k]);
     d28::add(acc, b);
   }
@@ -390,12 +398,65 @@ __global__ void __launch_bounds__(kBlock, 2)
     __syncthreads();
   }
   if (tid == 0) {
-    G1XYZZ o;
-    d28::to_gnark(o, acc);
-    u32* dst = reinterpret_cast<u32*>(&winsums[lw]);
-    const u32* src = reinterpret_cast<const u32*>(&o);
-    for (int k = 0; k < 48; k++) dst[k] = src[k];
+    const u32 nw = p.win_end - p.win_begin;
+    if (p.k == 1) {
+      G1XYZZ o;
+      d28::to_gnark(o, acc);
+      u32* dst = reinterpret_cast<u32*>(&winsums[lw]);
+      const u32* src = reinterpret_cast<const u32*>(&o);
+      for (int q = 0; q < 48; q++) dst[q] = src[q];
+    } else {
+      d28::store(&winsums28[(size_t)j * nw + lw], acc);
+    }
   }
+}
+
+// Batched calls: one lane per MSM does what the host does for a single MSM --
+// Horner over the window sums, the 2^shift scaling of a partial, and the
+// normalisation to the canonical Jacobian (x, y, 1) / (1, 1, 0) in gnark form.
+// ~255 doublings + one Fermat inversion per lane; with hundreds of MSMs in
+// flight the serial chain is amortised over the batch.
+__global__ void __launch_bounds__(kBlock, 2)
+    k_combine(const X28* __restrict__ winsums28, u64* __restrict__ results, MsmPlan p) {
+  const u32 j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= p.k) return;
+  const u32 nw = p.win_end - p.win_begin;
+  X28 acc, b;
+  d28::set_inf(acc);
+  for (int lw = (int)nw - 1; lw >= 0; lw--) {
+    d28::load(b, &winsums28[(size_t)j * nw + lw]);
+    d28::add(acc, b);
+    const int dbls = lw > 0 ? p.bits[p.win_begin + lw - 1] : p.shift[p.win_begin];
+    if (!d28::is_inf(acc))
+      for (int q = 0; q < dbls; q++) d28::dbl(acc);
+  }
+  u32 w[36];
+  F28 one;
+  d28::set_one(one);
+  if (d28::is_inf(acc)) {
+    d28::to_gnark(w, one);
+    for (int q = 0; q < 12; q++) {
+      w[12 + q] = w[q];
+      w[24 + q] = 0;
+    }
+  } else {
+    F28 t, inv, izz, izzz, x, y;
+    d28::mul(t, acc.zz, acc.zzz);
+    d28::set_one(inv);
+    for (int bit = 383; bit >= 0; bit--) {
+      d28::sqr(inv, inv);
+      if ((kPminus2[bit >> 5] >> (bit & 31)) & 1u) d28::mul(inv, inv, t);
+    }
+    d28::mul(izz, inv, acc.zzz);
+    d28::mul(izzz, inv, acc.zz);
+    d28::mul(x, acc.x, izz);
+    d28::mul(y, acc.y, izzz);
+    d28::to_gnark(w, x);
+    d28::to_gnark(w + 12, y);
+    d28::to_gnark(w + 24, one);
+  }
+  u32* dst = reinterpret_cast<u32*>(results + (size_t)j * 18);
+  for (int q = 0; q < 36; q++) dst[q] = w[q];
 }
 
 // ---------------------------------------------------------------------------
@@ -425,8 +486,8 @@ hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t str
   hipError_t e = sort_lds_optin();
   if (e != hipSuccess) return e;
   const u32 nw = p.win_end - p.win_begin;
-  hipLaunchKernelGGL(k_hist, dim3(cdiv(p.n, p.chunk), nw), dim3(kSortThreads), p.B * 4, stream, ws.digits, p, p.chunk,
-                     ws.counts);
+  hipLaunchKernelGGL(k_hist, dim3(cdiv(p.n_max, p.chunk), nw, p.k), dim3(kSortThreads), p.max_nbkt * 4, stream,
+                     ws.digits, p, ws.offsets, ws.counts);
   return hipGetLastError();
 }
 
@@ -439,7 +500,7 @@ static hipError_t scan_u32(const u32* in, u32 len, u32* out, u32* blocksum, hipS
 }
 
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  const u32 nb = (p.win_end - p.win_begin) * p.B;
+  const u32 nb = p.k * p.NB;
   hipError_t e = scan_u32(ws.counts, nb, ws.starts, ws.blocksum, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fix_starts, dim3(cdiv(nb, kBlock)), dim3(kBlock), 0, stream, ws.starts, ws.blocksum, ws.counts,
@@ -455,8 +516,8 @@ hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t 
   hipError_t e = sort_lds_optin();
   if (e != hipSuccess) return e;
   const u32 nw = p.win_end - p.win_begin;
-  hipLaunchKernelGGL(k_scatter, dim3(cdiv(p.n, p.chunk), nw), dim3(kSortThreads), p.B * 4, stream, ws.digits, p,
-                     p.chunk, ws.cursor, ws.sorted);
+  hipLaunchKernelGGL(k_scatter, dim3(cdiv(p.n_max, p.chunk), nw, p.k), dim3(kSortThreads), p.max_nbkt * 4, stream,
+                     ws.digits, p, ws.offsets, ws.cursor, ws.sorted);
   return hipGetLastError();
 }
 
@@ -468,7 +529,7 @@ hipError_t launch_convert_points(const MsmPlan& p, const MsmWorkspace& ws, const
 
 hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  const u32 nb = nw * p.B;
+  const u32 nb = p.k * p.NB;
   const u32 nlanes = cdiv((u64)nw * p.n, p.L);
   hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nlanes, kBlock)), dim3(kBlock), 0, stream,
                      reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
@@ -484,16 +545,21 @@ hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStrea
 
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv((u64)nw * p.nseg, kBlock)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p,
-                     nw);
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv(p.max_nbkt / p.seg, kBlock), nw, p.k), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
   return hipGetLastError();
 }
 
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  hipLaunchKernelGGL(k_window_sum, dim3(nw), dim3(kBlock), 0, stream, reinterpret_cast<const X28*>(ws.partials),
-                     ws.winsums, p);
+  hipLaunchKernelGGL(k_window_sum, dim3(nw, p.k), dim3(kBlock), 0, stream, reinterpret_cast<const X28*>(ws.partials),
+                     ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
+  return hipGetLastError();
+}
+
+hipError_t launch_combine(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
+  hipLaunchKernelGGL(k_combine, dim3(cdiv(p.k, kBlock)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const X28*>(ws.winsums28), ws.results, p);
   return hipGetLastError();
 }
 
@@ -502,9 +568,6 @@ hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream
 // layout.  table[j] = 2^j * Q (affine).  One lane per point: <= 27 mixed adds,
 // then one Fermat inversion of ZZ*ZZZ to normalise.
 // ---------------------------------------------------------------------------
-__constant__ u32 kPminus2[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
-                                 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
-
 __global__ void __launch_bounds__(kBlock, 2)
     k_synth_walk(const G1Affine* __restrict__ table, G1Affine p0, u32 n, uint4* __restrict__ out) {
   u32 i = blockIdx.x * kBlock + threadIdx.x;

@@ -41,8 +41,8 @@ OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
 SYMBOLS = [
     "curdle_init", "curdle_shutdown", "curdle_last_error", "curdle_device_available",
     "curdle_msm_g1", "curdle_msm_g1_device", "curdle_msm_g1_device_windows",
-    "curdle_msm_window_bits", "curdle_msm_num_windows", "curdle_g1_sum",
-    "curdle_msm_g1_batch", "curdle_msm_g1_multi",
+    "curdle_msm_window_bits", "curdle_msm_num_windows", "curdle_msm_window_widths", "curdle_g1_sum",
+    "curdle_msm_g1_batch", "curdle_msm_g1_batch_device", "curdle_msm_g1_multi",
     "curdle_rand_new", "curdle_rand_free", "curdle_rand_get_fr", "curdle_rand_get_g1_affine",
     "curdle_rand_permutation",
     "curdle_acc_new", "curdle_acc_free", "curdle_acc_accumulate_check", "curdle_acc_verify",
@@ -77,6 +77,8 @@ _msm_g1_device_windows = _sig("curdle_msm_g1_device_windows", C.c_int, _vp, _vp,
                               C.c_int, _vp, _vp)
 _window_bits = _sig("curdle_msm_window_bits", C.c_int, C.c_size_t)
 _num_windows = _sig("curdle_msm_num_windows", C.c_int, C.c_size_t, C.c_int)
+_window_widths = _sig("curdle_msm_window_widths", C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int))
+_msm_batch_device = _sig("curdle_msm_g1_batch_device", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp)
 _g1_sum = _sig("curdle_g1_sum", C.c_int, _vp, C.c_size_t, _vp)
 _msm_batch = _sig("curdle_msm_g1_batch", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
 _msm_multi = _sig("curdle_msm_g1_multi", C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp)
@@ -171,6 +173,24 @@ def num_windows(n: int, c: int = 0) -> int:
     if rc < 0:
         _check(rc)
     return rc
+
+
+def window_widths(n: int, c: int = 0):
+    """Widths (bits) of the Pippenger windows for (n, c), lowest first; the top one is unsigned."""
+    buf = (C.c_int * 64)()
+    W = _window_widths(n, c, buf)
+    if W < 0:
+        _check(W)
+    return [int(buf[i]) for i in range(W)]
+
+
+def msm_g1_batch_device(d_points: int, d_scalars: int, offsets, stream: int = 0) -> np.ndarray:
+    """k independent MSMs over device-resident, concatenated inputs -> uint64[k, 18]."""
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+    k = len(offs) - 1
+    out = np.zeros((k, 18), dtype=np.uint64)
+    _check(_msm_batch_device(d_points, d_scalars, _ptr(offs), k, _ptr(out), stream or None))
+    return out
 
 
 def g1_sum(jac_points) -> np.ndarray:

@@ -82,8 +82,8 @@ int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n,
                          uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
 
 /* Partial MSM over Pippenger windows [win_begin, win_end) of the
- * decomposition the library would use for (n, window_bits); the partial is
- * already scaled by 2^(window_bits*win_begin).  Summing the partials of a
+* decomposition the library would use for (n, window_bits); the partial is
+ * already scaled by 2^(bit offset of window win_begin).  Summing the partials of a
  * partition of [0, curdle_msm_num_windows()) with curdle_g1_sum() gives the
  * full MSM.  This is the multi-GPU split of north_star: one rank per GPU, each
  * taking a window range, 144-byte partials all-gathered over RCCL.
@@ -92,7 +92,11 @@ int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, si
                                  int window_bits, int win_begin, int win_end,
                                  uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
 int curdle_msm_window_bits(size_t n);              /* the library's choice of c for n   */
-int curdle_msm_num_windows(size_t n, int window_bits); /* ceil(256 / c) for that choice */
+int curdle_msm_num_windows(size_t n, int window_bits); /* W = ceil(255 / c) for that choice */
+/* Widths of the W windows for (n, window_bits), lowest window first (sum = 255):
+ * the scalar bits are spread as evenly as possible; all windows but the top one
+ * are recoded into signed digits, the top one is unsigned.  Returns W. */
+int curdle_msm_window_widths(size_t n, int window_bits, int widths[64]);
 
 /* out = sum of k Jacobian points (host memory, any representatives).
  * Replaces the chain of G1Jac.AddAssign a caller would do on partials. */
@@ -104,6 +108,10 @@ int curdle_g1_sum(const uint64_t* jac_points, size_t k, uint64_t out_jac[CURDLE_
  * offsets has k+1 entries.  out_jac holds k results. */
 int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scalars,
                         const size_t* offsets, size_t k, uint64_t* out_jac);
+
+/* The same with inputs resident in device memory (offsets stays a host array). */
+int curdle_msm_g1_batch_device(const void* d_points, const void* d_scalars, const size_t* offsets,
+                               size_t k, uint64_t* out_jac, void* stream);
 
 /* k MSMs that share ONE scalar vector against k base sets of n points each
  * (samemultiscalarargument.go:64-70 and :206,218,231; curdleproof.go:110,114).

@@ -55,36 +55,54 @@ def test_length_mismatch_is_an_error(cm):
 
 def test_window_plan(cm):
     assert cm.num_windows(1 << 20, 16) == 16
-    # c = 3, 5, 15 need one extra window: the top digit could otherwise borrow past the end
-    assert cm.num_windows(10, 15) == 18 and cm.num_windows(10, 5) == 52 and cm.num_windows(10, 3) == 86
-    assert cm.num_windows(10, 8) == 32 and cm.num_windows(10, 13) == 20
+    assert cm.window_widths(1 << 20, 16) == [16] * 15 + [15]
+    assert cm.window_widths(10, 15) == [15] * 17
+    assert cm.window_widths(10, 14) == [14] * 8 + [13] * 11
+    for c in range(4, 17):
+        w = cm.window_widths(10, c)
+        assert len(w) == cm.num_windows(10, c) == -(-255 // c)
+        assert sum(w) == 255 and max(w) <= c and max(w) - min(w) <= 1
+        assert w[-1] == min(w) and w[-1] <= 15          # top window: narrowest, unsigned, fits the LDS histogram
     for n in (1, 7, 308, 1268, 1 << 16, 1 << 20):
-        c = cm.window_bits(n)
-        assert 2 <= c <= 16
-        assert cm.num_windows(n, c) * c >= 255
-    with pytest.raises(cm.CurdleError):
-        cm.num_windows(10, 17)
+        assert 4 <= cm.window_bits(n) <= 16
+    for bad in (3, 17):
+        with pytest.raises(cm.CurdleError):
+            cm.num_windows(10, bad)
 
 
-def test_signed_digit_windows_cover_every_scalar(cm, oracle):
-    """Host restatement of the kernels' recoding: for every c the digits of r-1 (the
-    largest scalar) and of awkward values reconstruct the scalar within num_windows(c)."""
-    vals = [oracle.R - 1, oracle.R - 2, (1 << 254) + (1 << 253), (1 << 255) % oracle.R, 0x8000800080008000, 1, 0]
-    for c in range(2, 17):
-        W = cm.num_windows(10, c)
-        half = 1 << (c - 1)
+def recode(s, widths):
+    """Host restatement of the kernels' recoding (msm_kernels.hip for_each_digit):
+    signed digits below the top window, unsigned top window.  Returns [(digit, shift)]."""
+    out, carry, v, shift = [], 0, s, 0
+    for w, c in enumerate(widths):
+        raw = (v & ((1 << c) - 1)) + carry
+        v >>= c
+        carry = 0
+        d = raw
+        if w != len(widths) - 1 and raw > (1 << (c - 1)):
+            d, carry = raw - (1 << c), 1
+        out.append((d, shift))
+        shift += c
+    assert carry == 0 and v == 0
+    return out
+
+
+def test_digit_recoding_covers_every_scalar(cm, oracle):
+    """For every window plan the digits of r-1 (the largest scalar) and of awkward
+    values reconstruct the scalar, stay inside the bucket range of their window and
+    leave no carry behind."""
+    vals = [oracle.R - 1, oracle.R - 2, (1 << 254) + (1 << 253), (1 << 255) % oracle.R, 0x8000800080008000, 1, 0,
+            (1 << 254) - 1, int("5" * 63, 16) % oracle.R]
+    for c in range(4, 17):
+        widths = cm.window_widths(10, c)
         for s in vals:
-            carry, acc, v = 0, 0, s
-            for w in range(W):
-                raw = (v & ((1 << c) - 1)) + carry
-                v >>= c
-                if raw > half:
-                    d, carry = raw - (1 << c), 1
+            digs = recode(s, widths)
+            assert sum(d << sh for d, sh in digs) == s, (c, hex(s))
+            for w, (d, _) in enumerate(digs):
+                if w == len(widths) - 1:
+                    assert 0 <= d <= (1 << widths[w]), (c, w)       # 2^b slots, index d-1
                 else:
-                    d, carry = raw, 0
-                assert -half <= d <= half
-                acc += d << (c * w)
-            assert carry == 0 and v == 0 and acc == s, (c, hex(s))
+                    assert abs(d) <= 1 << (widths[w] - 1), (c, w)   # 2^(b-1) slots
 
 
 def test_g1_sum_host(cm, oracle):

@@ -22,27 +22,18 @@ def _free_port():
     return p
 
 
-def signed_digit_partial_scalars(scalars, c, W, begin, end, R):
-    """Value of digits [begin, end) of the signed c-bit recoding (what a rank covers)."""
-    half = 1 << (c - 1)
+def partial_scalars(scalars, widths, begin, end, R):
+    """Value of digits [begin, end) of the library's recoding (what a rank covers)."""
+    from test_abi import recode
     out = []
     for s in scalars:
-        carry, acc, v = 0, 0, s
-        for w in range(W):
-            raw = (v & ((1 << c) - 1)) + carry
-            v >>= c
-            if raw > half:
-                d, carry = raw - (1 << c), 1
-            else:
-                d, carry = raw, 0
-            if begin <= w < end:
-                acc += d << (c * w)
-        out.append(acc % R)
+        digs = recode(s, widths)
+        out.append(sum(d << sh for d, sh in digs[begin:end]) % R)
     return out
 
 
 def _worker(rank, world, port, n, result_dir):
-    sys.path[:0] = [os.path.join(ROOT, "oracle", "py"), PKG]
+    sys.path[:0] = [os.path.join(ROOT, "oracle", "py"), PKG, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     import bls12381_ref as o
@@ -57,8 +48,7 @@ def _worker(rank, world, port, n, result_dir):
         sc = np.array([o.fr_to_mont_limbs(s) for s in sc_int], dtype=np.uint64)
 
         def partial_fn(c, begin, end):
-            W = cm.num_windows(n, c)
-            ps = signed_digit_partial_scalars(sc_int, c, W, begin, end, o.R)
+            ps = partial_scalars(sc_int, cm.window_widths(n, c), begin, end, o.R)
             return co.msm_pippenger(pts, np.array([o.fr_to_mont_limbs(s) for s in ps], dtype=np.uint64), threads=2)
 
         res = {}

@@ -68,10 +68,10 @@ def test_golden_vectors_bit_exact(gpu, golden):
 
 
 def test_golden_vectors_every_window_size(gpu, golden):
-    """Each supported window width c (2..16), including the widths that need an
+    """Each supported window width c (4..16), including the widths that need an
     extra top window, on vectors that exercise carries and exceptional additions."""
     try:
-        for c in range(2, 17):
+        for c in range(4, 17):
             os.environ["CURDLE_WINDOW_BITS"] = str(c)
             for name in ("rand0_n16", "rand0_n257", "edge_window_boundaries", "edge_extreme_scalars",
                          "edge_duplicate_bases", "edge_opposite_points", "edge_infinity_bases"):
@@ -221,6 +221,30 @@ def test_batch_and_multi_entry_points(gpu, oracle, coracle):
     out = gpu.msm_g1_multi(sets, s)
     for j in range(3):
         assert (out[j] == coracle.msm_pippenger(sets[j], s, threads=4)).all()
+
+
+def test_large_batch_runs_in_one_pass(gpu, oracle, coracle):
+    """Config 5 shape: many independent 628-pair MSMs (the Whisk verifier's final MSM),
+    combined on the GPU, with empty and all-infinity members in the batch."""
+    import torch
+    k, q = oracle.Rand(13).get_frs(2)
+    sizes = [628] * 60 + [0, 1, 7, 628, 0, 300]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(offs[-1])
+    pts = coracle.points_walk(k, q, n)
+    pts[offs[3]:offs[4]] = 0                      # MSM 3: every base is infinity
+    sc = rand_scalars(np.random.default_rng(13), n, oracle)
+    out = gpu.msm_g1_batch(pts, sc, offs)
+    d_pts = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    out_dev = gpu.msm_g1_batch_device(d_pts.data_ptr(), d_sc.data_ptr(), offs)
+    assert (out == out_dev).all()
+    for j, (lo, hi) in enumerate(zip(offs[:-1], offs[1:])):
+        lo, hi = int(lo), int(hi)
+        assert (out[j] == coracle.msm_pippenger(pts[lo:hi], sc[lo:hi], threads=4)).all(), j
+    assert (out[3] == out[60]).all()              # infinity either way
+    # a batch of one takes the single-MSM path and must agree
+    assert (gpu.msm_g1_batch(pts[:628], sc[:628], [0, 628])[0] == out[0]).all()
 
 
 # ----------------------------------------------------- msmaccumulator (reference tests) ---
