@@ -72,6 +72,9 @@ CURDLE_D28_TABLE(kK8, 0x1ffd5558u, 0x1f7ffffeu, 0x1ffffdceu, 0x1fff58a8u, 0x1120
                  0x19c2895eu, 0x13ba5c26u, 0x15d66bb1u, 0x1d3db219u, 0x134d258cu, 0x1f51cbfeu, 0x00d0087u)
 CURDLE_D28_TABLE(kK16, 0x1ffaaab0u, 0x1efffffeu, 0x1ffffb9eu, 0x1ffeb152u, 0x1241eabeu, 0x10f6b0f5u, 0x16730d29u,
                  0x138512beu, 0x1774b84eu, 0x1bacd763u, 0x1a7b6433u, 0x169a4b1au, 0x1ea397fdu, 0x01a0110u)
+// 8p with limbs 0..12 >= 2^30 - 4: absorbs an unnormalised subtrahend with limbs < 2^30.
+CURDLE_D28_TABLE(kK8B, 0x4ffd5558u, 0x4f7ffffbu, 0x4ffffdcbu, 0x4fff58a5u, 0x4120f55bu, 0x407b5877u, 0x4b398691u,
+                 0x49c2895bu, 0x43ba5c23u, 0x45d66baeu, 0x4d3db216u, 0x434d2589u, 0x4f51cbfbu, 0x000d0084u)
 #undef CURDLE_D28_TABLE
 
 #include "mac28_gfx950.inc"
@@ -248,6 +251,35 @@ __device__ __forceinline__ void sub(F28& r, const F28& a, const F28& b) {
   norm(r);
 }
 
+// The same without the carry pass, for results that only feed products: limbs stay
+// < 2^28 + 2^29 < 2^30, which the 64-bit column accumulators of mul / sqr absorb
+// (14 * 2^59.2 + 14 * 2^56 < 2^64 even with both factors unnormalised).
+template <int K>
+__device__ __forceinline__ void sub_raw(F28& r, const F28& a, const F28& b) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const u32 k = K == 4 ? kK4(i) : (K == 8 ? kK8(i) : kK16(i));
+    r.l[i] = a.l[i] + k - b.l[i];
+  }
+}
+// r = a + a, no carry pass (limbs < 2^29).
+__device__ __forceinline__ void dbl_raw(F28& r, const F28& a) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = a.l[i] << 1;
+}
+// r = 3a, no carry pass (limbs < 3 * 2^28 < 2^30).
+__device__ __forceinline__ void triple_raw(F28& r, const F28& a) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = a.l[i] * 3u;
+}
+// r = rr - (c + 2q) + 8p in one pass and one carry pass (the X3 of every XYZZ
+// formula): rr, c, q normalised and < 2p each  =>  r < 10p.
+__device__ __forceinline__ void x3_fused(F28& r, const F28& rr, const F28& c, const F28& q) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = rr.l[i] + kK8B(i) - c.l[i] - 2u * q.l[i];
+  norm(r);
+}
+
 // ---------------------------------------------------------------------------
 // External <-> internal
 // ---------------------------------------------------------------------------
@@ -319,85 +351,86 @@ __device__ __forceinline__ void set_inf(X28& p) {
   set_zero(p.zzz);
 }
 
-// r = 2 * (x1, y1), affine input with x1, y1 < 4p, not infinity.  mdbl-2008-s-1.
+// r = 2 * (x1, y1), affine input with x1 < 2p, y1 < 4p + (normalised), not
+// infinity.  mdbl-2008-s-1.
 __device__ __forceinline__ void dbl_affine(X28& r, const F28& x1, const F28& y1) {
-  F28 u, v, w, s, m, t;
-  add(u, y1, y1);        // < 8p
-  sqr(v, u);             // V
-  mul(w, u, v);          // W
-  mul(s, x1, v);         // S
+  F28 u, v, w, s, m, t, s2;
+  dbl_raw(u, y1);         // 2 y1 < 10p, limbs < 2^29
+  sqr(v, u);              // V
+  mul(w, u, v);           // W
+  mul(s, x1, v);          // S
   sqr(t, x1);
-  add(m, t, t);
-  add(m, m, t);          // M = 3 x1^2 < 6p
-  sqr(r.x, m);
-  add(t, s, s);          // 2S < 4p
-  sub<8>(r.x, r.x, t);   // X3 < 10p
-  sub<16>(t, s, r.x);    // S - X3 < 18p
+  triple_raw(m, t);       // M = 3 x1^2 < 6p
+  sqr(t, m);
+  set_zero(s2);
+  x3_fused(r.x, t, s2, s);  // X3 = M^2 - 2S < 10p
+  sub_raw<16>(t, s, r.x);   // S - X3 < 18p
   mul(t, m, t);
   mul(u, w, y1);
-  sub<4>(r.y, t, u);     // Y3 < 6p
+  sub<4>(r.y, t, u);      // Y3 < 6p
   r.zz = v;
   r.zzz = w;
 }
 
 // p = 2p.  dbl-2008-s-1.  Infinity stays infinity (ZZ = 0 => ZZ3 = 0).
 __device__ __forceinline__ void dbl(X28& p) {
-  F28 u, v, w, s, m, t, x3;
-  add(u, p.y, p.y);      // < 20p
+  F28 u, v, w, s, m, t, x3, z;
+  dbl_raw(u, p.y);        // < 12p
   sqr(v, u);
   mul(w, u, v);
   mul(s, p.x, v);
   sqr(t, p.x);
-  add(m, t, t);
-  add(m, m, t);          // < 6p
-  sqr(x3, m);
-  add(t, s, s);
-  sub<8>(x3, x3, t);     // < 10p
-  sub<16>(t, s, x3);     // < 18p
+  triple_raw(m, t);       // < 6p
+  sqr(t, m);
+  set_zero(z);
+  x3_fused(x3, t, z, s);  // < 10p
+  sub_raw<16>(t, s, x3);  // < 18p
   mul(t, m, t);
   mul(u, w, p.y);
-  sub<4>(p.y, t, u);     // < 6p
+  sub<4>(p.y, t, u);      // < 6p
   p.x = x3;
   mul(p.zz, v, p.zz);
   mul(p.zzz, w, p.zzz);
 }
 
-// acc += (x2, y2), affine with x2 < 2p, y2 < 4p (a negated y is 4p - y), not
-// infinity.  madd-2008-s with the exceptional cases.
+// acc += (x2, y2), affine with x2 < 2p, y2 < 4p + (a negated y is 4p - y), limbs
+// < 2^30, not infinity.  madd-2008-s with the exceptional cases.
 __device__ __forceinline__ void madd(X28& acc, const F28& x2, const F28& y2) {
   if (is_inf(acc)) {
     acc.x = x2;
     acc.y = y2;
+    norm(acc.y);
     set_one(acc.zz);
     set_one(acc.zzz);
     return;
   }
   F28 pp, r, t, q, ppp, p;
   mul(p, x2, acc.zz);
-  sub<16>(p, p, acc.x);   // P = U2 - X1 < 18p
+  sub_raw<16>(p, p, acc.x);  // P = U2 - X1 < 18p
   mul(r, y2, acc.zzz);
-  sub<16>(r, r, acc.y);   // R = S2 - Y1 < 18p
-  sqr(pp, p);             // PP < 2p
-  if (is_zero_lt2p(pp)) {  // P == 0 mod p: same x
+  sub_raw<16>(r, r, acc.y);  // R = S2 - Y1 < 18p
+  sqr(pp, p);                // PP < 2p
+  if (is_zero_lt2p(pp)) {    // P == 0 mod p: same x
     sqr(t, r);
-    if (is_zero_lt2p(t))
-      dbl_affine(acc, x2, y2);
-    else
+    if (is_zero_lt2p(t)) {
+      F28 yn = y2;
+      norm(yn);
+      dbl_affine(acc, x2, yn);
+    } else {
       set_inf(acc);
+    }
     return;
   }
-  mul(ppp, p, pp);        // PPP
-  mul(q, acc.x, pp);      // Q
+  mul(ppp, p, pp);           // PPP
+  mul(q, acc.x, pp);         // Q
   mul(acc.zz, acc.zz, pp);
   mul(acc.zzz, acc.zzz, ppp);
   sqr(t, r);
-  add(p, ppp, q);
-  add(p, p, q);           // PPP + 2Q < 6p
-  sub<8>(t, t, p);        // X3 < 10p
-  sub<16>(q, q, t);       // Q - X3 < 18p
+  x3_fused(t, t, ppp, q);    // X3 = R^2 - PPP - 2Q < 10p
+  sub_raw<16>(q, q, t);      // Q - X3 < 18p
   mul(q, r, q);
   mul(ppp, acc.y, ppp);
-  sub<4>(acc.y, q, ppp);  // Y3 < 6p
+  sub<4>(acc.y, q, ppp);     // Y3 < 6p
   acc.x = t;
 }
 
@@ -413,8 +446,8 @@ __device__ __forceinline__ void add(X28& acc, const X28& b) {
   mul(u2, b.x, acc.zz);
   mul(s1, acc.y, b.zzz);
   mul(s2, b.y, acc.zzz);
-  sub<4>(p, u2, u1);      // < 6p
-  sub<4>(r, s2, s1);      // < 6p
+  sub_raw<4>(p, u2, u1);     // < 6p
+  sub_raw<4>(r, s2, s1);     // < 6p
   sqr(pp, p);
   if (is_zero_lt2p(pp)) {
     sqr(t, r);
@@ -431,13 +464,11 @@ __device__ __forceinline__ void add(X28& acc, const X28& b) {
   mul(t, acc.zzz, b.zzz);
   mul(acc.zzz, t, ppp);
   sqr(t, r);
-  add(p, ppp, q);
-  add(p, p, q);           // < 6p
-  sub<8>(t, t, p);        // X3 < 10p
-  sub<16>(q, q, t);       // < 18p
+  x3_fused(t, t, ppp, q);    // X3 < 10p
+  sub_raw<16>(q, q, t);      // < 18p
   mul(q, r, q);
   mul(s1, s1, ppp);
-  sub<4>(acc.y, q, s1);   // < 6p
+  sub<4>(acc.y, q, s1);      // < 6p
   acc.x = t;
 }
 

@@ -251,7 +251,8 @@ int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_
   if ((rc = ensure(C.sorted, (size_t)nw * n * 4))) return rc;
   if ((rc = ensure(C.points28, n * kA28Bytes))) return rc;
   if ((rc = ensure(C.frags, (nb + nlanes + 1) * kX28Bytes))) return rc;
-  if ((rc = ensure(C.partials, k * (size_t)p.NS * kX28Bytes))) return rc;
+  const size_t bpw = ((size_t)p.max_nbkt / p.seg + 255) / 256;  // bucket-reduce blocks per window
+  if ((rc = ensure(C.partials, k * (size_t)nw * bpw * kX28Bytes))) return rc;
   if ((rc = ensure(C.winsums, (size_t)nw * sizeof(G1XYZZ)))) return rc;
   if (k > 1) {
     if ((rc = ensure(C.winsums28, k * (size_t)nw * kX28Bytes))) return rc;

@@ -59,7 +59,7 @@ struct MsmWorkspace {
   uint32_t* sorted;   // [nw * n]  pair index | sign<<31, grouped by bucket
   void* points28;     // [n]       input points in internal form (d28::A28, 112 B)
   void* frags;        // [nb + lanes + 1]  d28::X28 (224 B)
-  void* partials;     // [k * NS]          d28::X28
+  void* partials;     // [k][nw][blocks per window]  d28::X28, one per bucket-reduce block
   void* winsums28;    // [k][nw]           d28::X28 (batched calls: combined on the GPU)
   G1XYZZ* winsums;    // [nw]      gnark-form XYZZ, canonical coordinates (k = 1: combined on the host)
   uint64_t* results;  // [k][18]   canonical Jacobian results of a batched call

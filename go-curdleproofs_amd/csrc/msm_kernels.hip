@@ -278,7 +278,17 @@ __global__ void __launch_bounds__(kBlock, 2)
   u32 gend = starts[lo];
   X28 acc;
   d28::set_inf(acc);
+  // the gather of position pos + 1 is issued before the addition of position pos
+  u32 e_next = sorted[pos];
+  A28 pt_next;
+  d28::load(pt_next, &points[e_next & 0x7fffffffu]);
   for (; pos < end; pos++) {
+    const u32 e = e_next;
+    A28 pt = pt_next;
+    if (pos + 1 < end) {
+      e_next = sorted[pos + 1];
+      d28::load(pt_next, &points[e_next & 0x7fffffffu]);
+    }
     if (pos == gend) {
       d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
       d28::set_inf(acc);
@@ -287,14 +297,11 @@ __global__ void __launch_bounds__(kBlock, 2)
         gend = starts[g + 1];
       } while (gend == pos);
     }
-    const u32 e = sorted[pos];
-    A28 pt;
-    d28::load(pt, &points[e & 0x7fffffffu]);
     if (d28::affine_is_inf(pt)) continue;  // (0,0) = infinity (curdleproof.go:23)
     if (e >> 31) {
       F28 z;
       d28::set_zero(z);
-      d28::sub<4>(pt.y, z, pt.y);  // 4p - y
+      d28::sub_raw<4>(pt.y, z, pt.y);  // 4p - y
     }
     d28::madd(acc, pt.x, pt.y);
   }
@@ -339,53 +346,40 @@ __global__ void __launch_bounds__(kBlock, 2)
 
 // One lane per segment of `seg` consecutive buckets of one window of one MSM
 // (grid: x = segment blocks, y = local window, z = MSM):
-//   out = sum_{u < seg} (lo + u + 1) * bucket[lo + u]
-// as the classic running sum over the segment plus lo * (segment total).  A
+//   sum_{u < seg} (lo + u + 1) * bucket[lo + u]
+// as the classic running sum over the segment plus lo * (segment total); a
 // bucket's value is the sum of its fragments, folded into the running sum here.
+// The block then tree-sums its 256 segment results in LDS and writes one partial.
 __global__ void __launch_bounds__(kBlock, 2)
     k_bucket_reduce(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
-                    X28* __restrict__ partials, MsmPlan p) {
-  const u32 w = p.win_begin + blockIdx.y, j = blockIdx.z;
-  const u32 t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= p.nbkt[w] / p.seg) return;
-  const u32 lo = t * p.seg;
-  const u32 g0 = j * p.NB + p.base[w] + lo;
-  X28 run, acc, b;
-  d28::set_inf(run);
-  d28::set_inf(acc);
-  for (int u = (int)p.seg - 1; u >= 0; u--) {
-    const u32 m = fragcnt[g0 + u];
-    const X28* f = frags + foff[g0 + u];
-    for (u32 k = 0; k < m; k++) {
-      d28::load(b, &f[k]);
-      d28::add(run, b);
-    }
-    d28::add(acc, run);
-  }
-  if (lo != 0) {
-    X28 s;
-    d28::mul_small(s, run, lo);
-    d28::add(acc, s);
-  }
-  d28::store(&partials[(size_t)j * p.NS + p.base[w] / p.seg + t], acc);
-}
-
-// One block per (local window, MSM): sum of the window's segment results.  A
-// single MSM gets its window sums in gnark form (canonical XYZZ coordinates) for
-// the host combine; a batch keeps them in internal form for k_combine.
-__global__ void __launch_bounds__(kBlock, 2)
-    k_window_sum(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28, MsmPlan p) {
+                    X28* __restrict__ partials, MsmPlan p, u32 blocks_per_window) {
   __shared__ X28 sh[kBlock];
-  const u32 lw = blockIdx.x, j = blockIdx.y;
+  const u32 lw = blockIdx.y, j = blockIdx.z;
   const u32 w = p.win_begin + lw;
   const u32 tid = threadIdx.x;
+  const u32 t = blockIdx.x * kBlock + tid;
   const u32 nseg = p.nbkt[w] / p.seg;
-  const X28* pw = partials + (size_t)j * p.NS + p.base[w] / p.seg;
+  if (blockIdx.x * kBlock >= nseg) return;  // block-uniform
   X28 acc, b;
   d28::set_inf(acc);
-  for (u32 k = tid; k < nseg; k += kBlock) {
-    d28::load(b, &pw[k]);
-    d28::add(acc, b);
+  if (t < nseg) {
+    const u32 lo = t * p.seg;
+    const u32 g0 = j * p.NB + p.base[w] + lo;
+    X28 run;
+    d28::set_inf(run);
+    for (int u = (int)p.seg - 1; u >= 0; u--) {
+      const u32 m = fragcnt[g0 + u];
+      const X28* f = frags + foff[g0 + u];
+      for (u32 k = 0; k < m; k++) {
+        d28::load(b, &f[k]);
+        d28::add(run, b);
+      }
+      d28::add(acc, run);
+    }
+    if (lo != 0) {
+      d28::mul_small(b, run, lo);
+      d28::add(acc, b);
+    }
   }
   sh[tid] = acc;
   __syncthreads();
@@ -399,6 +393,42 @@ __global__ void __launch_bounds__(kBlock, 2)
   }
   if (tid == 0) {
     const u32 nw = p.win_end - p.win_begin;
+    d28::store(&partials[((size_t)j * nw + lw) * blocks_per_window + blockIdx.x], acc);
+  }
+}
+
+// One 64-lane block per (local window, MSM): sum of the window's block partials.
+// A single MSM gets its window sums in gnark form (canonical XYZZ coordinates) for
+// the host combine; a batch keeps them in internal form for k_combine.
+__global__ void __launch_bounds__(64, 1)
+    k_window_sum(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28, MsmPlan p,
+                 u32 blocks_per_window) {
+  __shared__ X28 sh[64];
+  const u32 lw = blockIdx.x, j = blockIdx.y;
+  const u32 w = p.win_begin + lw;
+  const u32 tid = threadIdx.x;
+  const u32 nw = p.win_end - p.win_begin;
+  const u32 nblk = (p.nbkt[w] / p.seg + kBlock - 1) / kBlock;
+  const X28* pw = partials + ((size_t)j * nw + lw) * blocks_per_window;
+  X28 acc, b;
+  d28::set_inf(acc);
+  for (u32 k = tid; k < nblk; k += 64) {
+    d28::load(b, &pw[k]);
+    d28::add(acc, b);
+  }
+  u32 width = 1;
+  while (width < nblk && width < 64) width <<= 1;
+  sh[tid] = acc;
+  __syncthreads();
+  for (u32 off = width / 2; off > 0; off >>= 1) {
+    if (tid < off) {
+      b = sh[tid + off];
+      d28::add(acc, b);
+      sh[tid] = acc;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
     if (p.k == 1) {
       G1XYZZ o;
       d28::to_gnark(o, acc);
@@ -545,15 +575,18 @@ hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStrea
 
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv(p.max_nbkt / p.seg, kBlock), nw, p.k), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
+  const u32 bpw = cdiv(p.max_nbkt / p.seg, kBlock);
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(bpw, nw, p.k), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p,
+                     bpw);
   return hipGetLastError();
 }
 
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  hipLaunchKernelGGL(k_window_sum, dim3(nw, p.k), dim3(kBlock), 0, stream, reinterpret_cast<const X28*>(ws.partials),
-                     ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
+  const u32 bpw = cdiv(p.max_nbkt / p.seg, kBlock);
+  hipLaunchKernelGGL(k_window_sum, dim3(nw, p.k), dim3(64), 0, stream, reinterpret_cast<const X28*>(ws.partials),
+                     ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p, bpw);
   return hipGetLastError();
 }
 
