@@ -101,6 +101,8 @@ int init_locked(int device) {
   return CURDLE_OK;
 }
 
+static constexpr size_t kGpuCombineMin = 32;  // batches at least this large combine their window sums on the GPU
+
 int choose_window_bits(size_t n) {
   const char* env = getenv("CURDLE_WINDOW_BITS");
   if (env) {
@@ -162,6 +164,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (p.seg < 1) p.seg = 1;
   while (p.seg > min_nbkt || (p.seg & (p.seg - 1))) p.seg >>= 1;
   p.NS = p.NB / p.seg;
+  p.G = min_nbkt / p.seg < 256 ? min_nbkt / p.seg : 256;
   // Sorted positions per accumulate lane: about two full-chip rounds of lanes
   // (256 CUs x 4 SIMDs x 2 waves x 64 lanes) for large inputs, never below 8.
   const uint64_t entries = (uint64_t)(win_end - win_begin) * n_total;
@@ -181,6 +184,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (ch < 4096) ch = 4096;
   if (ch > n_max) ch = n_max ? n_max : 1;
   p.chunk = (uint32_t)ch;
+  p.gpu_combine = k >= kGpuCombineMin ? 1u : 0u;
   return CURDLE_OK;
 }
 
@@ -217,7 +221,9 @@ void set_out_infinity(uint64_t out[18]) {
   g1_to_canonical_jac(out, inf);
 }
 
-// The GPU phases + combine for k MSMs (k = 1: host combine; k > 1: GPU combine).
+// The GPU phases + combine for k MSMs.  The ~255-doubling window combine of each MSM
+// runs on the host for single MSMs and small batches (~0.15 ms each on one core) and on
+// the GPU, one lane per MSM, once a batch is large enough to amortise the ~4 ms chain.
 // Caller holds g_ctx.mu; d_points / d_scalars are device pointers holding the pairs
 // of all MSMs back to back; h_off has k + 1 entries.
 int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
@@ -251,14 +257,13 @@ int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_
   if ((rc = ensure(C.sorted, (size_t)nw * n * 4))) return rc;
   if ((rc = ensure(C.points28, n * kA28Bytes))) return rc;
   if ((rc = ensure(C.frags, (nb + nlanes + 1) * kX28Bytes))) return rc;
-  const size_t bpw = ((size_t)p.max_nbkt / p.seg + 255) / 256;  // bucket-reduce blocks per window
-  if ((rc = ensure(C.partials, k * (size_t)nw * bpw * kX28Bytes))) return rc;
-  if ((rc = ensure(C.winsums, (size_t)nw * sizeof(G1XYZZ)))) return rc;
-  if (k > 1) {
+  if ((rc = ensure(C.partials, (k * (size_t)p.NS / p.G + 1) * kX28Bytes))) return rc;
+  if ((rc = ensure(C.winsums, k * (size_t)nw * sizeof(G1XYZZ)))) return rc;
+  if (p.gpu_combine) {
     if ((rc = ensure(C.winsums28, k * (size_t)nw * kX28Bytes))) return rc;
     if ((rc = ensure(C.results, k * 144))) return rc;
   }
-  const size_t host_need = k > 1 ? k * 144 : (size_t)nw * sizeof(G1XYZZ);
+  const size_t host_need = p.gpu_combine ? k * 144 : k * (size_t)nw * sizeof(G1XYZZ);
   if (C.h_buf_cap < host_need) {
     if (C.h_buf) HIP_TRY(hipHostFree(C.h_buf));
     C.h_buf = nullptr;
@@ -307,7 +312,7 @@ int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_
   prof.mark("bucket_reduce");
   HIP_TRY(launch_window_sum(p, ws, stream));
   prof.mark("window_sum");
-  if (k > 1) {
+  if (p.gpu_combine) {
     HIP_TRY(launch_combine(p, ws, stream));
     prof.mark("combine");
     HIP_TRY(hipMemcpyAsync(C.h_buf, ws.results, k * 144, hipMemcpyDeviceToHost, stream));
@@ -316,7 +321,7 @@ int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_
     memcpy(out, C.h_buf, k * 144);
     return CURDLE_OK;
   }
-  HIP_TRY(hipMemcpyAsync(C.h_buf, ws.winsums, (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(C.h_buf, ws.winsums, k * (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof.finish(p);
 
@@ -325,7 +330,8 @@ int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_
   // (host/window_combine.cpp).
   int dbls[kMaxWindows];
   for (uint32_t lw = 0; lw < nw; lw++) dbls[lw] = lw > 0 ? p.bits[p.win_begin + lw - 1] : p.shift[p.win_begin];
-  curdle_window_combine(C.h_buf, (int)nw, dbls, out);
+  for (size_t j = 0; j < k; j++)
+    curdle_window_combine((const G1XYZZ*)C.h_buf + j * nw, (int)nw, dbls, out + 18 * j);
   return CURDLE_OK;
 }
 

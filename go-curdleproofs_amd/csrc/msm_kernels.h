@@ -29,11 +29,13 @@ struct MsmPlan {
   uint32_t NB;         // bucket slots per MSM over [win_begin, win_end)
   uint32_t NS;         // bucket-reduce segments per MSM = NB / seg
   uint32_t seg;        // buckets per running-sum segment
+  uint32_t G;          // segment results tree-summed per partial = min(256, smallest nbkt / seg)
   uint32_t max_nbkt;   // largest nbkt[] in range
   uint32_t L;          // sorted positions per accumulate lane
   uint32_t max_small;  // buckets with more fragments than this are pre-merged by a block
   uint32_t max_large;  // capacity of the large-bucket queue
   uint32_t chunk;      // pairs per sort block
+  uint32_t gpu_combine;  // 1: window sums combined on the GPU (large batches), 0: on the host
   uint8_t bits[kMaxWindows];    // width of window w
   uint16_t shift[kMaxWindows];  // bit offset of window w
   uint32_t nbkt[kMaxWindows];   // bucket slots of window w
@@ -59,9 +61,9 @@ struct MsmWorkspace {
   uint32_t* sorted;   // [nw * n]  pair index | sign<<31, grouped by bucket
   void* points28;     // [n]       input points in internal form (d28::A28, 112 B)
   void* frags;        // [nb + lanes + 1]  d28::X28 (224 B)
-  void* partials;     // [k][nw][blocks per window]  d28::X28, one per bucket-reduce block
-  void* winsums28;    // [k][nw]           d28::X28 (batched calls: combined on the GPU)
-  G1XYZZ* winsums;    // [nw]      gnark-form XYZZ, canonical coordinates (k = 1: combined on the host)
+  void* partials;     // [k * NS / G]      d28::X28, one per group of G bucket-reduce lanes
+  void* winsums28;    // [k][nw]           d28::X28 (large batches: combined on the GPU)
+  G1XYZZ* winsums;    // [k][nw]   gnark-form XYZZ, canonical coordinates (host combine)
   uint64_t* results;  // [k][18]   canonical Jacobian results of a batched call
 };
 

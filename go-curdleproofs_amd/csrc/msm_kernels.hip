@@ -344,26 +344,28 @@ __global__ void __launch_bounds__(kBlock, 2)
   }
 }
 
-// One lane per segment of `seg` consecutive buckets of one window of one MSM
-// (grid: x = segment blocks, y = local window, z = MSM):
+// One lane per segment of `seg` consecutive buckets; the lanes run flat over the
+// segments of all windows of all MSMs of the call (q = j * NS + base[w]/seg + t):
 //   sum_{u < seg} (lo + u + 1) * bucket[lo + u]
 // as the classic running sum over the segment plus lo * (segment total); a
 // bucket's value is the sum of its fragments, folded into the running sum here.
-// The block then tree-sums its 256 segment results in LDS and writes one partial.
+// Aligned groups of G lanes (G = min(256, smallest segment count of a window), a
+// power of two, so a group never straddles two windows) are then tree-summed in
+// LDS and one partial per group is written.
 __global__ void __launch_bounds__(kBlock, 2)
     k_bucket_reduce(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
-                    X28* __restrict__ partials, MsmPlan p, u32 blocks_per_window) {
+                    X28* __restrict__ partials, MsmPlan p) {
   __shared__ X28 sh[kBlock];
-  const u32 lw = blockIdx.y, j = blockIdx.z;
-  const u32 w = p.win_begin + lw;
   const u32 tid = threadIdx.x;
-  const u32 t = blockIdx.x * kBlock + tid;
-  const u32 nseg = p.nbkt[w] / p.seg;
-  if (blockIdx.x * kBlock >= nseg) return;  // block-uniform
+  const u32 q = blockIdx.x * kBlock + tid;
   X28 acc, b;
   d28::set_inf(acc);
-  if (t < nseg) {
-    const u32 lo = t * p.seg;
+  if (q < p.k * p.NS) {
+    const u32 j = q / p.NS;
+    const u32 r = q - j * p.NS;
+    int w = p.win_begin;
+    while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
+    const u32 lo = (r - p.base[w] / p.seg) * p.seg;
     const u32 g0 = j * p.NB + p.base[w] + lo;
     X28 run;
     d28::set_inf(run);
@@ -381,43 +383,59 @@ __global__ void __launch_bounds__(kBlock, 2)
       d28::add(acc, b);
     }
   }
-  sh[tid] = acc;
-  __syncthreads();
-  for (u32 off = kBlock / 2; off > 0; off >>= 1) {
-    if (tid < off) {
-      b = sh[tid + off];
-      d28::add(acc, b);
-      sh[tid] = acc;
-    }
+  if (p.G > 1) {
+    sh[tid] = acc;
     __syncthreads();
+    for (u32 off = p.G / 2; off > 0; off >>= 1) {
+      if ((tid & (p.G - 1)) < off) {
+        b = sh[tid + off];
+        d28::add(acc, b);
+        sh[tid] = acc;
+      }
+      __syncthreads();
+    }
   }
-  if (tid == 0) {
-    const u32 nw = p.win_end - p.win_begin;
-    d28::store(&partials[((size_t)j * nw + lw) * blocks_per_window + blockIdx.x], acc);
+  if ((tid & (p.G - 1)) == 0 && q < p.k * p.NS) d28::store(&partials[q / p.G], acc);
+}
+
+__device__ __forceinline__ void write_window_sum(const X28& acc, G1XYZZ* winsums, X28* winsums28, const MsmPlan& p,
+                                                 u32 j, u32 lw) {
+  const u32 nw = p.win_end - p.win_begin;
+  if (!p.gpu_combine) {
+    G1XYZZ o;
+    d28::to_gnark(o, acc);
+    u32* dst = reinterpret_cast<u32*>(&winsums[(size_t)j * nw + lw]);
+    const u32* src = reinterpret_cast<const u32*>(&o);
+    for (int q = 0; q < 48; q++) dst[q] = src[q];
+  } else {
+    d28::store(&winsums28[(size_t)j * nw + lw], acc);
   }
 }
 
-// One 64-lane block per (local window, MSM): sum of the window's block partials.
-// A single MSM gets its window sums in gnark form (canonical XYZZ coordinates) for
-// the host combine; a batch keeps them in internal form for k_combine.
+// Window sums from the group partials.  A window owns nseg / G consecutive
+// partials.  Wide windows (many partials): one 64-lane block per (window, MSM)
+// with an LDS tree.  A call whose windows all have <= 4 partials (batches of small
+// MSMs): one lane per window, so tens of thousands of windows fill the chip.
+// With the host combine (single MSMs, small batches) the window sums are written in
+// gnark form (canonical XYZZ coordinates); a large batch keeps them in internal form
+// for k_combine.
 __global__ void __launch_bounds__(64, 1)
-    k_window_sum(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28, MsmPlan p,
-                 u32 blocks_per_window) {
+    k_window_sum_wide(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28,
+                      MsmPlan p) {
   __shared__ X28 sh[64];
   const u32 lw = blockIdx.x, j = blockIdx.y;
   const u32 w = p.win_begin + lw;
   const u32 tid = threadIdx.x;
-  const u32 nw = p.win_end - p.win_begin;
-  const u32 nblk = (p.nbkt[w] / p.seg + kBlock - 1) / kBlock;
-  const X28* pw = partials + ((size_t)j * nw + lw) * blocks_per_window;
+  const u32 np = p.nbkt[w] / p.seg / p.G;
+  const X28* pw = partials + ((size_t)j * p.NS + p.base[w] / p.seg) / p.G;
   X28 acc, b;
   d28::set_inf(acc);
-  for (u32 k = tid; k < nblk; k += 64) {
+  for (u32 k = tid; k < np; k += 64) {
     d28::load(b, &pw[k]);
     d28::add(acc, b);
   }
   u32 width = 1;
-  while (width < nblk && width < 64) width <<= 1;
+  while (width < np && width < 64) width <<= 1;
   sh[tid] = acc;
   __syncthreads();
   for (u32 off = width / 2; off > 0; off >>= 1) {
@@ -428,17 +446,26 @@ __global__ void __launch_bounds__(64, 1)
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    if (p.k == 1) {
-      G1XYZZ o;
-      d28::to_gnark(o, acc);
-      u32* dst = reinterpret_cast<u32*>(&winsums[lw]);
-      const u32* src = reinterpret_cast<const u32*>(&o);
-      for (int q = 0; q < 48; q++) dst[q] = src[q];
-    } else {
-      d28::store(&winsums28[(size_t)j * nw + lw], acc);
-    }
+  if (tid == 0) write_window_sum(acc, winsums, winsums28, p, j, lw);
+}
+
+__global__ void __launch_bounds__(kBlock, 2)
+    k_window_sum_flat(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28,
+                      MsmPlan p) {
+  const u32 nw = p.win_end - p.win_begin;
+  const u32 gw = blockIdx.x * kBlock + threadIdx.x;
+  if (gw >= p.k * nw) return;
+  const u32 j = gw / nw, lw = gw - j * nw;
+  const u32 w = p.win_begin + lw;
+  const u32 np = p.nbkt[w] / p.seg / p.G;
+  const X28* pw = partials + ((size_t)j * p.NS + p.base[w] / p.seg) / p.G;
+  X28 acc, b;
+  d28::load(acc, &pw[0]);
+  for (u32 k = 1; k < np; k++) {
+    d28::load(b, &pw[k]);
+    d28::add(acc, b);
   }
+  write_window_sum(acc, winsums, winsums28, p, j, lw);
 }
 
 // Batched calls: one lane per MSM does what the host does for a single MSM --
@@ -574,19 +601,19 @@ hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStrea
 }
 
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  const u32 nw = p.win_end - p.win_begin;
-  const u32 bpw = cdiv(p.max_nbkt / p.seg, kBlock);
-  hipLaunchKernelGGL(k_bucket_reduce, dim3(bpw, nw, p.k), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p,
-                     bpw);
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv((u64)p.k * p.NS, kBlock)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
   return hipGetLastError();
 }
 
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  const u32 bpw = cdiv(p.max_nbkt / p.seg, kBlock);
-  hipLaunchKernelGGL(k_window_sum, dim3(nw, p.k), dim3(64), 0, stream, reinterpret_cast<const X28*>(ws.partials),
-                     ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p, bpw);
+  if (p.max_nbkt / p.seg / p.G > 4)
+    hipLaunchKernelGGL(k_window_sum_wide, dim3(nw, p.k), dim3(64), 0, stream, reinterpret_cast<const X28*>(ws.partials),
+                       ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
+  else
+    hipLaunchKernelGGL(k_window_sum_flat, dim3(cdiv((u64)p.k * nw, kBlock)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
   return hipGetLastError();
 }
 
