@@ -1,5 +1,6 @@
-// C ABI of libcurdlemsm.so (include/curdle_msm.h): context, workspace, phase
-// sequencing, the host-side window combine and the accumulator / rand handles.
+// C ABI of libcurdlemsm.so (include/curdle_msm.h): context, workspace slots,
+// phase sequencing, the host-side window combine and the accumulator / rand
+// handles.
 //
 // There is deliberately no CPU implementation of the MSM behind these entry
 // points: if the HIP runtime has no device, they fail with CURDLE_ENODEV.
@@ -9,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 
@@ -44,28 +46,59 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 // ---------------------------------------------------------------------------
-// Context: one device per process, one stream, a grow-only workspace.
+// Context: one device per process; kSlots independent workspaces, each with its
+// own HIP stream, so several MSMs can be in flight (curdle_msm_g1_device_submit /
+// curdle_msm_wait): the latency-bound tail of one MSM (bucket reduce at one wave
+// per SIMD, D2H, host combine) overlaps the throughput-bound accumulation of the
+// next.  Workspaces only grow; nothing is allocated in steady state.
 // ---------------------------------------------------------------------------
 namespace {
+
+static constexpr int kSlots = 3;
+static constexpr size_t kGpuCombineMin = 32;  // batches at least this large combine their window sums on the GPU
 
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
 };
 
-struct Ctx {
-  std::mutex mu;
-  bool inited = false;
-  int device = 0;
-  hipStream_t stream = nullptr;
+struct Slot {
+  hipStream_t stream = nullptr;  // high priority: the tail phases
+  hipEvent_t acc_done = nullptr;
   Buf points, scalars, offsets, points28, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials,
       winsums, winsums28, results;
-  void* h_buf = nullptr;  // pinned: window sums (k = 1) or results (batch)
+  void* h_buf = nullptr;  // pinned: window sums (host combine) or results (GPU combine)
   size_t h_buf_cap = 0;
-  // profiling
-  bool profile = false;
   hipEvent_t ev[CURDLE_PROF_MAX_KERNELS + 1];
   bool ev_made = false;
+  // the call in flight
+  bool busy = false;
+  hipStream_t run_stream = nullptr;
+  MsmPlan plan;
+  bool profiled = false;
+  int prof_n = 0;
+  const char* prof_name[CURDLE_PROF_MAX_KERNELS];
+
+  Buf* all_bufs(int i) {
+    Buf* b[] = {&points, &scalars, &offsets, &points28, &counts, &starts, &cursor, &fragcnt, &foff, &small,
+                &digits, &sorted,  &frags,   &partials, &winsums, &winsums28, &results};
+    return i < (int)(sizeof(b) / sizeof(b[0])) ? b[i] : nullptr;
+  }
+};
+
+struct Ctx {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool inited = false;
+  int device = 0;
+  hipStream_t util_stream = nullptr;  // synthetic inputs, self-test
+  // Sort + accumulate of every MSM run in order on this normal-priority stream; each
+  // slot's latency-bound tail (merge / bucket reduce / window sum / D2H) runs on the
+  // slot's own high-priority stream, so it fills the chip's idle issue slots beside the
+  // next MSM's accumulation instead of two accumulations time-slicing each other.
+  hipStream_t main_stream = nullptr;
+  Slot slots[kSlots];
+  bool profile = false;
   curdle_profile last = {};
 };
 
@@ -95,13 +128,20 @@ int init_locked(int device) {
     return fail(CURDLE_ENODEV, "no HIP device visible (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
   if (device < 0 || device >= ndev) return fail(CURDLE_EINVAL, "device %d out of range (%d visible)", device, ndev);
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.util_stream, hipStreamNonBlocking));
+  int prio_least = 0, prio_greatest = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+  HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_stream, hipStreamNonBlocking, prio_least));
+  for (Slot& s : g_ctx.slots) {
+    HIP_TRY(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_greatest));
+    HIP_TRY(hipEventCreateWithFlags(&s.acc_done, hipEventDisableTiming));
+  }
   g_ctx.device = device;
   g_ctx.inited = true;
   return CURDLE_OK;
 }
 
-static constexpr size_t kGpuCombineMin = 32;  // batches at least this large combine their window sums on the GPU
+int init_default_locked() { return init_locked(g_ctx.inited ? g_ctx.device : 0); }
 
 int choose_window_bits(size_t n) {
   const char* env = getenv("CURDLE_WINDOW_BITS");
@@ -156,6 +196,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
     if (p.nbkt[w] < min_nbkt) min_nbkt = p.nbkt[w];
   }
   if (p.max_nbkt > 32768) return fail(CURDLE_EINVAL, "window of %u buckets exceeds the LDS histogram", p.max_nbkt);
+  if (win_begin == win_end) return CURDLE_OK;
   const uint64_t nbk = (uint64_t)k * p.NB;
   // Buckets per running-sum segment: long segments amortise the per-segment scalar
   // multiple, short ones keep the serial chain short when there are few buckets.
@@ -188,112 +229,132 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   return CURDLE_OK;
 }
 
-struct Prof {
-  Ctx& c;
-  hipStream_t s;
-  int k = 0;
-  bool on;
-  explicit Prof(Ctx& ctx, hipStream_t st) : c(ctx), s(st), on(ctx.profile) {
-    if (on && !c.ev_made) {
-      for (auto& e : c.ev) (void)hipEventCreate(&e);
-      c.ev_made = true;
-    }
-    if (on) (void)hipEventRecord(c.ev[0], s);
-  }
-  void mark(const char* name) {
-    if (!on || k >= CURDLE_PROF_MAX_KERNELS) return;
-    c.last.name[k] = name;
-    k++;
-    (void)hipEventRecord(c.ev[k], s);
-  }
-  void finish(const MsmPlan& p) {
-    if (!on) return;
-    c.last.n_kernels = k;
-    for (int i = 0; i < k; i++) (void)hipEventElapsedTime(&c.last.ms[i], c.ev[i], c.ev[i + 1]);
-    c.last.window_bits = p.c;
-    c.last.num_windows = p.W;
-  }
-};
-
 void set_out_infinity(uint64_t out[18]) {
   G1XYZZ inf;
   g1_set_inf(inf);
   g1_to_canonical_jac(out, inf);
 }
 
-// The GPU phases + combine for k MSMs.  The ~255-doubling window combine of each MSM
-// runs on the host for single MSMs and small batches (~0.15 ms each on one core) and on
-// the GPU, one lane per MSM, once a batch is large enough to amortise the ~4 ms chain.
-// Caller holds g_ctx.mu; d_points / d_scalars are device pointers holding the pairs
-// of all MSMs back to back; h_off has k + 1 entries.
-int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
-                      int win_begin, int win_end, uint64_t* out, hipStream_t stream) {
+// --- slot management -----------------------------------------------------------
+// A slot belongs to the caller from acquire to release; the context mutex only
+// guards the busy flags, so several threads can run MSMs concurrently.
+int acquire_slot(bool block, int* idx) {
+  std::unique_lock<std::mutex> g(g_ctx.mu);
+  int rc = init_default_locked();
+  if (rc) return rc;
+  for (;;) {
+    for (int i = 0; i < kSlots; i++) {
+      if (!g_ctx.slots[i].busy) {
+        g_ctx.slots[i].busy = true;
+        *idx = i;
+        return CURDLE_OK;
+      }
+    }
+    if (!block) return fail(CURDLE_EBUSY, "all %d MSM slots are in flight; call curdle_msm_wait first", kSlots);
+    g_ctx.cv.wait(g);
+  }
+}
+
+void release_slot(int idx) {
+  {
+    std::lock_guard<std::mutex> g(g_ctx.mu);
+    g_ctx.slots[idx].busy = false;
+  }
+  g_ctx.cv.notify_one();
+}
+
+struct Prof {
+  Slot& s;
+  hipStream_t st;
+  bool on;
+  Prof(Slot& slot, hipStream_t stream, bool enabled) : s(slot), st(stream), on(enabled) {
+    s.profiled = on;
+    s.prof_n = 0;
+    if (on && !s.ev_made) {
+      for (auto& e : s.ev) (void)hipEventCreate(&e);
+      s.ev_made = true;
+    }
+    if (on) (void)hipEventRecord(s.ev[0], st);
+  }
+  void mark(const char* name) {
+    if (!on || s.prof_n >= CURDLE_PROF_MAX_KERNELS) return;
+    s.prof_name[s.prof_n++] = name;
+    (void)hipEventRecord(s.ev[s.prof_n], st);
+  }
+};
+
+// Enqueue every GPU phase of k MSMs on the slot's stream (no host synchronisation).
+// d_points / d_scalars are device pointers holding the pairs of all MSMs back to back
+// and must stay valid until the matching finish_slot(); h_off has k + 1 entries.
+int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
+                 int win_begin, int win_end, hipStream_t stream, hipStream_t tail) {
   const size_t n = h_off[k];
   size_t n_max = 0;
   for (size_t j = 0; j < k; j++) {
     if (h_off[j + 1] < h_off[j]) return fail(CURDLE_EINVAL, "offsets not monotone at %zu", j);
     if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
   }
-  MsmPlan p;
+  MsmPlan& p = S.plan;
   int rc = make_plan(p, n, k, n_max, c, win_begin, win_end);
   if (rc) return rc;
+  S.run_stream = tail;
+  S.profiled = false;
   const uint32_t nw = p.win_end - p.win_begin;
-  if (n == 0 || nw == 0) {
-    for (size_t j = 0; j < k; j++) set_out_infinity(out + 18 * j);
-    return CURDLE_OK;
-  }
-  Ctx& C = g_ctx;
+  if (n == 0 || nw == 0) return CURDLE_OK;  // finish_slot writes infinities
   const size_t nb = k * (size_t)p.NB;
   if (nb > (size_t)1024 * 4096) return fail(CURDLE_EINVAL, "%zu bucket slots exceed the scan capacity", nb);
   const size_t nlanes = ((size_t)nw * n + p.L - 1) / p.L;
-  if ((rc = ensure(C.offsets, (k + 1) * 4))) return rc;
-  if ((rc = ensure(C.counts, nb * 4))) return rc;
-  if ((rc = ensure(C.starts, (nb + 1) * 4))) return rc;
-  if ((rc = ensure(C.cursor, nb * 4))) return rc;
-  if ((rc = ensure(C.fragcnt, nb * 4))) return rc;
-  if ((rc = ensure(C.foff, (nb + 1) * 4))) return rc;
-  if ((rc = ensure(C.small, (1024 + 1 + (size_t)p.max_large) * 4))) return rc;
-  if ((rc = ensure(C.digits, (size_t)nw * n * 4))) return rc;
-  if ((rc = ensure(C.sorted, (size_t)nw * n * 4))) return rc;
-  if ((rc = ensure(C.points28, n * kA28Bytes))) return rc;
-  if ((rc = ensure(C.frags, (nb + nlanes + 1) * kX28Bytes))) return rc;
-  if ((rc = ensure(C.partials, (k * (size_t)p.NS / p.G + 1) * kX28Bytes))) return rc;
-  if ((rc = ensure(C.winsums, k * (size_t)nw * sizeof(G1XYZZ)))) return rc;
+  if ((rc = ensure(S.offsets, (k + 1) * 4))) return rc;
+  if ((rc = ensure(S.counts, nb * 4))) return rc;
+  if ((rc = ensure(S.starts, (nb + 1) * 4))) return rc;
+  if ((rc = ensure(S.cursor, nb * 4))) return rc;
+  if ((rc = ensure(S.fragcnt, nb * 4))) return rc;
+  if ((rc = ensure(S.foff, (nb + 1) * 4))) return rc;
+  if ((rc = ensure(S.small, (1024 + 1 + (size_t)p.max_large) * 4))) return rc;
+  if ((rc = ensure(S.digits, (size_t)nw * n * 4))) return rc;
+  if ((rc = ensure(S.sorted, (size_t)nw * n * 4))) return rc;
+  if ((rc = ensure(S.points28, n * kA28Bytes))) return rc;
+  if ((rc = ensure(S.frags, (nb + nlanes + 1) * kX28Bytes))) return rc;
+  if ((rc = ensure(S.partials, (k * (size_t)p.NS / p.G + 1) * kX28Bytes))) return rc;
+  if ((rc = ensure(S.winsums, k * (size_t)nw * sizeof(G1XYZZ)))) return rc;
   if (p.gpu_combine) {
-    if ((rc = ensure(C.winsums28, k * (size_t)nw * kX28Bytes))) return rc;
-    if ((rc = ensure(C.results, k * 144))) return rc;
+    if ((rc = ensure(S.winsums28, k * (size_t)nw * kX28Bytes))) return rc;
+    if ((rc = ensure(S.results, k * 144))) return rc;
   }
-  const size_t host_need = p.gpu_combine ? k * 144 : k * (size_t)nw * sizeof(G1XYZZ);
-  if (C.h_buf_cap < host_need) {
-    if (C.h_buf) HIP_TRY(hipHostFree(C.h_buf));
-    C.h_buf = nullptr;
-    C.h_buf_cap = 0;
-    HIP_TRY(hipHostMalloc(&C.h_buf, host_need + 4096, hipHostMallocDefault));
-    C.h_buf_cap = host_need + 4096;
+  const size_t host_need = (p.gpu_combine ? k * 144 : k * (size_t)nw * sizeof(G1XYZZ)) + (k + 1) * 4;
+  if (S.h_buf_cap < host_need) {
+    if (S.h_buf) HIP_TRY(hipHostFree(S.h_buf));
+    S.h_buf = nullptr;
+    S.h_buf_cap = 0;
+    HIP_TRY(hipHostMalloc(&S.h_buf, host_need + 4096, hipHostMallocDefault));
+    S.h_buf_cap = host_need + 4096;
   }
   MsmWorkspace ws;
-  ws.offsets = (const uint32_t*)C.offsets.p;
-  ws.counts = (uint32_t*)C.counts.p;
-  ws.starts = (uint32_t*)C.starts.p;
-  ws.cursor = (uint32_t*)C.cursor.p;
-  ws.fragcnt = (uint32_t*)C.fragcnt.p;
-  ws.foff = (uint32_t*)C.foff.p;
-  ws.blocksum = (uint32_t*)C.small.p;
+  ws.offsets = (const uint32_t*)S.offsets.p;
+  ws.counts = (uint32_t*)S.counts.p;
+  ws.starts = (uint32_t*)S.starts.p;
+  ws.cursor = (uint32_t*)S.cursor.p;
+  ws.fragcnt = (uint32_t*)S.fragcnt.p;
+  ws.foff = (uint32_t*)S.foff.p;
+  ws.blocksum = (uint32_t*)S.small.p;
   ws.nlarge = ws.blocksum + 1024;
   ws.large = ws.blocksum + 1025;
-  ws.digits = (uint32_t*)C.digits.p;
-  ws.sorted = (uint32_t*)C.sorted.p;
-  ws.points28 = C.points28.p;
-  ws.frags = C.frags.p;
-  ws.partials = C.partials.p;
-  ws.winsums28 = C.winsums28.p;
-  ws.winsums = (G1XYZZ*)C.winsums.p;
-  ws.results = (uint64_t*)C.results.p;
+  ws.digits = (uint32_t*)S.digits.p;
+  ws.sorted = (uint32_t*)S.sorted.p;
+  ws.points28 = S.points28.p;
+  ws.frags = S.frags.p;
+  ws.partials = S.partials.p;
+  ws.winsums28 = S.winsums28.p;
+  ws.winsums = (G1XYZZ*)S.winsums.p;
+  ws.results = (uint64_t*)S.results.p;
 
-  HIP_TRY(hipMemcpyAsync(C.offsets.p, h_off, (k + 1) * 4, hipMemcpyHostToDevice, stream));
+  // the offsets are staged in pinned memory (tail of h_buf) so the copy is truly asynchronous
+  uint32_t* h_off_pinned = (uint32_t*)((char*)S.h_buf + host_need - (k + 1) * 4);
+  memcpy(h_off_pinned, h_off, (k + 1) * 4);
+  HIP_TRY(hipMemcpyAsync(S.offsets.p, h_off_pinned, (k + 1) * 4, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, stream));
   HIP_TRY(hipMemsetAsync(ws.nlarge, 0, 4, stream));
-  Prof prof(C, stream);
+  Prof prof(S, stream, g_ctx.profile);
   HIP_TRY(launch_convert_points(p, ws, d_points, stream));
   prof.mark("convert_points");
   HIP_TRY(launch_digits(p, ws, d_scalars, stream));
@@ -306,6 +367,12 @@ int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_
   prof.mark("scatter");
   HIP_TRY(launch_accumulate(p, ws, stream));
   prof.mark("accumulate");
+  if (tail != stream) {
+    HIP_TRY(hipEventRecord(S.acc_done, stream));
+    HIP_TRY(hipStreamWaitEvent(tail, S.acc_done, 0));
+    stream = tail;
+    prof.st = tail;
+  }
   HIP_TRY(launch_merge_large(p, ws, stream));
   prof.mark("merge_large");
   HIP_TRY(launch_bucket_reduce(p, ws, stream));
@@ -315,34 +382,98 @@ int msm_device_locked(const void* d_points, const void* d_scalars, const uint32_
   if (p.gpu_combine) {
     HIP_TRY(launch_combine(p, ws, stream));
     prof.mark("combine");
-    HIP_TRY(hipMemcpyAsync(C.h_buf, ws.results, k * 144, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    prof.finish(p);
-    memcpy(out, C.h_buf, k * 144);
+    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.results, k * 144, hipMemcpyDeviceToHost, stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.winsums, k * (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
+  }
+  return CURDLE_OK;
+}
+
+// Wait for the slot's GPU work and produce the k results (host combine unless the
+// batch combined on the GPU).
+int finish_slot(Slot& S, uint64_t* out) {
+  const MsmPlan& p = S.plan;
+  const size_t k = p.k;
+  const uint32_t nw = p.win_end - p.win_begin;
+  if (p.n == 0 || nw == 0) {
+    for (size_t j = 0; j < k; j++) set_out_infinity(out + 18 * j);
     return CURDLE_OK;
   }
-  HIP_TRY(hipMemcpyAsync(C.h_buf, ws.winsums, k * (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  prof.finish(p);
-
+  HIP_TRY(hipStreamSynchronize(S.run_stream));
+  if (S.profiled) {
+    std::lock_guard<std::mutex> g(g_ctx.mu);
+    curdle_profile& L = g_ctx.last;
+    L.n_kernels = S.prof_n;
+    for (int i = 0; i < S.prof_n; i++) {
+      L.name[i] = S.prof_name[i];
+      (void)hipEventElapsedTime(&L.ms[i], S.ev[i], S.ev[i + 1]);
+    }
+    L.window_bits = p.c;
+    L.num_windows = p.W;
+  }
+  if (p.gpu_combine) {
+    memcpy(out, S.h_buf, k * 144);
+    return CURDLE_OK;
+  }
   // Window combine on the host: Horner from the top window down, each step shifting
   // by the width of the window below, then the 2^shift scaling of a partial
   // (host/window_combine.cpp).
   int dbls[kMaxWindows];
   for (uint32_t lw = 0; lw < nw; lw++) dbls[lw] = lw > 0 ? p.bits[p.win_begin + lw - 1] : p.shift[p.win_begin];
   for (size_t j = 0; j < k; j++)
-    curdle_window_combine((const G1XYZZ*)C.h_buf + j * nw, (int)nw, dbls, out + 18 * j);
+    curdle_window_combine((const G1XYZZ*)S.h_buf + j * nw, (int)nw, dbls, out + 18 * j);
   return CURDLE_OK;
 }
 
-int upload_locked(const uint64_t* points, const uint64_t* scalars, size_t n, hipStream_t stream) {
-  Ctx& C = g_ctx;
-  int rc;
-  if ((rc = ensure(C.points, n * 96))) return rc;
-  if ((rc = ensure(C.scalars, n * 32))) return rc;
-  HIP_TRY(hipMemcpyAsync(C.points.p, points, n * 96, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(C.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, stream));
-  return CURDLE_OK;
+void drain_slot(Slot& S) {
+  (void)hipStreamSynchronize(g_ctx.main_stream);
+  (void)hipStreamSynchronize(S.stream);
+}
+
+// Synchronous run of k MSMs with inputs on the device.
+int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c, int win_begin,
+               int win_end, uint64_t* out, void* user_stream) {
+  int idx;
+  int rc = acquire_slot(true, &idx);
+  if (rc) return rc;
+  Slot& S = g_ctx.slots[idx];
+  hipError_t he = hipSetDevice(g_ctx.device);
+  if (he != hipSuccess) {
+    release_slot(idx);
+    return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
+  }
+  if (user_stream)
+    rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, (hipStream_t)user_stream,
+                      (hipStream_t)user_stream);
+  else
+    rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, g_ctx.main_stream, S.stream);
+  if (!rc) rc = finish_slot(S, out);
+  else drain_slot(S);
+  release_slot(idx);
+  return rc;
+}
+
+// Synchronous run with inputs in host memory: staged through the slot's own buffers.
+int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_off, size_t k, uint64_t* out) {
+  int idx;
+  int rc = acquire_slot(true, &idx);
+  if (rc) return rc;
+  Slot& S = g_ctx.slots[idx];
+  const size_t n = h_off[k];
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    int r;
+    if ((r = ensure(S.points, n * 96))) return r;
+    if ((r = ensure(S.scalars, n * 32))) return r;
+    HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, g_ctx.main_stream));
+    HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.main_stream));
+    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, g_ctx.main_stream, S.stream))) return r;
+    return finish_slot(S, out);
+  };
+  rc = body();
+  if (rc) drain_slot(S);
+  release_slot(idx);
+  return rc;
 }
 
 }  // namespace
@@ -359,22 +490,32 @@ extern "C" int curdle_shutdown(void) {
   std::lock_guard<std::mutex> g(g_ctx.mu);
   Ctx& C = g_ctx;
   if (!C.inited) return CURDLE_OK;
+  for (Slot& S : C.slots)
+    if (S.busy) return fail(CURDLE_EBUSY, "an MSM is still in flight");
   (void)hipSetDevice(C.device);
-  (void)hipStreamSynchronize(C.stream);
-  for (Buf* b : {&C.points, &C.scalars, &C.offsets, &C.points28, &C.counts, &C.starts, &C.cursor, &C.fragcnt, &C.foff,
-                 &C.small, &C.digits, &C.sorted, &C.frags, &C.partials, &C.winsums, &C.winsums28, &C.results}) {
-    if (b->p) (void)hipFree(b->p);
-    b->p = nullptr;
-    b->cap = 0;
+  for (Slot& S : C.slots) {
+    (void)hipStreamSynchronize(S.stream);
+    for (int i = 0; Buf* b = S.all_bufs(i); i++) {
+      if (b->p) (void)hipFree(b->p);
+      b->p = nullptr;
+      b->cap = 0;
+    }
+    if (S.h_buf) (void)hipHostFree(S.h_buf);
+    S.h_buf = nullptr;
+    S.h_buf_cap = 0;
+    if (S.ev_made)
+      for (auto& e : S.ev) (void)hipEventDestroy(e);
+    S.ev_made = false;
+    (void)hipStreamDestroy(S.stream);
+    S.stream = nullptr;
+    (void)hipEventDestroy(S.acc_done);
+    S.acc_done = nullptr;
   }
-  if (C.h_buf) (void)hipHostFree(C.h_buf);
-  C.h_buf = nullptr;
-  C.h_buf_cap = 0;
-  if (C.ev_made)
-    for (auto& e : C.ev) (void)hipEventDestroy(e);
-  C.ev_made = false;
-  (void)hipStreamDestroy(C.stream);
-  C.stream = nullptr;
+  (void)hipStreamSynchronize(C.main_stream);
+  (void)hipStreamDestroy(C.main_stream);
+  C.main_stream = nullptr;
+  (void)hipStreamDestroy(C.util_stream);
+  C.util_stream = nullptr;
   C.inited = false;
   return CURDLE_OK;
 }
@@ -416,13 +557,8 @@ extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, si
   }
   if (!points || !scalars) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if ((rc = upload_locked(points, scalars, n, g_ctx.stream))) return rc;
   const uint32_t off[2] = {0, (uint32_t)n};
-  return msm_device_locked(g_ctx.points.p, g_ctx.scalars.p, off, 1, 0, 0, -1, out_jac, g_ctx.stream);
+  return run_host(points, scalars, off, 1, out_jac);
 }
 
 extern "C" int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, size_t n, int window_bits,
@@ -430,13 +566,8 @@ extern "C" int curdle_msm_g1_device_windows(const void* d_points, const void* d_
   if (!out_jac) return fail(CURDLE_EINVAL, "out_jac is null");
   if (n && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
   const uint32_t off[2] = {0, (uint32_t)n};
-  return msm_device_locked(d_points, d_scalars, off, 1, window_bits, win_begin, win_end, out_jac, s);
+  return run_device(d_points, d_scalars, off, 1, window_bits, win_begin, win_end, out_jac, stream);
 }
 
 extern "C" int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n, uint64_t out_jac[18],
@@ -444,26 +575,62 @@ extern "C" int curdle_msm_g1_device(const void* d_points, const void* d_scalars,
   return curdle_msm_g1_device_windows(d_points, d_scalars, n, 0, 0, -1, out_jac, stream);
 }
 
+// Asynchronous pair: submit enqueues all GPU phases of one MSM (or one window range)
+// on a free workspace slot and returns at once; wait blocks for it and finishes on
+// the host.  Up to CURDLE_MSM_SLOTS calls can be in flight.
+extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_scalars, size_t n, int window_bits,
+                                           int win_begin, int win_end, int* ticket) {
+  if (!ticket) return fail(CURDLE_EINVAL, "ticket is null");
+  if (n && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
+  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
+  int idx;
+  int rc = acquire_slot(false, &idx);
+  if (rc) return rc;
+  Slot& S = g_ctx.slots[idx];
+  hipError_t he = hipSetDevice(g_ctx.device);
+  if (he != hipSuccess) {
+    release_slot(idx);
+    return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
+  }
+  const uint32_t off[2] = {0, (uint32_t)n};
+  rc = enqueue_slot(S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, g_ctx.main_stream, S.stream);
+  if (rc) {
+    drain_slot(S);
+    release_slot(idx);
+    return rc;
+  }
+  *ticket = idx;
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_msm_wait(int ticket, uint64_t out_jac[18]) {
+  if (ticket < 0 || ticket >= kSlots || !out_jac) return fail(CURDLE_EINVAL, "bad ticket or null output");
+  {
+    std::lock_guard<std::mutex> g(g_ctx.mu);
+    if (!g_ctx.inited || !g_ctx.slots[ticket].busy) return fail(CURDLE_EINVAL, "ticket %d is not in flight", ticket);
+  }
+  hipError_t he = hipSetDevice(g_ctx.device);
+  if (he != hipSuccess) return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
+  int rc = finish_slot(g_ctx.slots[ticket], out_jac);
+  release_slot(ticket);
+  return rc;
+}
+
 // k MSMs in one pass of the pipeline; inputs resident on the device.
 extern "C" int curdle_msm_g1_batch_device(const void* d_points, const void* d_scalars, const size_t* offsets, size_t k,
                                           uint64_t* out_jac, void* stream) {
   if (!offsets || (k && !out_jac)) return fail(CURDLE_EINVAL, "null argument");
   if (k == 0) return CURDLE_OK;
-  if (offsets[k] > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", offsets[k]);
-  if (offsets[k] && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null");
+  if (offsets[k] - offsets[0] > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "more than the supported 2^27 pairs");
+  if (offsets[k] != offsets[0] && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null");
   std::vector<uint32_t> off(k + 1);
   for (size_t j = 0; j <= k; j++) {
     if (j && offsets[j] < offsets[j - 1]) return fail(CURDLE_EINVAL, "offsets not monotone at %zu", j - 1);
     off[j] = (uint32_t)(offsets[j] - offsets[0]);
   }
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
   const char* dp = (const char*)d_points + offsets[0] * 96;
   const char* ds = (const char*)d_scalars + offsets[0] * 32;
-  return msm_device_locked(dp, ds, off.data(), k, 0, 0, -1, out_jac, s);
+  return run_device(dp, ds, off.data(), k, 0, 0, -1, out_jac, stream);
 }
 
 extern "C" int curdle_g1_sum(const uint64_t* jac_points, size_t k, uint64_t out_jac[18]) {
@@ -496,12 +663,7 @@ extern "C" int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scala
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
   std::vector<uint32_t> off(k + 1);
   for (size_t j = 0; j <= k; j++) off[j] = (uint32_t)(offsets[j] - lo);
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  if ((rc = upload_locked(points + 12 * lo, scalars + 4 * lo, n, g_ctx.stream))) return rc;
-  return msm_device_locked(g_ctx.points.p, g_ctx.scalars.p, off.data(), k, 0, 0, -1, out_jac, g_ctx.stream);
+  return run_host(points + 12 * lo, scalars + 4 * lo, off.data(), k, out_jac);
 }
 
 // k base sets against one scalar vector: run as a batch of k MSMs whose scalar
@@ -519,24 +681,34 @@ extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k,
   if (k * n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "k*n = %zu exceeds the supported 2^27 pairs", k * n);
   for (size_t j = 0; j < k; j++)
     if (!points_sets[j]) return fail(CURDLE_EINVAL, "points_sets[%zu] is null", j);
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  int idx;
+  int rc = acquire_slot(true, &idx);
   if (rc) return rc;
-  HIP_TRY(hipSetDevice(g_ctx.device));
-  Ctx& C = g_ctx;
-  if ((rc = ensure(C.points, k * n * 96))) return rc;
-  if ((rc = ensure(C.scalars, k * n * 32))) return rc;
-  std::vector<uint32_t> off(k + 1);
-  for (size_t j = 0; j < k; j++) {
-    off[j] = (uint32_t)(j * n);
-    HIP_TRY(hipMemcpyAsync((char*)C.points.p + j * n * 96, points_sets[j], n * 96, hipMemcpyHostToDevice, C.stream));
-    if (j == 0)
-      HIP_TRY(hipMemcpyAsync(C.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, C.stream));
-    else
-      HIP_TRY(hipMemcpyAsync((char*)C.scalars.p + j * n * 32, C.scalars.p, n * 32, hipMemcpyDeviceToDevice, C.stream));
-  }
-  off[k] = (uint32_t)(k * n);
-  return msm_device_locked(C.points.p, C.scalars.p, off.data(), k, 0, 0, -1, out_jac, C.stream);
+  Slot& S = g_ctx.slots[idx];
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    int r;
+    if ((r = ensure(S.points, k * n * 96))) return r;
+    if ((r = ensure(S.scalars, k * n * 32))) return r;
+    std::vector<uint32_t> off(k + 1);
+    for (size_t j = 0; j < k; j++) {
+      off[j] = (uint32_t)(j * n);
+      HIP_TRY(hipMemcpyAsync((char*)S.points.p + j * n * 96, points_sets[j], n * 96, hipMemcpyHostToDevice,
+                             g_ctx.main_stream));
+      if (j == 0)
+        HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.main_stream));
+      else
+        HIP_TRY(hipMemcpyAsync((char*)S.scalars.p + j * n * 32, S.scalars.p, n * 32, hipMemcpyDeviceToDevice,
+                               g_ctx.main_stream));
+    }
+    off[k] = (uint32_t)(k * n);
+    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, off.data(), k, 0, 0, -1, g_ctx.main_stream, S.stream))) return r;
+    return finish_slot(S, out_jac);
+  };
+  rc = body();
+  if (rc) drain_slot(S);
+  release_slot(idx);
+  return rc;
 }
 
 // ---------------------------------------------------------------------------
@@ -564,9 +736,9 @@ extern "C" int curdle_synth_points_walk_device(const uint64_t k[4], const uint64
   }
   void* d_table = nullptr;
   HIP_TRY(hipMalloc(&d_table, sizeof(table)));
-  HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, g_ctx.stream));
-  HIP_TRY(launch_synth_walk((const G1Affine*)d_table, p0, (uint32_t)n, d_out, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, g_ctx.util_stream));
+  HIP_TRY(launch_synth_walk((const G1Affine*)d_table, p0, (uint32_t)n, d_out, g_ctx.util_stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.util_stream));
   HIP_TRY(hipFree(d_table));
   return CURDLE_OK;
 }
@@ -634,10 +806,10 @@ extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64
   void *d_in = nullptr, *d_out = nullptr;
   HIP_TRY(hipMalloc(&d_in, n * in_w * 4));
   HIP_TRY(hipMalloc(&d_out, n * out_w * 4));
-  HIP_TRY(hipMemcpyAsync(d_in, in, n * in_w * 4, hipMemcpyHostToDevice, g_ctx.stream));
-  HIP_TRY(launch_selftest(op, (const uint32_t*)d_in, n, (uint32_t*)d_out, g_ctx.stream));
-  HIP_TRY(hipMemcpyAsync(out, d_out, n * out_w * 4, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(d_in, in, n * in_w * 4, hipMemcpyHostToDevice, g_ctx.util_stream));
+  HIP_TRY(launch_selftest(op, (const uint32_t*)d_in, n, (uint32_t*)d_out, g_ctx.util_stream));
+  HIP_TRY(hipMemcpyAsync(out, d_out, n * out_w * 4, hipMemcpyDeviceToHost, g_ctx.util_stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.util_stream));
   (void)hipFree(d_in);
   (void)hipFree(d_out);
   return CURDLE_OK;

@@ -252,6 +252,38 @@ __global__ void __launch_bounds__(kBlock, 2)
   d28::store(&out[i], a);
 }
 
+// Sum of `acc` over aligned groups of G lanes (G a power of two <= 256) of a
+// 256-thread block, by wave shuffles; the result is valid in the first lane of each
+// group.  No LDS tile (a 56 KiB one would keep the next MSM's LDS-histogram blocks
+// off the CU while this latency-bound kernel runs): only 4 x 224 B when G = 256.
+__device__ __forceinline__ void shfl_down_x28(X28& dst, const X28& src, u32 off) {
+  const u32* s = reinterpret_cast<const u32*>(&src);
+  u32* d = reinterpret_cast<u32*>(&dst);
+#pragma unroll
+  for (int i = 0; i < 56; i++) d[i] = __shfl_down(s[i], off, 64);
+}
+__device__ __forceinline__ void group_sum(X28& acc, u32 G, X28* wave_partials /* LDS, 4 entries */) {
+  const u32 tid = threadIdx.x;
+  const u32 lane = tid & 63u;
+  const u32 gw = G < 64u ? G : 64u;
+  X28 b;
+  for (u32 off = gw / 2; off > 0; off >>= 1) {
+    shfl_down_x28(b, acc, off);
+    if ((lane & (gw - 1)) >= off) d28::set_inf(b);  // lanes outside the live half contribute nothing
+    d28::add(acc, b);
+  }
+  if (G > 64u) {  // G = 128 or 256: combine the waves' results
+    if (lane == 0) wave_partials[tid >> 6] = acc;
+    __syncthreads();
+    if ((tid & (G - 1)) == 0) {
+      for (u32 k = 1; k < G / 64u; k++) {
+        b = wave_partials[(tid >> 6) + k];
+        d28::add(acc, b);
+      }
+    }
+  }
+}
+
 // Balanced bucket accumulation.  Lane t owns L consecutive positions of the
 // bucket-sorted point list, whatever buckets they belong to, so every lane of
 // every wave does the same number of mixed additions however skewed the scalars
@@ -313,7 +345,7 @@ __global__ void __launch_bounds__(kBlock, 2)
 __global__ void __launch_bounds__(kBlock, 2)
     k_merge_large(const u32* __restrict__ large, const u32* __restrict__ nlarge, const u32* __restrict__ foff,
                   u32* __restrict__ fragcnt, X28* __restrict__ frags, u32 max_large) {
-  __shared__ X28 sh[kBlock];
+  __shared__ X28 sh[4];
   const u32 nl = min(*nlarge, max_large);
   const u32 tid = threadIdx.x;
   for (u32 q = blockIdx.x; q < nl; q += gridDim.x) {  // block-uniform trip count
@@ -326,16 +358,7 @@ __global__ void __launch_bounds__(kBlock, 2)
       d28::load(b, &f[k]);
       d28::add(acc, b);
     }
-    sh[tid] = acc;
-    __syncthreads();
-    for (u32 off = kBlock / 2; off > 0; off >>= 1) {
-      if (tid < off) {
-        b = sh[tid + off];
-        d28::add(acc, b);
-        sh[tid] = acc;
-      }
-      __syncthreads();
-    }
+    group_sum(acc, kBlock, sh);
     if (tid == 0) {
       d28::store(&f[0], acc);
       fragcnt[g] = 1;
@@ -352,10 +375,13 @@ __global__ void __launch_bounds__(kBlock, 2)
 // Aligned groups of G lanes (G = min(256, smallest segment count of a window), a
 // power of two, so a group never straddles two windows) are then tree-summed in
 // LDS and one partial per group is written.
-__global__ void __launch_bounds__(kBlock, 2)
+// WAVES = waves per SIMD the register budget is sized for: 1 (512 VGPRs, no spills)
+// when the launch has at most one wave per SIMD anyway, 2 for large batches.
+template <int WAVES>
+__global__ void __launch_bounds__(kBlock, WAVES)
     k_bucket_reduce(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
                     X28* __restrict__ partials, MsmPlan p) {
-  __shared__ X28 sh[kBlock];
+  __shared__ X28 sh[4];
   const u32 tid = threadIdx.x;
   const u32 q = blockIdx.x * kBlock + tid;
   X28 acc, b;
@@ -383,18 +409,7 @@ __global__ void __launch_bounds__(kBlock, 2)
       d28::add(acc, b);
     }
   }
-  if (p.G > 1) {
-    sh[tid] = acc;
-    __syncthreads();
-    for (u32 off = p.G / 2; off > 0; off >>= 1) {
-      if ((tid & (p.G - 1)) < off) {
-        b = sh[tid + off];
-        d28::add(acc, b);
-        sh[tid] = acc;
-      }
-      __syncthreads();
-    }
-  }
+  if (p.G > 1) group_sum(acc, p.G, sh);
   if ((tid & (p.G - 1)) == 0 && q < p.k * p.NS) d28::store(&partials[q / p.G], acc);
 }
 
@@ -601,7 +616,10 @@ hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStrea
 }
 
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv((u64)p.k * p.NS, kBlock)), dim3(kBlock), 0, stream,
+  // The 256-register build (2 waves per SIMD) even when the launch has one wave per SIMD:
+  // it leaves room for an accumulate wave of the next MSM on the same SIMD.
+  const u64 lanes = (u64)p.k * p.NS;
+  hipLaunchKernelGGL(k_bucket_reduce<2>, dim3(cdiv(lanes, kBlock)), dim3(kBlock), 0, stream,
                      reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
   return hipGetLastError();
 }

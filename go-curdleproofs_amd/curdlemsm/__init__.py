@@ -35,12 +35,14 @@ except Exception:  # torch absent: the system ROCm runtime is used
 
 _lib = C.CDLL(LIB_PATH)
 
-OK, EINVAL, ENODEV, EHIP, ENOMEM = 0, -1, -2, -3, -4
+OK, EINVAL, ENODEV, EHIP, ENOMEM, EBUSY = 0, -1, -2, -3, -4, -5
+MSM_SLOTS = 3
 
 # Every symbol include/curdle_msm.h declares (tests check they are all exported).
 SYMBOLS = [
     "curdle_init", "curdle_shutdown", "curdle_last_error", "curdle_device_available",
     "curdle_msm_g1", "curdle_msm_g1_device", "curdle_msm_g1_device_windows",
+    "curdle_msm_g1_device_submit", "curdle_msm_wait",
     "curdle_msm_window_bits", "curdle_msm_num_windows", "curdle_msm_window_widths", "curdle_g1_sum",
     "curdle_msm_g1_batch", "curdle_msm_g1_batch_device", "curdle_msm_g1_multi",
     "curdle_rand_new", "curdle_rand_free", "curdle_rand_get_fr", "curdle_rand_get_g1_affine",
@@ -75,6 +77,9 @@ _msm_g1 = _sig("curdle_msm_g1", C.c_int, _vp, _vp, C.c_size_t, _vp)
 _msm_g1_device = _sig("curdle_msm_g1_device", C.c_int, _vp, _vp, C.c_size_t, _vp, _vp)
 _msm_g1_device_windows = _sig("curdle_msm_g1_device_windows", C.c_int, _vp, _vp, C.c_size_t, C.c_int, C.c_int,
                               C.c_int, _vp, _vp)
+_msm_submit = _sig("curdle_msm_g1_device_submit", C.c_int, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                   C.POINTER(C.c_int))
+_msm_wait = _sig("curdle_msm_wait", C.c_int, C.c_int, _vp)
 _window_bits = _sig("curdle_msm_window_bits", C.c_int, C.c_size_t)
 _num_windows = _sig("curdle_msm_num_windows", C.c_int, C.c_size_t, C.c_int)
 _window_widths = _sig("curdle_msm_window_widths", C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int))
@@ -161,6 +166,20 @@ def msm_g1_device(d_points: int, d_scalars: int, n: int, stream: int = 0, window
     out = np.zeros(18, dtype=np.uint64)
     _check(_msm_g1_device_windows(d_points, d_scalars, n, window_bits, win_begin, win_end, _ptr(out),
                                   stream or None))
+    return out
+
+
+def msm_g1_device_submit(d_points: int, d_scalars: int, n: int, window_bits: int = 0, win_begin: int = 0,
+                         win_end: int = -1) -> int:
+    """Enqueue one MSM (or window range) and return a ticket; see msm_wait()."""
+    t = C.c_int(-1)
+    _check(_msm_submit(d_points, d_scalars, n, window_bits, win_begin, win_end, C.byref(t)))
+    return t.value
+
+
+def msm_wait(ticket: int) -> np.ndarray:
+    out = np.zeros(18, dtype=np.uint64)
+    _check(_msm_wait(ticket, _ptr(out)))
     return out
 
 

@@ -41,7 +41,8 @@ extern "C" {
 #define CURDLE_ENODEV (-2) /* no usable HIP device / library not initialised    */
 #define CURDLE_EHIP (-3)   /* a HIP runtime call failed                         */
 #define CURDLE_ENOMEM (-4) /* device or host allocation failed                  */
-#define CURDLE_EFALSE (-5) /* reserved                                          */
+#define CURDLE_EBUSY (-5)  /* every MSM slot is in flight (async API)              */
+#define CURDLE_MSM_SLOTS 3 /* MSMs that can be in flight at once                   */
 
 #define CURDLE_G1_AFFINE_U64 12
 #define CURDLE_G1_JAC_U64 18
@@ -80,6 +81,18 @@ int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n,
  * library's own stream.  This is what bench.py times. */
 int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n,
                          uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
+
+/* Asynchronous form of the device-resident MSM.  submit() enqueues every GPU phase
+ * of one MSM (window range as below; window_bits = 0, win_begin = 0, win_end = -1 for
+ * the whole MSM) on a free workspace slot and returns immediately with a ticket;
+ * wait() blocks until that MSM is done, finishes it on the host and writes the
+ * result.  Up to CURDLE_MSM_SLOTS MSMs can be in flight: the latency-bound tail of
+ * one (bucket reduce, D2H, host combine) then overlaps the accumulation of the next.
+ * The device inputs must stay valid and unchanged until wait() returns.  submit()
+ * fails with CURDLE_EBUSY when every slot is in flight. */
+int curdle_msm_g1_device_submit(const void* d_points, const void* d_scalars, size_t n,
+                                int window_bits, int win_begin, int win_end, int* ticket);
+int curdle_msm_wait(int ticket, uint64_t out_jac[CURDLE_G1_JAC_U64]);
 
 /* Partial MSM over Pippenger windows [win_begin, win_end) of the
 * decomposition the library would use for (n, window_bits); the partial is

@@ -247,6 +247,50 @@ def test_large_batch_runs_in_one_pass(gpu, oracle, coracle):
     assert (gpu.msm_g1_batch(pts[:628], sc[:628], [0, 628])[0] == out[0]).all()
 
 
+def test_async_submit_wait_and_concurrent_callers(gpu, oracle, coracle):
+    """Several MSMs in flight on the workspace slots (submit / wait), waits in any
+    order, CURDLE_EBUSY when every slot is taken; and concurrent synchronous callers
+    from threads (the reference's tests run t.Parallel())."""
+    import threading
+    import torch
+    k, q = oracle.Rand(14).get_frs(2)
+    sizes = [1 << 12, 3000, 1 << 13]
+    pts = [coracle.points_walk(k + i, q, n) for i, n in enumerate(sizes)]
+    scs = [rand_scalars(np.random.default_rng(100 + i), n, oracle) for i, n in enumerate(sizes)]
+    exp = [coracle.msm_pippenger(p, s, threads=8) for p, s in zip(pts, scs)]
+    d_p = [torch.from_numpy(p.view(np.int64)).to("cuda:0") for p in pts]
+    d_s = [torch.from_numpy(s.view(np.int64)).to("cuda:0") for s in scs]
+    for _ in range(3):
+        tickets = [gpu.msm_g1_device_submit(d_p[i].data_ptr(), d_s[i].data_ptr(), sizes[i]) for i in range(3)]
+        assert sorted(tickets) == [0, 1, 2]
+        with pytest.raises(gpu.CurdleError) as e:
+            gpu.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), sizes[0])
+        assert e.value.code == gpu.EBUSY
+        for i in (1, 2, 0):                         # out-of-order waits
+            assert (gpu.msm_wait(tickets[i]) == exp[i]).all(), i
+        with pytest.raises(gpu.CurdleError):
+            gpu.msm_wait(tickets[0])                # already collected
+    # a window-range partial submitted asynchronously
+    W = gpu.num_windows(sizes[0], 12)
+    t1 = gpu.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), sizes[0], window_bits=12, win_begin=0, win_end=W // 2)
+    t2 = gpu.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), sizes[0], window_bits=12, win_begin=W // 2, win_end=W)
+    assert (gpu.g1_sum(np.stack([gpu.msm_wait(t1), gpu.msm_wait(t2)])) == exp[0]).all()
+    # threads
+    errs = []
+
+    def worker(i):
+        try:
+            for _ in range(4):
+                if not (gpu.msm_g1(pts[i % 3], scs[i % 3]) == exp[i % 3]).all():
+                    errs.append(i)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert errs == []
+
+
 # ----------------------------------------------------- msmaccumulator (reference tests) ---
 def test_msm_accumulator_reference_test(gpu):
     """msmaccumulator/msmaccumulator_test.go:12-50, sizes 0..3 (the Go loop ranges
