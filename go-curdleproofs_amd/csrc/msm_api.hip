@@ -65,6 +65,7 @@ struct Buf {
 struct Slot {
   hipStream_t stream = nullptr;  // high priority: the tail phases
   hipEvent_t acc_done = nullptr;
+  hipEvent_t pre_done = nullptr;
   Buf points, scalars, offsets, points28, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials,
       winsums, winsums28, results;
   void* h_buf = nullptr;  // pinned: window sums (host combine) or results (GPU combine)
@@ -97,6 +98,9 @@ struct Ctx {
   // slot's own high-priority stream, so it fills the chip's idle issue slots beside the
   // next MSM's accumulation instead of two accumulations time-slicing each other.
   hipStream_t main_stream = nullptr;
+  // Recoding + bucket sort of every MSM, in order; light, memory/LDS-bound phases that
+  // overlap the previous MSM's accumulation.
+  hipStream_t pre_stream = nullptr;
   Slot slots[kSlots];
   bool profile = false;
   curdle_profile last = {};
@@ -132,9 +136,11 @@ int init_locked(int device) {
   int prio_least = 0, prio_greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_stream, hipStreamNonBlocking, prio_least));
+  HIP_TRY(hipStreamCreateWithPriority(&g_ctx.pre_stream, hipStreamNonBlocking, prio_least));
   for (Slot& s : g_ctx.slots) {
     HIP_TRY(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_greatest));
     HIP_TRY(hipEventCreateWithFlags(&s.acc_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
   }
   g_ctx.device = device;
   g_ctx.inited = true;
@@ -287,7 +293,7 @@ struct Prof {
 // d_points / d_scalars are device pointers holding the pairs of all MSMs back to back
 // and must stay valid until the matching finish_slot(); h_off has k + 1 entries.
 int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
-                 int win_begin, int win_end, hipStream_t stream, hipStream_t tail) {
+                 int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail) {
   const size_t n = h_off[k];
   size_t n_max = 0;
   for (size_t j = 0; j < k; j++) {
@@ -351,20 +357,26 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
   // the offsets are staged in pinned memory (tail of h_buf) so the copy is truly asynchronous
   uint32_t* h_off_pinned = (uint32_t*)((char*)S.h_buf + host_need - (k + 1) * 4);
   memcpy(h_off_pinned, h_off, (k + 1) * 4);
-  HIP_TRY(hipMemcpyAsync(S.offsets.p, h_off_pinned, (k + 1) * 4, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, stream));
-  HIP_TRY(hipMemsetAsync(ws.nlarge, 0, 4, stream));
-  Prof prof(S, stream, g_ctx.profile);
-  HIP_TRY(launch_convert_points(p, ws, d_points, stream));
+  HIP_TRY(hipMemcpyAsync(S.offsets.p, h_off_pinned, (k + 1) * 4, hipMemcpyHostToDevice, pre));
+  HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, pre));
+  HIP_TRY(hipMemsetAsync(ws.nlarge, 0, 4, pre));
+  Prof prof(S, pre, g_ctx.profile);
+  HIP_TRY(launch_convert_points(p, ws, d_points, pre));
   prof.mark("convert_points");
-  HIP_TRY(launch_digits(p, ws, d_scalars, stream));
+  HIP_TRY(launch_digits(p, ws, d_scalars, pre));
   prof.mark("digits");
-  HIP_TRY(launch_hist(p, ws, stream));
+  HIP_TRY(launch_hist(p, ws, pre));
   prof.mark("hist");
-  HIP_TRY(launch_scan(p, ws, stream));
+  HIP_TRY(launch_scan(p, ws, pre));
   prof.mark("scan");
-  HIP_TRY(launch_scatter(p, ws, stream));
+  HIP_TRY(launch_scatter(p, ws, pre));
   prof.mark("scatter");
+  if (stream != pre) {
+    HIP_TRY(hipEventRecord(S.pre_done, pre));
+    HIP_TRY(hipStreamWaitEvent(stream, S.pre_done, 0));
+    prof.st = stream;
+    prof.mark("(queue)");  // not a kernel: time this MSM waited for the accumulate stream
+  }
   HIP_TRY(launch_accumulate(p, ws, stream));
   prof.mark("accumulate");
   if (tail != stream) {
@@ -426,6 +438,7 @@ int finish_slot(Slot& S, uint64_t* out) {
 }
 
 void drain_slot(Slot& S) {
+  (void)hipStreamSynchronize(g_ctx.pre_stream);
   (void)hipStreamSynchronize(g_ctx.main_stream);
   (void)hipStreamSynchronize(S.stream);
 }
@@ -444,9 +457,10 @@ int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_of
   }
   if (user_stream)
     rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, (hipStream_t)user_stream,
-                      (hipStream_t)user_stream);
+                      (hipStream_t)user_stream, (hipStream_t)user_stream);
   else
-    rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, g_ctx.main_stream, S.stream);
+    rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, g_ctx.pre_stream, g_ctx.main_stream,
+                      S.stream);
   if (!rc) rc = finish_slot(S, out);
   else drain_slot(S);
   release_slot(idx);
@@ -465,9 +479,10 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
     int r;
     if ((r = ensure(S.points, n * 96))) return r;
     if ((r = ensure(S.scalars, n * 32))) return r;
-    HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, g_ctx.main_stream));
-    HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.main_stream));
-    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, g_ctx.main_stream, S.stream))) return r;
+    HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, g_ctx.pre_stream));
+    HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.pre_stream));
+    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, g_ctx.pre_stream, g_ctx.main_stream, S.stream)))
+      return r;
     return finish_slot(S, out);
   };
   rc = body();
@@ -510,10 +525,15 @@ extern "C" int curdle_shutdown(void) {
     S.stream = nullptr;
     (void)hipEventDestroy(S.acc_done);
     S.acc_done = nullptr;
+    (void)hipEventDestroy(S.pre_done);
+    S.pre_done = nullptr;
   }
   (void)hipStreamSynchronize(C.main_stream);
   (void)hipStreamDestroy(C.main_stream);
   C.main_stream = nullptr;
+  (void)hipStreamSynchronize(C.pre_stream);
+  (void)hipStreamDestroy(C.pre_stream);
+  C.pre_stream = nullptr;
   (void)hipStreamDestroy(C.util_stream);
   C.util_stream = nullptr;
   C.inited = false;
@@ -593,7 +613,8 @@ extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_s
     return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
   }
   const uint32_t off[2] = {0, (uint32_t)n};
-  rc = enqueue_slot(S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, g_ctx.main_stream, S.stream);
+  rc = enqueue_slot(S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, g_ctx.pre_stream, g_ctx.main_stream,
+                    S.stream);
   if (rc) {
     drain_slot(S);
     release_slot(idx);
@@ -694,15 +715,17 @@ extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k,
     for (size_t j = 0; j < k; j++) {
       off[j] = (uint32_t)(j * n);
       HIP_TRY(hipMemcpyAsync((char*)S.points.p + j * n * 96, points_sets[j], n * 96, hipMemcpyHostToDevice,
-                             g_ctx.main_stream));
+                             g_ctx.pre_stream));
       if (j == 0)
-        HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.main_stream));
+        HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.pre_stream));
       else
         HIP_TRY(hipMemcpyAsync((char*)S.scalars.p + j * n * 32, S.scalars.p, n * 32, hipMemcpyDeviceToDevice,
-                               g_ctx.main_stream));
+                               g_ctx.pre_stream));
     }
     off[k] = (uint32_t)(k * n);
-    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, off.data(), k, 0, 0, -1, g_ctx.main_stream, S.stream))) return r;
+    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, off.data(), k, 0, 0, -1, g_ctx.pre_stream, g_ctx.main_stream,
+                          S.stream)))
+      return r;
     return finish_slot(S, out_jac);
   };
   rc = body();

@@ -23,6 +23,7 @@
 //
 // This is 381-bit integer arithmetic: no MFMA, no floating point.  Wave size 64.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "msm_kernels.h"
 
@@ -291,7 +292,8 @@ __device__ __forceinline__ void group_sum(X28& acc, u32 G, X28* wave_partials /*
 // next bucket the lane stores its running sum as a fragment of the finished
 // bucket and starts again from infinity.  Fragments of one bucket are
 // contiguous: slot = foff[bucket] + (t - start[bucket] / L).
-__global__ void __launch_bounds__(kBlock, 2)
+template <int WAVES>
+__global__ void __launch_bounds__(kBlock, WAVES)
     k_accumulate(const A28* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ starts,
                  const u32* __restrict__ foff, X28* __restrict__ frags, u32 nb, u32 L) {
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
@@ -603,9 +605,18 @@ hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream
   const u32 nw = p.win_end - p.win_begin;
   const u32 nb = p.k * p.NB;
   const u32 nlanes = cdiv((u64)nw * p.n, p.L);
-  hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nlanes, kBlock)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
-                     reinterpret_cast<X28*>(ws.frags), nb, p.L);
+  static const int waves = [] {
+    const char* e = getenv("CURDLE_ACC_WAVES");
+    return e ? atoi(e) : 2;
+  }();
+  if (waves == 3)
+    hipLaunchKernelGGL(k_accumulate<3>, dim3(cdiv(nlanes, kBlock)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
+                       reinterpret_cast<X28*>(ws.frags), nb, p.L);
+  else
+    hipLaunchKernelGGL(k_accumulate<2>, dim3(cdiv(nlanes, kBlock)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
+                       reinterpret_cast<X28*>(ws.frags), nb, p.L);
   return hipGetLastError();
 }
 

@@ -167,7 +167,7 @@ int curdle_acc_export(const curdle_acc* a, uint64_t* points, uint64_t* scalars);
  * Profiling and diagnostics (used by bench.py and tests; not part of the
  * reference's surface).
  * ------------------------------------------------------------------------- */
-#define CURDLE_PROF_MAX_KERNELS 16
+#define CURDLE_PROF_MAX_KERNELS 16 /* phases incl. the "(queue)" pseudo-phase */
 typedef struct {
   int n_kernels;
   const char* name[CURDLE_PROF_MAX_KERNELS];

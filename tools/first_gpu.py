@@ -61,7 +61,7 @@ for n in (0, 1, 2, 3, 16, 64, 257, 300):
     log(f"msm n={n}: parity", got == exp, cm.profile_last() if False else "")
 # every window size
 exp64 = o.msm(base_pts[:64], base_sc[:64])
-for c in range(2, 17):
+for c in range(4, 17):
     os.environ["CURDLE_WINDOW_BITS"] = str(c)
     got = o.jac_from_mont_limbs([int(x) for x in cm.msm_g1(P_l[:64], S_l[:64])])
     log(f"msm n=64 c={c}: parity", got == exp64)

@@ -5,12 +5,13 @@ wide (16 B/lane) read at 64 B, so the read side is doubled; WRITE_SIZE is exact.
 Both counters are in KiB.
     python tools/pmc_summary.py <fetch.csv> <write.csv> [out.json]
 """
-import collections, csv, json, sys
+import collections, csv, json, re, sys
 
 def per_kernel(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0].replace("curdle::k_", "").replace("curdle::", "")
+        m = re.search(r"curdle::k_(\w+)", r["Kernel_Name"])
+        name = m.group(1) if m else r["Kernel_Name"].split("(")[0]
         agg[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
