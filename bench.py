@@ -36,6 +36,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "go-curdleproofs_amd"))
+# The library keeps up to 10 HIP streams busy (sort, accumulate, one tail per MSM in flight);
+# ROCm's default of 4 hardware queues per process makes some of them share a queue and
+# serialise.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 R_INV = pow(1 << 256, -1, R_MOD)
@@ -71,6 +75,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3,
                     help="MSMs in flight (curdle_msm_g1_device_submit/wait); 1 = strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: on ONE GPU, run only the window range rank 0 of an N-rank job would "
+                         "run (no collective); prints the per-rank step time, not a bench line")
     args = ap.parse_args()
 
     import torch
@@ -86,8 +93,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("CURDLE_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on one GPU
+        if backend != "nccl":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if not cm.device_available():
         raise SystemExit("bench.py: no HIP device visible; the MSM has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -111,19 +124,29 @@ def main():
     if world > 1:
         from curdlemsm.distributed import gather_partials, window_partition
         wb, we = window_partition(W, world, rank)
+    elif args.emulate_world > 1:
+        from curdlemsm.distributed import window_partition
+        wb, we = window_partition(W, args.emulate_world, 0)
     else:
         wb, we = 0, W
 
+    host_t = {"submit": 0.0, "wait": 0.0}
+
     def submit():
-        return cm.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c, win_begin=wb, win_end=we)
+        t_ = time.perf_counter()
+        tk = cm.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c, win_begin=wb, win_end=we)
+        host_t["submit"] += time.perf_counter() - t_
+        return tk
 
     def collect(ticket):
         """Result of one step on every rank: wait for this rank's window range, then (N > 1)
         all-gather the 144-byte partials over RCCL and add them."""
+        t_ = time.perf_counter()
         part = cm.msm_wait(ticket)
+        host_t["wait"] += time.perf_counter() - t_
         if world == 1:
             return part
-        return cm.g1_sum(gather_partials(part, device=dev))
+        return cm.g1_sum(gather_partials(part, device=dev if dist.get_backend() == "nccl" else None))
 
     def run_steps(count, on_step=None):
         """`count` steps with up to `depth` MSMs in flight; every step is submitted,
@@ -155,16 +178,18 @@ def main():
             kernel_ms.setdefault(name, []).append(ms)
 
     barrier()
+    host_t["submit"] = host_t["wait"] = 0.0
     t0 = time.perf_counter()
     result = run_steps(args.steps, record)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
     value = n * args.steps / elapsed
+    host_ms = {k_: round(v * 1e3 / args.steps, 4) for k_, v in host_t.items()}   # host time per step in submit / wait
     # after the timed region: latency of one call with nothing else in flight, and the
     # kernels' durations when they run alone (with several MSMs in flight the HIP-event
     # spans of the timed region include the time a kernel shares the chip with the
@@ -180,6 +205,11 @@ def main():
             solo_ms.setdefault(name, []).append(ms)
     single_call_ms = float(np.median(lat))
 
+    if args.emulate_world > 1:
+        print(json.dumps({"emulated_world": args.emulate_world, "windows": [wb, we], "ms_per_step_rank0": ms_per_step,
+                          "single_call_ms": single_call_ms, "in_flight": depth, "host_ms_per_step": host_ms,
+                          "kernel_ms": {k_: round(float(np.mean(v)), 4) for k_, v in kernel_ms.items()}}))
+        return
     if rank == 0:
         # dominant kernel: bucket accumulation.  One launch covers this rank's windows
         # over all n pairs; algorithmic bytes per launch = 128 B x n (inputs read once).

@@ -54,7 +54,7 @@ static int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 namespace {
 
-static constexpr int kSlots = 3;
+static constexpr int kSlots = 8;
 static constexpr size_t kGpuCombineMin = 32;  // batches at least this large combine their window sums on the GPU
 
 struct Buf {
@@ -137,8 +137,13 @@ int init_locked(int device) {
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_stream, hipStreamNonBlocking, prio_least));
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.pre_stream, hipStreamNonBlocking, prio_least));
+  // Tail streams at normal priority by default: on ROCm 7.2 all high-priority streams of a
+  // process appear to share one hardware queue, which serialises the tails of consecutive
+  // MSMs (measured: 0.93 vs 0.84 ms per 2-window partial).  CURDLE_TAIL_PRIO=1 restores it.
+  const char* tp = getenv("CURDLE_TAIL_PRIO");
+  const int tail_prio = (tp && atoi(tp) == 1) ? prio_greatest : prio_least;
   for (Slot& s : g_ctx.slots) {
-    HIP_TRY(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, tail_prio));
     HIP_TRY(hipEventCreateWithFlags(&s.acc_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
   }
@@ -174,7 +179,8 @@ int window_widths(int c, uint8_t bits[kMaxWindows]) {
 }
 
 // Plan for k MSMs of n_total pairs in all, the largest having n_max pairs.
-int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end) {
+int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end,
+              bool latency_mode) {
   if (n_total > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n_total);
   if (c == 0) c = choose_window_bits(n_max);
   if (c < 4 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", c);
@@ -211,7 +217,15 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (p.seg < 1) p.seg = 1;
   while (p.seg > min_nbkt || (p.seg & (p.seg - 1))) p.seg >>= 1;
   p.NS = p.NB / p.seg;
-  p.G = min_nbkt / p.seg < 256 ? min_nbkt / p.seg : 256;
+  // Four lanes per point operation in the latency-bound kernels when the caller waits for
+  // this very call (synchronous entry points) and even the four-fold lane count is at most
+  // one round of the chip at two waves per SIMD.  It shortens the tail of an isolated call
+  // by ~0.4 ms but costs ~40 % more multiplier work, so pipelined (submit / wait) calls,
+  // whose tails overlap other MSMs' accumulation anyway, keep one lane per operation.
+  p.quad = latency_mode && (uint64_t)k * p.NS * 4 <= 131072 ? 1u : 0u;
+  if (const char* env = getenv("CURDLE_QUAD")) p.quad = atoi(env) ? 1u : 0u;
+  const uint32_t gmax = p.quad ? 64u : 256u;
+  p.G = min_nbkt / p.seg < gmax ? min_nbkt / p.seg : gmax;
   // Sorted positions per accumulate lane: about two full-chip rounds of lanes
   // (256 CUs x 4 SIMDs x 2 waves x 64 lanes) for large inputs, never below 8.
   const uint64_t entries = (uint64_t)(win_end - win_begin) * n_total;
@@ -293,7 +307,8 @@ struct Prof {
 // d_points / d_scalars are device pointers holding the pairs of all MSMs back to back
 // and must stay valid until the matching finish_slot(); h_off has k + 1 entries.
 int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
-                 int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail) {
+                 int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail,
+                 bool latency_mode = true) {
   const size_t n = h_off[k];
   size_t n_max = 0;
   for (size_t j = 0; j < k; j++) {
@@ -301,7 +316,7 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
     if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
   }
   MsmPlan& p = S.plan;
-  int rc = make_plan(p, n, k, n_max, c, win_begin, win_end);
+  int rc = make_plan(p, n, k, n_max, c, win_begin, win_end, latency_mode);
   if (rc) return rc;
   S.run_stream = tail;
   S.profiled = false;
@@ -614,7 +629,7 @@ extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_s
   }
   const uint32_t off[2] = {0, (uint32_t)n};
   rc = enqueue_slot(S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, g_ctx.pre_stream, g_ctx.main_stream,
-                    S.stream);
+                    S.stream, /*latency_mode=*/false);
   if (rc) {
     drain_slot(S);
     release_slot(idx);

@@ -415,6 +415,72 @@ __global__ void __launch_bounds__(kBlock, WAVES)
   if ((tid & (p.G - 1)) == 0 && q < p.k * p.NS) d28::store(&partials[q / p.G], acc);
 }
 
+// ---------------------------------------------------------------------------
+// Quad variants of the latency-bound kernels (fp28.h "Lane-cooperative point
+// arithmetic"): four adjacent lanes per logical lane, so a 256-thread block carries
+// 64 logical lanes.  Used when the launch has few enough logical lanes that the
+// four-fold lane count still fits the chip in one round.
+// ---------------------------------------------------------------------------
+// Sum over aligned groups of G logical lanes (G a power of two <= 64); valid in the
+// first quad of each group.
+__device__ __forceinline__ void group_sum_quad(X28& acc, u32 G, X28* wave_partials /* LDS, 4 entries */) {
+  const u32 tid = threadIdx.x;
+  const u32 ll = (tid & 63u) >> 2;       // logical lane inside the wave, 0..15
+  const u32 gw = G < 16u ? G : 16u;
+  X28 b;
+  for (u32 off = gw / 2; off > 0; off >>= 1) {
+    shfl_down_x28(b, acc, off * 4);      // all four copies move together
+    if ((ll & (gw - 1)) >= off) d28::set_inf(b);
+    d28::quad_add(acc, b);
+  }
+  if (G > 16u) {  // G = 32 or 64: combine the waves' results
+    if ((tid & 63u) == 0) wave_partials[tid >> 6] = acc;
+    __syncthreads();
+    const u32 lt = tid >> 2;             // logical lane inside the block, 0..63
+    if ((lt & (G - 1)) == 0) {           // whole quads take this branch
+      for (u32 k = 1; k < G / 16u; k++) {
+        b = wave_partials[(tid >> 6) + k];
+        d28::quad_add(acc, b);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock, 2)
+    k_bucket_reduce_quad(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
+                         X28* __restrict__ partials, MsmPlan p) {
+  __shared__ X28 sh[4];
+  const u32 tid = threadIdx.x;
+  const u32 q = blockIdx.x * (kBlock / 4) + (tid >> 2);  // logical lane
+  X28 acc, b;
+  d28::set_inf(acc);
+  if (q < p.k * p.NS) {
+    const u32 j = q / p.NS;
+    const u32 r = q - j * p.NS;
+    int w = p.win_begin;
+    while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
+    const u32 lo = (r - p.base[w] / p.seg) * p.seg;
+    const u32 g0 = j * p.NB + p.base[w] + lo;
+    X28 run;
+    d28::set_inf(run);
+    for (int u = (int)p.seg - 1; u >= 0; u--) {
+      const u32 m = fragcnt[g0 + u];
+      const X28* f = frags + foff[g0 + u];
+      for (u32 k = 0; k < m; k++) {
+        d28::load(b, &f[k]);
+        d28::quad_add(run, b);
+      }
+      d28::quad_add(acc, run);
+    }
+    if (lo != 0) {
+      d28::quad_mul_small(b, run, lo);
+      d28::quad_add(acc, b);
+    }
+  }
+  if (p.G > 1) group_sum_quad(acc, p.G, sh);
+  if (((tid >> 2) & (p.G - 1)) == 0 && (tid & 3u) == 0 && q < p.k * p.NS) d28::store(&partials[q / p.G], acc);
+}
+
 __device__ __forceinline__ void write_window_sum(const X28& acc, G1XYZZ* winsums, X28* winsums28, const MsmPlan& p,
                                                  u32 j, u32 lw) {
   const u32 nw = p.win_end - p.win_begin;
@@ -463,6 +529,26 @@ __global__ void __launch_bounds__(64, 1)
     }
     __syncthreads();
   }
+  if (tid == 0) write_window_sum(acc, winsums, winsums28, p, j, lw);
+}
+
+__global__ void __launch_bounds__(kBlock, 2)
+    k_window_sum_wide_quad(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28,
+                           MsmPlan p) {
+  __shared__ X28 sh[4];
+  const u32 lw = blockIdx.x, j = blockIdx.y;
+  const u32 w = p.win_begin + lw;
+  const u32 tid = threadIdx.x;
+  const u32 lt = tid >> 2;  // logical lane 0..63
+  const u32 np = p.nbkt[w] / p.seg / p.G;
+  const X28* pw = partials + ((size_t)j * p.NS + p.base[w] / p.seg) / p.G;
+  X28 acc, b;
+  d28::set_inf(acc);
+  for (u32 k = lt; k < np; k += 64) {
+    d28::load(b, &pw[k]);
+    d28::quad_add(acc, b);
+  }
+  group_sum_quad(acc, 64, sh);
   if (tid == 0) write_window_sum(acc, winsums, winsums28, p, j, lw);
 }
 
@@ -630,14 +716,21 @@ hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStr
   // The 256-register build (2 waves per SIMD) even when the launch has one wave per SIMD:
   // it leaves room for an accumulate wave of the next MSM on the same SIMD.
   const u64 lanes = (u64)p.k * p.NS;
-  hipLaunchKernelGGL(k_bucket_reduce<2>, dim3(cdiv(lanes, kBlock)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
+  if (p.quad)
+    hipLaunchKernelGGL(k_bucket_reduce_quad, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
+  else
+    hipLaunchKernelGGL(k_bucket_reduce<2>, dim3(cdiv(lanes, kBlock)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
   return hipGetLastError();
 }
 
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  if (p.max_nbkt / p.seg / p.G > 4)
+  if (p.max_nbkt / p.seg / p.G > 4 && p.quad)
+    hipLaunchKernelGGL(k_window_sum_wide_quad, dim3(nw, p.k), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
+  else if (p.max_nbkt / p.seg / p.G > 4)
     hipLaunchKernelGGL(k_window_sum_wide, dim3(nw, p.k), dim3(64), 0, stream, reinterpret_cast<const X28*>(ws.partials),
                        ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
   else

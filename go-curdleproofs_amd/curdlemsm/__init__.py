@@ -36,7 +36,7 @@ except Exception:  # torch absent: the system ROCm runtime is used
 _lib = C.CDLL(LIB_PATH)
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, EBUSY = 0, -1, -2, -3, -4, -5
-MSM_SLOTS = 3
+MSM_SLOTS = 8
 
 # Every symbol include/curdle_msm.h declares (tests check they are all exported).
 SYMBOLS = [

@@ -42,7 +42,7 @@ extern "C" {
 #define CURDLE_EHIP (-3)   /* a HIP runtime call failed                         */
 #define CURDLE_ENOMEM (-4) /* device or host allocation failed                  */
 #define CURDLE_EBUSY (-5)  /* every MSM slot is in flight (async API)              */
-#define CURDLE_MSM_SLOTS 3 /* MSMs that can be in flight at once                   */
+#define CURDLE_MSM_SLOTS 8 /* MSMs that can be in flight at once                   */
 
 #define CURDLE_G1_AFFINE_U64 12
 #define CURDLE_G1_JAC_U64 18

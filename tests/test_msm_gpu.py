@@ -94,6 +94,32 @@ def test_segment_lengths(gpu, golden):
         os.environ.pop("CURDLE_SEG_LEN", None)
 
 
+def test_quad_and_single_lane_reduce_paths(gpu, golden, oracle, coracle):
+    """The latency-bound kernels exist in two builds (one lane or four cooperating lanes
+    per point operation, fp28.h); both must give the same bits, including on inputs that
+    reach the doubling / infinity branches inside the reduction."""
+    k, q = oracle.Rand(15).get_frs(2)
+    n = 3000
+    pts = coracle.points_walk(k, q, n)
+    sc = rand_scalars(np.random.default_rng(15), n, oracle)
+    exp = coracle.msm_pippenger(pts, sc, threads=8)
+    try:
+        for quad in ("0", "1"):
+            os.environ["CURDLE_QUAD"] = quad
+            for name in ("rand0_n16", "rand0_n257", "rand0_n1024", "edge_duplicate_bases", "edge_opposite_points",
+                         "edge_cancels_to_infinity", "edge_all_equal_scalars", "edge_small_scalars",
+                         "edge_window_boundaries", "edge_all_infinity"):
+                got = gpu.msm_g1(golden[name + "_points"], golden[name + "_scalars"])
+                assert (got == golden[name + "_expected"]).all(), (name, quad)
+            for c in (6, 11, 16):
+                os.environ["CURDLE_WINDOW_BITS"] = str(c)
+                assert (gpu.msm_g1(pts, sc) == exp).all(), (quad, c)
+            os.environ.pop("CURDLE_WINDOW_BITS", None)
+    finally:
+        os.environ.pop("CURDLE_QUAD", None)
+        os.environ.pop("CURDLE_WINDOW_BITS", None)
+
+
 # ------------------------------------------------------- seeded random vs C oracle ---
 @pytest.mark.parametrize("n", [5, 6, 7, 8, 9, 60, 64, 124, 128, 252, 256, 308, 628, 1268, 2548, 1 << 12, 1 << 14])
 def test_random_inputs_match_c_oracle(gpu, oracle, coracle, n):
@@ -261,13 +287,14 @@ def test_async_submit_wait_and_concurrent_callers(gpu, oracle, coracle):
     d_p = [torch.from_numpy(p.view(np.int64)).to("cuda:0") for p in pts]
     d_s = [torch.from_numpy(s.view(np.int64)).to("cuda:0") for s in scs]
     for _ in range(3):
-        tickets = [gpu.msm_g1_device_submit(d_p[i].data_ptr(), d_s[i].data_ptr(), sizes[i]) for i in range(3)]
-        assert sorted(tickets) == [0, 1, 2]
+        ns = gpu.MSM_SLOTS
+        tickets = [gpu.msm_g1_device_submit(d_p[i % 3].data_ptr(), d_s[i % 3].data_ptr(), sizes[i % 3]) for i in range(ns)]
+        assert sorted(tickets) == list(range(ns))
         with pytest.raises(gpu.CurdleError) as e:
             gpu.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), sizes[0])
         assert e.value.code == gpu.EBUSY
-        for i in (1, 2, 0):                         # out-of-order waits
-            assert (gpu.msm_wait(tickets[i]) == exp[i]).all(), i
+        for i in [1, 2, 0] + list(range(3, ns)):    # out-of-order waits
+            assert (gpu.msm_wait(tickets[i]) == exp[i % 3]).all(), i
         with pytest.raises(gpu.CurdleError):
             gpu.msm_wait(tickets[0])                # already collected
     # a window-range partial submitted asynchronously
