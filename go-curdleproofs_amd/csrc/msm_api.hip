@@ -243,6 +243,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // (an MSM of a batch is never split below that).
   uint64_t ch = (entries + 511) / 512;
   if (ch < 4096) ch = 4096;
+  if (const char* env = getenv("CURDLE_SORT_CHUNK")) ch = (uint64_t)atoll(env);
   if (ch > n_max) ch = n_max ? n_max : 1;
   p.chunk = (uint32_t)ch;
   p.gpu_combine = k >= kGpuCombineMin ? 1u : 0u;

@@ -153,6 +153,51 @@ def test_skewed_scalar_sets_match_c_oracle(gpu, oracle, coracle):
     assert (gpu.msm_g1(p2, sc) == coracle.msm_pippenger(p2, sc, threads=8)).all()
 
 
+def test_randomised_differential_small_cases(gpu, oracle, coracle):
+    """150 random small MSMs with random structure -- duplicated bases, negated twins,
+    infinity bases, zero / tiny / huge scalars, repeated scalars -- under random window
+    widths and segment lengths, against the C oracle.  Small cases make buckets collide,
+    which is what reaches the doubling and cancellation branches of the group law inside
+    accumulate, merge and reduce."""
+    rng = np.random.default_rng(2024)
+    k, q = oracle.Rand(16).get_frs(2)
+    pool = coracle.points_walk(k, q, 64)
+    neg = pool.copy()
+    for i in range(len(neg)):                     # -P: y -> p - y on the Montgomery limbs
+        y = oracle._from_limbs(neg[i, 6:12])
+        neg[i, 6:12] = oracle._limbs((oracle.P - y) % oracle.P, 6)
+    special = [0, 1, 2, oracle.R - 1, oracle.R - 2, (1 << 128), (1 << 200) + 5, 77]
+    try:
+        for case in range(150):
+            n = int(rng.integers(1, 48))
+            idx = rng.integers(0, 12 if case % 3 == 0 else 64, n)      # few distinct bases -> collisions
+            pts = pool[idx].copy()
+            flip = rng.random(n) < 0.25
+            pts[flip] = neg[idx[flip]]
+            pts[rng.random(n) < 0.08] = 0                                # infinity bases
+            sc_int = []
+            for _ in range(n):
+                r = rng.random()
+                if r < 0.3:
+                    sc_int.append(int(special[int(rng.integers(0, len(special)))]))
+                elif r < 0.5:
+                    sc_int.append(int(rng.integers(0, 1 << 20)))
+                elif r < 0.6 and sc_int:
+                    sc_int.append(sc_int[-1])
+                else:
+                    sc_int.append(int.from_bytes(rng.bytes(32), "big") % oracle.R)
+            sc = np.array([oracle.fr_to_mont_limbs(v) for v in sc_int], dtype=np.uint64)
+            os.environ["CURDLE_WINDOW_BITS"] = str(int(rng.integers(4, 17)))
+            os.environ["CURDLE_SEG_LEN"] = str(int(rng.integers(8, 40)))
+            os.environ["CURDLE_QUAD"] = str(case % 2)
+            got = gpu.msm_g1(pts, sc)
+            exp = coracle.msm_naive(pts, sc)
+            assert (got == exp).all(), (case, n, os.environ["CURDLE_WINDOW_BITS"], os.environ["CURDLE_SEG_LEN"])
+    finally:
+        for v in ("CURDLE_WINDOW_BITS", "CURDLE_SEG_LEN", "CURDLE_QUAD"):
+            os.environ.pop(v, None)
+
+
 # ---------------------------------------------------- full sizes via properties ---
 def _walk_expected(oracle, coracle, k, q, sc):
     """P_i = (k + i q) G  =>  MSM = (k * sum s_i + q * sum i s_i) G  (SURVEY.md 8d)."""
