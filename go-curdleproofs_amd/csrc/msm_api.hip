@@ -37,6 +37,9 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// for the other translation units of the library (host/proto_api.cpp)
+extern "C" int curdle_set_last_error(int code, const char* msg) { return fail(code, "%s", msg); }
+
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \

@@ -51,6 +51,9 @@ SYMBOLS = [
     "curdle_acc_get_A_c", "curdle_acc_num_bases", "curdle_acc_export",
     "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op",
     "curdle_synth_points_walk_device",
+    "curdle_crs_generate", "curdle_crs_free", "curdle_crs_size", "curdle_shuffle_permute_commit",
+    "curdle_prove", "curdle_verify", "curdle_proof_reencode", "curdle_merlin_test_vector",
+    "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error",
 ]
 
 _u64p = C.POINTER(C.c_uint64)
@@ -103,6 +106,21 @@ _profile_enable = _sig("curdle_profile_enable", C.c_int, C.c_int)
 _profile_last = _sig("curdle_profile_last", C.c_int, C.POINTER(_Profile))
 _synth_walk = _sig("curdle_synth_points_walk_device", C.c_int, _vp, _vp, C.c_size_t, _vp)
 _selftest_op = _sig("curdle_selftest_op", C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_int)
+
+
+_crs_generate = _sig("curdle_crs_generate", _vp, C.c_size_t, _vp)
+_crs_free = _sig("curdle_crs_free", None, _vp)
+_crs_size = _sig("curdle_crs_size", C.c_size_t, _vp)
+_spc = _sig("curdle_shuffle_permute_commit", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
+_prove = _sig("curdle_prove", C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t,
+              C.POINTER(C.c_size_t))
+_verify = _sig("curdle_verify", C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp,
+               C.POINTER(C.c_int))
+_reencode = _sig("curdle_proof_reencode", C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t))
+_merlin_tv = _sig("curdle_merlin_test_vector", C.c_int, C.c_char_p, C.c_char_p, _vp, C.c_size_t, C.c_char_p, _vp,
+                  C.c_size_t)
+_g1_compress = _sig("curdle_g1_compress", C.c_int, _vp, _vp)
+_g1_decompress = _sig("curdle_g1_decompress", C.c_int, _vp, C.c_int, _vp)
 
 
 class CurdleError(RuntimeError):
@@ -358,3 +376,88 @@ def synth_points_walk_device(k: int, q: int, n: int, d_out: int) -> None:
     (n * 96 bytes).  k, q are canonical integers < r."""
     ka, qa = int_to_limbs(k), int_to_limbs(q)
     _check(_synth_walk(_ptr(ka), _ptr(qa), n, d_out))
+
+
+# ---------------------------------------------------------------------------
+# Protocol layers (host restatement of curdleproof.Prove / Verify; include/curdle_msm.h)
+# ---------------------------------------------------------------------------
+class CRS:
+    """curdleproof.CRS from GenerateCRS(ell, rand) (crs.go:20)."""
+
+    def __init__(self, ell: int, rand: Rand):
+        self._h = _crs_generate(ell, rand._h)
+        if not self._h:
+            raise MemoryError("curdle_crs_generate")
+        self.ell = ell
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _crs_free(h)
+
+
+def shuffle_permute_commit(crs: CRS, Rs, Ss, perm, k, rand: Rand):
+    """common.ShufflePermuteCommit (common/util.go:45) -> (Ts, Us, M, rs_m)."""
+    Rs, Ss = _as_u64(Rs, 12), _as_u64(Ss, 12)
+    perm = np.ascontiguousarray(perm, dtype=np.uint32)
+    k = _as_u64(k)
+    ell = crs.ell
+    Ts = np.zeros((ell, 12), dtype=np.uint64)
+    Us = np.zeros((ell, 12), dtype=np.uint64)
+    M = np.zeros(18, dtype=np.uint64)
+    rs_m = np.zeros((4, 4), dtype=np.uint64)
+    _check(_spc(crs._h, _ptr(Rs), _ptr(Ss), ell, _ptr(perm), _ptr(k), rand._h, _ptr(Ts), _ptr(Us), _ptr(M), _ptr(rs_m)))
+    return Ts, Us, M, rs_m
+
+
+def prove(crs: CRS, Rs, Ss, Ts, Us, M, perm, k, rs_m, rand: Rand) -> bytes:
+    """curdleproof.Prove (curdleproof.go:38); returns the serialised proof."""
+    Rs, Ss, Ts, Us = (_as_u64(a, 12) for a in (Rs, Ss, Ts, Us))
+    M, k, rs_m = _as_u64(M), _as_u64(k), _as_u64(rs_m)
+    perm = np.ascontiguousarray(perm, dtype=np.uint32)
+    cap = 1 << 16
+    buf = np.zeros(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    _check(_prove(crs._h, _ptr(Rs), _ptr(Ss), _ptr(Ts), _ptr(Us), crs.ell, _ptr(M), _ptr(perm), _ptr(k), _ptr(rs_m),
+                  rand._h, _ptr(buf), cap, C.byref(n)))
+    return bytes(buf[: n.value])
+
+
+def verify(crs: CRS, proof: bytes, Rs, Ss, Ts, Us, M, rand: Rand) -> bool:
+    """curdleproof.Verify (curdleproof.go:199): the accept bit; raises CurdleError for (false, err)."""
+    Rs, Ss, Ts, Us = (_as_u64(a, 12) for a in (Rs, Ss, Ts, Us))
+    M = _as_u64(M)
+    pb = np.frombuffer(proof, dtype=np.uint8).copy()
+    ok = C.c_int(0)
+    _check(_verify(crs._h, _ptr(pb), len(pb), _ptr(Rs), _ptr(Ss), _ptr(Ts), _ptr(Us), crs.ell, _ptr(M), rand._h,
+                   C.byref(ok)))
+    return bool(ok.value)
+
+
+def proof_reencode(proof: bytes) -> bytes:
+    pb = np.frombuffer(proof, dtype=np.uint8).copy()
+    out = np.zeros(len(pb) + 64, dtype=np.uint8)
+    n = C.c_size_t(0)
+    _check(_reencode(_ptr(pb), len(pb), _ptr(out), len(out), C.byref(n)))
+    return bytes(out[: n.value])
+
+
+def merlin_test_vector(protocol: bytes, label: bytes, msg: bytes, challenge_label: bytes, n: int) -> bytes:
+    m = np.frombuffer(msg, dtype=np.uint8).copy()
+    out = np.zeros(n, dtype=np.uint8)
+    _check(_merlin_tv(protocol, label, _ptr(m), len(m), challenge_label, _ptr(out), n))
+    return bytes(out)
+
+
+def g1_compress(jac) -> bytes:
+    jac = _as_u64(jac)
+    out = np.zeros(48, dtype=np.uint8)
+    _check(_g1_compress(_ptr(jac), _ptr(out)))
+    return bytes(out)
+
+
+def g1_decompress(data: bytes, subgroup_check: bool = True) -> np.ndarray:
+    b = np.frombuffer(data, dtype=np.uint8).copy()
+    out = np.zeros(18, dtype=np.uint64)
+    _check(_g1_decompress(_ptr(b), 1 if subgroup_check else 0, _ptr(out)))
+    return out

@@ -1,0 +1,122 @@
+// Small algebra layer for the host-side protocol code: Fr scalars and G1 points as
+// value types with operators, the byte encodings gnark uses on the wire, and the one
+// function every MSM of the protocol goes through (alg::MultiExp -> the GPU, via the
+// C ABI).  Built on bls12_381.h / host_math.h.
+//
+// Replaces what the reference's protocol packages get from gnark-crypto
+// (fr.Element, bls12381.G1Jac / G1Affine and their Bytes / SetBytes, go.mod:6).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../csrc/host_math.h"
+
+namespace curdle {
+namespace alg {
+
+struct Scalar {
+  Fr v;  // Montgomery form, as fr.Element
+
+  static Scalar Zero() {
+    Scalar s;
+    f_zero(s.v);
+    return s;
+  }
+  static Scalar One() {
+    Scalar s;
+    f_one(s.v);
+    return s;
+  }
+  static Scalar FromU64(uint64_t x);  // fr.NewElement
+  static Scalar FromMont(const uint64_t limbs[4]) {
+    Scalar s;
+    memcpy(&s.v, limbs, 32);
+    return s;
+  }
+  Scalar operator+(const Scalar& o) const {
+    Scalar r;
+    fr_add(r.v, v, o.v);
+    return r;
+  }
+  Scalar operator-(const Scalar& o) const {
+    Scalar r;
+    fr_sub(r.v, v, o.v);
+    return r;
+  }
+  Scalar operator*(const Scalar& o) const {
+    Scalar r;
+    fr_mul(r.v, v, o.v);
+    return r;
+  }
+  Scalar Neg() const { return Zero() - *this; }
+  Scalar Inverse() const;          // 0 -> 0, as fr.Element.Inverse
+  Scalar Pow(uint64_t e) const;    // fr.Element.Exp with a small exponent
+  bool IsZero() const { return f_is_zero(v); }
+  bool operator==(const Scalar& o) const { return f_eq(v, o.v); }
+  bool operator!=(const Scalar& o) const { return !f_eq(v, o.v); }
+  void Canonical(u32 out[8]) const;             // the integer, little-endian limbs (fr.Element.BigInt)
+  void Bytes(uint8_t out[32]) const;            // fr.Element.Bytes: big-endian canonical
+  static bool SetBytesCanonical(const uint8_t in[32], Scalar* out);  // false if >= r
+};
+
+std::vector<Scalar> BatchInvert(const std::vector<Scalar>& xs);      // fr.BatchInvert (zeros stay zero)
+Scalar InnerProduct(const std::vector<Scalar>& a, const std::vector<Scalar>& b);  // common.IPA, util.go:26
+
+struct Point {
+  G1XYZZ p;
+
+  static Point Infinity() {
+    Point r;
+    g1_set_inf(r.p);
+    return r;
+  }
+  static Point FromAffine(const G1Affine& a) {
+    Point r;
+    g1_from_affine(r.p, a);
+    return r;
+  }
+  static Point FromJac(const uint64_t jac[18]);
+  static Point Generator();
+  Point operator+(const Point& o) const {
+    Point r = *this;
+    g1_add(r.p, o.p);
+    return r;
+  }
+  Point Neg() const {
+    Point r = *this;
+    if (!g1_is_inf(r.p)) fp_neg(r.p.y, r.p.y);
+    return r;
+  }
+  Point operator-(const Point& o) const { return *this + o.Neg(); }
+  Point Mul(const Scalar& k) const;   // ScalarMultiplication with FrToBigInt(k)
+  bool IsInfinity() const { return g1_is_inf(p); }
+  bool operator==(const Point& o) const { return g1_equal(p, o.p); }   // G1Jac.Equal
+  G1Affine Affine() const {
+    G1Affine a;
+    g1_to_affine(a, p);
+    return a;
+  }
+  void Jac(uint64_t out[18]) const { g1_to_canonical_jac(out, p); }
+  // gnark G1Affine.Bytes(): 48 bytes, big-endian x, flags in the top three bits
+  // (0x80 compressed, 0x40 infinity, 0x20 y is the lexicographically larger root).
+  void Compressed(uint8_t out[48]) const;
+  // G1Affine.SetBytes: false on a malformed encoding or a point not on the curve;
+  // the (slow, [r]P) subgroup check is optional.
+  static bool FromCompressed(const uint8_t in[48], Point* out, bool subgroup_check);
+};
+
+std::vector<G1Affine> BatchToAffine(const std::vector<Point>& pts);   // BatchJacobianToAffineG1
+
+// common.MultiExp: every MSM of the protocol code funnels through
+// here and runs on the GPU (curdle_msm_g1).  Throws std::runtime_error on a length
+// mismatch or a device error, with the Go error text.
+Point MultiExp(const std::vector<G1Affine>& points, const std::vector<Scalar>& scalars);
+// Several MSMs in one GPU pass (curdle_msm_g1_batch): results[i] = MultiExp(points[i], scalars[i]).
+std::vector<Point> MultiExpBatch(const std::vector<const std::vector<G1Affine>*>& points,
+                                 const std::vector<const std::vector<Scalar>*>& scalars);
+
+}  // namespace alg
+}  // namespace curdle

@@ -1,0 +1,854 @@
+// Curdleproofs protocol layers around the MSM hot path -- see curdleproofs.h.
+// Each function cites the reference lines it restates (paths relative to
+// /root/reference).  Transcript labels are those of SURVEY.md appendix A.
+#include "curdleproofs.h"
+
+#include <stdexcept>
+
+namespace curdle {
+namespace proto {
+
+using transcript::Transcript;
+using msmaccumulator::MsmAccumulator;
+
+namespace {
+
+std::runtime_error err(const std::string& s) { return std::runtime_error(s); }
+
+std::vector<Scalar> GetFrs(common::Rand& rand, size_t n) {
+  std::vector<Fr> raw;
+  rand.GetFrs(n, raw);
+  std::vector<Scalar> out(n);
+  for (size_t i = 0; i < n; i++) out[i].v = raw[i];
+  return out;
+}
+Scalar GetFr(common::Rand& rand) {
+  Scalar s;
+  rand.GetFr(s.v);
+  return s;
+}
+
+// msmAccumulator.AccumulateCheck(C, x, v, rand) on the host mirror.
+void Accumulate(MsmAccumulator& acc, const Point& C, const std::vector<Scalar>& x, const std::vector<G1Affine>& v,
+                common::Rand& rand, const char* what) {
+  G1Jac cj;
+  uint64_t buf[18];
+  C.Jac(buf);
+  memcpy(&cj, buf, sizeof(cj));
+  std::vector<Fr> xs(x.size());
+  for (size_t i = 0; i < x.size(); i++) xs[i] = x[i].v;
+  msmaccumulator::Status st = acc.AccumulateCheck(cj, xs, v, &rand);
+  if (!st.ok) throw err(std::string(what) + ": " + st.err);
+}
+
+template <class T>
+std::vector<T> Concat(const std::vector<T>& a, const std::vector<T>& b) {
+  std::vector<T> out(a);
+  out.insert(out.end(), b.begin(), b.end());
+  return out;
+}
+
+// common.Permute (util.go:37): ret[i] = vs[perm[i]]
+template <class T>
+std::vector<T> Permute(const std::vector<T>& vs, const std::vector<uint32_t>& perm) {
+  std::vector<T> out(vs.size());
+  for (size_t i = 0; i < perm.size(); i++) out[i] = vs[perm[i]];
+  return out;
+}
+
+int Log2Exact(size_t n, const char* what) {
+  if (n == 0 || (n & (n - 1))) throw err(std::string(what) + " is not a power of two");
+  int m = 0;
+  while (((size_t)1 << m) < n) m++;
+  return m;
+}
+
+G1Affine AffineOf(const Point& p) { return p.Affine(); }
+
+const G1Affine kZeroPoint = [] {
+  G1Affine z;
+  f_zero(z.x);
+  f_zero(z.y);
+  return z;
+}();
+
+}  // namespace
+
+// =========================================================== wire format =====
+void Writer::PutPoint(const Point& p) {
+  uint8_t b[48];
+  p.Compressed(b);
+  buf.insert(buf.end(), b, b + 48);
+}
+void Writer::PutScalar(const Scalar& s) {
+  uint8_t b[32];
+  s.Bytes(b);
+  buf.insert(buf.end(), b, b + 32);
+}
+void Writer::PutPoints(const std::vector<Point>& v) {
+  const uint32_t n = (uint32_t)v.size();  // gnark Encoder: uint32 big-endian slice length
+  const uint8_t len[4] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n};
+  buf.insert(buf.end(), len, len + 4);
+  for (const auto& p : v) PutPoint(p);
+}
+Point Reader::GetPoint(const char* what) {
+  if (left < 48) throw err(std::string("decoding ") + what + ": unexpected end of input");
+  Point out;
+  if (!Point::FromCompressed(p, &out, subgroup_check)) throw err(std::string("decoding ") + what + ": invalid point");
+  p += 48;
+  left -= 48;
+  return out;
+}
+Scalar Reader::GetScalar(const char* what) {
+  if (left < 32) throw err(std::string("decoding ") + what + ": unexpected end of input");
+  Scalar s;
+  if (!Scalar::SetBytesCanonical(p, &s)) throw err(std::string("decoding ") + what + ": scalar not canonical");
+  p += 32;
+  left -= 32;
+  return s;
+}
+std::vector<Point> Reader::GetPoints(const char* what) {
+  if (left < 4) throw err(std::string("decoding ") + what + ": unexpected end of input");
+  const uint32_t n = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+  p += 4;
+  left -= 4;
+  if ((size_t)n * 48 > left) throw err(std::string("decoding ") + what + ": slice longer than the input");
+  std::vector<Point> out;
+  out.reserve(n);
+  for (uint32_t i = 0; i < n; i++) out.push_back(GetPoint(what));
+  return out;
+}
+
+// ======================================================== groupcommitment =====
+GroupCommitment GroupCommitment::New(const Point& crsG, const Point& crsH, const Point& T, const Scalar& r) {
+  GroupCommitment g;  // groupcommitment.go:17-31
+  g.T_1 = crsG.Mul(r);
+  g.T_2 = T + crsH.Mul(r);
+  return g;
+}
+GroupCommitment GroupCommitment::Add(const GroupCommitment& cm) const { return GroupCommitment{T_1 + cm.T_1, T_2 + cm.T_2}; }
+GroupCommitment GroupCommitment::Mul(const Scalar& s) const { return GroupCommitment{T_1.Mul(s), T_2.Mul(s)}; }
+bool GroupCommitment::Eq(const GroupCommitment& cm) const { return T_1 == cm.T_1 && T_2 == cm.T_2; }
+void GroupCommitment::Serialize(Writer& w) const {
+  w.PutPoint(T_1);
+  w.PutPoint(T_2);
+}
+void GroupCommitment::FromReader(Reader& r) {
+  T_1 = r.GetPoint("T_1");
+  T_2 = r.GetPoint("T_2");
+}
+
+// ==================================================================== CRS =====
+CRS GenerateCRS(size_t size, common::Rand& rand) {
+  CRS crs;  // crs.go:20-59; draw order: Gs, Hs, H, Gt, Gu
+  rand.GetG1Affines(size, crs.Gs);
+  rand.GetG1Affines(N_BLINDERS, crs.Hs);
+  G1Affine t;
+  rand.GetG1Affine(t);
+  crs.H = Point::FromAffine(t);
+  rand.GetG1Affine(t);
+  crs.Gt = Point::FromAffine(t);
+  rand.GetG1Affine(t);
+  crs.Gu = Point::FromAffine(t);
+  Point gs = Point::Infinity(), hs = Point::Infinity();
+  for (const auto& g : crs.Gs) gs = gs + Point::FromAffine(g);  // :41-48, sequential adds
+  for (const auto& h : crs.Hs) hs = hs + Point::FromAffine(h);
+  crs.Gsum = gs.Affine();
+  crs.Hsum = hs.Affine();
+  return crs;
+}
+
+ShuffleCommit ShufflePermuteCommit(const std::vector<G1Affine>& crsGs, const std::vector<G1Affine>& crsHs,
+                                   const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                                   const std::vector<uint32_t>& perm, const Scalar& k, common::Rand& rand) {
+  ShuffleCommit out;  // common/util.go:45-88
+  std::vector<G1Affine> Ts(Rs.size()), Us(Ss.size());
+  for (size_t i = 0; i < Rs.size(); i++) Ts[i] = Point::FromAffine(Rs[i]).Mul(k).Affine();  // :55-58
+  for (size_t i = 0; i < Ss.size(); i++) Us[i] = Point::FromAffine(Ss[i]).Mul(k).Affine();  // :60-63
+  out.Ts = Permute(Ts, perm);
+  out.Us = Permute(Us, perm);
+  std::vector<Scalar> range(crsGs.size(), Scalar::Zero());
+  for (size_t i = 0; i < perm.size(); i++) range[i] = Scalar::FromU64(i);  // :68-71
+  std::vector<Scalar> permRange = Permute(range, perm);
+  Point M1 = alg::MultiExp(crsGs, permRange);                             // :75
+  out.rs_m = GetFrs(rand, N_BLINDERS);                                    // :78
+  Point M2 = alg::MultiExp(crsHs, out.rs_m);                              // :82
+  out.M = M1 + M2;
+  return out;
+}
+
+// ====================================================== samescalarargument =====
+namespace samescalar {
+static const char* kPoints = "sameexp_points";
+static const char* kAlpha = "sameexp_alpha";
+
+static void AppendStatement(Transcript& tr, const Point& R, const Point& S, const GroupCommitment& T,
+                            const GroupCommitment& U, const GroupCommitment& A, const GroupCommitment& B) {
+  tr.AppendPoints(kPoints, {R, S, T.T_1, T.T_2, U.T_1, U.T_2, A.T_1, A.T_2, B.T_1, B.T_2});
+}
+
+Proof Prove(const Point& Gt, const Point& Gu, const Point& H, const Point& R, const Point& S,
+            const GroupCommitment& T, const GroupCommitment& U, const Scalar& k, const Scalar& r_t, const Scalar& r_u,
+            Transcript& tr, common::Rand& rand) {
+  // samescalarargument.go:34-81
+  const Scalar r_a = GetFr(rand), r_b = GetFr(rand), r_k = GetFr(rand);
+  Proof p;
+  p.A = GroupCommitment::New(Gt, H, R.Mul(r_k), r_a);
+  p.B = GroupCommitment::New(Gu, H, S.Mul(r_k), r_b);
+  AppendStatement(tr, R, S, T, U, p.A, p.B);
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+  p.Z_k = r_k + k * alpha;
+  p.Z_t = r_a + r_t * alpha;
+  p.Z_u = r_b + r_u * alpha;
+  return p;
+}
+
+bool Verify(const Proof& proof, const Point& Gt, const Point& Gu, const Point& H, const Point& R, const Point& S,
+            const GroupCommitment& T, const GroupCommitment& U, Transcript& tr) {
+  // samescalarargument.go:83-100
+  AppendStatement(tr, R, S, T, U, proof.A, proof.B);
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+  const GroupCommitment e1 = GroupCommitment::New(Gt, H, R.Mul(proof.Z_k), proof.Z_t);
+  const GroupCommitment e2 = GroupCommitment::New(Gu, H, S.Mul(proof.Z_k), proof.Z_u);
+  return proof.A.Add(T.Mul(alpha)).Eq(e1) && proof.B.Add(U.Mul(alpha)).Eq(e2);
+}
+
+void Proof::Serialize(Writer& w) const {  // :122-140
+  A.Serialize(w);
+  B.Serialize(w);
+  w.PutScalar(Z_k);
+  w.PutScalar(Z_t);
+  w.PutScalar(Z_u);
+}
+void Proof::FromReader(Reader& r) {  // :102-120
+  A.FromReader(r);
+  B.FromReader(r);
+  Z_k = r.GetScalar("Z_k");
+  Z_t = r.GetScalar("Z_t");
+  Z_u = r.GetScalar("Z_u");
+}
+}  // namespace samescalar
+
+// ==================================================== innerproductargument =====
+namespace ipa {
+static const char* kStep1 = "ipa_step1";
+static const char* kAlpha = "ipa_alpha";
+static const char* kBeta = "ipa_beta";
+static const char* kLoop = "ipa_loop";
+static const char* kGamma = "ipa_gamma";
+
+// generateIPABlinders (innerproductargument.go:299-391): r, z with <r,d> + <z,c> = 0 and
+// <r,z> = 0; all but the last two z are random, the last two solve the 2x2 system.
+static void GenerateBlinders(common::Rand& rand, const std::vector<Scalar>& cs, const std::vector<Scalar>& ds,
+                             std::vector<Scalar>* rs_out, std::vector<Scalar>* zs_out) {
+  const size_t n = cs.size();
+  std::vector<Scalar> rs = GetFrs(rand, n);
+  std::vector<Scalar> zs = GetFrs(rand, n - 2);
+  const std::vector<Scalar> cs_head(cs.begin(), cs.begin() + (n - 2));
+  const std::vector<Scalar> rs_head(rs.begin(), rs.begin() + (n - 2));
+  const Scalar omega = alg::InnerProduct(rs, ds) + alg::InnerProduct(zs, cs_head);
+  const Scalar delta = alg::InnerProduct(rs_head, zs);
+  const Scalar inv_c = cs[n - 2].Inverse();
+  const Scalar num = rs[n - 2] * inv_c * omega - delta;
+  const Scalar den = rs[n - 2].Neg() * inv_c * cs[n - 1] + rs[n - 1];
+  if (den.IsZero()) throw err("last_z_term2 is zero");
+  const Scalar last_z = num * den.Inverse();
+  const Scalar penultimate_z = inv_c.Neg() * (last_z * cs[n - 1] + omega);
+  zs.push_back(penultimate_z);
+  zs.push_back(last_z);
+  if (!(alg::InnerProduct(rs, ds) + alg::InnerProduct(zs, cs)).IsZero() || !alg::InnerProduct(rs, zs).IsZero())
+    throw err("failed to generate IPA blinders: constraints not satisfied");
+  *rs_out = std::move(rs);
+  *zs_out = std::move(zs);
+}
+
+Proof Prove(std::vector<G1Affine> Gs, std::vector<G1Affine> Gs_prime, const Point& Hcrs, const Point& C,
+            const Point& D, const Scalar& z, std::vector<Scalar> cs, std::vector<Scalar> ds, Transcript& tr,
+            common::Rand& rand) {
+  // innerproductargument.go:42-188
+  if (cs.size() != ds.size()) throw err("cs and ds are not the same length");
+  if (cs.empty() || (cs.size() & (cs.size() - 1))) throw err("cs and ds are not a power of two");
+
+  std::vector<Scalar> rs_c, rs_d;
+  GenerateBlinders(rand, cs, ds, &rs_c, &rs_d);
+  Proof proof;
+  {
+    std::vector<Point> b = alg::MultiExpBatch({&Gs, &Gs_prime}, {&rs_c, &rs_d});  // :66, :70
+    proof.B_c = b[0];
+    proof.B_d = b[1];
+  }
+  tr.AppendPoints(kStep1, {C, D});
+  tr.AppendScalar(kStep1, z);
+  tr.AppendPoints(kStep1, {proof.B_c, proof.B_d});
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+  const Scalar beta = tr.GetAndAppendChallenge(kBeta);
+
+  size_t n = cs.size();
+  for (size_t i = 0; i < n; i++) {  // :83-89
+    cs[i] = rs_c[i] + alpha * cs[i];
+    ds[i] = rs_d[i] + alpha * ds[i];
+  }
+  const Point H = Hcrs.Mul(beta);  // :91-92
+
+  while (n > 1) {  // :101-173
+    n /= 2;
+    const std::vector<Scalar> c_L(cs.begin(), cs.begin() + n), c_R(cs.begin() + n, cs.begin() + 2 * n);
+    const std::vector<Scalar> d_L(ds.begin(), ds.begin() + n), d_R(ds.begin() + n, ds.begin() + 2 * n);
+    const std::vector<G1Affine> G_L(Gs.begin(), Gs.begin() + n), G_R(Gs.begin() + n, Gs.begin() + 2 * n);
+    const std::vector<G1Affine> Gp_L(Gs_prime.begin(), Gs_prime.begin() + n),
+        Gp_R(Gs_prime.begin() + n, Gs_prime.begin() + 2 * n);
+
+    // the four MSMs of a round (:109, :121, :126, :138) are independent: one GPU pass
+    std::vector<Point> ms = alg::MultiExpBatch({&G_R, &Gp_L, &G_L, &Gp_R}, {&c_L, &d_R, &c_R, &d_L});
+    const Point L_C = ms[0] + H.Mul(alg::InnerProduct(c_L, d_R));
+    const Point L_D = ms[1];
+    const Point R_C = ms[2] + H.Mul(alg::InnerProduct(c_R, d_L));
+    const Point R_D = ms[3];
+    proof.L_Cs.push_back(L_C);
+    proof.L_Ds.push_back(L_D);
+    proof.R_Cs.push_back(R_C);
+    proof.R_Ds.push_back(R_D);
+
+    tr.AppendPoints(kLoop, {L_C, L_D, R_C, R_D});
+    const Scalar gamma = tr.GetAndAppendChallenge(kGamma);
+    if (gamma.IsZero()) throw err("ipa gamma challenge is zero");
+    const Scalar gamma_inv = gamma.Inverse();
+
+    for (size_t i = 0; i < n; i++) {  // fold, :155-166
+      cs[i] = c_L[i] + gamma_inv * c_R[i];
+      ds[i] = d_L[i] + gamma * d_R[i];
+      Gs[i] = (Point::FromAffine(G_L[i]) + Point::FromAffine(G_R[i]).Mul(gamma)).Affine();
+      Gs_prime[i] = (Point::FromAffine(Gp_L[i]) + Point::FromAffine(Gp_R[i]).Mul(gamma_inv)).Affine();
+    }
+    cs.resize(n);
+    ds.resize(n);
+    Gs.resize(n);
+    Gs_prime.resize(n);
+  }
+  proof.c0 = cs[0];
+  proof.d0 = ds[0];
+  return proof;
+}
+
+bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const Point& Hcrs, const Point& C, const Point& D,
+            const Scalar& z, const std::vector<Scalar>& us, Transcript& tr, MsmAccumulator& acc,
+            common::Rand& rand) {
+  // innerproductargument.go:190-297
+  tr.AppendPoints(kStep1, {C, D});
+  tr.AppendScalar(kStep1, z);
+  tr.AppendPoints(kStep1, {proof.B_c, proof.B_d});
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+  Scalar beta = tr.GetAndAppendChallenge(kBeta);
+
+  const size_t n = Gs.size();
+  const int m = Log2Exact(n, "ipa n");
+  if ((int)proof.L_Cs.size() != m || (int)proof.R_Cs.size() != m || (int)proof.L_Ds.size() != m ||
+      (int)proof.R_Ds.size() != m)
+    throw err("ipa proof has the wrong number of rounds");
+  if (us.size() != n) throw err("ipa us has the wrong length");
+
+  std::vector<Scalar> gamma;
+  for (int i = 0; i < m; i++) {  // :215-219
+    tr.AppendPoints(kLoop, {proof.L_Cs[i], proof.L_Ds[i], proof.R_Cs[i], proof.R_Ds[i]});
+    gamma.push_back(tr.GetAndAppendChallenge(kGamma));
+  }
+  const std::vector<Scalar> gamma_inv = alg::BatchInvert(gamma);
+
+  std::vector<Scalar> s(n, Scalar::One()), s_prime(n, Scalar::One());  // :223-234
+  for (size_t i = 0; i < n; i++)
+    for (int j = 0; j < m; j++)
+      if (i & ((size_t)1 << j)) {
+        s[i] = s[i] * gamma[m - j - 1];
+        s_prime[i] = s_prime[i] * gamma_inv[m - j - 1];
+      }
+
+  // the four size-m MSMs (:238, :249, :275, :280) in one GPU pass
+  const std::vector<G1Affine> LC = alg::BatchToAffine(proof.L_Cs), RC = alg::BatchToAffine(proof.R_Cs),
+                              LD = alg::BatchToAffine(proof.L_Ds), RD = alg::BatchToAffine(proof.R_Ds);
+  const std::vector<Point> ms = alg::MultiExpBatch({&LC, &RC, &LD, &RD}, {&gamma, &gamma_inv, &gamma, &gamma_inv});
+
+  // accumulate check 1 (:237-271)
+  const Point betaH = Hcrs.Mul(beta);
+  const Point AC1 = ms[0] + proof.B_c + C.Mul(alpha) + betaH.Mul(alpha * alpha * z) + ms[1];
+  std::vector<G1Affine> GplusH(Gs);
+  GplusH.push_back(AffineOf(Hcrs));
+  std::vector<Scalar> scalars(n + 1);
+  for (size_t i = 0; i < n; i++) scalars[i] = s[i] * proof.c0;
+  beta = beta * proof.d0 * proof.c0;
+  scalars[n] = beta;
+  Accumulate(acc, AC1, scalars, GplusH, rand, "accumulate check 1");
+
+  // accumulate check 2 (:273-294)
+  const Point AC2 = ms[2] + proof.B_d + D.Mul(alpha) + ms[3];
+  std::vector<Scalar> scalars2(n);
+  for (size_t i = 0; i < n; i++) scalars2[i] = s_prime[i] * us[i] * proof.d0;
+  Accumulate(acc, AC2, scalars2, Gs, rand, "accumulate check 2");
+  return true;
+}
+
+void Proof::Serialize(Writer& w) const {  // :428-460
+  w.PutPoint(B_c);
+  w.PutPoint(B_d);
+  w.PutPoints(L_Cs);
+  w.PutPoints(R_Cs);
+  w.PutPoints(L_Ds);
+  w.PutPoints(R_Ds);
+  w.PutScalar(c0);
+  w.PutScalar(d0);
+}
+void Proof::FromReader(Reader& r) {  // :393-426
+  B_c = r.GetPoint("B_c");
+  B_d = r.GetPoint("B_d");
+  L_Cs = r.GetPoints("L_Cs");
+  R_Cs = r.GetPoints("R_Cs");
+  L_Ds = r.GetPoints("L_Ds");
+  R_Ds = r.GetPoints("R_Ds");
+  c0 = r.GetScalar("c0");
+  d0 = r.GetScalar("d0");
+}
+}  // namespace ipa
+
+// ==================================================== grandproductargument =====
+namespace gprod {
+static const char* kStep1 = "gprod_step1";
+static const char* kStep2 = "gprod_step2";
+static const char* kAlpha = "gprod_alpha";
+static const char* kBeta = "gprod_beta";
+
+Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H, const Point& B,
+            const Scalar& result, const std::vector<Scalar>& bs, const std::vector<Scalar>& r_bs, Transcript& tr,
+            common::Rand& rand) {
+  // grandproductargument.go:42-204
+  const size_t ell = Gs.size(), nb = r_bs.size();
+  tr.AppendPoint(kStep1, B);
+  tr.AppendScalar(kStep1, result);
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+
+  // step 2: partial products c_i = b_0 ... b_{i-1}
+  std::vector<Scalar> cs(ell);
+  cs[0] = Scalar::One();
+  for (size_t i = 1; i < ell; i++) cs[i] = cs[i - 1] * bs[i - 1];
+  const std::vector<Scalar> r_cs = GetFrs(rand, nb);
+  Proof proof;
+  {
+    std::vector<Point> cc = alg::MultiExpBatch({&Gs, &Hs}, {&cs, &r_cs});  // :67, :70
+    proof.C = cc[0] + cc[1];
+  }
+  std::vector<Scalar> r_b_plus_alpha(nb);
+  for (size_t i = 0; i < nb; i++) r_b_plus_alpha[i] = r_bs[i] + alpha;
+  proof.Rp = alg::InnerProduct(r_b_plus_alpha, r_cs);
+
+  tr.AppendPoint(kStep2, proof.C);
+  tr.AppendScalar(kStep2, proof.Rp);
+  const Scalar beta = tr.GetAndAppendChallenge(kBeta);
+  if (beta.IsZero()) throw err("beta is zero");
+
+  // step 3: rescaled bases G'_i = beta^-(i+1) G_i, H'_i = beta^-(ell+1) H_i (:94-103)
+  const Scalar betaInv = beta.Inverse();
+  std::vector<G1Affine> Gs_prime(ell), Hs_prime(Hs.size());
+  Scalar bi = betaInv;
+  for (size_t i = 0; i < ell; i++) {
+    Gs_prime[i] = Point::FromAffine(Gs[i]).Mul(bi).Affine();
+    bi = bi * betaInv;
+  }
+  for (size_t i = 0; i < Hs.size(); i++) Hs_prime[i] = Point::FromAffine(Hs[i]).Mul(bi).Affine();
+
+  std::vector<Scalar> betaPowers(ell), ds(ell);
+  Scalar bp = Scalar::One();  // beta^i
+  for (size_t i = 0; i < ell; i++) {
+    betaPowers[i] = bp;
+    ds[i] = bs[i] * bp * beta - bp;  // b_i beta^(i+1) - beta^i  (:104-117)
+    bp = bp * beta;
+  }
+  const Scalar betaExpL = bp;                 // beta^ell
+  const Scalar betaExpLPlus1 = bp * beta;     // beta^(ell+1)  (:120-121)
+  std::vector<Scalar> r_ds(nb), alphaBeta(nb, alpha * betaExpLPlus1);
+  for (size_t i = 0; i < nb; i++) r_ds[i] = betaExpLPlus1 * r_b_plus_alpha[i];
+  Point D;
+  {
+    std::vector<Point> dd = alg::MultiExpBatch({&Gs_prime, &Hs_prime}, {&betaPowers, &alphaBeta});  // :132, :135
+    D = B - dd[0] + dd[1];
+  }
+
+  // step 4: the inner-product instance (:141-176)
+  const std::vector<G1Affine> G_full = Concat(Gs, Hs), Gp_full = Concat(Gs_prime, Hs_prime);
+  const Scalar z = proof.Rp * betaExpLPlus1 + result * betaExpL - Scalar::One();
+  const std::vector<Scalar> cs_full = Concat(cs, r_cs), ds_full = Concat(ds, r_ds);
+  if (alg::InnerProduct(cs_full, ds_full) != z) throw err("IPA(C, D) != z");
+  {
+    std::vector<Point> chk = alg::MultiExpBatch({&G_full, &Gp_full}, {&cs_full, &ds_full});  // :165, :172 self-checks
+    if (!(chk[0] == proof.C)) throw err("msm(G, c) != C");
+    if (!(chk[1] == D)) throw err("msm(G', d) != D");
+  }
+  proof.IPAProof = ipa::Prove(G_full, Gp_full, H, proof.C, D, z, cs_full, ds_full, tr, rand);
+  return proof;
+}
+
+bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H,
+            const G1Affine& Gsum, const G1Affine& Hsum, const Point& B, const Scalar& result, int numBlinders,
+            Transcript& tr, MsmAccumulator& acc, common::Rand& rand) {
+  // grandproductargument.go:206-286
+  const size_t ell = Gs.size();
+  tr.AppendPoint(kStep1, B);
+  tr.AppendScalar(kStep1, result);
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+  tr.AppendPoint(kStep2, proof.C);
+  tr.AppendScalar(kStep2, proof.Rp);
+  const Scalar beta = tr.GetAndAppendChallenge(kBeta);
+  if (beta.IsZero()) throw err("beta is zero");
+
+  const Scalar betaInv = beta.Inverse();
+  std::vector<Scalar> us(ell + numBlinders);
+  Scalar bi = betaInv;
+  for (size_t i = 0; i < ell; i++) {  // :234-242
+    us[i] = bi;
+    bi = bi * betaInv;
+  }
+  for (size_t i = ell; i < us.size(); i++) us[i] = bi;
+  const Point D = B - Point::FromAffine(Gsum).Mul(betaInv) + Point::FromAffine(Hsum).Mul(alpha);  // :243-246
+
+  const std::vector<G1Affine> G_full = Concat(Gs, Hs);
+  const Scalar betaExpL = beta.Pow(ell);
+  const Scalar z = result * betaExpL + proof.Rp * (betaExpL * beta) - Scalar::One();  // :253-260
+  return ipa::Verify(proof.IPAProof, G_full, H, proof.C, D, z, us, tr, acc, rand);
+}
+
+void Proof::Serialize(Writer& w) const {  // :304-318
+  w.PutPoint(C);
+  w.PutScalar(Rp);
+  IPAProof.Serialize(w);
+}
+void Proof::FromReader(Reader& r) {  // :288-302
+  C = r.GetPoint("C");
+  Rp = r.GetScalar("Rp");
+  IPAProof.FromReader(r);
+}
+}  // namespace gprod
+
+// ================================================= samepermutationargument =====
+namespace sameperm {
+static const char* kStep1 = "same_perm_step1";
+static const char* kAlpha = "same_perm_alpha";
+static const char* kBeta = "same_perm_beta";
+
+Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H, const Point& A,
+            const Point& M, const std::vector<Scalar>& as, const std::vector<uint32_t>& permutation,
+            const std::vector<Scalar>& rs_a, const std::vector<Scalar>& rs_m, Transcript& tr, common::Rand& rand) {
+  // samepermutationargument.go:32-101
+  tr.AppendPoints(kStep1, {A, M});
+  tr.AppendScalars(kStep1, as);
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+  const Scalar beta = tr.GetAndAppendChallenge(kBeta);
+
+  const std::vector<Scalar> permutedAs = Permute(as, permutation);
+  std::vector<Scalar> bs(as.size());
+  Scalar p = Scalar::One();
+  for (size_t i = 0; i < as.size(); i++) {
+    bs[i] = alpha * Scalar::FromU64(permutation[i]) + permutedAs[i] + beta;
+    p = p * bs[i];
+  }
+  const std::vector<Scalar> betas(Gs.size(), beta);
+  Proof proof;
+  proof.B = A + M.Mul(alpha) + alg::MultiExp(Gs, betas);  // :67, all-equal scalars
+  std::vector<Scalar> rs_b(rs_a.size());
+  for (size_t i = 0; i < rs_a.size(); i++) rs_b[i] = alpha * rs_m[i] + rs_a[i];
+  proof.gpaProof = gprod::Prove(Gs, Hs, H, proof.B, p, bs, rs_b, tr, rand);
+  return proof;
+}
+
+bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H,
+            const G1Affine& Gsum, const G1Affine& Hsum, const Point& A, const Point& M, const std::vector<Scalar>& as,
+            int numBlinders, Transcript& tr, MsmAccumulator& acc, common::Rand& rand) {
+  // samepermutationargument.go:103-164
+  tr.AppendPoints(kStep1, {A, M});
+  tr.AppendScalars(kStep1, as);
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+  const Scalar beta = tr.GetAndAppendChallenge(kBeta);
+
+  Scalar p = Scalar::One();
+  for (size_t i = 0; i < as.size(); i++) p = p * (Scalar::FromU64(i) * alpha + beta + as[i]);  // :125-130
+  const std::vector<Scalar> betas(Gs.size(), beta);
+  const Point C = proof.B - A - M.Mul(alpha);                                                   // :136-139
+  Accumulate(acc, C, betas, Gs, rand, "failed to accumulate check");                            // :140
+  return gprod::Verify(proof.gpaProof, Gs, Hs, H, Gsum, Hsum, proof.B, p, numBlinders, tr, acc, rand);
+}
+
+void Proof::Serialize(Writer& w) const {  // :181-192
+  w.PutPoint(B);
+  gpaProof.Serialize(w);
+}
+void Proof::FromReader(Reader& r) {  // :166-179
+  B = r.GetPoint("B");
+  gpaProof.FromReader(r);
+}
+}  // namespace sameperm
+
+// ================================================= samemultiscalarargument =====
+namespace samemsm {
+static const char* kStep1 = "same_msm_step1";
+static const char* kAlpha = "same_msm_alpha";
+static const char* kLoop = "same_msm_loop";
+static const char* kGamma = "same_msm_gamma";
+
+static void AppendStatement(Transcript& tr, const Point& A, const Point& Z_t, const Point& Z_u,
+                            const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, const Point& B_a,
+                            const Point& B_t, const Point& B_u) {
+  tr.AppendPoints(kStep1, {A, Z_t, Z_u});
+  tr.AppendPointsAffine(kStep1, T);
+  tr.AppendPointsAffine(kStep1, U);
+  tr.AppendPoints(kStep1, {B_a, B_t, B_u});
+}
+
+Proof Prove(std::vector<G1Affine> G, const Point& A, const Point& Z_t, const Point& Z_u, std::vector<G1Affine> T,
+            std::vector<G1Affine> U, std::vector<Scalar> x, Transcript& tr, common::Rand& rand) {
+  // samemultiscalarargument.go:37-157
+  size_t n = x.size();
+  Log2Exact(n, "same msm n");
+  const std::vector<Scalar> r = GetFrs(rand, n);
+  Proof proof;
+  {
+    std::vector<Point> b = alg::MultiExpBatch({&G, &T, &U}, {&r, &r, &r});  // :64-70, one scalar vector, three base sets
+    proof.B_a = b[0];
+    proof.B_t = b[1];
+    proof.B_u = b[2];
+  }
+  AppendStatement(tr, A, Z_t, Z_u, T, U, proof.B_a, proof.B_t, proof.B_u);
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+  for (size_t i = 0; i < n; i++) x[i] = r[i] + x[i] * alpha;  // :78-81
+
+  while (n > 1) {  // :83-141
+    n /= 2;
+    const std::vector<Scalar> x_L(x.begin(), x.begin() + n), x_R(x.begin() + n, x.begin() + 2 * n);
+    const std::vector<G1Affine> T_L(T.begin(), T.begin() + n), T_R(T.begin() + n, T.begin() + 2 * n);
+    const std::vector<G1Affine> U_L(U.begin(), U.begin() + n), U_R(U.begin() + n, U.begin() + 2 * n);
+    const std::vector<G1Affine> G_L(G.begin(), G.begin() + n), G_R(G.begin() + n, G.begin() + 2 * n);
+    // six MSMs per round (:94-109): x_L against the right halves, x_R against the left halves
+    std::vector<Point> ms = alg::MultiExpBatch({&G_R, &T_R, &U_R, &G_L, &T_L, &U_L}, {&x_L, &x_L, &x_L, &x_R, &x_R, &x_R});
+    proof.L_A.push_back(ms[0]);
+    proof.L_T.push_back(ms[1]);
+    proof.L_U.push_back(ms[2]);
+    proof.R_A.push_back(ms[3]);
+    proof.R_T.push_back(ms[4]);
+    proof.R_U.push_back(ms[5]);
+    tr.AppendPoints(kLoop, {ms[0], ms[1], ms[2], ms[3], ms[4], ms[5]});
+    const Scalar gamma = tr.GetAndAppendChallenge(kGamma);
+    if (gamma.IsZero()) throw err("gamma is zero");
+    const Scalar gamma_inv = gamma.Inverse();
+    for (size_t i = 0; i < n; i++) {  // fold vectors and bases, :128-135
+      x[i] = x_L[i] + gamma_inv * x_R[i];
+      T[i] = (Point::FromAffine(T_L[i]) + Point::FromAffine(T_R[i]).Mul(gamma)).Affine();
+      U[i] = (Point::FromAffine(U_L[i]) + Point::FromAffine(U_R[i]).Mul(gamma)).Affine();
+      G[i] = (Point::FromAffine(G_L[i]) + Point::FromAffine(G_R[i]).Mul(gamma)).Affine();
+    }
+    x.resize(n);
+    T.resize(n);
+    U.resize(n);
+    G.resize(n);
+  }
+  proof.x = x[0];
+  return proof;
+}
+
+bool Verify(const Proof& proof, const std::vector<G1Affine>& G, const Point& A, const Point& Z_t, const Point& Z_u,
+            const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, Transcript& tr, MsmAccumulator& acc,
+            common::Rand& rand) {
+  // samemultiscalarargument.go:159-236 and unfoldedScalars :239-280
+  const size_t n = T.size();
+  AppendStatement(tr, A, Z_t, Z_u, T, U, proof.B_a, proof.B_t, proof.B_u);
+  const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+
+  const size_t lg_n = proof.L_A.size();
+  if (lg_n >= 32) throw err("recursive steps greater than expected");
+  if (n != ((size_t)1 << lg_n)) throw err("must by log2(L_a)");
+  if (proof.L_T.size() != lg_n || proof.L_U.size() != lg_n || proof.R_A.size() != lg_n || proof.R_T.size() != lg_n ||
+      proof.R_U.size() != lg_n)
+    throw err("same msm proof vectors differ in length");
+  std::vector<Scalar> gamma;
+  for (size_t i = 0; i < lg_n; i++) {
+    tr.AppendPoints(kLoop, {proof.L_A[i], proof.L_T[i], proof.L_U[i], proof.R_A[i], proof.R_T[i], proof.R_U[i]});
+    gamma.push_back(tr.GetAndAppendChallenge(kGamma));
+  }
+  std::vector<Scalar> xs(n);
+  for (size_t i = 0; i < n; i++) {  // :267-277
+    Scalar t = Scalar::One();
+    for (size_t k = lg_n; k-- > 0;)
+      if (i & ((size_t)1 << (lg_n - k - 1))) t = t * gamma[k];
+    xs[i] = proof.x * t;  // x * s_i, :184-187
+  }
+  const std::vector<Scalar> gamma_inv = alg::BatchInvert(gamma);
+
+  // six size-lg_n MSMs (:196, :200, :210, :214, :223, :227) in one GPU pass
+  const std::vector<G1Affine> LA = alg::BatchToAffine(proof.L_A), RA = alg::BatchToAffine(proof.R_A),
+                              LT = alg::BatchToAffine(proof.L_T), RT = alg::BatchToAffine(proof.R_T),
+                              LU = alg::BatchToAffine(proof.L_U), RU = alg::BatchToAffine(proof.R_U);
+  const std::vector<Point> ms = alg::MultiExpBatch({&LA, &RA, &LT, &RT, &LU, &RU},
+                                                   {&gamma, &gamma_inv, &gamma, &gamma_inv, &gamma, &gamma_inv});
+  const Point pA = proof.B_a + A.Mul(alpha) + ms[0] + ms[1];
+  Accumulate(acc, pA, xs, G, rand, "accumulating msm 1");  // :206
+  const Point pT = proof.B_t + Z_t.Mul(alpha) + ms[2] + ms[3];
+  Accumulate(acc, pT, xs, T, rand, "accumulating msm 2");  // :218
+  const Point pU = proof.B_u + Z_u.Mul(alpha) + ms[4] + ms[5];
+  Accumulate(acc, pU, xs, U, rand, "accumulating msm 3");  // :231
+  return true;
+}
+
+void Proof::Serialize(Writer& w) const {  // :325-365
+  w.PutPoint(B_a);
+  w.PutPoint(B_t);
+  w.PutPoint(B_u);
+  w.PutPoints(L_A);
+  w.PutPoints(L_T);
+  w.PutPoints(L_U);
+  w.PutPoints(R_A);
+  w.PutPoints(R_T);
+  w.PutPoints(R_U);
+  w.PutScalar(x);
+}
+void Proof::FromReader(Reader& r) {  // :282-323
+  B_a = r.GetPoint("B_a");
+  B_t = r.GetPoint("B_t");
+  B_u = r.GetPoint("B_u");
+  L_A = r.GetPoints("L_A");
+  L_T = r.GetPoints("L_T");
+  L_U = r.GetPoints("L_U");
+  R_A = r.GetPoints("R_A");
+  R_T = r.GetPoints("R_T");
+  R_U = r.GetPoints("R_U");
+  x = r.GetScalar("x");
+}
+}  // namespace samemsm
+
+// ============================================================= curdleproof =====
+static const char* kTranscript = "curdleproofs";
+static const char* kStep1 = "curdleproofs_step1";
+static const char* kVecA = "curdleproofs_vec_a";
+
+static void AppendInstance(Transcript& tr, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                           const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M) {
+  tr.AppendPointsAffine(kStep1, Rs);
+  tr.AppendPointsAffine(kStep1, Ss);
+  tr.AppendPointsAffine(kStep1, Ts);
+  tr.AppendPointsAffine(kStep1, Us);
+  tr.AppendPoint(kStep1, M);
+}
+
+// The bases of the same-multiscalar argument (curdleproof.go:150-164 / :271-285):
+// G = Gs | Hs[:2] | Gt | Gu,  T' = Ts | 0 | 0 | H | 0,  U' = Us | 0 | 0 | 0 | H.
+static void MultiscalarBases(const CRS& crs, const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us,
+                             std::vector<G1Affine>* G, std::vector<G1Affine>* Tp, std::vector<G1Affine>* Up) {
+  *G = crs.Gs;
+  G->insert(G->end(), crs.Hs.begin(), crs.Hs.begin() + (N_BLINDERS - 2));
+  G->push_back(AffineOf(crs.Gt));
+  G->push_back(AffineOf(crs.Gu));
+  const G1Affine Haff = AffineOf(crs.H);
+  *Tp = Ts;
+  Tp->insert(Tp->end(), {kZeroPoint, kZeroPoint, Haff, kZeroPoint});
+  *Up = Us;
+  Up->insert(Up->end(), {kZeroPoint, kZeroPoint, kZeroPoint, Haff});
+}
+
+Proof Prove(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+            const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M,
+            const std::vector<uint32_t>& perm, const Scalar& k, const std::vector<Scalar>& rs_m,
+            common::Rand& rand) {
+  // curdleproof.go:38-197
+  Transcript tr(kTranscript);
+  AppendInstance(tr, Rs, Ss, Ts, Us, M);
+  const std::vector<Scalar> as = tr.GetAndAppendChallenges(kVecA, Rs.size());
+
+  // step 2 (:66-103)
+  const std::vector<Scalar> rs_a = GetFrs(rand, N_BLINDERS - 2);
+  std::vector<Scalar> rs_a_prime(rs_a);
+  rs_a_prime.push_back(Scalar::Zero());
+  rs_a_prime.push_back(Scalar::Zero());
+  const std::vector<Scalar> perm_as = Permute(as, perm);
+  Proof proof;
+  {
+    std::vector<Point> aa = alg::MultiExpBatch({&crs.Gs, &crs.Hs}, {&perm_as, &rs_a_prime});  // :73, :76
+    proof.A = aa[0] + aa[1];
+  }
+  proof.proofSamePermutation =
+      sameperm::Prove(crs.Gs, crs.Hs, crs.H, proof.A, M, as, perm, rs_a_prime, rs_m, tr, rand);
+
+  // step 3 (:105-146)
+  const Scalar r_t = GetFr(rand), r_u = GetFr(rand);
+  {
+    std::vector<Point> rs = alg::MultiExpBatch({&Rs, &Ss}, {&as, &as});  // :110, :114, shared scalars
+    proof.R = rs[0];
+    proof.S = rs[1];
+  }
+  proof.T = GroupCommitment::New(crs.Gt, crs.H, proof.R.Mul(k), r_t);
+  proof.U = GroupCommitment::New(crs.Gu, crs.H, proof.S.Mul(k), r_u);
+  proof.proofSameScalar =
+      samescalar::Prove(crs.Gt, crs.Gu, crs.H, proof.R, proof.S, proof.T, proof.U, k, r_t, r_u, tr, rand);
+
+  // step 4 (:148-185)
+  const Point A_prime = proof.A + proof.T.T_1 + proof.U.T_1;
+  std::vector<G1Affine> G, Tp, Up;
+  MultiscalarBases(crs, Ts, Us, &G, &Tp, &Up);
+  std::vector<Scalar> x(perm_as);
+  x.insert(x.end(), rs_a.begin(), rs_a.end());
+  x.push_back(r_t);
+  x.push_back(r_u);
+  proof.proofSameMultiscalar = samemsm::Prove(G, A_prime, proof.T.T_2, proof.U.T_2, Tp, Up, x, tr, rand);
+  return proof;
+}
+
+bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+            const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand) {
+  // curdleproof.go:199-318
+  Transcript tr(kTranscript);
+  MsmAccumulator acc;
+  if (Ts.empty() || g1_affine_is_inf(Ts[0])) throw err("randomizer is zero");  // :213-215
+
+  AppendInstance(tr, Rs, Ss, Ts, Us, M);
+  const std::vector<Scalar> as = tr.GetAndAppendChallenges(kVecA, Rs.size());
+
+  if (!sameperm::Verify(proof.proofSamePermutation, crs.Gs, crs.Hs, crs.H, crs.Gsum, crs.Hsum, proof.A, M, as,
+                        N_BLINDERS, tr, acc, rand))
+    return false;
+  if (!samescalar::Verify(proof.proofSameScalar, crs.Gt, crs.Gu, crs.H, proof.R, proof.S, proof.T, proof.U, tr))
+    return false;
+
+  const Point Aprime = proof.A + proof.T.T_1 + proof.U.T_1;
+  std::vector<G1Affine> G, Tp, Up;
+  MultiscalarBases(crs, Ts, Us, &G, &Tp, &Up);
+  if (!samemsm::Verify(proof.proofSameMultiscalar, G, Aprime, proof.T.T_2, proof.U.T_2, Tp, Up, tr, acc, rand))
+    return false;
+
+  Accumulate(acc, proof.R, as, Rs, rand, "msm accumulator check R, as, Rs");  // :306
+  Accumulate(acc, proof.S, as, Ss, rand, "msm accumulator check S, as, Ss");  // :309
+  bool ok = false;
+  msmaccumulator::Status st = acc.Verify(&ok);                                // :313, the batched MSM on the GPU
+  if (!st.ok) throw err("verifying msm accumulator: " + st.err);
+  return ok;
+}
+
+std::vector<uint8_t> Proof::Serialize() const {  // :358-387
+  Writer w;
+  w.PutPoint(A);
+  T.Serialize(w);
+  U.Serialize(w);
+  w.PutPoint(R);
+  w.PutPoint(S);
+  proofSamePermutation.Serialize(w);
+  proofSameScalar.Serialize(w);
+  proofSameMultiscalar.Serialize(w);
+  return w.buf;
+}
+Proof Proof::FromBytes(const uint8_t* data, size_t len, bool subgroup_check) {  // :320-356
+  Reader r(data, len, subgroup_check);
+  Proof p;
+  p.A = r.GetPoint("A");
+  p.T.FromReader(r);
+  p.U.FromReader(r);
+  p.R = r.GetPoint("R");
+  p.S = r.GetPoint("S");
+  p.proofSamePermutation.FromReader(r);
+  p.proofSameScalar.FromReader(r);
+  p.proofSameMultiscalar.FromReader(r);
+  return p;
+}
+
+}  // namespace proto
+}  // namespace curdle

@@ -1,0 +1,154 @@
+// C ABI of the host-side protocol restatement (curdleproofs.h): CRS, the shuffle
+// instance, curdleproof.Prove / Verify on serialised proofs.  Declared in
+// include/curdle_msm.h under "Protocol layers".
+#include <string.h>
+
+#include <exception>
+#include <new>
+#include <stdexcept>
+#include <vector>
+
+#include "../../include/curdle_msm.h"
+#include "curdleproofs.h"
+
+using namespace curdle;
+using alg::Point;
+using alg::Scalar;
+
+// defined in msm_api.hip
+extern "C" int curdle_set_last_error(int code, const char* msg);
+
+struct curdle_rand {  // same layout as in msm_api.hip
+  common::Rand r;
+  explicit curdle_rand(uint64_t seed) : r(seed) {}
+};
+struct curdle_crs {
+  proto::CRS crs;
+};
+
+static std::vector<G1Affine> Affines(const uint64_t* p, size_t n) {
+  std::vector<G1Affine> v(n);
+  if (n) memcpy(v.data(), p, n * 96);
+  return v;
+}
+
+template <class F>
+static int Guard(F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return curdle_set_last_error(CURDLE_ENOMEM, "out of memory");
+  } catch (const std::exception& e) {
+    const char* m = e.what();
+    int code = strstr(m, "no HIP device") ? CURDLE_ENODEV : (strstr(m, "computing msm") ? CURDLE_EHIP : CURDLE_EINVAL);
+    return curdle_set_last_error(code, m);
+  }
+}
+
+extern "C" curdle_crs* curdle_crs_generate(size_t ell, curdle_rand* rand) {
+  if (!rand) return nullptr;
+  try {
+    curdle_crs* c = new curdle_crs();
+    c->crs = proto::GenerateCRS(ell, rand->r);
+    return c;
+  } catch (...) {
+    return nullptr;
+  }
+}
+extern "C" void curdle_crs_free(curdle_crs* c) { delete c; }
+extern "C" size_t curdle_crs_size(const curdle_crs* c) { return c ? c->crs.Gs.size() : 0; }
+
+extern "C" int curdle_shuffle_permute_commit(const curdle_crs* crs, const uint64_t* Rs, const uint64_t* Ss, size_t ell,
+                                             const uint32_t* perm, const uint64_t k[4], curdle_rand* rand,
+                                             uint64_t* Ts_out, uint64_t* Us_out, uint64_t M_out[18],
+                                             uint64_t rs_m_out[16]) {
+  if (!crs || !Rs || !Ss || !perm || !k || !rand || !Ts_out || !Us_out || !M_out || !rs_m_out)
+    return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  if (ell != crs->crs.Gs.size()) return curdle_set_last_error(CURDLE_EINVAL, "ell does not match the CRS");
+  return Guard([&]() {
+    std::vector<uint32_t> pv(perm, perm + ell);
+    for (uint32_t v : pv)
+      if (v >= ell) throw std::runtime_error("permutation entry out of range");
+    proto::ShuffleCommit sc = proto::ShufflePermuteCommit(crs->crs.Gs, crs->crs.Hs, Affines(Rs, ell), Affines(Ss, ell),
+                                                          pv, Scalar::FromMont(k), rand->r);
+    memcpy(Ts_out, sc.Ts.data(), ell * 96);
+    memcpy(Us_out, sc.Us.data(), ell * 96);
+    sc.M.Jac(M_out);
+    for (int i = 0; i < proto::N_BLINDERS; i++) memcpy(rs_m_out + 4 * i, &sc.rs_m[i].v, 32);
+    return CURDLE_OK;
+  });
+}
+
+extern "C" int curdle_prove(const curdle_crs* crs, const uint64_t* Rs, const uint64_t* Ss, const uint64_t* Ts,
+                            const uint64_t* Us, size_t ell, const uint64_t M[18], const uint32_t* perm,
+                            const uint64_t k[4], const uint64_t rs_m[16], curdle_rand* rand, uint8_t* proof_out,
+                            size_t cap, size_t* proof_len) {
+  if (!crs || !Rs || !Ss || !Ts || !Us || !M || !perm || !k || !rs_m || !rand || !proof_len)
+    return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  if (ell != crs->crs.Gs.size()) return curdle_set_last_error(CURDLE_EINVAL, "ell does not match the CRS");
+  return Guard([&]() {
+    std::vector<Scalar> rsm(proto::N_BLINDERS);
+    for (int i = 0; i < proto::N_BLINDERS; i++) rsm[i] = Scalar::FromMont(rs_m + 4 * i);
+    proto::Proof p = proto::Prove(crs->crs, Affines(Rs, ell), Affines(Ss, ell), Affines(Ts, ell), Affines(Us, ell),
+                                  Point::FromJac(M), std::vector<uint32_t>(perm, perm + ell), Scalar::FromMont(k), rsm,
+                                  rand->r);
+    std::vector<uint8_t> bytes = p.Serialize();
+    *proof_len = bytes.size();
+    if (!proof_out || cap < bytes.size()) return curdle_set_last_error(CURDLE_EINVAL, "proof buffer too small");
+    memcpy(proof_out, bytes.data(), bytes.size());
+    return CURDLE_OK;
+  });
+}
+
+extern "C" int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t proof_len, const uint64_t* Rs,
+                             const uint64_t* Ss, const uint64_t* Ts, const uint64_t* Us, size_t ell,
+                             const uint64_t M[18], curdle_rand* rand, int* ok) {
+  if (!crs || !proof || !Rs || !Ss || !Ts || !Us || !M || !rand || !ok)
+    return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  *ok = 0;
+  if (ell != crs->crs.Gs.size()) return curdle_set_last_error(CURDLE_EINVAL, "ell does not match the CRS");
+  return Guard([&]() {
+    proto::Proof p = proto::Proof::FromBytes(proof, proof_len);
+    bool accept = proto::Verify(p, crs->crs, Affines(Rs, ell), Affines(Ss, ell), Affines(Ts, ell), Affines(Us, ell),
+                                Point::FromJac(M), rand->r);
+    *ok = accept ? 1 : 0;
+    return CURDLE_OK;
+  });
+}
+
+// Round trip of the wire format: decode, re-encode (curdleproof_test.go "encode/decode").
+extern "C" int curdle_proof_reencode(const uint8_t* proof, size_t proof_len, uint8_t* out, size_t cap, size_t* out_len) {
+  if (!proof || !out_len) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  return Guard([&]() {
+    proto::Proof p = proto::Proof::FromBytes(proof, proof_len, /*subgroup_check=*/true);
+    std::vector<uint8_t> bytes = p.Serialize();
+    *out_len = bytes.size();
+    if (!out || cap < bytes.size()) return curdle_set_last_error(CURDLE_EINVAL, "buffer too small");
+    memcpy(out, bytes.data(), bytes.size());
+    return CURDLE_OK;
+  });
+}
+
+// transcript pieces exposed for the known-answer test of the Merlin construction
+extern "C" int curdle_merlin_test_vector(const char* protocol, const char* label, const uint8_t* msg, size_t msg_len,
+                                         const char* challenge_label, uint8_t* out, size_t out_len) {
+  if (!protocol || !label || !challenge_label || !out) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  transcript::Merlin m(protocol);
+  m.AppendMessage(label, msg, msg_len);
+  m.ChallengeBytes(challenge_label, out, out_len);
+  return CURDLE_OK;
+}
+
+// G1 compressed encoding helpers (gnark G1Affine.Bytes / SetBytes)
+extern "C" int curdle_g1_compress(const uint64_t jac[18], uint8_t out[48]) {
+  if (!jac || !out) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  Point::FromJac(jac).Compressed(out);
+  return CURDLE_OK;
+}
+extern "C" int curdle_g1_decompress(const uint8_t in[48], int subgroup_check, uint64_t out_jac[18]) {
+  if (!in || !out_jac) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  Point p;
+  if (!Point::FromCompressed(in, &p, subgroup_check != 0)) return curdle_set_last_error(CURDLE_EINVAL, "invalid point");
+  p.Jac(out_jac);
+  return CURDLE_OK;
+}

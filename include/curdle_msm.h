@@ -164,6 +164,44 @@ size_t curdle_acc_num_bases(const curdle_acc* a);
 int curdle_acc_export(const curdle_acc* a, uint64_t* points, uint64_t* scalars);
 
 /* ------------------------------------------------------------------------- *
+ * Protocol layers around the hot path: a host-side
+ * restatement of the reference's CRS, ShufflePermuteCommit, curdleproof.Prove and
+ * curdleproof.Verify, so that a whole Verify (all sub-argument MSMs + the final
+ * batched msmaccumulator MSM on the GPU) can be run without a Go toolchain.  The Go
+ * package keeps its own protocol code; this is the caller either side of the MSM,
+ * for end-to-end tests and the verifies/s measurement.  UNVERIFIED against
+ * Go-produced proofs.
+ * Points are gnark G1Affine arrays (ell x 12 u64), M a G1Jac, scalars fr.Elements.
+ * ------------------------------------------------------------------------- */
+typedef struct curdle_crs curdle_crs;
+curdle_crs* curdle_crs_generate(size_t ell, curdle_rand* rand);   /* GenerateCRS, crs.go:20           */
+void curdle_crs_free(curdle_crs* crs);
+size_t curdle_crs_size(const curdle_crs* crs);
+/* common.ShufflePermuteCommit, common/util.go:45 */
+int curdle_shuffle_permute_commit(const curdle_crs* crs, const uint64_t* Rs, const uint64_t* Ss, size_t ell,
+                                  const uint32_t* perm, const uint64_t k[4], curdle_rand* rand,
+                                  uint64_t* Ts_out, uint64_t* Us_out, uint64_t M_out[18], uint64_t rs_m_out[16]);
+/* curdleproof.Prove, curdleproof.go:38; the proof is returned serialised (Proof.Serialize, :358).
+ * If cap is too small *proof_len still receives the needed size. */
+int curdle_prove(const curdle_crs* crs, const uint64_t* Rs, const uint64_t* Ss, const uint64_t* Ts,
+                 const uint64_t* Us, size_t ell, const uint64_t M[18], const uint32_t* perm,
+                 const uint64_t k[4], const uint64_t rs_m[16], curdle_rand* rand,
+                 uint8_t* proof_out, size_t cap, size_t* proof_len);
+/* curdleproof.Verify, curdleproof.go:199, on a serialised proof (Proof.FromReader, :320):
+ * returns CURDLE_OK with *ok = accept bit for (true|false, nil); a negative code for
+ * (false, err) -- malformed proof, zero randomizer, device failure. */
+int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t proof_len, const uint64_t* Rs,
+                  const uint64_t* Ss, const uint64_t* Ts, const uint64_t* Us, size_t ell,
+                  const uint64_t M[18], curdle_rand* rand, int* ok);
+int curdle_proof_reencode(const uint8_t* proof, size_t proof_len, uint8_t* out, size_t cap, size_t* out_len);
+/* pieces exposed for known-answer tests */
+int curdle_merlin_test_vector(const char* protocol, const char* label, const uint8_t* msg, size_t msg_len,
+                              const char* challenge_label, uint8_t* out, size_t out_len);
+int curdle_g1_compress(const uint64_t jac[18], uint8_t out[48]);
+int curdle_g1_decompress(const uint8_t in[48], int subgroup_check, uint64_t out_jac[18]);
+int curdle_set_last_error(int code, const char* msg);  /* internal: shared by the library's translation units */
+
+/* ------------------------------------------------------------------------- *
  * Profiling and diagnostics (used by bench.py and tests; not part of the
  * reference's surface).
  * ------------------------------------------------------------------------- */
