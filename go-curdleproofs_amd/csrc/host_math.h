@@ -38,7 +38,14 @@ inline bool g1_to_affine(G1Affine& out, const G1XYZZ& p) {
     f_zero(out.y);
     return false;
   }
-  // 1/ZZZ, then 1/ZZ = ZZ^2 / ZZZ^2 * ... cheaper: invert ZZ*ZZZ once.
+  Fp one;
+  f_one(one);
+  if (f_eq(p.zz, one) && f_eq(p.zzz, one)) {  // already normalised (affine inputs, decoded points)
+    out.x = p.x;
+    out.y = p.y;
+    return true;
+  }
+  // invert ZZ*ZZZ once: 1/ZZ = ZZZ / (ZZ ZZZ), 1/ZZZ = ZZ / (ZZ ZZZ)
   Fp t, ti, izz, izzz;
   fp_mul(t, p.zz, p.zzz);
   fp_inv(ti, t);

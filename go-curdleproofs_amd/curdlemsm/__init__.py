@@ -271,7 +271,7 @@ class Rand:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _rand_free is not None:      # module globals may be gone at interpreter exit
             _rand_free(h)
 
     def get_fr(self) -> np.ndarray:
@@ -306,7 +306,7 @@ class MsmAccumulator:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _acc_free is not None:
             _acc_free(h)
 
     def accumulate_check(self, C_jac, x, v, rand: Rand) -> None:
@@ -392,7 +392,7 @@ class CRS:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _crs_free is not None:
             _crs_free(h)
 
 
