@@ -84,14 +84,26 @@ inline void g1_to_canonical_jac(u64 out[18], const G1XYZZ& p) {
   memcpy(out, &j, sizeof(j));
 }
 
-// r = k * p, k canonical (not Montgomery) little-endian limbs; left-to-right
-// double-and-add.  Host only (used O(1) times per call).
+// r = k * p, k canonical (not Montgomery) little-endian limbs; fixed 4-bit windows,
+// most significant first: 4 doublings + at most one addition per window, after 14
+// additions to tabulate 1p .. 15p.  Host only.
 inline void g1_scalar_mul(G1XYZZ& r, const G1XYZZ& p, const u32* k, int nlimbs) {
+  G1XYZZ tab[16];
+  g1_set_inf(tab[0]);
+  tab[1] = p;
+  tab[2] = p;
+  g1_dbl(tab[2]);
+  for (int i = 3; i < 16; i++) {
+    tab[i] = tab[i - 1];
+    g1_add(tab[i], p);
+  }
   G1XYZZ acc;
   g1_set_inf(acc);
-  for (int i = nlimbs * 32 - 1; i >= 0; i--) {
-    g1_dbl(acc);
-    if ((k[i / 32] >> (i % 32)) & 1) g1_add(acc, p);
+  for (int i = nlimbs * 8 - 1; i >= 0; i--) {
+    if (!g1_is_inf(acc))
+      for (int d = 0; d < 4; d++) g1_dbl(acc);
+    u32 w = (k[i / 8] >> (4 * (i % 8))) & 15u;
+    if (w) g1_add(acc, tab[w]);
   }
   r = acc;
 }

@@ -448,7 +448,7 @@ int finish_slot(Slot& S, uint64_t* out) {
   }
   // Window combine on the host: Horner from the top window down, each step shifting
   // by the width of the window below, then the 2^shift scaling of a partial
-  // (host/window_combine.cpp).
+  // (host/host_ops.cpp).
   int dbls[kMaxWindows];
   for (uint32_t lw = 0; lw < nw; lw++) dbls[lw] = lw > 0 ? p.bits[p.win_begin + lw - 1] : p.shift[p.win_begin];
   for (size_t j = 0; j < k; j++)

@@ -1,12 +1,20 @@
 // Fr / G1 value types, wire encodings and the MSM funnel -- see algebra.h.
 #include "algebra.h"
 
+#include "host_ops.h"
+
 #include <stdexcept>
 
 #include "../../include/curdle_msm.h"
 
 namespace curdle {
 namespace alg {
+
+// single-point group operations go through the ISA-dispatched builds (host_ops.cpp)
+static void ScalarMulImpl(G1XYZZ& r, const G1XYZZ& p, const u32* k) { curdle_host_scalar_mul(&r, &p, k); }
+static void AddImpl(G1XYZZ& acc, const G1XYZZ& b) { curdle_host_add(&acc, &b); }
+static bool ToAffineImpl(G1Affine& out, const G1XYZZ& p) { return curdle_host_to_affine(&out, &p) != 0; }
+static void FpPowImpl(Fp& r, const Fp& a, const u32* e) { curdle_host_fp_pow(&r, &a, e); }
 
 // ------------------------------------------------------------------ Scalar ---
 Scalar Scalar::FromU64(uint64_t x) {
@@ -130,6 +138,18 @@ static bool y_is_larger(const Fp& y_mont) {
   return !fp_lt(c, kFpHalf) && !f_eq(c, *reinterpret_cast<const Fp*>(kFpHalf));  // y > (p-1)/2
 }
 
+Point Point::operator+(const Point& o) const {
+  Point r = *this;
+  AddImpl(r.p, o.p);
+  return r;
+}
+
+G1Affine Point::Affine() const {
+  G1Affine a;
+  ToAffineImpl(a, p);
+  return a;
+}
+
 Point Point::FromJac(const uint64_t jac[18]) {
   G1Jac j;
   memcpy(&j, jac, sizeof(j));
@@ -148,13 +168,13 @@ Point Point::Mul(const Scalar& k) const {
   u32 c[8];
   k.Canonical(c);
   Point r;
-  g1_scalar_mul(r.p, p, c, 8);
+  ScalarMulImpl(r.p, p, c);
   return r;
 }
 
 void Point::Compressed(uint8_t out[48]) const {
   G1Affine a;
-  if (!g1_to_affine(a, p)) {
+  if (!ToAffineImpl(a, p)) {
     memset(out, 0, 48);
     out[0] = 0xc0;
     return;
@@ -197,7 +217,7 @@ bool Point::FromCompressed(const uint8_t in[48], Point* out, bool subgroup_check
   fp_dbl(four, four);
   fp_dbl(four, four);
   fp_add(rhs, x3, four);  // x^3 + 4
-  fp_pow(y, rhs, kFpSqrtExp, 12);
+  FpPowImpl(y, rhs, kFpSqrtExp);
   fp_sqr(y2, y);
   if (!f_eq(y2, rhs)) return false;  // not on the curve
   if (y_is_larger(y) != ((flags & 0x20) != 0)) fp_neg(y, y);
@@ -217,7 +237,7 @@ bool Point::FromCompressed(const uint8_t in[48], Point* out, bool subgroup_check
 
 std::vector<G1Affine> BatchToAffine(const std::vector<Point>& pts) {
   std::vector<G1Affine> out(pts.size());
-  for (size_t i = 0; i < pts.size(); i++) g1_to_affine(out[i], pts[i].p);
+  for (size_t i = 0; i < pts.size(); i++) ToAffineImpl(out[i], pts[i].p);
   return out;
 }
 

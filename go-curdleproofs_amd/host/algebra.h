@@ -80,11 +80,7 @@ struct Point {
   }
   static Point FromJac(const uint64_t jac[18]);
   static Point Generator();
-  Point operator+(const Point& o) const {
-    Point r = *this;
-    g1_add(r.p, o.p);
-    return r;
-  }
+  Point operator+(const Point& o) const;
   Point Neg() const {
     Point r = *this;
     if (!g1_is_inf(r.p)) fp_neg(r.p.y, r.p.y);
@@ -94,11 +90,7 @@ struct Point {
   Point Mul(const Scalar& k) const;   // ScalarMultiplication with FrToBigInt(k)
   bool IsInfinity() const { return g1_is_inf(p); }
   bool operator==(const Point& o) const { return g1_equal(p, o.p); }   // G1Jac.Equal
-  G1Affine Affine() const {
-    G1Affine a;
-    g1_to_affine(a, p);
-    return a;
-  }
+  G1Affine Affine() const;
   void Jac(uint64_t out[18]) const { g1_to_canonical_jac(out, p); }
   // gnark G1Affine.Bytes(): 48 bytes, big-endian x, flags in the top three bits
   // (0x80 compressed, 0x40 infinity, 0x20 y is the lexicographically larger root).

@@ -1,0 +1,11 @@
+// Serial host-side group operations with run-time ISA dispatch (host_ops.cpp).
+#pragma once
+#include <stdint.h>
+
+extern "C" {
+void curdle_window_combine(const void* winsums_xyzz, int nw, const int* dbls, uint64_t out[18]);
+void curdle_host_scalar_mul(void* r_xyzz, const void* p_xyzz, const uint32_t* k8);
+void curdle_host_add(void* acc_xyzz, const void* b_xyzz);
+int curdle_host_to_affine(void* out_affine, const void* p_xyzz);
+void curdle_host_fp_pow(void* r, const void* a, const uint32_t* e12);
+}

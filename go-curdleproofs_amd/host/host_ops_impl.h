@@ -1,0 +1,56 @@
+// Bodies of the serial host-side group operations, compiled twice (generic x86-64 and
+// BMI2+ADX) -- see host_ops.cpp.  The including file defines CURDLE_ISA_SUFFIX and, for
+// the BMI2 build, renames namespace `curdle` so the two builds' inline functions do not
+// collide.
+//
+//  * window combine: out = canonical Jacobian of sum_lw 2^(shift of window lw) * winsums[lw],
+//    the last step of the MSM (the Horner pass over the window sums the GPU produced):
+//    ~255 doublings with a strictly serial dependency, which a CPU core does in ~0.1 ms
+//    and a GPU lane would take milliseconds over;
+//  * the single-point operations of the protocol layers (one 255-bit scalar multiplication
+//    per AccumulateCheck / commitment opening / fold step, point addition, normalisation,
+//    the square root of point decompression).
+#include "../csrc/host_math.h"
+
+#define CURDLE_CAT_(a, b) a##b
+#define CURDLE_CAT(a, b) CURDLE_CAT_(a, b)
+#define CURDLE_FN(name) CURDLE_CAT(name, CURDLE_ISA_SUFFIX)
+
+extern "C" void CURDLE_FN(curdle_window_combine)(const void* winsums_xyzz, int nw, const int* dbls, uint64_t out[18]) {
+  using namespace curdle;
+  const G1XYZZ* ws = static_cast<const G1XYZZ*>(winsums_xyzz);
+  G1XYZZ acc;
+  g1_set_inf(acc);
+  // dbls[lw] = width of the window below lw (lw > 0) or the bit offset of the lowest
+  // window computed (lw = 0): acc = 2^dbls[lw] * (acc + ws[lw]), top window first.
+  for (int lw = nw - 1; lw >= 0; lw--) {
+    g1_add(acc, ws[lw]);
+    if (!g1_is_inf(acc))
+      for (int k = 0; k < dbls[lw]; k++) g1_dbl(acc);
+  }
+  g1_to_canonical_jac(out, acc);
+}
+
+// r = k * p, k = 8 canonical little-endian 32-bit limbs
+extern "C" void CURDLE_FN(curdle_host_scalar_mul)(void* r_xyzz, const void* p_xyzz, const uint32_t* k) {
+  using namespace curdle;
+  g1_scalar_mul(*static_cast<G1XYZZ*>(r_xyzz), *static_cast<const G1XYZZ*>(p_xyzz), k, 8);
+}
+
+// acc += b
+extern "C" void CURDLE_FN(curdle_host_add)(void* acc_xyzz, const void* b_xyzz) {
+  using namespace curdle;
+  g1_add(*static_cast<G1XYZZ*>(acc_xyzz), *static_cast<const G1XYZZ*>(b_xyzz));
+}
+
+// XYZZ -> affine, 0 for infinity
+extern "C" int CURDLE_FN(curdle_host_to_affine)(void* out_affine, const void* p_xyzz) {
+  using namespace curdle;
+  return g1_to_affine(*static_cast<G1Affine*>(out_affine), *static_cast<const G1XYZZ*>(p_xyzz)) ? 1 : 0;
+}
+
+// r = a^e over Fp, e = 12 little-endian 32-bit limbs
+extern "C" void CURDLE_FN(curdle_host_fp_pow)(void* r, const void* a, const uint32_t* e) {
+  using namespace curdle;
+  fp_pow(*static_cast<Fp*>(r), *static_cast<const Fp*>(a), e, 12);
+}

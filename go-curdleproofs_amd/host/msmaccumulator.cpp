@@ -6,9 +6,17 @@
 
 #include "../../include/curdle_msm.h"
 #include "../csrc/host_math.h"
+#include "host_ops.h"
 
 namespace curdle {
 namespace msmaccumulator {
+
+// alpha * C and the addition into A_c, through the ISA-dispatched builds (host_ops.cpp)
+static void MulAdd(G1XYZZ& acc, const G1XYZZ& c, const u32* k) {
+  G1XYZZ t;
+  curdle_host_scalar_mul(&t, &c, k);
+  curdle_host_add(&acc, &t);
+}
 
 MsmAccumulator::MsmAccumulator() { g1_set_inf(A_c); }
 
@@ -36,10 +44,9 @@ Status MsmAccumulator::AccumulateCheck(const G1Jac& C, const std::vector<Fr>& x,
   // A_c += alpha * C  (:44, ScalarMultiplication with the canonical big.Int of alpha)
   Fr alpha_c;
   f_from_mont<FrParams>(alpha_c, alpha);
-  G1XYZZ Cx, t;
+  G1XYZZ Cx;
   g1_from_jac(Cx, C);
-  g1_scalar_mul(t, Cx, alpha_c.l, 8);
-  g1_add(A_c, t);
+  MulAdd(A_c, Cx, alpha_c.l);
   return Status::OK();
 }
 
