@@ -322,10 +322,43 @@ CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) {
 }
 #elif defined(__HIP_DEVICE_COMPILE__)
 CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) { f_mul_inl<FpParams>(r, a, b); }
+#elif defined(__x86_64__) && defined(__BMI2__) && defined(__ADX__)
+// Host, BMI2 + ADX translation units (host/host_ops_bmi2.cpp): 6 x 64-bit limbs, one row
+// of the operand-scanning Montgomery product per multiplier word with the two carry chains
+// of adcx / adox running side by side, and the reduction row folded in right behind it
+// (p < 2^383, so the running value never needs a seventh limb).  The asm body is generated
+// by gen_mont_x86.py into mont_x86_64.inc.
+CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) {
+  static const u64 P64[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
+                             0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+  static const u64 N0 = 0x89f3fffcfffcfffdull;
+  u64 x[6], y[6];
+  __builtin_memcpy(x, a.l, 48);
+  __builtin_memcpy(y, b.l, 48);
+  u64 t0, t1, t2, t3, t4, t5, A, ax, bx, dx;
+  asm(
+#include "mont_x86_64.inc"
+      : [t0] "=&r"(t0), [t1] "=&r"(t1), [t2] "=&r"(t2), [t3] "=&r"(t3), [t4] "=&r"(t4), [t5] "=&r"(t5), [A] "=&r"(A),
+        [ax] "=&r"(ax), [bx] "=&r"(bx), "=&d"(dx)
+      : [x] "r"(x), [y] "r"(y), [p] "r"(P64), [ninv] "m"(N0), "m"(x), "m"(y), "m"(P64)
+      : "cc");
+  // t < 2p: one conditional subtraction
+  u64 d0, d1, d2, d3, d4, d5;
+  unsigned long long s;
+  unsigned char bw = 0;
+  bw = __builtin_ia32_sbb_u64(bw, t0, P64[0], &s), d0 = s;
+  bw = __builtin_ia32_sbb_u64(bw, t1, P64[1], &s), d1 = s;
+  bw = __builtin_ia32_sbb_u64(bw, t2, P64[2], &s), d2 = s;
+  bw = __builtin_ia32_sbb_u64(bw, t3, P64[3], &s), d3 = s;
+  bw = __builtin_ia32_sbb_u64(bw, t4, P64[4], &s), d4 = s;
+  bw = __builtin_ia32_sbb_u64(bw, t5, P64[5], &s), d5 = s;
+  u64 o[6] = {bw ? t0 : d0, bw ? t1 : d1, bw ? t2 : d2, bw ? t3 : d3, bw ? t4 : d4, bw ? t5 : d5};
+  __builtin_memcpy(r.l, o, 48);
+}
 #else
-// Host: the window combine after the GPU phases is a serial chain of ~2,400
-// field multiplications, so the host path uses 64-bit limbs (mulx-friendly)
-// instead of the kernels' 32-bit columns.  Same Montgomery form, same results.
+// Host, generic build: the window combine after the GPU phases is a serial chain of ~2,400
+// field multiplications, so the host path uses 64-bit limbs instead of the kernels' 32-bit
+// columns.  Same Montgomery form, same results.
 CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) {
   typedef unsigned __int128 u128;
   static const u64 P64[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
@@ -372,10 +405,56 @@ CURDLE_HD void fp_mul(Fp& r, const Fp& a, const Fp& b) {
 }
 #endif
 CURDLE_HD void fp_sqr(Fp& r, const Fp& a) { fp_mul(r, a, a); }
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__) && defined(__BMI2__) && defined(__ADX__)
+// Host, BMI2 + ADX translation units: additions and subtractions on six 64-bit limbs
+// (adc / sbb chains) instead of the generic twelve 32-bit ones.
+namespace x86 {
+static const u64 kP64[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
+                            0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+inline unsigned char add6(u64* r, const u64* a, const u64* b) {
+  unsigned char c = 0;
+  unsigned long long s;
+  for (int i = 0; i < 6; i++) c = __builtin_ia32_addcarryx_u64(c, a[i], b[i], &s), r[i] = s;
+  return c;
+}
+inline unsigned char sub6(u64* r, const u64* a, const u64* b) {
+  unsigned char c = 0;
+  unsigned long long s;
+  for (int i = 0; i < 6; i++) c = __builtin_ia32_sbb_u64(c, a[i], b[i], &s), r[i] = s;
+  return c;
+}
+}  // namespace x86
+CURDLE_HD void fp_add(Fp& r, const Fp& a, const Fp& b) {
+  u64 x[6], y[6], s[6], d[6];
+  __builtin_memcpy(x, a.l, 48);
+  __builtin_memcpy(y, b.l, 48);
+  x86::add6(s, x, y);  // a, b < p < 2^383: no carry out
+  const bool lt = x86::sub6(d, s, x86::kP64);
+  __builtin_memcpy(r.l, lt ? s : d, 48);
+}
+CURDLE_HD void fp_sub(Fp& r, const Fp& a, const Fp& b) {
+  u64 x[6], y[6], d[6], e[6];
+  __builtin_memcpy(x, a.l, 48);
+  __builtin_memcpy(y, b.l, 48);
+  const bool lt = x86::sub6(d, x, y);
+  x86::add6(e, d, x86::kP64);
+  __builtin_memcpy(r.l, lt ? e : d, 48);
+}
+CURDLE_HD void fp_neg(Fp& r, const Fp& a) {
+  u64 x[6], d[6];
+  __builtin_memcpy(x, a.l, 48);
+  const bool nz = (x[0] | x[1] | x[2] | x[3] | x[4] | x[5]) != 0;
+  x86::sub6(d, x86::kP64, x);
+  for (int i = 0; i < 6; i++) d[i] = nz ? d[i] : 0;
+  __builtin_memcpy(r.l, d, 48);
+}
+CURDLE_HD void fp_dbl(Fp& r, const Fp& a) { fp_add(r, a, a); }
+#else
 CURDLE_HD void fp_add(Fp& r, const Fp& a, const Fp& b) { f_add<FpParams>(r, a, b); }
 CURDLE_HD void fp_sub(Fp& r, const Fp& a, const Fp& b) { f_sub<FpParams>(r, a, b); }
 CURDLE_HD void fp_neg(Fp& r, const Fp& a) { f_neg<FpParams>(r, a); }
 CURDLE_HD void fp_dbl(Fp& r, const Fp& a) { f_dbl<FpParams>(r, a); }
+#endif
 CURDLE_HD void fr_mul(Fr& r, const Fr& a, const Fr& b) { f_mul_inl<FrParams>(r, a, b); }
 CURDLE_HD void fr_add(Fr& r, const Fr& a, const Fr& b) { f_add<FrParams>(r, a, b); }
 CURDLE_HD void fr_sub(Fr& r, const Fr& a, const Fr& b) { f_sub<FrParams>(r, a, b); }
