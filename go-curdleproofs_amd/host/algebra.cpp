@@ -15,6 +15,7 @@ static void ScalarMulImpl(G1XYZZ& r, const G1XYZZ& p, const u32* k) { curdle_hos
 static void AddImpl(G1XYZZ& acc, const G1XYZZ& b) { curdle_host_add(&acc, &b); }
 static bool ToAffineImpl(G1Affine& out, const G1XYZZ& p) { return curdle_host_to_affine(&out, &p) != 0; }
 static void FpPowImpl(Fp& r, const Fp& a, const u32* e) { curdle_host_fp_pow(&r, &a, e); }
+static void FpFromMontImpl(Fp& r, const Fp& a) { curdle_host_fp_from_mont(&r, &a); }
 
 // ------------------------------------------------------------------ Scalar ---
 Scalar Scalar::FromU64(uint64_t x) {
@@ -134,7 +135,7 @@ static const u32 kFpSqrtExp[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aa
 
 static bool y_is_larger(const Fp& y_mont) {
   Fp c;
-  f_from_mont<FpParams>(c, y_mont);
+  FpFromMontImpl(c, y_mont);
   return !fp_lt(c, kFpHalf) && !f_eq(c, *reinterpret_cast<const Fp*>(kFpHalf));  // y > (p-1)/2
 }
 
@@ -149,6 +150,8 @@ G1Affine Point::Affine() const {
   ToAffineImpl(a, p);
   return a;
 }
+
+bool Point::operator==(const Point& o) const { return curdle_host_equal(&p, &o.p) != 0; }
 
 Point Point::FromJac(const uint64_t jac[18]) {
   G1Jac j;
@@ -180,7 +183,7 @@ void Point::Compressed(uint8_t out[48]) const {
     return;
   }
   Fp xc;
-  f_from_mont<FpParams>(xc, a.x);
+  FpFromMontImpl(xc, a.x);
   for (int i = 0; i < 12; i++) {
     u32 w = xc.l[11 - i];
     out[4 * i] = (uint8_t)(w >> 24);
@@ -229,7 +232,7 @@ bool Point::FromCompressed(const uint8_t in[48], Point* out, bool subgroup_check
     u32 r[8];
     for (int i = 0; i < 8; i++) r[i] = FrParams::mod(i);
     G1XYZZ t;
-    g1_scalar_mul(t, out->p, r, 8);
+    ScalarMulImpl(t, out->p, r);
     if (!g1_is_inf(t)) return false;
   }
   return true;

@@ -89,7 +89,7 @@ struct Point {
   Point operator-(const Point& o) const { return *this + o.Neg(); }
   Point Mul(const Scalar& k) const;   // ScalarMultiplication with FrToBigInt(k)
   bool IsInfinity() const { return g1_is_inf(p); }
-  bool operator==(const Point& o) const { return g1_equal(p, o.p); }   // G1Jac.Equal
+  bool operator==(const Point& o) const;   // G1Jac.Equal
   G1Affine Affine() const;
   void Jac(uint64_t out[18]) const { g1_to_canonical_jac(out, p); }
   // gnark G1Affine.Bytes(): 48 bytes, big-endian x, flags in the top three bits

@@ -1,6 +1,8 @@
 // common.Rand mirror -- see common_rand.h.  Reference: /root/reference/common/rand.go.
 #include "common_rand.h"
 
+#include "keccak.h"
+
 #include <string.h>
 
 #include "../csrc/host_math.h"
@@ -11,43 +13,12 @@ namespace common {
 // ---------------------------------------------------------------------------
 // SHAKE256 (FIPS 202)
 // ---------------------------------------------------------------------------
-static const uint64_t kRC[24] = {
-    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
-    0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
-    0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
-    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
-    0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
-    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-static const int kRot[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-static const int kPi[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
-static constexpr size_t kRate = 136;  // SHAKE256: 1600 - 2*256 bits
 
-static inline uint64_t rotl(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+static constexpr size_t kRate = 136;  // SHAKE256: 1600 - 2*256 bits
 
 Shake256::Shake256() : pos_(0), squeezing_(false) { memset(st_, 0, sizeof(st_)); }
 
-void Shake256::Permute() {
-  uint64_t bc[5];
-  for (int round = 0; round < 24; round++) {
-    for (int i = 0; i < 5; i++) bc[i] = st_[i] ^ st_[i + 5] ^ st_[i + 10] ^ st_[i + 15] ^ st_[i + 20];
-    for (int i = 0; i < 5; i++) {
-      uint64_t t = bc[(i + 4) % 5] ^ rotl(bc[(i + 1) % 5], 1);
-      for (int j = 0; j < 25; j += 5) st_[j + i] ^= t;
-    }
-    uint64_t t = st_[1];
-    for (int i = 0; i < 24; i++) {
-      int j = kPi[i];
-      uint64_t b = st_[j];
-      st_[j] = rotl(t, kRot[i]);
-      t = b;
-    }
-    for (int j = 0; j < 25; j += 5) {
-      for (int i = 0; i < 5; i++) bc[i] = st_[j + i];
-      for (int i = 0; i < 5; i++) st_[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
-    }
-    st_[0] ^= kRC[round];
-  }
-}
+void Shake256::Permute() { keccak_f1600(st_); }
 
 void Shake256::Write(const uint8_t* data, size_t len) {
   uint8_t* sb = reinterpret_cast<uint8_t*>(st_);  // little-endian host

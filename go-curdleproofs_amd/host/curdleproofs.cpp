@@ -31,13 +31,9 @@ Scalar GetFr(common::Rand& rand) {
 // msmAccumulator.AccumulateCheck(C, x, v, rand) on the host mirror.
 void Accumulate(MsmAccumulator& acc, const Point& C, const std::vector<Scalar>& x, const std::vector<G1Affine>& v,
                 common::Rand& rand, const char* what) {
-  G1Jac cj;
-  uint64_t buf[18];
-  C.Jac(buf);
-  memcpy(&cj, buf, sizeof(cj));
   std::vector<Fr> xs(x.size());
   for (size_t i = 0; i < x.size(); i++) xs[i] = x[i].v;
-  msmaccumulator::Status st = acc.AccumulateCheck(cj, xs, v, &rand);
+  msmaccumulator::Status st = acc.AccumulateCheckXYZZ(C.p, xs, v, &rand);
   if (!st.ok) throw err(std::string(what) + ": " + st.err);
 }
 

@@ -9,6 +9,8 @@ void curdle_host_scalar_mul_bmi2(void*, const void*, const uint32_t*);
 void curdle_host_add_bmi2(void*, const void*);
 int curdle_host_to_affine_bmi2(void*, const void*);
 void curdle_host_fp_pow_bmi2(void*, const void*, const uint32_t*);
+void curdle_host_fp_from_mont_bmi2(void*, const void*);
+int curdle_host_equal_bmi2(const void*, const void*);
 }
 
 static bool fast_isa() {
@@ -46,4 +48,15 @@ extern "C" void curdle_host_fp_pow(void* r, const void* a, const uint32_t* e) {
     curdle_host_fp_pow_bmi2(r, a, e);
   else
     curdle_host_fp_pow_generic(r, a, e);
+}
+
+extern "C" void curdle_host_fp_from_mont(void* r, const void* a) {
+  if (fast_isa())
+    curdle_host_fp_from_mont_bmi2(r, a);
+  else
+    curdle_host_fp_from_mont_generic(r, a);
+}
+
+extern "C" int curdle_host_equal(const void* a_xyzz, const void* b_xyzz) {
+  return fast_isa() ? curdle_host_equal_bmi2(a_xyzz, b_xyzz) : curdle_host_equal_generic(a_xyzz, b_xyzz);
 }

@@ -54,3 +54,18 @@ extern "C" void CURDLE_FN(curdle_host_fp_pow)(void* r, const void* a, const uint
   using namespace curdle;
   fp_pow(*static_cast<Fp*>(r), *static_cast<const Fp*>(a), e, 12);
 }
+
+// Montgomery -> canonical residue over Fp (one product with the integer 1)
+extern "C" void CURDLE_FN(curdle_host_fp_from_mont)(void* r, const void* a) {
+  using namespace curdle;
+  Fp one;
+  f_zero(one);
+  one.l[0] = 1;
+  fp_mul(*static_cast<Fp*>(r), *static_cast<const Fp*>(a), one);
+}
+
+// projective equality of two XYZZ points
+extern "C" int CURDLE_FN(curdle_host_equal)(const void* a_xyzz, const void* b_xyzz) {
+  using namespace curdle;
+  return g1_equal(*static_cast<const G1XYZZ*>(a_xyzz), *static_cast<const G1XYZZ*>(b_xyzz)) ? 1 : 0;
+}

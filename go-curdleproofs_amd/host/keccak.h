@@ -1,0 +1,100 @@
+// Keccak-f[1600] (FIPS 202) for the two sponge users on the host: SHAKE256 behind
+// common.Rand (common_rand.cpp) and STROBE-128 behind the Merlin transcript
+// (transcript.cpp).  One verification absorbs ~100 KB of framed transcript data, i.e.
+// more than a thousand permutations, so the round is written out over named lanes
+// (theta / rho+pi / chi / iota with every index a compile-time constant) rather than as
+// the table-driven loop.
+#pragma once
+#include <stdint.h>
+
+namespace curdle {
+
+static inline uint64_t keccak_rotl(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+// st: 25 lanes, lane (x, y) at st[x + 5 y], little-endian lanes.
+static inline void keccak_f1600(uint64_t st[25]) {
+  static const uint64_t RC[24] = {
+      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
+      0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+      0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+      0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
+      0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  uint64_t a00 = st[0], a10 = st[1], a20 = st[2], a30 = st[3], a40 = st[4];
+  uint64_t a01 = st[5], a11 = st[6], a21 = st[7], a31 = st[8], a41 = st[9];
+  uint64_t a02 = st[10], a12 = st[11], a22 = st[12], a32 = st[13], a42 = st[14];
+  uint64_t a03 = st[15], a13 = st[16], a23 = st[17], a33 = st[18], a43 = st[19];
+  uint64_t a04 = st[20], a14 = st[21], a24 = st[22], a34 = st[23], a44 = st[24];
+  for (int round = 0; round < 24; round++) {
+    // theta
+    const uint64_t c0 = a00 ^ a01 ^ a02 ^ a03 ^ a04;
+    const uint64_t c1 = a10 ^ a11 ^ a12 ^ a13 ^ a14;
+    const uint64_t c2 = a20 ^ a21 ^ a22 ^ a23 ^ a24;
+    const uint64_t c3 = a30 ^ a31 ^ a32 ^ a33 ^ a34;
+    const uint64_t c4 = a40 ^ a41 ^ a42 ^ a43 ^ a44;
+    const uint64_t d0 = c4 ^ keccak_rotl(c1, 1);
+    const uint64_t d1 = c0 ^ keccak_rotl(c2, 1);
+    const uint64_t d2 = c1 ^ keccak_rotl(c3, 1);
+    const uint64_t d3 = c2 ^ keccak_rotl(c4, 1);
+    const uint64_t d4 = c3 ^ keccak_rotl(c0, 1);
+    // rho + pi: b[y][2x+3y] = rotl(a[x][y] ^ d[x], r[x][y])
+    const uint64_t b00 = a00 ^ d0;
+    const uint64_t b13 = keccak_rotl(a01 ^ d0, 36);
+    const uint64_t b21 = keccak_rotl(a02 ^ d0, 3);
+    const uint64_t b34 = keccak_rotl(a03 ^ d0, 41);
+    const uint64_t b42 = keccak_rotl(a04 ^ d0, 18);
+    const uint64_t b02 = keccak_rotl(a10 ^ d1, 1);
+    const uint64_t b10 = keccak_rotl(a11 ^ d1, 44);
+    const uint64_t b23 = keccak_rotl(a12 ^ d1, 10);
+    const uint64_t b31 = keccak_rotl(a13 ^ d1, 45);
+    const uint64_t b44 = keccak_rotl(a14 ^ d1, 2);
+    const uint64_t b04 = keccak_rotl(a20 ^ d2, 62);
+    const uint64_t b12 = keccak_rotl(a21 ^ d2, 6);
+    const uint64_t b20 = keccak_rotl(a22 ^ d2, 43);
+    const uint64_t b33 = keccak_rotl(a23 ^ d2, 15);
+    const uint64_t b41 = keccak_rotl(a24 ^ d2, 61);
+    const uint64_t b01 = keccak_rotl(a30 ^ d3, 28);
+    const uint64_t b14 = keccak_rotl(a31 ^ d3, 55);
+    const uint64_t b22 = keccak_rotl(a32 ^ d3, 25);
+    const uint64_t b30 = keccak_rotl(a33 ^ d3, 21);
+    const uint64_t b43 = keccak_rotl(a34 ^ d3, 56);
+    const uint64_t b03 = keccak_rotl(a40 ^ d4, 27);
+    const uint64_t b11 = keccak_rotl(a41 ^ d4, 20);
+    const uint64_t b24 = keccak_rotl(a42 ^ d4, 39);
+    const uint64_t b32 = keccak_rotl(a43 ^ d4, 8);
+    const uint64_t b40 = keccak_rotl(a44 ^ d4, 14);
+    // chi (+ iota on lane (0,0))
+    a00 = b00 ^ (~b10 & b20) ^ RC[round];
+    a10 = b10 ^ (~b20 & b30);
+    a20 = b20 ^ (~b30 & b40);
+    a30 = b30 ^ (~b40 & b00);
+    a40 = b40 ^ (~b00 & b10);
+    a01 = b01 ^ (~b11 & b21);
+    a11 = b11 ^ (~b21 & b31);
+    a21 = b21 ^ (~b31 & b41);
+    a31 = b31 ^ (~b41 & b01);
+    a41 = b41 ^ (~b01 & b11);
+    a02 = b02 ^ (~b12 & b22);
+    a12 = b12 ^ (~b22 & b32);
+    a22 = b22 ^ (~b32 & b42);
+    a32 = b32 ^ (~b42 & b02);
+    a42 = b42 ^ (~b02 & b12);
+    a03 = b03 ^ (~b13 & b23);
+    a13 = b13 ^ (~b23 & b33);
+    a23 = b23 ^ (~b33 & b43);
+    a33 = b33 ^ (~b43 & b03);
+    a43 = b43 ^ (~b03 & b13);
+    a04 = b04 ^ (~b14 & b24);
+    a14 = b14 ^ (~b24 & b34);
+    a24 = b24 ^ (~b34 & b44);
+    a34 = b34 ^ (~b44 & b04);
+    a44 = b44 ^ (~b04 & b14);
+  }
+  st[0] = a00, st[1] = a10, st[2] = a20, st[3] = a30, st[4] = a40;
+  st[5] = a01, st[6] = a11, st[7] = a21, st[8] = a31, st[9] = a41;
+  st[10] = a02, st[11] = a12, st[12] = a22, st[13] = a32, st[14] = a42;
+  st[15] = a03, st[16] = a13, st[17] = a23, st[18] = a33, st[19] = a43;
+  st[20] = a04, st[21] = a14, st[22] = a24, st[23] = a34, st[24] = a44;
+}
+
+}  // namespace curdle

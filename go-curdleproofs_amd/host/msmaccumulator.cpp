@@ -22,6 +22,13 @@ MsmAccumulator::MsmAccumulator() { g1_set_inf(A_c); }
 
 Status MsmAccumulator::AccumulateCheck(const G1Jac& C, const std::vector<Fr>& x, const std::vector<G1Affine>& v,
                                        common::Rand* rand) {
+  G1XYZZ Cx;
+  g1_from_jac(Cx, C);
+  return AccumulateCheckXYZZ(Cx, x, v, rand);
+}
+
+Status MsmAccumulator::AccumulateCheckXYZZ(const G1XYZZ& Cx, const std::vector<Fr>& x, const std::vector<G1Affine>& v,
+                                           common::Rand* rand) {
   if (v.size() != x.size()) return Status::Error("x and v must have the same length");  // :28-30
 
   Fr alpha;
@@ -44,8 +51,6 @@ Status MsmAccumulator::AccumulateCheck(const G1Jac& C, const std::vector<Fr>& x,
   // A_c += alpha * C  (:44, ScalarMultiplication with the canonical big.Int of alpha)
   Fr alpha_c;
   f_from_mont<FrParams>(alpha_c, alpha);
-  G1XYZZ Cx;
-  g1_from_jac(Cx, C);
   MulAdd(A_c, Cx, alpha_c.l);
   return Status::OK();
 }
@@ -64,7 +69,7 @@ Status MsmAccumulator::Verify(bool* ok) {
   memcpy(&j, out, sizeof(j));
   G1XYZZ res;
   g1_from_jac(res, j);
-  *ok = g1_equal(res, A_c);  // :63
+  *ok = curdle_host_equal(&res, &A_c) != 0;  // :63
   return Status::OK();
 }
 

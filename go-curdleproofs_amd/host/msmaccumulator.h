@@ -33,6 +33,11 @@ class MsmAccumulator {
   Status AccumulateCheck(const G1Jac& C, const std::vector<Fr>& x, const std::vector<G1Affine>& v,
                          common::Rand* rand);
 
+  // Same with C already in the library's XYZZ form (the protocol layer's points): skips
+  // the normalisation a round trip through G1Jac would cost.
+  Status AccumulateCheckXYZZ(const G1XYZZ& C, const std::vector<Fr>& x, const std::vector<G1Affine>& v,
+                             common::Rand* rand);
+
   // Verify(), msmaccumulator.go:49-64: flatten the map, one MultiExp, Equal(A_c).
   Status Verify(bool* ok);
 

@@ -1,44 +1,18 @@
 // Merlin / STROBE-128 transcript and the reference's wrapper -- see transcript.h.
 #include "transcript.h"
 
+#include "keccak.h"
+
 #include <string.h>
 
 namespace curdle {
 namespace transcript {
 
-// Keccak-f[1600] on a byte state (little-endian lanes).
+// Keccak-f[1600] on STROBE's byte state (little-endian lanes; keccak.h has the round).
 static void keccak_f1600(uint8_t st8[200]) {
-  static const uint64_t RC[24] = {
-      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
-      0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
-      0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
-      0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
-      0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
-      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-  static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-  static const int PI[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
   uint64_t st[25];
   memcpy(st, st8, 200);
-  for (int round = 0; round < 24; round++) {
-    uint64_t bc[5];
-    for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
-    for (int i = 0; i < 5; i++) {
-      uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63));
-      for (int j = 0; j < 25; j += 5) st[j + i] ^= t;
-    }
-    uint64_t t = st[1];
-    for (int i = 0; i < 24; i++) {
-      int j = PI[i];
-      uint64_t b = st[j];
-      st[j] = (t << ROT[i]) | (t >> (64 - ROT[i]));
-      t = b;
-    }
-    for (int j = 0; j < 25; j += 5) {
-      for (int i = 0; i < 5; i++) bc[i] = st[j + i];
-      for (int i = 0; i < 5; i++) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
-    }
-    st[0] ^= RC[round];
-  }
+  curdle::keccak_f1600(st);
   memcpy(st8, st, 200);
 }
 
