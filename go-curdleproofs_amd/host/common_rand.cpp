@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../csrc/host_math.h"
+#include "host_ops.h"
 
 namespace curdle {
 namespace common {
@@ -98,8 +99,8 @@ void Rand::GetG1Affine(G1Affine& out) {
   g1_generator(g);
   G1XYZZ gp, r;
   g1_from_affine(gp, g);
-  g1_scalar_mul(r, gp, c.l, 8);
-  g1_to_affine(out, r);
+  curdle_host_scalar_mul(&r, &gp, c.l);  // ISA-dispatched build, host_ops.cpp
+  curdle_host_to_affine(&out, &r);
 }
 
 void Rand::GetG1Affines(size_t n, std::vector<G1Affine>& out) {
