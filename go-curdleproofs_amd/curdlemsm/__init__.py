@@ -52,7 +52,7 @@ SYMBOLS = [
     "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op",
     "curdle_synth_points_walk_device",
     "curdle_crs_generate", "curdle_crs_free", "curdle_crs_size", "curdle_shuffle_permute_commit",
-    "curdle_prove", "curdle_verify", "curdle_proof_reencode", "curdle_merlin_test_vector",
+    "curdle_prove", "curdle_verify", "curdle_verify_set_eager", "curdle_proof_reencode", "curdle_merlin_test_vector",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error",
 ]
 
@@ -116,6 +116,7 @@ _prove = _sig("curdle_prove", C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp,
               C.POINTER(C.c_size_t))
 _verify = _sig("curdle_verify", C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp,
                C.POINTER(C.c_int))
+_verify_set_eager = _sig("curdle_verify_set_eager", C.c_int, C.c_int)
 _reencode = _sig("curdle_proof_reencode", C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t))
 _merlin_tv = _sig("curdle_merlin_test_vector", C.c_int, C.c_char_p, C.c_char_p, _vp, C.c_size_t, C.c_char_p, _vp,
                   C.c_size_t)
@@ -432,6 +433,12 @@ def verify(crs: CRS, proof: bytes, Rs, Ss, Ts, Us, M, rand: Rand) -> bool:
     _check(_verify(crs._h, _ptr(pb), len(pb), _ptr(Rs), _ptr(Ss), _ptr(Ts), _ptr(Us), crs.ell, _ptr(M), rand._h,
                    C.byref(ok)))
     return bool(ok.value)
+
+
+def verify_set_eager(eager: bool) -> bool:
+    """Evaluate the verifier's check points eagerly (the reference's order of operations)
+    instead of deferring them into the accumulator's one MSM; returns the previous mode."""
+    return bool(_verify_set_eager(1 if eager else 0))
 
 
 def proof_reencode(proof: bytes) -> bytes:

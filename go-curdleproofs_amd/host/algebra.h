@@ -46,6 +46,11 @@ struct Scalar {
     fr_sub(r.v, v, o.v);
     return r;
   }
+  Scalar operator-() const {
+    Scalar r;
+    f_neg<FrParams>(r.v, v);
+    return r;
+  }
   Scalar operator*(const Scalar& o) const {
     Scalar r;
     fr_mul(r.v, v, o.v);

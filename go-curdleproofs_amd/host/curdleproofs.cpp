@@ -3,6 +3,10 @@
 // /root/reference).  Transcript labels are those of SURVEY.md appendix A.
 #include "curdleproofs.h"
 
+#include <stdlib.h>
+
+#include <atomic>
+
 #include <stdexcept>
 
 namespace curdle {
@@ -34,6 +38,45 @@ void Accumulate(MsmAccumulator& acc, const Point& C, const std::vector<Scalar>& 
   std::vector<Fr> xs(x.size());
   for (size_t i = 0; i < x.size(); i++) xs[i] = x[i].v;
   msmaccumulator::Status st = acc.AccumulateCheckXYZZ(C.p, xs, v, &rand);
+  if (!st.ok) throw err(std::string(what) + ": " + st.err);
+}
+
+// The verifier's check points (the C of each AccumulateCheck) are linear combinations of
+// proof and statement points.  By default they are handed to the accumulator as such
+// (MsmAccumulator::AccumulateCheckDeferred), so one verification is ONE MSM on the GPU
+// and no alpha * C scalar multiplications on the host.  CURDLE_VERIFY_EAGER=1 evaluates
+// every C where the reference does (MultiExp per argument, then AccumulateCheck) --
+// same accept bit, kept for differential testing.
+std::atomic<int>& EagerFlag() {
+  static std::atomic<int> eager([] {
+    const char* e = getenv("CURDLE_VERIFY_EAGER");
+    return (e && *e && *e != '0') ? 1 : 0;
+  }());
+  return eager;
+}
+bool EagerChecks() { return EagerFlag().load(std::memory_order_relaxed) != 0; }
+
+struct Terms {
+  std::vector<Scalar> s;
+  std::vector<G1Affine> p;
+  void Add(const Scalar& k, const Point& pt) {
+    s.push_back(k);
+    p.push_back(pt.Affine());
+  }
+  void Add(const std::vector<Scalar>& ks, const std::vector<Point>& pts) {
+    for (size_t i = 0; i < pts.size(); i++) Add(ks[i], pts[i]);
+  }
+  // the eager value: one MSM on the GPU
+  Point Eval() const { return alg::MultiExp(p, s); }
+};
+
+void Accumulate(MsmAccumulator& acc, const Terms& C, const std::vector<Scalar>& x, const std::vector<G1Affine>& v,
+                common::Rand& rand, const char* what) {
+  if (EagerChecks()) return Accumulate(acc, C.Eval(), x, v, rand, what);
+  std::vector<Fr> xs(x.size()), cs(C.s.size());
+  for (size_t i = 0; i < x.size(); i++) xs[i] = x[i].v;
+  for (size_t i = 0; i < cs.size(); i++) cs[i] = C.s[i].v;
+  msmaccumulator::Status st = acc.AccumulateCheckDeferred(cs, C.p, xs, v, &rand);
   if (!st.ok) throw err(std::string(what) + ": " + st.err);
 }
 
@@ -69,6 +112,8 @@ const G1Affine kZeroPoint = [] {
 }();
 
 }  // namespace
+
+int SetEagerChecks(int eager) { return EagerFlag().exchange(eager ? 1 : 0); }
 
 // =========================================================== wire format =====
 void Writer::PutPoint(const Point& p) {
@@ -358,14 +403,13 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const Point& Hc
         s_prime[i] = s_prime[i] * gamma_inv[m - j - 1];
       }
 
-  // the four size-m MSMs (:238, :249, :275, :280) in one GPU pass
-  const std::vector<G1Affine> LC = alg::BatchToAffine(proof.L_Cs), RC = alg::BatchToAffine(proof.R_Cs),
-                              LD = alg::BatchToAffine(proof.L_Ds), RD = alg::BatchToAffine(proof.R_Ds);
-  const std::vector<Point> ms = alg::MultiExpBatch({&LC, &RC, &LD, &RD}, {&gamma, &gamma_inv, &gamma, &gamma_inv});
-
-  // accumulate check 1 (:237-271)
-  const Point betaH = Hcrs.Mul(beta);
-  const Point AC1 = ms[0] + proof.B_c + C.Mul(alpha) + betaH.Mul(alpha * alpha * z) + ms[1];
+  // accumulate check 1 (:237-271): AC1 = <gamma, L_C> + B_c + alpha C + (beta alpha^2 z) H + <gamma^-1, R_C>
+  Terms AC1;
+  AC1.Add(gamma, proof.L_Cs);
+  AC1.Add(Scalar::One(), proof.B_c);
+  AC1.Add(alpha, C);
+  AC1.Add(beta * alpha * alpha * z, Hcrs);
+  AC1.Add(gamma_inv, proof.R_Cs);
   std::vector<G1Affine> GplusH(Gs);
   GplusH.push_back(AffineOf(Hcrs));
   std::vector<Scalar> scalars(n + 1);
@@ -375,7 +419,11 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const Point& Hc
   Accumulate(acc, AC1, scalars, GplusH, rand, "accumulate check 1");
 
   // accumulate check 2 (:273-294)
-  const Point AC2 = ms[2] + proof.B_d + D.Mul(alpha) + ms[3];
+  Terms AC2;  // <gamma, L_D> + B_d + alpha D + <gamma^-1, R_D>
+  AC2.Add(gamma, proof.L_Ds);
+  AC2.Add(Scalar::One(), proof.B_d);
+  AC2.Add(alpha, D);
+  AC2.Add(gamma_inv, proof.R_Ds);
   std::vector<Scalar> scalars2(n);
   for (size_t i = 0; i < n; i++) scalars2[i] = s_prime[i] * us[i] * proof.d0;
   Accumulate(acc, AC2, scalars2, Gs, rand, "accumulate check 2");
@@ -564,8 +612,11 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const std::vect
   Scalar p = Scalar::One();
   for (size_t i = 0; i < as.size(); i++) p = p * (Scalar::FromU64(i) * alpha + beta + as[i]);  // :125-130
   const std::vector<Scalar> betas(Gs.size(), beta);
-  const Point C = proof.B - A - M.Mul(alpha);                                                   // :136-139
-  Accumulate(acc, C, betas, Gs, rand, "failed to accumulate check");                            // :140
+  Terms C;  // proof.B - A - alpha M, :136-139
+  C.Add(Scalar::One(), proof.B);
+  C.Add(-Scalar::One(), A);
+  C.Add(-alpha, M);
+  Accumulate(acc, C, betas, Gs, rand, "failed to accumulate check");  // :140
   return gprod::Verify(proof.gpaProof, Gs, Hs, H, Gsum, Hsum, proof.B, p, numBlinders, tr, acc, rand);
 }
 
@@ -673,17 +724,20 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& G, const Point& A, 
   }
   const std::vector<Scalar> gamma_inv = alg::BatchInvert(gamma);
 
-  // six size-lg_n MSMs (:196, :200, :210, :214, :223, :227) in one GPU pass
-  const std::vector<G1Affine> LA = alg::BatchToAffine(proof.L_A), RA = alg::BatchToAffine(proof.R_A),
-                              LT = alg::BatchToAffine(proof.L_T), RT = alg::BatchToAffine(proof.R_T),
-                              LU = alg::BatchToAffine(proof.L_U), RU = alg::BatchToAffine(proof.R_U);
-  const std::vector<Point> ms = alg::MultiExpBatch({&LA, &RA, &LT, &RT, &LU, &RU},
-                                                   {&gamma, &gamma_inv, &gamma, &gamma_inv, &gamma, &gamma_inv});
-  const Point pA = proof.B_a + A.Mul(alpha) + ms[0] + ms[1];
+  // the three check points (:196-231): B + alpha Z + <gamma, L> + <gamma^-1, R>
+  auto check_point = [&](const Point& B, const Point& Z, const std::vector<Point>& L, const std::vector<Point>& R) {
+    Terms t;
+    t.Add(Scalar::One(), B);
+    t.Add(alpha, Z);
+    t.Add(gamma, L);
+    t.Add(gamma_inv, R);
+    return t;
+  };
+  const Terms pA = check_point(proof.B_a, A, proof.L_A, proof.R_A);
   Accumulate(acc, pA, xs, G, rand, "accumulating msm 1");  // :206
-  const Point pT = proof.B_t + Z_t.Mul(alpha) + ms[2] + ms[3];
+  const Terms pT = check_point(proof.B_t, Z_t, proof.L_T, proof.R_T);
   Accumulate(acc, pT, xs, T, rand, "accumulating msm 2");  // :218
-  const Point pU = proof.B_u + Z_u.Mul(alpha) + ms[4] + ms[5];
+  const Terms pU = check_point(proof.B_u, Z_u, proof.L_U, proof.R_U);
   Accumulate(acc, pU, xs, U, rand, "accumulating msm 3");  // :231
   return true;
 }
@@ -812,8 +866,11 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
   if (!samemsm::Verify(proof.proofSameMultiscalar, G, Aprime, proof.T.T_2, proof.U.T_2, Tp, Up, tr, acc, rand))
     return false;
 
-  Accumulate(acc, proof.R, as, Rs, rand, "msm accumulator check R, as, Rs");  // :306
-  Accumulate(acc, proof.S, as, Ss, rand, "msm accumulator check S, as, Ss");  // :309
+  Terms R, S;
+  R.Add(Scalar::One(), proof.R);
+  S.Add(Scalar::One(), proof.S);
+  Accumulate(acc, R, as, Rs, rand, "msm accumulator check R, as, Rs");  // :306
+  Accumulate(acc, S, as, Ss, rand, "msm accumulator check S, as, Ss");  // :309
   bool ok = false;
   msmaccumulator::Status st = acc.Verify(&ok);                                // :313, the batched MSM on the GPU
   if (!st.ok) throw err("verifying msm accumulator: " + st.err);

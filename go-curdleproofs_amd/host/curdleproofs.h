@@ -182,5 +182,9 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M,
             common::Rand& rand);                                            // :199
 
+// Deferred (default) or eager evaluation of the verifier's check points; see
+// curdle_verify_set_eager in include/curdle_msm.h.  Returns the previous setting.
+int SetEagerChecks(int eager);
+
 }  // namespace proto
 }  // namespace curdle

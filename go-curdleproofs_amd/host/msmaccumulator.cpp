@@ -37,21 +37,45 @@ Status MsmAccumulator::AccumulateCheckXYZZ(const G1XYZZ& Cx, const std::vector<F
   Fr tmp;
   for (size_t i = 0; i < v.size(); i++) {  // :38-43
     fr_mul(tmp, alpha, x[i]);
-    std::string key(reinterpret_cast<const char*>(&v[i]), sizeof(G1Affine));
-    auto it = index_.find(key);
-    if (it == index_.end()) {
-      index_.emplace(std::move(key), bases_.size());
-      bases_.push_back(v[i]);
-      scalars_.push_back(tmp);
-    } else {
-      fr_add(scalars_[it->second], scalars_[it->second], tmp);
-    }
+    AddTerm(v[i], tmp);
   }
 
   // A_c += alpha * C  (:44, ScalarMultiplication with the canonical big.Int of alpha)
   Fr alpha_c;
   f_from_mont<FrParams>(alpha_c, alpha);
   MulAdd(A_c, Cx, alpha_c.l);
+  return Status::OK();
+}
+
+void MsmAccumulator::AddTerm(const G1Affine& base, const Fr& scalar) {
+  std::string key(reinterpret_cast<const char*>(&base), sizeof(G1Affine));
+  auto it = index_.find(key);
+  if (it == index_.end()) {
+    index_.emplace(std::move(key), bases_.size());
+    bases_.push_back(base);
+    scalars_.push_back(scalar);
+  } else {
+    fr_add(scalars_[it->second], scalars_[it->second], scalar);
+  }
+}
+
+Status MsmAccumulator::AccumulateCheckDeferred(const std::vector<Fr>& c_scalars, const std::vector<G1Affine>& c_points,
+                                               const std::vector<Fr>& x, const std::vector<G1Affine>& v,
+                                               common::Rand* rand) {
+  if (v.size() != x.size()) return Status::Error("x and v must have the same length");
+  if (c_scalars.size() != c_points.size()) return Status::Error("c_scalars and c_points must have the same length");
+  Fr alpha, tmp;
+  rand->GetFr(alpha);
+  for (size_t i = 0; i < v.size(); i++) {
+    fr_mul(tmp, alpha, x[i]);
+    AddTerm(v[i], tmp);
+  }
+  for (size_t j = 0; j < c_points.size(); j++) {
+    if (g1_affine_is_inf(c_points[j])) continue;  // contributes nothing; (0,0) is not a valid MSM base key
+    fr_mul(tmp, alpha, c_scalars[j]);
+    f_neg<FrParams>(tmp, tmp);
+    AddTerm(c_points[j], tmp);
+  }
   return Status::OK();
 }
 

@@ -38,6 +38,16 @@ class MsmAccumulator {
   Status AccumulateCheckXYZZ(const G1XYZZ& C, const std::vector<Fr>& x, const std::vector<G1Affine>& v,
                              common::Rand* rand);
 
+  // The same check with C handed over as the linear combination it was going to be
+  // computed from, C = sum_j c_scalars[j] * c_points[j]: instead of evaluating C (one MSM)
+  // and alpha * C (one scalar multiplication) now, the terms -alpha * c_scalars[j] join
+  // the base / scalar map, so Verify()'s single MSM checks
+  //     sum_i alpha x_i v_i - sum_j alpha c_j P_j == A_c
+  // which is the reference's equation with alpha * C moved to the other side.  Draws
+  // alpha exactly like AccumulateCheck, so the accept bit is identical for every input.
+  Status AccumulateCheckDeferred(const std::vector<Fr>& c_scalars, const std::vector<G1Affine>& c_points,
+                                 const std::vector<Fr>& x, const std::vector<G1Affine>& v, common::Rand* rand);
+
   // Verify(), msmaccumulator.go:49-64: flatten the map, one MultiExp, Equal(A_c).
   Status Verify(bool* ok);
 
@@ -52,6 +62,7 @@ class MsmAccumulator {
   // baseScalarMap map[G1Affine]fr.Element (:13): keyed by the 96 key bytes, so
   // a base shared by several checks merges; kept in insertion order (Go's map
   // order is random per run, :53-56, so only the group element is defined).
+  void AddTerm(const G1Affine& base, const Fr& scalar);
   std::unordered_map<std::string, size_t> index_;
   std::vector<G1Affine> bases_;
   std::vector<Fr> scalars_;

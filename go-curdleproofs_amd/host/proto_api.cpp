@@ -116,6 +116,8 @@ extern "C" int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t
   });
 }
 
+extern "C" int curdle_verify_set_eager(int eager) { return proto::SetEagerChecks(eager); }
+
 // Round trip of the wire format: decode, re-encode (curdleproof_test.go "encode/decode").
 extern "C" int curdle_proof_reencode(const uint8_t* proof, size_t proof_len, uint8_t* out, size_t cap, size_t* out_len) {
   if (!proof || !out_len) return curdle_set_last_error(CURDLE_EINVAL, "null argument");

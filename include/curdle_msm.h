@@ -193,6 +193,13 @@ int curdle_prove(const curdle_crs* crs, const uint64_t* Rs, const uint64_t* Ss, 
 int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t proof_len, const uint64_t* Rs,
                   const uint64_t* Ss, const uint64_t* Ts, const uint64_t* Us, size_t ell,
                   const uint64_t M[18], curdle_rand* rand, int* ok);
+/* How curdle_verify evaluates the check points it hands to the accumulator.  0 (default):
+ * deferred -- each is passed as the linear combination of proof / statement points it is,
+ * so a verification is ONE MSM on the GPU.  1: eager -- evaluated where the reference
+ * evaluates them (a MultiExp per argument, then AccumulateCheck's alpha * C on the host).
+ * Identical accept bit; the eager mode exists for differential tests.  Initial value from
+ * the environment variable CURDLE_VERIFY_EAGER.  Returns the previous setting. */
+int curdle_verify_set_eager(int eager);
 int curdle_proof_reencode(const uint8_t* proof, size_t proof_len, uint8_t* out, size_t cap, size_t* out_len);
 /* pieces exposed for known-answer tests */
 int curdle_merlin_test_vector(const char* protocol, const char* label, const uint8_t* msg, size_t msg_len,

@@ -23,7 +23,15 @@ def setup(cm, n):
     return crs, Rs, Ss, Ts, Us, M, perm, k, rs_m
 
 
-def test_completeness(gpu):
+@pytest.fixture(params=["deferred", "eager"])
+def check_mode(gpu, request):
+    """Both ways of evaluating the verifier's check points must give the same accept bit."""
+    prev = gpu.verify_set_eager(request.param == "eager")
+    yield request.param
+    gpu.verify_set_eager(prev)
+
+
+def test_completeness(gpu, check_mode):
     # curdleproof_test.go:16-46, n = 64, prover seed 42, verifier seed 43
     crs, Rs, Ss, Ts, Us, M, perm, k, rs_m = setup(gpu, 64)
     proof = gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(42))
@@ -32,7 +40,7 @@ def test_completeness(gpu):
     assert gpu.verify(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(7)) is True
 
 
-def test_soundness_and_encoding(gpu, oracle):
+def test_soundness_and_encoding(gpu, oracle, check_mode):
     # curdleproof_test.go:48-182, n = 128
     n = 128
     crs, Rs, Ss, Ts, Us, M, perm, k, rs_m = setup(gpu, n)
