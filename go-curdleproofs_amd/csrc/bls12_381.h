@@ -455,7 +455,48 @@ CURDLE_HD void fp_sub(Fp& r, const Fp& a, const Fp& b) { f_sub<FpParams>(r, a, b
 CURDLE_HD void fp_neg(Fp& r, const Fp& a) { f_neg<FpParams>(r, a); }
 CURDLE_HD void fp_dbl(Fp& r, const Fp& a) { f_dbl<FpParams>(r, a); }
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
 CURDLE_HD void fr_mul(Fr& r, const Fr& a, const Fr& b) { f_mul_inl<FrParams>(r, a, b); }
+#else
+// Host: four 64-bit limbs, one operand-scanning row + one reduction row per multiplier
+// word (the verifier's challenge algebra is a few thousand of these per proof).
+CURDLE_HD void fr_mul(Fr& r, const Fr& a, const Fr& b) {
+  typedef unsigned __int128 u128;
+  static const u64 R64[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+  static const u64 N0 = 0xfffffffeffffffffull;  // -r^-1 mod 2^64
+  u64 x[4], y[4], t[5] = {0, 0, 0, 0, 0};
+  __builtin_memcpy(x, a.l, 32);
+  __builtin_memcpy(y, b.l, 32);
+  for (int i = 0; i < 4; i++) {
+    u64 c = 0;
+    for (int j = 0; j < 4; j++) {
+      u128 s = (u128)x[j] * y[i] + t[j] + c;
+      t[j] = (u64)s;
+      c = (u64)(s >> 64);
+    }
+    const u64 top = t[4] + c;  // running value < 2r < 2^256: fits
+    const u64 m = t[0] * N0;
+    u128 s = (u128)m * R64[0] + t[0];
+    c = (u64)(s >> 64);
+    for (int j = 1; j < 4; j++) {
+      s = (u128)m * R64[j] + t[j] + c;
+      t[j - 1] = (u64)s;
+      c = (u64)(s >> 64);
+    }
+    s = (u128)top + c;
+    t[3] = (u64)s;
+    t[4] = (u64)(s >> 64);
+  }
+  u64 d[4], borrow = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 s = (u128)t[i] - R64[i] - borrow;
+    d[i] = (u64)s;
+    borrow = (u64)(s >> 64) & 1;
+  }
+  const bool ge = t[4] != 0 || borrow == 0;
+  __builtin_memcpy(r.l, ge ? d : t, 32);
+}
+#endif
 CURDLE_HD void fr_add(Fr& r, const Fr& a, const Fr& b) { f_add<FrParams>(r, a, b); }
 CURDLE_HD void fr_sub(Fr& r, const Fr& a, const Fr& b) { f_sub<FrParams>(r, a, b); }
 

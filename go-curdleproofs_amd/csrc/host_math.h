@@ -13,12 +13,24 @@
 namespace curdle {
 
 // a^e for a multi-limb exponent e (little-endian 32-bit limbs), Montgomery in/out.
+// Fixed 4-bit windows, most significant first (square roots and inversions over Fp are
+// 381-bit exponentiations: 4 squarings + at most one product per nibble).
 inline void fp_pow(Fp& r, const Fp& a, const u32* e, int nlimbs) {
+  Fp tab[16];
+  f_one(tab[0]);
+  tab[1] = a;
+  for (int i = 2; i < 16; i++) fp_mul(tab[i], tab[i - 1], a);
   Fp acc;
   f_one(acc);
-  for (int i = nlimbs * 32 - 1; i >= 0; i--) {
-    fp_sqr(acc, acc);
-    if ((e[i / 32] >> (i % 32)) & 1) fp_mul(acc, acc, a);
+  bool started = false;
+  for (int i = nlimbs * 8 - 1; i >= 0; i--) {
+    if (started)
+      for (int k = 0; k < 4; k++) fp_sqr(acc, acc);
+    const u32 w = (e[i / 8] >> (4 * (i % 8))) & 15u;
+    if (w) {
+      fp_mul(acc, acc, tab[w]);
+      started = true;
+    }
   }
   r = acc;
 }

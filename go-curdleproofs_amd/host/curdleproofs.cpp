@@ -395,13 +395,14 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const Point& Hc
   }
   const std::vector<Scalar> gamma_inv = alg::BatchInvert(gamma);
 
-  std::vector<Scalar> s(n, Scalar::One()), s_prime(n, Scalar::One());  // :223-234
-  for (size_t i = 0; i < n; i++)
-    for (int j = 0; j < m; j++)
-      if (i & ((size_t)1 << j)) {
-        s[i] = s[i] * gamma[m - j - 1];
-        s_prime[i] = s_prime[i] * gamma_inv[m - j - 1];
-      }
+  // s_i = prod_{j : bit j of i set} gamma_{m-j-1}, s'_i likewise over the inverses (:223-234);
+  // built by doubling -- index i with top bit j extends index i - 2^j -- n products instead of n m / 2
+  std::vector<Scalar> s(n, Scalar::One()), s_prime(n, Scalar::One());
+  for (int j = 0; j < m; j++)
+    for (size_t i = (size_t)1 << j; i < ((size_t)2 << j); i++) {
+      s[i] = s[i - ((size_t)1 << j)] * gamma[m - j - 1];
+      s_prime[i] = s_prime[i - ((size_t)1 << j)] * gamma_inv[m - j - 1];
+    }
 
   // accumulate check 1 (:237-271): AC1 = <gamma, L_C> + B_c + alpha C + (beta alpha^2 z) H + <gamma^-1, R_C>
   Terms AC1;
@@ -715,13 +716,11 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& G, const Point& A, 
     tr.AppendPoints(kLoop, {proof.L_A[i], proof.L_T[i], proof.L_U[i], proof.R_A[i], proof.R_T[i], proof.R_U[i]});
     gamma.push_back(tr.GetAndAppendChallenge(kGamma));
   }
-  std::vector<Scalar> xs(n);
-  for (size_t i = 0; i < n; i++) {  // :267-277
-    Scalar t = Scalar::One();
-    for (size_t k = lg_n; k-- > 0;)
-      if (i & ((size_t)1 << (lg_n - k - 1))) t = t * gamma[k];
-    xs[i] = proof.x * t;  // x * s_i, :184-187
-  }
+  // unfoldedScalars (:267-277): s_i = prod_{b : bit b of i set} gamma_{lg_n-b-1}, by doubling
+  std::vector<Scalar> xs(n, Scalar::One());
+  for (size_t b = 0; b < lg_n; b++)
+    for (size_t i = (size_t)1 << b; i < ((size_t)2 << b); i++) xs[i] = xs[i - ((size_t)1 << b)] * gamma[lg_n - b - 1];
+  for (size_t i = 0; i < n; i++) xs[i] = proof.x * xs[i];  // x * s_i, :184-187
   const std::vector<Scalar> gamma_inv = alg::BatchInvert(gamma);
 
   // the three check points (:196-231): B + alpha Z + <gamma, L> + <gamma^-1, R>
