@@ -45,6 +45,7 @@ R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 R_INV = pow(1 << 256, -1, R_MOD)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_PAIR = 128           # 96 B affine point + 32 B scalar, read once
+MADS_PER_MADD = 3878           # v_mad_u64_u32 per mixed XYZZ addition in k_accumulate
 
 
 def uniform_scalars(rng, n):
@@ -227,10 +228,23 @@ def main():
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+            # The kernel is bound by 32-bit integer multiply issue, not by HBM or MFMA, so the
+            # explanatory fraction is reported next to the contract's HBM one: lane-level
+            # v_mad_u64_u32 per launch (one mixed addition per pair and window, MADS_PER_MADD
+            # multiply-adds each) over the measured duration, against 1024 SIMDs x 64 lanes x
+            # 2.4 GHz / 4.9 cycles per wave instruction (profiles/r01_ubench_valu.txt).
+            valu = None
+            if dom == "accumulate":
+                mads = float(we - wb) * n * MADS_PER_MADD
+                peak = 1024 * 64 * 2.4e9 / 4.9
+                ach_v = mads / (avg[dom] * 1e-3)
+                valu = {"unit": "lane v_mad_u64_u32 /s", "achieved": ach_v, "peak": peak, "frac": round(ach_v / peak, 4)}
+                if solo.get(dom):
+                    valu["frac_kernel_alone"] = round(mads / (solo[dom] * 1e-3) / peak, 4)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
                         "kernel_ms": {kname: round(v, 4) for kname, v in avg.items()},
-                        "kernel_ms_alone": solo,
+                        "kernel_ms_alone": solo, "valu": valu,
                         "note": "integer-VALU bound (381-bit Montgomery arithmetic), see DESIGN.md"}
         out = {
             "metric": "BLS12-381 G1 MSM scalar-point pairs/sec at N=2^20",
