@@ -912,6 +912,22 @@ extern "C" int curdle_acc_accumulate_check(curdle_acc* a, const uint64_t C_jac[1
   return CURDLE_OK;
 }
 
+extern "C" int curdle_acc_accumulate_check_deferred(curdle_acc* a, const uint64_t* c_scalars, const uint64_t* c_points,
+                                                    size_t c_len, const uint64_t* x, size_t x_len, const uint64_t* v,
+                                                    size_t v_len, curdle_rand* rand) {
+  if (!a || !rand || (c_len && (!c_scalars || !c_points)) || (x_len && !x) || (v_len && !v))
+    return fail(CURDLE_EINVAL, "null argument");
+  std::vector<Fr> cs(c_len), xs(x_len);
+  std::vector<G1Affine> cp(c_len), vs(v_len);
+  if (c_len) memcpy(cs.data(), c_scalars, c_len * 32);
+  if (c_len) memcpy(cp.data(), c_points, c_len * 96);
+  if (x_len) memcpy(xs.data(), x, x_len * 32);
+  if (v_len) memcpy(vs.data(), v, v_len * 96);
+  msmaccumulator::Status st = a->a.AccumulateCheckDeferred(cs, cp, xs, vs, &rand->r);
+  if (!st.ok) return fail(CURDLE_EINVAL, "%s", st.err.c_str());
+  return CURDLE_OK;
+}
+
 extern "C" int curdle_acc_verify(curdle_acc* a, int* ok) {
   if (!a || !ok) return fail(CURDLE_EINVAL, "null argument");
   bool b = false;

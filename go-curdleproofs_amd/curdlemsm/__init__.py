@@ -47,7 +47,8 @@ SYMBOLS = [
     "curdle_msm_g1_batch", "curdle_msm_g1_batch_device", "curdle_msm_g1_multi",
     "curdle_rand_new", "curdle_rand_free", "curdle_rand_get_fr", "curdle_rand_get_g1_affine",
     "curdle_rand_permutation",
-    "curdle_acc_new", "curdle_acc_free", "curdle_acc_accumulate_check", "curdle_acc_verify",
+    "curdle_acc_new", "curdle_acc_free", "curdle_acc_accumulate_check", "curdle_acc_accumulate_check_deferred",
+    "curdle_acc_verify",
     "curdle_acc_get_A_c", "curdle_acc_num_bases", "curdle_acc_export",
     "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op",
     "curdle_synth_points_walk_device",
@@ -98,6 +99,8 @@ _rand_perm = _sig("curdle_rand_permutation", C.c_int, _vp, C.c_size_t, _vp)
 _acc_new = _sig("curdle_acc_new", _vp)
 _acc_free = _sig("curdle_acc_free", None, _vp)
 _acc_check = _sig("curdle_acc_accumulate_check", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp)
+_acc_check_deferred = _sig("curdle_acc_accumulate_check_deferred", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t,
+                           _vp, C.c_size_t, _vp)
 _acc_verify = _sig("curdle_acc_verify", C.c_int, _vp, C.POINTER(C.c_int))
 _acc_get_A_c = _sig("curdle_acc_get_A_c", C.c_int, _vp, _vp)
 _acc_num_bases = _sig("curdle_acc_num_bases", C.c_size_t, _vp)
@@ -317,6 +320,15 @@ class MsmAccumulator:
         nx = x.shape[0] if x.size else 0
         nv = v.shape[0] if v.size else 0
         _check(_acc_check(self._h, _ptr(C_jac), _ptr(x), nx, _ptr(v), nv, rand._h))
+
+    def accumulate_check_deferred(self, c_scalars, c_points, x, v, rand: Rand) -> None:
+        """AccumulateCheck with C = sum_j c_scalars[j] * c_points[j] folded into the map."""
+        cs = _as_u64(c_scalars, 4)
+        cp = _as_u64(c_points, 12)
+        x = _as_u64(x, 4)
+        v = _as_u64(v, 12)
+        n = lambda a: a.shape[0] if a.size else 0
+        _check(_acc_check_deferred(self._h, _ptr(cs), _ptr(cp), n(cs), _ptr(x), n(x), _ptr(v), n(v), rand._h))
 
     def verify(self) -> bool:
         ok = C.c_int(0)

@@ -155,6 +155,15 @@ void curdle_acc_free(curdle_acc* a);
 int curdle_acc_accumulate_check(curdle_acc* a, const uint64_t C_jac[18],
                                 const uint64_t* x, size_t x_len,
                                 const uint64_t* v, size_t v_len, curdle_rand* rand);
+/* The same check with C given as the linear combination it would have been computed
+ * from, C = sum_j c_scalars[j] * c_points[j] (affine points, Montgomery scalars): alpha is
+ * drawn exactly as in AccumulateCheck and the terms -alpha * c_scalars[j] join the base /
+ * scalar map, so Verify()'s one MSM checks the reference's equation with alpha * C moved
+ * to the other side -- no MSM for C and no alpha * C scalar multiplication now.  A_c is
+ * left unchanged.  Same accept bit as accumulate_check(C) for every input. */
+int curdle_acc_accumulate_check_deferred(curdle_acc* a, const uint64_t* c_scalars, const uint64_t* c_points,
+                                         size_t c_len, const uint64_t* x, size_t x_len,
+                                         const uint64_t* v, size_t v_len, curdle_rand* rand);
 /* Verify(), msmaccumulator.go:49: *ok = 1 iff MSM(bases, scalars) == A_c.  The
  * MSM runs on the GPU through curdle_msm_g1. */
 int curdle_acc_verify(curdle_acc* a, int* ok);

@@ -155,3 +155,41 @@ def test_accumulator_merges_shared_bases_and_infinity_key(cm, oracle):
     for p, s in zip(pts, sc):
         key = oracle.affine_from_mont_limbs([int(v) for v in p])
         assert o_acc.base_scalar_map[key if key is not None else "inf"] == oracle.fr_from_mont_limbs([int(v) for v in s])
+
+
+def test_accumulate_check_deferred_is_the_same_equation(cm, oracle):
+    """AccumulateCheckDeferred hands C over as sum_j c_j P_j: alpha is drawn like
+    AccumulateCheck's, A_c stays put and the map gains -alpha c_j P_j, so
+    MSM(map) - A_c is the same group element either way (zero iff the check holds)."""
+    r = oracle.Rand(11)
+    V = r.get_g1_affines(4)
+    x = r.get_frs(4)
+    P = r.get_g1_affines(3) + [V[1]]           # one check-point base is also a statement base: entries merge
+    c = r.get_frs(4)
+    C_true = oracle.msm(P, c)
+    to_pts = lambda pts: np.array([oracle.affine_to_mont_limbs(p) for p in pts], dtype=np.uint64)
+    to_frs = lambda frs: np.array([oracle.fr_to_mont_limbs(s) for s in frs], dtype=np.uint64)
+
+    def residual(acc):
+        pts, sc = acc.export()
+        bases = [oracle.affine_from_mont_limbs([int(v) for v in p]) for p in pts]
+        scal = [oracle.fr_from_mont_limbs([int(v) for v in s]) for s in sc]
+        lhs = oracle.msm(bases, scal)
+        a_c = oracle.jac_from_mont_limbs([int(v) for v in acc.A_c])
+        return oracle.add(lhs, oracle.neg(a_c))
+
+    eager, deferred = cm.MsmAccumulator(), cm.MsmAccumulator()
+    eager.accumulate_check(np.array(oracle.jac_to_mont_limbs(C_true), dtype=np.uint64), to_frs(x), to_pts(V), cm.Rand(3))
+    deferred.accumulate_check_deferred(to_frs(c), to_pts(P), to_frs(x), to_pts(V), cm.Rand(3))
+    assert oracle.jac_from_mont_limbs([int(v) for v in deferred.A_c]) is None      # A_c untouched (infinity)
+    assert deferred.num_bases() == 4 + 3                                           # V[1] merged
+    assert residual(eager) == residual(deferred)
+    # and the residual is zero exactly when C really is MSM(V, x)
+    ok_e, ok_d = cm.MsmAccumulator(), cm.MsmAccumulator()
+    ok_e.accumulate_check(np.array(oracle.jac_to_mont_limbs(oracle.msm(V, x)), dtype=np.uint64), to_frs(x), to_pts(V), cm.Rand(4))
+    ok_d.accumulate_check_deferred(to_frs(x), to_pts(V), to_frs(x), to_pts(V), cm.Rand(4))
+    assert residual(ok_e) is None and residual(ok_d) is None
+    # mismatched lengths are the same structural error
+    with pytest.raises(cm.CurdleError) as e:
+        cm.MsmAccumulator().accumulate_check_deferred(to_frs(c), to_pts(P), to_frs(x[:3]), to_pts(V), cm.Rand(0))
+    assert e.value.code == cm.EINVAL and "same length" in e.value.msg
