@@ -53,7 +53,7 @@ SYMBOLS = [
     "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op",
     "curdle_synth_points_walk_device",
     "curdle_crs_generate", "curdle_crs_free", "curdle_crs_size", "curdle_shuffle_permute_commit",
-    "curdle_prove", "curdle_verify", "curdle_verify_set_eager", "curdle_proof_reencode", "curdle_merlin_test_vector",
+    "curdle_prove", "curdle_verify", "curdle_verify_batch", "curdle_verify_set_eager", "curdle_proof_reencode", "curdle_merlin_test_vector",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error",
 ]
 
@@ -119,6 +119,8 @@ _prove = _sig("curdle_prove", C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp,
               C.POINTER(C.c_size_t))
 _verify = _sig("curdle_verify", C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp,
                C.POINTER(C.c_int))
+_verify_batch = _sig("curdle_verify_batch", C.c_int, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp,
+                     C.c_int, _vp)
 _verify_set_eager = _sig("curdle_verify_set_eager", C.c_int, C.c_int)
 _reencode = _sig("curdle_proof_reencode", C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t))
 _merlin_tv = _sig("curdle_merlin_test_vector", C.c_int, C.c_char_p, C.c_char_p, _vp, C.c_size_t, C.c_char_p, _vp,
@@ -445,6 +447,28 @@ def verify(crs: CRS, proof: bytes, Rs, Ss, Ts, Us, M, rand: Rand) -> bool:
     _check(_verify(crs._h, _ptr(pb), len(pb), _ptr(Rs), _ptr(Ss), _ptr(Ts), _ptr(Us), crs.ell, _ptr(M), rand._h,
                    C.byref(ok)))
     return bool(ok.value)
+
+
+def verify_batch(crs: CRS, proofs, Rs, Ss, Ts, Us, Ms, rand: Rand, nthreads: int = 8):
+    """Cross-proof batch verification: k proofs over one CRS, one shared accumulator, one MSM.
+    proofs: list of bytes; Rs/Ss/Ts/Us: lists of (ell, 12) arrays; Ms: list of 18-limb points.
+    Returns the list of accept bits (exact: a failing batch is settled proof by proof)."""
+    k = len(proofs)
+    keep = []
+
+    def ptr_array(arrs, width):
+        a = [_as_u64(x, width) for x in arrs]
+        keep.append(a)
+        return (C.c_void_p * k)(*[x.ctypes.data for x in a])
+
+    pbufs = [np.frombuffer(p, dtype=np.uint8).copy() for p in proofs]
+    pp = (C.c_void_p * k)(*[b.ctypes.data for b in pbufs])
+    lens = (C.c_size_t * k)(*[len(b) for b in pbufs])
+    ms = np.ascontiguousarray(np.stack([_as_u64(m) for m in Ms]) if k else np.zeros((0, 18), dtype=np.uint64))
+    oks = (C.c_int * k)()
+    _check(_verify_batch(crs._h, k, pp, lens, ptr_array(Rs, 12), ptr_array(Ss, 12), ptr_array(Ts, 12),
+                         ptr_array(Us, 12), crs.ell, _ptr(ms), rand._h, int(nthreads), oks))
+    return [bool(v) for v in oks]
 
 
 def verify_set_eager(eager: bool) -> bool:

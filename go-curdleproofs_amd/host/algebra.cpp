@@ -245,10 +245,10 @@ std::vector<G1Affine> BatchToAffine(const std::vector<Point>& pts) {
 }
 
 // --------------------------------------------------------------------- MSM ---
-static std::runtime_error msm_error(int rc) {
+static MsmError msm_error(int rc) {
   char buf[256];
   curdle_last_error(buf, sizeof(buf));
-  return std::runtime_error(std::string("computing msm: ") + buf + " (rc " + std::to_string(rc) + ")");
+  return MsmError(std::string("computing msm: ") + buf + " (rc " + std::to_string(rc) + ")", rc);
 }
 
 Point MultiExp(const std::vector<G1Affine>& points, const std::vector<Scalar>& scalars) {

@@ -6,6 +6,8 @@
 // Replaces what the reference's protocol packages get from gnark-crypto
 // (fr.Element, bls12381.G1Jac / G1Affine and their Bytes / SetBytes, go.mod:6).
 #pragma once
+#include <stdexcept>
+#include <string>
 #include <stdint.h>
 #include <string.h>
 
@@ -16,6 +18,13 @@
 
 namespace curdle {
 namespace alg {
+
+// A failed call into the MSM entry points (no device, HIP error, ...): distinct from the
+// protocol's structural errors so callers can tell "reject" from "could not compute".
+struct MsmError : std::runtime_error {
+  int rc;
+  MsmError(const std::string& what, int code) : std::runtime_error(what), rc(code) {}
+};
 
 struct Scalar {
   Fr v;  // Montgomery form, as fr.Element

@@ -5,7 +5,11 @@
 
 #include <stdlib.h>
 
+#include "../../include/curdle_msm.h"
+
 #include <atomic>
+#include <mutex>
+#include <thread>
 
 #include <stdexcept>
 
@@ -843,11 +847,14 @@ Proof Prove(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G
   return proof;
 }
 
-bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
-            const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand) {
-  // curdleproof.go:199-318
+// The body of curdleproof.Verify up to, but not including, the accumulator's final MSM:
+// false = a direct (non-accumulated) check already failed.  Split out so several proofs
+// can share one accumulator (VerifyBatch).
+bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
+                MsmAccumulator& acc) {
+  // curdleproof.go:199-311
   Transcript tr(kTranscript);
-  MsmAccumulator acc;
   if (Ts.empty() || g1_affine_is_inf(Ts[0])) throw err("randomizer is zero");  // :213-215
 
   AppendInstance(tr, Rs, Ss, Ts, Us, M);
@@ -870,10 +877,120 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
   S.Add(Scalar::One(), proof.S);
   Accumulate(acc, R, as, Rs, rand, "msm accumulator check R, as, Rs");  // :306
   Accumulate(acc, S, as, Ss, rand, "msm accumulator check S, as, Ss");  // :309
+  return true;
+}
+
+bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+            const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand) {
+  // curdleproof.go:199-318: every sub-argument folds its checks into one accumulator,
+  // whose single MSM (:313) decides
+  MsmAccumulator acc;
+  if (!VerifyInto(proof, crs, Rs, Ss, Ts, Us, M, rand, acc)) return false;
   bool ok = false;
   msmaccumulator::Status st = acc.Verify(&ok);                                // :313, the batched MSM on the GPU
-  if (!st.ok) throw err("verifying msm accumulator: " + st.err);
+  if (!st.ok) throw alg::MsmError("verifying msm accumulator: " + st.err, CURDLE_EHIP);  // device failure
   return ok;
+}
+
+// Cross-proof batch verification (no reference counterpart): the
+// host part of every proof (decoding, transcript, challenge algebra, the direct
+// same-scalar check) runs on `nthreads` worker threads.  Each worker folds the checks of
+// the proofs it handles into one pending group -- concatenated base / scalar lists, no
+// cross-proof merging: the GPU does not care about repeated bases, and hashing ~1,400 keys
+// per proof into one shared map would serialise the batch -- and every `flush` proofs (and
+// at the end) settles the group with ONE MSM on the GPU, from its own thread, so the
+// groups' MSMs overlap the other workers' host work.  Per-proof randomness is derived from
+// `rand`.  If a group's MSM fails, its proofs are verified one by one, so oks[] is exact
+// either way; a proof that does not decode or fails a direct check is rejected without
+// joining a group.
+std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items, common::Rand& rand, int nthreads) {
+  const size_t k = items.size();
+  std::vector<int> oks(k, 0);
+  if (k == 0) return oks;
+  std::vector<uint64_t> seeds(k);
+  for (size_t i = 0; i < k; i++) {
+    Fr f;
+    rand.GetFr(f);
+    seeds[i] = (uint64_t)f.l[0] | ((uint64_t)f.l[1] << 32);
+  }
+  if (nthreads < 1) nthreads = 1;
+  if ((size_t)nthreads > k) nthreads = (int)k;
+  size_t flush = 32;
+  if (const char* e = getenv("CURDLE_BATCH_GROUP")) flush = (size_t)atoi(e);
+  if (flush < 1) flush = 1;
+
+  std::atomic<size_t> next(0);
+  std::atomic<bool> failed(false);
+  std::string first_error;
+  std::mutex err_mu;
+  auto worker = [&]() {
+    std::vector<G1Affine> bases;
+    std::vector<Scalar> scalars;
+    std::vector<size_t> members;
+    Point a_c = Point::Infinity();
+    auto settle = [&]() {
+      if (members.empty()) return;
+      const bool all = alg::MultiExp(bases, scalars) == a_c;  // the group's one MSM, on the GPU
+      for (size_t i : members) {
+        if (all) {
+          oks[i] = 1;
+          continue;
+        }
+        try {  // some accumulated check of the group failed: find out whose
+          const BatchItem& it = items[i];
+          Proof p = Proof::FromBytes(it.proof, it.proof_len);
+          common::Rand r(seeds[i]);
+          oks[i] = Verify(p, crs, *it.Rs, *it.Ss, *it.Ts, *it.Us, it.M, r) ? 1 : 0;
+        } catch (const alg::MsmError&) {
+          throw;  // device failure, not a verdict
+        } catch (const std::runtime_error&) {
+          oks[i] = 0;
+        }
+      }
+      bases.clear();
+      scalars.clear();
+      members.clear();
+      a_c = Point::Infinity();
+    };
+    try {
+      for (size_t i = next.fetch_add(1); i < k && !failed.load(); i = next.fetch_add(1)) {
+        const BatchItem& it = items[i];
+        MsmAccumulator mine;  // joins the group only if the proof's direct checks pass
+        bool pre = false;
+        try {
+          Proof p = Proof::FromBytes(it.proof, it.proof_len);
+          common::Rand r(seeds[i]);
+          pre = VerifyInto(p, crs, *it.Rs, *it.Ss, *it.Ts, *it.Us, it.M, r, mine);
+        } catch (const alg::MsmError&) {
+          throw;  // device failure (eager mode computes MSMs here), not a verdict
+        } catch (const std::runtime_error&) {
+          pre = false;  // malformed proof / zero randomizer: rejected in a batch
+        }
+        if (!pre) continue;
+        bases.insert(bases.end(), mine.Bases().begin(), mine.Bases().end());
+        for (const Fr& f : mine.Scalars()) {
+          Scalar sc;
+          sc.v = f;
+          scalars.push_back(sc);
+        }
+        Point ac;
+        ac.p = mine.A_c;
+        a_c = a_c + ac;
+        members.push_back(i);
+        if (members.size() >= flush) settle();
+      }
+      settle();
+    } catch (const std::exception& e) {  // device failure inside an MSM: the whole call fails
+      std::lock_guard<std::mutex> g(err_mu);
+      if (!failed.exchange(true)) first_error = e.what();
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; t++) th.emplace_back(worker);
+  worker();
+  for (auto& x : th) x.join();
+  if (failed.load()) throw alg::MsmError("batch verification: " + first_error, CURDLE_EHIP);
+  return oks;
 }
 
 std::vector<uint8_t> Proof::Serialize() const {  // :358-387

@@ -182,6 +182,16 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M,
             common::Rand& rand);                                            // :199
 
+// Cross-proof batch verification over one CRS: one shared accumulator, one MSM (see the
+// definition).  Returns the per-proof accept bits.
+struct BatchItem {
+  const uint8_t* proof;
+  size_t proof_len;
+  const std::vector<G1Affine>*Rs, *Ss, *Ts, *Us;
+  Point M;
+};
+std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items, common::Rand& rand, int nthreads);
+
 // Deferred (default) or eager evaluation of the verifier's check points; see
 // curdle_verify_set_eager in include/curdle_msm.h.  Returns the previous setting.
 int SetEagerChecks(int eager);

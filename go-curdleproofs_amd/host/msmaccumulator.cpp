@@ -79,6 +79,11 @@ Status MsmAccumulator::AccumulateCheckDeferred(const std::vector<Fr>& c_scalars,
   return Status::OK();
 }
 
+void MsmAccumulator::Merge(const MsmAccumulator& other) {
+  for (size_t i = 0; i < other.bases_.size(); i++) AddTerm(other.bases_[i], other.scalars_[i]);
+  curdle_host_add(&A_c, &other.A_c);
+}
+
 Status MsmAccumulator::Verify(bool* ok) {
   *ok = false;
   uint64_t out[CURDLE_G1_JAC_U64];

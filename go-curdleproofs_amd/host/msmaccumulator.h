@@ -48,6 +48,11 @@ class MsmAccumulator {
   Status AccumulateCheckDeferred(const std::vector<Fr>& c_scalars, const std::vector<G1Affine>& c_points,
                                  const std::vector<Fr>& x, const std::vector<G1Affine>& v, common::Rand* rand);
 
+  // Fold another accumulator's pending checks into this one (bases shared by both merge,
+  // A_c adds): the union is one random linear combination of all their checks, so one
+  // Verify() answers "do all of them hold" with one MSM (cross-proof batch verification).
+  void Merge(const MsmAccumulator& other);
+
   // Verify(), msmaccumulator.go:49-64: flatten the map, one MultiExp, Equal(A_c).
   Status Verify(bool* ok);
 

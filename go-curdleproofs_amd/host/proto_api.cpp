@@ -116,6 +116,30 @@ extern "C" int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t
   });
 }
 
+extern "C" int curdle_verify_batch(const curdle_crs* crs, size_t k, const uint8_t* const* proofs, const size_t* proof_lens,
+                                   const uint64_t* const* Rs, const uint64_t* const* Ss, const uint64_t* const* Ts,
+                                   const uint64_t* const* Us, size_t ell, const uint64_t* Ms, curdle_rand* rand,
+                                   int nthreads, int* oks) {
+  if (!crs || !rand || !oks || (k && (!proofs || !proof_lens || !Rs || !Ss || !Ts || !Us || !Ms)))
+    return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  if (ell != crs->crs.Gs.size()) return curdle_set_last_error(CURDLE_EINVAL, "ell does not match the CRS");
+  return Guard([&]() {
+    std::vector<std::vector<G1Affine>> r(k), s(k), t(k), u(k);
+    std::vector<proto::BatchItem> items(k);
+    for (size_t i = 0; i < k; i++) {
+      if (!proofs[i] || !Rs[i] || !Ss[i] || !Ts[i] || !Us[i]) throw std::runtime_error("null argument in batch item");
+      r[i] = Affines(Rs[i], ell);
+      s[i] = Affines(Ss[i], ell);
+      t[i] = Affines(Ts[i], ell);
+      u[i] = Affines(Us[i], ell);
+      items[i] = proto::BatchItem{proofs[i], proof_lens[i], &r[i], &s[i], &t[i], &u[i], Point::FromJac(Ms + 18 * i)};
+    }
+    std::vector<int> res = proto::VerifyBatch(crs->crs, items, rand->r, nthreads);
+    for (size_t i = 0; i < k; i++) oks[i] = res[i];
+    return CURDLE_OK;
+  });
+}
+
 extern "C" int curdle_verify_set_eager(int eager) { return proto::SetEagerChecks(eager); }
 
 // Round trip of the wire format: decode, re-encode (curdleproof_test.go "encode/decode").

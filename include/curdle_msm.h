@@ -202,6 +202,18 @@ int curdle_prove(const curdle_crs* crs, const uint64_t* Rs, const uint64_t* Ss, 
 int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t proof_len, const uint64_t* Rs,
                   const uint64_t* Ss, const uint64_t* Ts, const uint64_t* Us, size_t ell,
                   const uint64_t M[18], curdle_rand* rand, int* ok);
+/* Cross-proof batch verification (the reference verifies one proof
+ * at a time): k proofs over the same CRS and the same ell.  The host part of each proof runs
+ * on `nthreads` worker threads; all proofs' checks are folded into ONE accumulator (per-proof
+ * randomness derived from `rand`; the CRS bases merge) and ONE MSM of ~k * (4 ell + 100) pairs
+ * decides.  oks[i] receives each proof's accept bit: if the batch MSM fails, the proofs are
+ * settled one by one, so the bits are exact either way.  A malformed proof or a zero
+ * randomizer counts as rejected here (curdle_verify reports those as errors).
+ * proofs / Rs / Ss / Ts / Us: arrays of k pointers; Ms: k x 18 limbs. */
+int curdle_verify_batch(const curdle_crs* crs, size_t k, const uint8_t* const* proofs, const size_t* proof_lens,
+                        const uint64_t* const* Rs, const uint64_t* const* Ss, const uint64_t* const* Ts,
+                        const uint64_t* const* Us, size_t ell, const uint64_t* Ms, curdle_rand* rand,
+                        int nthreads, int* oks);
 /* How curdle_verify evaluates the check points it hands to the accumulator.  0 (default):
  * deferred -- each is passed as the linear combination of proof / statement points it is,
  * so a verification is ONE MSM on the GPU.  1: eager -- evaluated where the reference

@@ -134,3 +134,19 @@ def test_no_device_means_loud_failure_not_fallback(cm, oracle):
     with pytest.raises(cm.CurdleError) as e:
         acc.verify()
     assert e.value.code == cm.ENODEV and "computing msm" in e.value.msg  # msmaccumulator.go:60
+
+
+@pytest.mark.skipif(os.environ.get("CURDLE_EXPECT_GPU") == "1", reason="GPU box")
+def test_protocol_layer_has_no_cpu_msm_either(cm):
+    """The protocol restatement funnels every MultiExp into the GPU entry points: without
+    a device ShufflePermuteCommit (common/util.go:75) fails with ENODEV, it does not fall
+    back to a host MSM."""
+    if cm.device_available():
+        pytest.skip("a device is visible")
+    ell = 4
+    rand = cm.Rand(0)
+    crs = cm.CRS(ell, rand)                      # host only: hashing + scalar multiplications
+    Rs, Ss = rand.get_g1_affines(ell), rand.get_g1_affines(ell)
+    with pytest.raises(cm.CurdleError) as e:
+        cm.shuffle_permute_commit(crs, Rs, Ss, rand.generate_permutation(ell), rand.get_fr(), rand)
+    assert e.value.code == cm.ENODEV

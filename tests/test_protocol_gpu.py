@@ -93,3 +93,30 @@ def test_prover_is_deterministic_in_its_seed(gpu):
     c = gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(6))
     assert a == b and a != c
     assert gpu.verify(crs, c, Rs, Ss, Ts, Us, M, gpu.Rand(1)) is True
+
+
+def test_batch_verification_shares_one_accumulator(gpu, check_mode):
+    """curdle_verify_batch: several proofs over one CRS, one shared
+    accumulator and one MSM; the per-proof bits stay exact when one proof is bad."""
+    n = 32
+    ell = n - 4
+    rand = gpu.Rand(0)
+    crs = gpu.CRS(ell, rand)
+    inst = []
+    for j in range(5):
+        perm = gpu.Rand(100 + j).generate_permutation(ell)
+        k = rand.get_fr()
+        Rs, Ss = rand.get_g1_affines(ell), rand.get_g1_affines(ell)
+        Ts, Us, M, rs_m = gpu.shuffle_permute_commit(crs, Rs, Ss, perm, k, rand)
+        proof = gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(42 + j))
+        inst.append((proof, Rs, Ss, Ts, Us, M))
+    cols = lambda items: [list(c) for c in zip(*items)]
+    proofs, Rs, Ss, Ts, Us, Ms = cols(inst)
+    assert gpu.verify_batch(crs, proofs, Rs, Ss, Ts, Us, Ms, gpu.Rand(9), nthreads=3) == [True] * 5
+    assert gpu.verify_batch(crs, proofs[:1], Rs[:1], Ss[:1], Ts[:1], Us[:1], Ms[:1], gpu.Rand(9), nthreads=4) == [True]
+    assert gpu.verify_batch(crs, [], [], [], [], [], [], gpu.Rand(9)) == []
+    # proof 2 checked against proof 3's instance, proof 4 truncated: exact bits, the others still accept
+    bad = [list(x) for x in (proofs, Rs, Ss, Ts, Us, Ms)]
+    bad[1][2], bad[2][2] = Rs[3], Ss[3]
+    bad[0][4] = proofs[4][:-7]
+    assert gpu.verify_batch(crs, *bad, gpu.Rand(9), nthreads=2) == [True, True, False, True, False]
