@@ -120,6 +120,32 @@ inline void g1_scalar_mul(G1XYZZ& r, const G1XYZZ& p, const u32* k, int nlimbs) 
   r = acc;
 }
 
+// Membership in the prime-order subgroup G1 for a point already known to be on the curve
+// (what gnark's Decoder / SetBytes check after decompression).  With beta the cube root of
+// unity for which phi(x, y) = (beta x, y) acts on G1 as [z^2 - 1] (z = -0xd201000000010000
+// the curve parameter, r = z^4 - z^2 + 1), P is in G1 iff [z^2] phi(P) + P is the point at
+// infinity: two 64-bit scalar multiplications (weight 6) instead of one by the 255-bit r.
+inline bool g1_in_subgroup(const G1XYZZ& p) {
+  if (g1_is_inf(p)) return true;
+  static const u32 kBeta[12] = {0x8671f071u, 0xcd03c9e4u, 0x1fcda5d2u, 0x5dab2246u, 0xd3851b95u, 0x587042afu,
+                                0x01bacb9eu, 0x8eb60ebeu, 0x83d050d2u, 0x03f97d6eu, 0x54638741u, 0x18f02065u};
+  Fp beta;
+  for (int i = 0; i < 12; i++) beta.l[i] = kBeta[i];
+  G1XYZZ q = p;
+  fp_mul(q.x, q.x, beta);
+  const u64 z = 0xd201000000010000ull;  // |z|; the sign cancels in z^2
+  for (int rep = 0; rep < 2; rep++) {
+    G1XYZZ acc = q;  // top bit (63) is set
+    for (int i = 62; i >= 0; i--) {
+      g1_dbl(acc);
+      if ((z >> i) & 1) g1_add(acc, q);
+    }
+    q = acc;
+  }
+  g1_add(q, p);
+  return g1_is_inf(q);
+}
+
 // Projective equality of two XYZZ points (gnark G1Jac.Equal, msmaccumulator.go:63).
 inline bool g1_equal(const G1XYZZ& a, const G1XYZZ& b) {
   bool ia = g1_is_inf(a), ib = g1_is_inf(b);

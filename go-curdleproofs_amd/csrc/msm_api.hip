@@ -513,6 +513,38 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// Batched point decoding (decode_kernels.hip)
+// ---------------------------------------------------------------------------
+extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgroup_check, uint64_t* out_affine,
+                                          uint8_t* status) {
+  if (n && (!in || !out_affine || !status)) return fail(CURDLE_EINVAL, "null argument");
+  if (n == 0) return CURDLE_OK;
+  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 points", n);
+  int idx;
+  int rc = acquire_slot(true, &idx);
+  if (rc) return rc;
+  Slot& S = g_ctx.slots[idx];
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    int r;
+    // the slot's generic buffers: compressed input, decoded output, status bytes
+    if ((r = ensure(S.scalars, n * 48))) return r;
+    if ((r = ensure(S.points, n * 96))) return r;
+    if ((r = ensure(S.counts, n))) return r;
+    HIP_TRY(hipMemcpyAsync(S.scalars.p, in, n * 48, hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(launch_g1_decompress((const uint8_t*)S.scalars.p, (uint32_t)n, subgroup_check, (uint32_t*)S.points.p,
+                                 (uint8_t*)S.counts.p, S.stream));
+    HIP_TRY(hipMemcpyAsync(out_affine, S.points.p, n * 96, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipMemcpyAsync(status, S.counts.p, n, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    return CURDLE_OK;
+  };
+  rc = body();
+  release_slot(idx);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
 // Life cycle
 // ---------------------------------------------------------------------------
 extern "C" int curdle_init(int device) {

@@ -87,4 +87,9 @@ hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32
 // Element-wise primitive test (curdle_selftest_op); all pointers are device memory.
 hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream);
 
+// decode_kernels.hip: n compressed G1 points (48 B each) -> n gnark affine points (24 u32
+// each) + one CURDLE_DECODE_* status byte per point.
+hipError_t launch_g1_decompress(const uint8_t* in, uint32_t n, int subgroup_check, uint32_t* out, uint8_t* status,
+                                hipStream_t stream);
+
 }  // namespace curdle

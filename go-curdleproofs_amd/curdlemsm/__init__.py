@@ -53,7 +53,10 @@ SYMBOLS = [
     "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op",
     "curdle_synth_points_walk_device",
     "curdle_crs_generate", "curdle_crs_free", "curdle_crs_size", "curdle_shuffle_permute_commit",
-    "curdle_prove", "curdle_verify", "curdle_verify_batch", "curdle_verify_set_eager", "curdle_proof_reencode", "curdle_merlin_test_vector",
+    "curdle_prove", "curdle_verify", "curdle_proof_from_bytes", "curdle_proof_free", "curdle_verify_proof",
+    "curdle_verify_batch", "curdle_verify_set_eager",
+    "curdle_whisk_is_valid_shuffle_proof", "curdle_whisk_generate_shuffle_proof",
+    "curdle_whisk_is_valid_tracker_proof", "curdle_whisk_generate_tracker_proof", "curdle_proof_reencode", "curdle_merlin_test_vector", "curdle_g1_decompress_batch",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error",
 ]
 
@@ -119,8 +122,16 @@ _prove = _sig("curdle_prove", C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp,
               C.POINTER(C.c_size_t))
 _verify = _sig("curdle_verify", C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp,
                C.POINTER(C.c_int))
+_proof_from_bytes = _sig("curdle_proof_from_bytes", C.c_int, _vp, C.c_size_t, C.POINTER(_vp))
+_proof_free = _sig("curdle_proof_free", None, _vp)
+_verify_proof = _sig("curdle_verify_proof", C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, C.POINTER(C.c_int))
 _verify_batch = _sig("curdle_verify_batch", C.c_int, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp,
                      C.c_int, _vp)
+_whisk_valid_shuffle = _sig("curdle_whisk_is_valid_shuffle_proof", C.c_int, _vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp,
+                            C.POINTER(C.c_int))
+_whisk_gen_shuffle = _sig("curdle_whisk_generate_shuffle_proof", C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp)
+_whisk_valid_tracker = _sig("curdle_whisk_is_valid_tracker_proof", C.c_int, _vp, _vp, _vp, C.POINTER(C.c_int))
+_whisk_gen_tracker = _sig("curdle_whisk_generate_tracker_proof", C.c_int, _vp, _vp, _vp, _vp)
 _verify_set_eager = _sig("curdle_verify_set_eager", C.c_int, C.c_int)
 _reencode = _sig("curdle_proof_reencode", C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t))
 _merlin_tv = _sig("curdle_merlin_test_vector", C.c_int, C.c_char_p, C.c_char_p, _vp, C.c_size_t, C.c_char_p, _vp,
@@ -449,6 +460,30 @@ def verify(crs: CRS, proof: bytes, Rs, Ss, Ts, Us, M, rand: Rand) -> bool:
     return bool(ok.value)
 
 
+class Proof:
+    """A decoded curdleproof.Proof (Proof.FromReader, curdleproof.go:320: every point curve- and
+    subgroup-checked).  verify_proof() is the reference's Verify(proof Proof, ...) on it."""
+
+    def __init__(self, data: bytes):
+        pb = np.frombuffer(data, dtype=np.uint8).copy()
+        h = _vp()
+        _check(_proof_from_bytes(_ptr(pb), len(pb), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _proof_free is not None:
+            _proof_free(h)
+
+
+def verify_proof(crs: CRS, proof: Proof, Rs, Ss, Ts, Us, M, rand: Rand) -> bool:
+    Rs, Ss, Ts, Us = (_as_u64(a, 12) for a in (Rs, Ss, Ts, Us))
+    M = _as_u64(M)
+    ok = C.c_int(0)
+    _check(_verify_proof(crs._h, proof._h, _ptr(Rs), _ptr(Ss), _ptr(Ts), _ptr(Us), crs.ell, _ptr(M), rand._h, C.byref(ok)))
+    return bool(ok.value)
+
+
 def verify_batch(crs: CRS, proofs, Rs, Ss, Ts, Us, Ms, rand: Rand, nthreads: int = 8):
     """Cross-proof batch verification: k proofs over one CRS, one shared accumulator, one MSM.
     proofs: list of bytes; Rs/Ss/Ts/Us: lists of (ell, 12) arrays; Ms: list of 18-limb points.
@@ -471,6 +506,55 @@ def verify_batch(crs: CRS, proofs, Rs, Ss, Ts, Us, Ms, rand: Rand, nthreads: int
     return [bool(v) for v in oks]
 
 
+# ---- whisk package (whisk/whisk.go, whisk/types.go): trackers are 96-byte strings rG || krG ----
+WHISK_ELL = 124
+WHISK_TRACKER_PROOF_SIZE = 128
+WHISK_SHUFFLE_PROOF_SIZE = 4576
+
+
+def _bytes_arr(b: bytes) -> np.ndarray:
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
+def whisk_is_valid_shuffle_proof(crs: CRS, pre_trackers, post_trackers, proof: bytes, rand: Rand) -> bool:
+    """IsValidWhiskShuffleProof (whisk.go:20): trackers are lists of 96-byte strings."""
+    if len(proof) != WHISK_SHUFFLE_PROOF_SIZE:
+        raise ValueError("a whisk shuffle proof is %d bytes" % WHISK_SHUFFLE_PROOF_SIZE)
+    pre, post, pb = _bytes_arr(b"".join(pre_trackers)), _bytes_arr(b"".join(post_trackers)), _bytes_arr(proof)
+    ok = C.c_int(0)
+    _check(_whisk_valid_shuffle(crs._h, _ptr(pre), _ptr(post), len(pre_trackers), len(post_trackers), _ptr(pb), rand._h,
+                                C.byref(ok)))
+    return bool(ok.value)
+
+
+def whisk_generate_shuffle_proof(crs: CRS, pre_trackers, rand: Rand):
+    """GenerateWhiskShuffleProof (whisk.go:63) -> (post_trackers, proof bytes)."""
+    pre = _bytes_arr(b"".join(pre_trackers))
+    post = np.zeros(96 * len(pre_trackers), dtype=np.uint8)
+    proof = np.zeros(WHISK_SHUFFLE_PROOF_SIZE, dtype=np.uint8)
+    _check(_whisk_gen_shuffle(crs._h, _ptr(pre), len(pre_trackers), rand._h, _ptr(post), _ptr(proof)))
+    pb = post.tobytes()
+    return [pb[96 * i: 96 * (i + 1)] for i in range(len(pre_trackers))], proof.tobytes()
+
+
+def whisk_is_valid_tracker_proof(tracker: bytes, k_commitment: bytes, proof: bytes) -> bool:
+    """IsValidWhiskTrackerProof (whisk.go:116)."""
+    if len(tracker) != 96 or len(k_commitment) != 48 or len(proof) != WHISK_TRACKER_PROOF_SIZE:
+        raise ValueError("tracker 96 B, k commitment 48 B, tracker proof 128 B")
+    t, kc, pb = _bytes_arr(tracker), _bytes_arr(k_commitment), _bytes_arr(proof)
+    ok = C.c_int(0)
+    _check(_whisk_valid_tracker(_ptr(t), _ptr(kc), _ptr(pb), C.byref(ok)))
+    return bool(ok.value)
+
+
+def whisk_generate_tracker_proof(tracker: bytes, k, rand: Rand) -> bytes:
+    """GenerateWhiskTrackerProof (whisk.go:149); k = Montgomery fr limbs."""
+    t, kk = _bytes_arr(tracker), _as_u64(k)
+    out = np.zeros(WHISK_TRACKER_PROOF_SIZE, dtype=np.uint8)
+    _check(_whisk_gen_tracker(_ptr(t), _ptr(kk), rand._h, _ptr(out)))
+    return out.tobytes()
+
+
 def verify_set_eager(eager: bool) -> bool:
     """Evaluate the verifier's check points eagerly (the reference's order of operations)
     instead of deferring them into the accumulator's one MSM; returns the previous mode."""
@@ -490,6 +574,22 @@ def merlin_test_vector(protocol: bytes, label: bytes, msg: bytes, challenge_labe
     out = np.zeros(n, dtype=np.uint8)
     _check(_merlin_tv(protocol, label, _ptr(m), len(m), challenge_label, _ptr(out), n))
     return bytes(out)
+
+
+_decompress_batch = _sig("curdle_g1_decompress_batch", C.c_int, _vp, C.c_size_t, C.c_int, _vp, _vp)
+DECODE_OK, DECODE_INFINITY, DECODE_BAD_ENCODING, DECODE_NOT_ON_CURVE, DECODE_NOT_IN_SUBGROUP = range(5)
+
+
+def g1_decompress_batch(data: bytes, subgroup_check: bool = True):
+    """n x 48 bytes of compressed points -> ((n, 12) gnark affine points, (n,) status bytes), on the GPU."""
+    b = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    if len(b) % 48:
+        raise ValueError("compressed G1 points are 48 bytes each")
+    n = len(b) // 48
+    out = np.zeros((n, 12), dtype=np.uint64)
+    st = np.zeros(n, dtype=np.uint8)
+    _check(_decompress_batch(_ptr(b), n, 1 if subgroup_check else 0, _ptr(out), _ptr(st)))
+    return out, st
 
 
 def g1_compress(jac) -> bytes:

@@ -229,11 +229,7 @@ bool Point::FromCompressed(const uint8_t in[48], Point* out, bool subgroup_check
   a.y = y;
   *out = FromAffine(a);
   if (subgroup_check) {
-    u32 r[8];
-    for (int i = 0; i < 8; i++) r[i] = FrParams::mod(i);
-    G1XYZZ t;
-    ScalarMulImpl(t, out->p, r);
-    if (!g1_is_inf(t)) return false;
+    if (!curdle_host_in_subgroup(&out->p)) return false;  // endomorphism test, host_math.h
   }
   return true;
 }

@@ -938,7 +938,7 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
         }
         try {  // some accumulated check of the group failed: find out whose
           const BatchItem& it = items[i];
-          Proof p = Proof::FromBytes(it.proof, it.proof_len);
+          Proof p = Proof::FromBytes(it.proof, it.proof_len, /*subgroup_check=*/true);
           common::Rand r(seeds[i]);
           oks[i] = Verify(p, crs, *it.Rs, *it.Ss, *it.Ts, *it.Us, it.M, r) ? 1 : 0;
         } catch (const alg::MsmError&) {
@@ -958,7 +958,7 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
         MsmAccumulator mine;  // joins the group only if the proof's direct checks pass
         bool pre = false;
         try {
-          Proof p = Proof::FromBytes(it.proof, it.proof_len);
+          Proof p = Proof::FromBytes(it.proof, it.proof_len, /*subgroup_check=*/true);
           common::Rand r(seeds[i]);
           pre = VerifyInto(p, crs, *it.Rs, *it.Ss, *it.Ts, *it.Us, it.M, r, mine);
         } catch (const alg::MsmError&) {
@@ -1007,6 +1007,9 @@ std::vector<uint8_t> Proof::Serialize() const {  // :358-387
 }
 Proof Proof::FromBytes(const uint8_t* data, size_t len, bool subgroup_check) {  // :320-356
   Reader r(data, len, subgroup_check);
+  return FromReader(r);
+}
+Proof Proof::FromReader(Reader& r) {
   Proof p;
   p.A = r.GetPoint("A");
   p.T.FromReader(r);

@@ -173,6 +173,7 @@ struct Proof {
   samemsm::Proof proofSameMultiscalar;
   std::vector<uint8_t> Serialize() const;                                    // curdleproof.go:358
   static Proof FromBytes(const uint8_t* data, size_t len, bool subgroup_check = false);  // :320
+  static Proof FromReader(Reader& r);  // the same from a stream position (trailing bytes are left unread)
 };
 Proof Prove(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M,

@@ -11,6 +11,7 @@ int curdle_host_to_affine_bmi2(void*, const void*);
 void curdle_host_fp_pow_bmi2(void*, const void*, const uint32_t*);
 void curdle_host_fp_from_mont_bmi2(void*, const void*);
 int curdle_host_equal_bmi2(const void*, const void*);
+int curdle_host_in_subgroup_bmi2(const void*);
 }
 
 static bool fast_isa() {
@@ -59,4 +60,8 @@ extern "C" void curdle_host_fp_from_mont(void* r, const void* a) {
 
 extern "C" int curdle_host_equal(const void* a_xyzz, const void* b_xyzz) {
   return fast_isa() ? curdle_host_equal_bmi2(a_xyzz, b_xyzz) : curdle_host_equal_generic(a_xyzz, b_xyzz);
+}
+
+extern "C" int curdle_host_in_subgroup(const void* p_xyzz) {
+  return fast_isa() ? curdle_host_in_subgroup_bmi2(p_xyzz) : curdle_host_in_subgroup_generic(p_xyzz);
 }

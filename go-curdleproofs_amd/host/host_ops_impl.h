@@ -69,3 +69,9 @@ extern "C" int CURDLE_FN(curdle_host_equal)(const void* a_xyzz, const void* b_xy
   using namespace curdle;
   return g1_equal(*static_cast<const G1XYZZ*>(a_xyzz), *static_cast<const G1XYZZ*>(b_xyzz)) ? 1 : 0;
 }
+
+// on-curve point -> is it in the prime-order subgroup (g1_in_subgroup)
+extern "C" int CURDLE_FN(curdle_host_in_subgroup)(const void* p_xyzz) {
+  using namespace curdle;
+  return g1_in_subgroup(*static_cast<const G1XYZZ*>(p_xyzz)) ? 1 : 0;
+}

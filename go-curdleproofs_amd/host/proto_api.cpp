@@ -10,6 +10,7 @@
 
 #include "../../include/curdle_msm.h"
 #include "curdleproofs.h"
+#include "whisk.h"
 
 using namespace curdle;
 using alg::Point;
@@ -24,6 +25,9 @@ struct curdle_rand {  // same layout as in msm_api.hip
 };
 struct curdle_crs {
   proto::CRS crs;
+};
+struct curdle_proof {
+  proto::Proof p;
 };
 
 static std::vector<G1Affine> Affines(const uint64_t* p, size_t n) {
@@ -108,8 +112,41 @@ extern "C" int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t
   *ok = 0;
   if (ell != crs->crs.Gs.size()) return curdle_set_last_error(CURDLE_EINVAL, "ell does not match the CRS");
   return Guard([&]() {
-    proto::Proof p = proto::Proof::FromBytes(proof, proof_len);
+    // gnark's Decoder checks curve and subgroup membership of every point (curdleproof.go:322)
+    proto::Proof p = proto::Proof::FromBytes(proof, proof_len, /*subgroup_check=*/true);
     bool accept = proto::Verify(p, crs->crs, Affines(Rs, ell), Affines(Ss, ell), Affines(Ts, ell), Affines(Us, ell),
+                                Point::FromJac(M), rand->r);
+    *ok = accept ? 1 : 0;
+    return CURDLE_OK;
+  });
+}
+
+extern "C" int curdle_proof_from_bytes(const uint8_t* proof, size_t proof_len, curdle_proof** out) {
+  if (!proof || !out) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  *out = nullptr;
+  return Guard([&]() {
+    curdle_proof* h = new curdle_proof();
+    try {
+      h->p = proto::Proof::FromBytes(proof, proof_len, /*subgroup_check=*/true);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+    return CURDLE_OK;
+  });
+}
+extern "C" void curdle_proof_free(curdle_proof* p) { delete p; }
+
+extern "C" int curdle_verify_proof(const curdle_crs* crs, const curdle_proof* proof, const uint64_t* Rs, const uint64_t* Ss,
+                                   const uint64_t* Ts, const uint64_t* Us, size_t ell, const uint64_t M[18],
+                                   curdle_rand* rand, int* ok) {
+  if (!crs || !proof || !Rs || !Ss || !Ts || !Us || !M || !rand || !ok)
+    return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  *ok = 0;
+  if (ell != crs->crs.Gs.size()) return curdle_set_last_error(CURDLE_EINVAL, "ell does not match the CRS");
+  return Guard([&]() {
+    bool accept = proto::Verify(proof->p, crs->crs, Affines(Rs, ell), Affines(Ss, ell), Affines(Ts, ell), Affines(Us, ell),
                                 Point::FromJac(M), rand->r);
     *ok = accept ? 1 : 0;
     return CURDLE_OK;
@@ -136,6 +173,63 @@ extern "C" int curdle_verify_batch(const curdle_crs* crs, size_t k, const uint8_
     }
     std::vector<int> res = proto::VerifyBatch(crs->crs, items, rand->r, nthreads);
     for (size_t i = 0; i < k; i++) oks[i] = res[i];
+    return CURDLE_OK;
+  });
+}
+
+// ---- whisk package (whisk/whisk.go) ----
+static std::vector<whisk::WhiskTracker> Trackers(const uint8_t* p, size_t n) {
+  std::vector<whisk::WhiskTracker> v(n);
+  static_assert(sizeof(whisk::WhiskTracker) == 96, "tracker layout");
+  if (n) memcpy(v.data(), p, n * 96);
+  return v;
+}
+
+extern "C" int curdle_whisk_is_valid_shuffle_proof(const curdle_crs* crs, const uint8_t* pre_trackers,
+                                                   const uint8_t* post_trackers, size_t n_pre, size_t n_post,
+                                                   const uint8_t* proof, curdle_rand* rand, int* ok) {
+  if (!crs || !proof || !rand || !ok || (n_pre && !pre_trackers) || (n_post && !post_trackers))
+    return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  *ok = 0;
+  return Guard([&]() {
+    *ok = whisk::IsValidWhiskShuffleProof(crs->crs, Trackers(pre_trackers, n_pre), Trackers(post_trackers, n_post), proof,
+                                          rand->r)
+              ? 1
+              : 0;
+    return CURDLE_OK;
+  });
+}
+
+extern "C" int curdle_whisk_generate_shuffle_proof(const curdle_crs* crs, const uint8_t* pre_trackers, size_t n,
+                                                   curdle_rand* rand, uint8_t* post_trackers_out, uint8_t* proof_out) {
+  if (!crs || !pre_trackers || !rand || !post_trackers_out || !proof_out)
+    return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  return Guard([&]() {
+    std::vector<whisk::WhiskTracker> post = whisk::GenerateWhiskShuffleProof(crs->crs, Trackers(pre_trackers, n), rand->r, proof_out);
+    memcpy(post_trackers_out, post.data(), post.size() * 96);
+    return CURDLE_OK;
+  });
+}
+
+extern "C" int curdle_whisk_is_valid_tracker_proof(const uint8_t* tracker, const uint8_t* k_commitment, const uint8_t* proof,
+                                                   int* ok) {
+  if (!tracker || !k_commitment || !proof || !ok) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  *ok = 0;
+  return Guard([&]() {
+    whisk::WhiskTracker t;
+    memcpy(&t, tracker, 96);
+    *ok = whisk::IsValidWhiskTrackerProof(t, k_commitment, proof) ? 1 : 0;
+    return CURDLE_OK;
+  });
+}
+
+extern "C" int curdle_whisk_generate_tracker_proof(const uint8_t* tracker, const uint64_t k[4], curdle_rand* rand,
+                                                   uint8_t* proof_out) {
+  if (!tracker || !k || !rand || !proof_out) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  return Guard([&]() {
+    whisk::WhiskTracker t;
+    memcpy(&t, tracker, 96);
+    whisk::GenerateWhiskTrackerProof(t, Scalar::FromMont(k), rand->r, proof_out);
     return CURDLE_OK;
   });
 }

@@ -1,0 +1,190 @@
+// whisk package restatement -- see whisk.h.  Reference: /root/reference/whisk/whisk.go, types.go.
+#include "whisk.h"
+
+#include <string.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace curdle {
+namespace whisk {
+
+using alg::Point;
+using alg::Scalar;
+
+namespace {
+const char* kWhiskOpeningProof = "whisk_opening_proof";                          // whisk.go:15
+const char* kTrackerOpeningProof = "tracker_opening_proof";                      // :16
+const char* kTrackerOpeningProofChallenge = "tracker_opening_proof_challenge";   // :17
+
+std::runtime_error err(const std::string& m) { return std::runtime_error(m); }
+
+// G1Affine.SetBytes on a 48-byte compressed point: curve + subgroup checked (gnark default)
+Point SetBytes(const uint8_t in[G1POINT_SIZE], const char* what) {
+  Point p;
+  if (!Point::FromCompressed(in, &p, /*subgroup_check=*/true)) throw err(std::string("failed to set ") + what);
+  return p;
+}
+
+// WhiskTracker.getPoints, types.go:85-95
+void GetPoints(const WhiskTracker& wt, G1Affine* rG, G1Affine* krG) {
+  *rG = SetBytes(wt.rG, "rG").Affine();
+  *krG = SetBytes(wt.krG, "krG").Affine();
+}
+}  // namespace
+
+WhiskTracker NewWhiskTracker(const G1Affine& rG, const G1Affine& krG) {
+  WhiskTracker t;
+  Point::FromAffine(rG).Compressed(t.rG);
+  Point::FromAffine(krG).Compressed(t.krG);
+  return t;
+}
+
+TrackerProof TrackerProof::FromBytes(const uint8_t buf[TRACKER_PROOF_SIZE]) {
+  TrackerProof tp;
+  Point a, b;
+  if (!Point::FromCompressed(buf, &a, true)) throw err("failed to decode A");
+  if (!Point::FromCompressed(buf + 48, &b, true)) throw err("failed to decode B");
+  if (!Scalar::SetBytesCanonical(buf + 96, &tp.S)) throw err("failed to decode s");
+  tp.A = a.Affine();
+  tp.B = b.Affine();
+  return tp;
+}
+
+void TrackerProof::Serialize(uint8_t out[TRACKER_PROOF_SIZE]) const {
+  Point::FromAffine(A).Compressed(out);
+  Point::FromAffine(B).Compressed(out + 48);
+  S.Bytes(out + 96);
+}
+
+bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTracker>& preST,
+                              const std::vector<WhiskTracker>& postST, const uint8_t proof[WHISK_SHUFFLE_PROOF_SIZE],
+                              common::Rand& rand) {
+  if (preST.size() != postST.size()) throw err("pre and post shuffle trackers must be the same length");  // :21-23
+
+  // WhiskShuffleProof.FromReader, types.go:39-51: M, then the curdleproof; the fixed-size
+  // array's zero padding after the proof is never read
+  proto::Reader r(proof, WHISK_SHUFFLE_PROOF_SIZE, /*subgroup=*/true);
+  Point M;
+  proto::Proof p;
+  try {
+    M = r.GetPoint("M");
+    p = proto::Proof::FromReader(r);
+  } catch (const std::runtime_error& e) {
+    throw err(std::string("decoding proof: ") + e.what());
+  }
+
+  const size_t n = preST.size();
+  std::vector<G1Affine> Rs(n), Ss(n), Ts(n), Us(n);
+  for (size_t i = 0; i < n; i++) {  // :35-44
+    try {
+      GetPoints(preST[i], &Rs[i], &Ss[i]);
+    } catch (const std::runtime_error& e) {
+      throw err(std::string("getting pre shuffle points: ") + e.what());
+    }
+    try {
+      GetPoints(postST[i], &Ts[i], &Us[i]);
+    } catch (const std::runtime_error& e) {
+      throw err(std::string("getting post shuffle points: ") + e.what());
+    }
+  }
+  try {
+    return proto::Verify(p, crs, Rs, Ss, Ts, Us, M, rand);  // :46-58
+  } catch (const alg::MsmError&) {
+    throw;
+  } catch (const std::runtime_error& e) {
+    throw err(std::string("verifying proof: ") + e.what());
+  }
+}
+
+std::vector<WhiskTracker> GenerateWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTracker>& preTrackers,
+                                                    common::Rand& rand, uint8_t proof_out[WHISK_SHUFFLE_PROOF_SIZE]) {
+  std::vector<uint32_t> permutation;
+  rand.GeneratePermutation(ELL, permutation);  // :64
+  Scalar k;
+  rand.GetFr(k.v);                             // :68
+  const size_t n = preTrackers.size();
+  if (n != ELL) throw err("shuffling and permuting: the whisk shuffle works on ELL trackers");  // permutation length, util.go:49
+  std::vector<G1Affine> Rs(n), Ss(n);
+  for (size_t i = 0; i < n; i++) {
+    try {
+      GetPoints(preTrackers[i], &Rs[i], &Ss[i]);
+    } catch (const std::runtime_error& e) {
+      throw err(std::string("getting points: ") + e.what());
+    }
+  }
+  proto::ShuffleCommit sc = proto::ShufflePermuteCommit(crs.Gs, crs.Hs, Rs, Ss, permutation, k, rand);  // :83
+  proto::Proof proof = proto::Prove(crs, Rs, Ss, sc.Ts, sc.Us, sc.M, permutation, k, sc.rs_m, rand);      // :88
+
+  // WhiskShuffleProof.Serialize, types.go:53-71: M, the proof, zero padding up to the array size
+  proto::Writer w;
+  w.PutPoint(sc.M);
+  const std::vector<uint8_t> body = proof.Serialize();
+  if (w.buf.size() + body.size() > WHISK_SHUFFLE_PROOF_SIZE) throw err("serializing proof: larger than WHISK_SHUFFLE_PROOF_SIZE");
+  memset(proof_out, 0, WHISK_SHUFFLE_PROOF_SIZE);
+  memcpy(proof_out, w.buf.data(), w.buf.size());
+  memcpy(proof_out + w.buf.size(), body.data(), body.size());
+
+  std::vector<WhiskTracker> post(n);
+  for (size_t i = 0; i < n; i++) post[i] = NewWhiskTracker(sc.Ts[i], sc.Us[i]);  // :109-112
+  return post;
+}
+
+bool IsValidWhiskTrackerProof(const WhiskTracker& tracker, const uint8_t kComm[G1POINT_SIZE],
+                              const uint8_t trackerProofBytes[TRACKER_PROOF_SIZE]) {
+  TrackerProof tp;
+  try {
+    tp = TrackerProof::FromBytes(trackerProofBytes);
+  } catch (const std::runtime_error& e) {
+    throw err(std::string("decoding proof: ") + e.what());
+  }
+  G1Affine rG, krG;
+  try {
+    GetPoints(tracker, &rG, &krG);
+  } catch (const std::runtime_error& e) {
+    throw err(std::string("deserializing rG and krG: ") + e.what());
+  }
+  Point kG;
+  try {
+    kG = SetBytes(kComm, "kG");
+  } catch (const std::runtime_error&) {
+    throw err("deserializing kG: invalid point");
+  }
+  const Point g = Point::Generator();
+  transcript::Transcript tr(kWhiskOpeningProof);  // :131-134
+  tr.AppendPointsAffine(kTrackerOpeningProof, {kG.Affine(), g.Affine(), krG, rG, tp.A, tp.B});
+  const Scalar challenge = tr.GetAndAppendChallenge(kTrackerOpeningProofChallenge);
+
+  const Point A_prime = g.Mul(tp.S) + kG.Mul(challenge);                                        // :136-139
+  const Point B_prime = Point::FromAffine(rG).Mul(tp.S) + Point::FromAffine(krG).Mul(challenge); // :141-144
+  return A_prime == Point::FromAffine(tp.A) && B_prime == Point::FromAffine(tp.B);
+}
+
+void GenerateWhiskTrackerProof(const WhiskTracker& tracker, const Scalar& k, common::Rand& rand,
+                               uint8_t out[TRACKER_PROOF_SIZE]) {
+  G1Affine rG, krG;
+  try {
+    GetPoints(tracker, &rG, &krG);
+  } catch (const std::runtime_error& e) {
+    throw err(std::string("deserializing rG and krG: ") + e.what());
+  }
+  const Point g = Point::Generator();
+  const Point kG = g.Mul(k);  // :156
+  Scalar blinder;
+  rand.GetFr(blinder.v);      // :157
+  const Point A = g.Mul(blinder);
+  const Point B = Point::FromAffine(rG).Mul(blinder);
+
+  transcript::Transcript tr(kWhiskOpeningProof);
+  tr.AppendPointsAffine(kTrackerOpeningProof, {kG.Affine(), g.Affine(), krG, rG, A.Affine(), B.Affine()});
+  const Scalar challenge = tr.GetAndAppendChallenge(kTrackerOpeningProofChallenge);
+
+  TrackerProof tp;
+  tp.A = A.Affine();
+  tp.B = B.Affine();
+  tp.S = blinder - challenge * k;  // :171-172
+  tp.Serialize(out);
+}
+
+}  // namespace whisk
+}  // namespace curdle

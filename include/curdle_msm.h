@@ -202,6 +202,16 @@ int curdle_prove(const curdle_crs* crs, const uint64_t* Rs, const uint64_t* Ss, 
 int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t proof_len, const uint64_t* Rs,
                   const uint64_t* Ss, const uint64_t* Ts, const uint64_t* Us, size_t ell,
                   const uint64_t M[18], curdle_rand* rand, int* ok);
+/* The same split as the reference's API, where Verify takes a decoded `Proof` value
+ * (curdleproof.go:199) and decoding is Proof.FromReader (:320): decode once -- curve and
+ * subgroup checks on every point -- into a handle, verify the handle (this is what the
+ * reference's BenchmarkVerifier times, curdleproof_test.go:210-237), free it. */
+typedef struct curdle_proof curdle_proof;
+int curdle_proof_from_bytes(const uint8_t* proof, size_t proof_len, curdle_proof** out);
+void curdle_proof_free(curdle_proof* p);
+int curdle_verify_proof(const curdle_crs* crs, const curdle_proof* proof, const uint64_t* Rs,
+                        const uint64_t* Ss, const uint64_t* Ts, const uint64_t* Us, size_t ell,
+                        const uint64_t M[18], curdle_rand* rand, int* ok);
 /* Cross-proof batch verification (the reference verifies one proof
  * at a time): k proofs over the same CRS and the same ell.  The host part of each proof runs
  * on `nthreads` worker threads; all proofs' checks are folded into ONE accumulator (per-proof
@@ -222,11 +232,47 @@ int curdle_verify_batch(const curdle_crs* crs, size_t k, const uint8_t* const* p
  * the environment variable CURDLE_VERIFY_EAGER.  Returns the previous setting. */
 int curdle_verify_set_eager(int eager);
 int curdle_proof_reencode(const uint8_t* proof, size_t proof_len, uint8_t* out, size_t cap, size_t* out_len);
+/* The reference's `whisk` package (whisk/whisk.go, whisk/types.go): the byte-level API of the
+ * Whisk SSLE spec.  A tracker is 96 bytes (rG || krG, gnark compressed points, types.go:73-76);
+ * a shuffle proof is CURDLE_WHISK_SHUFFLE_PROOF_SIZE bytes (M, the curdleproof, zero padding,
+ * types.go:53-71) over CURDLE_WHISK_ELL trackers; a tracker (opening) proof is 128 bytes (A, B, s).
+ * Every decoded point is curve- and subgroup-checked, as gnark's Decoder / SetBytes do.
+ * Return CURDLE_OK with *ok = the accept bit for (true|false, nil); negative for (false, err). */
+#define CURDLE_WHISK_ELL 124
+#define CURDLE_WHISK_TRACKER_SIZE 96
+#define CURDLE_WHISK_TRACKER_PROOF_SIZE 128
+#define CURDLE_WHISK_SHUFFLE_PROOF_SIZE 4576
+/* IsValidWhiskShuffleProof, whisk.go:20 */
+int curdle_whisk_is_valid_shuffle_proof(const curdle_crs* crs, const uint8_t* pre_trackers, const uint8_t* post_trackers,
+                                        size_t n_pre, size_t n_post,
+                                        const uint8_t proof[CURDLE_WHISK_SHUFFLE_PROOF_SIZE], curdle_rand* rand, int* ok);
+/* GenerateWhiskShuffleProof, whisk.go:63: n must be CURDLE_WHISK_ELL (the permutation length is fixed there) */
+int curdle_whisk_generate_shuffle_proof(const curdle_crs* crs, const uint8_t* pre_trackers, size_t n, curdle_rand* rand,
+                                        uint8_t* post_trackers_out, uint8_t proof_out[CURDLE_WHISK_SHUFFLE_PROOF_SIZE]);
+/* IsValidWhiskTrackerProof, whisk.go:116 (host only: four scalar multiplications) */
+int curdle_whisk_is_valid_tracker_proof(const uint8_t tracker[CURDLE_WHISK_TRACKER_SIZE], const uint8_t k_commitment[48],
+                                        const uint8_t proof[CURDLE_WHISK_TRACKER_PROOF_SIZE], int* ok);
+/* GenerateWhiskTrackerProof, whisk.go:149 */
+int curdle_whisk_generate_tracker_proof(const uint8_t tracker[CURDLE_WHISK_TRACKER_SIZE], const uint64_t k[4],
+                                        curdle_rand* rand, uint8_t proof_out[CURDLE_WHISK_TRACKER_PROOF_SIZE]);
 /* pieces exposed for known-answer tests */
 int curdle_merlin_test_vector(const char* protocol, const char* label, const uint8_t* msg, size_t msg_len,
                               const char* challenge_label, uint8_t* out, size_t out_len);
 int curdle_g1_compress(const uint64_t jac[18], uint8_t out[48]);
 int curdle_g1_decompress(const uint8_t in[48], int subgroup_check, uint64_t out_jac[18]);
+/* Batched decoding of gnark's compressed G1 encoding ON THE GPU (one lane per point: square
+ * root, curve check, sign selection, and with subgroup_check != 0 the endomorphism subgroup
+ * test gnark's Decoder / SetBytes apply): n x 48 bytes in, n x 12 limbs of gnark affine
+ * points out (directly usable as MSM bases), one status byte per point.  Invalid points
+ * do not fail the call: they get a non-zero status and (0, 0).  Replaces the per-point
+ * G1Affine.SetBytes loops of whisk/types.go:85-95 (4 * ell tracker points per shuffle) and
+ * of Proof.FromReader (curdleproof.go:320-356). */
+#define CURDLE_DECODE_OK 0
+#define CURDLE_DECODE_INFINITY 1        /* valid encoding of the point at infinity; out = (0, 0) */
+#define CURDLE_DECODE_BAD_ENCODING 2    /* not the compressed form, x >= p, or stray bits with the infinity flag */
+#define CURDLE_DECODE_NOT_ON_CURVE 3
+#define CURDLE_DECODE_NOT_IN_SUBGROUP 4
+int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgroup_check, uint64_t* out_affine, uint8_t* status);
 int curdle_set_last_error(int code, const char* msg);  /* internal: shared by the library's translation units */
 
 /* ------------------------------------------------------------------------- *

@@ -193,3 +193,42 @@ def test_accumulate_check_deferred_is_the_same_equation(cm, oracle):
     with pytest.raises(cm.CurdleError) as e:
         cm.MsmAccumulator().accumulate_check_deferred(to_frs(c), to_pts(P), to_frs(x[:3]), to_pts(V), cm.Rand(0))
     assert e.value.code == cm.EINVAL and "same length" in e.value.msg
+
+
+def test_subgroup_check_of_the_decoder(cm, oracle):
+    """gnark's Decoder / SetBytes reject curve points outside G1.  The host uses the
+    endomorphism test [z^2] phi(P) + P == inf; it must agree with the definition [r] P == inf
+    on subgroup points, on random curve points (cofactor ~2^126, so essentially never in G1)
+    and on points of small order."""
+    p, r = oracle.P, oracle.R
+    rnd = random.Random(5)
+    # G1 points decode with the check on
+    for k in (1, 2, r - 1, rnd.randrange(r)):
+        pt = oracle.scalar_mul(k, oracle.G1)
+        got = cm.g1_decompress(oracle.compress(pt), True)
+        assert oracle.jac_from_mont_limbs([int(v) for v in got]) == pt
+    # random curve points
+    found = 0
+    while found < 6:
+        x = rnd.randrange(p)
+        rhs = (x * x * x + 4) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p != rhs:
+            continue
+        found += 1
+        pt = (x, y)
+        in_g1 = oracle.scalar_mul(r, pt) is None
+        assert not in_g1
+        enc = oracle.compress(pt)
+        assert oracle.jac_from_mont_limbs([int(v) for v in cm.g1_decompress(enc, False)]) == pt   # on the curve: fine unchecked
+        with pytest.raises(cm.CurdleError):
+            cm.g1_decompress(enc, True)
+        # clearing the cofactor lands in G1 and is accepted
+        h = 0x396C8C005555E1568C00AAAB0000AAAB
+        cleared = oracle.scalar_mul(h, pt)
+        assert oracle.scalar_mul(r, cleared) is None
+        cm.g1_decompress(oracle.compress(cleared), True)
+        # a point of order dividing the cofactor only (r * pt) is rejected unless it is infinity
+        small = oracle.scalar_mul(r, pt)
+        with pytest.raises(cm.CurdleError):
+            cm.g1_decompress(oracle.compress(small), True)

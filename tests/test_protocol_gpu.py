@@ -38,6 +38,12 @@ def test_completeness(gpu, check_mode):
     assert gpu.verify(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(43)) is True
     # the accept bit does not depend on the verifier's randomness
     assert gpu.verify(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(7)) is True
+    # the reference's split: Proof.FromReader once, Verify(proof Proof, ...) on the value
+    decoded = gpu.Proof(proof)
+    assert gpu.verify_proof(crs, decoded, Rs, Ss, Ts, Us, M, gpu.Rand(43)) is True
+    assert gpu.verify_proof(crs, decoded, Ss, Rs, Ts, Us, M, gpu.Rand(43)) is False
+    with pytest.raises(gpu.CurdleError):
+        gpu.Proof(proof[:-1])
 
 
 def test_soundness_and_encoding(gpu, oracle, check_mode):
@@ -120,3 +126,68 @@ def test_batch_verification_shares_one_accumulator(gpu, check_mode):
     bad[1][2], bad[2][2] = Rs[3], Ss[3]
     bad[0][4] = proofs[4][:-7]
     assert gpu.verify_batch(crs, *bad, gpu.Rand(9), nthreads=2) == [True, True, False, True, False]
+
+
+def test_batched_point_decoding_on_the_gpu(gpu, oracle):
+    """curdle_g1_decompress_batch: every status class, against the oracle's compress / curve /
+    subgroup definitions and the host decoder."""
+    import random
+    p, r = oracle.P, oracle.R
+    rnd = random.Random(11)
+    recs, want_pt, want_st = [], [], []
+
+    def put(enc, pt, st):
+        recs.append(enc)
+        want_pt.append(pt)
+        want_st.append(st)
+
+    for k in [1, 2, 3, r - 1] + [rnd.randrange(r) for _ in range(40)]:
+        pt = oracle.scalar_mul(k, oracle.G1)
+        put(oracle.compress(pt), pt, gpu.DECODE_OK)
+        put(oracle.compress(oracle.neg(pt)), oracle.neg(pt), gpu.DECODE_OK)      # the other root / sign flag
+    put(oracle.compress(None), None, gpu.DECODE_INFINITY)
+    put(b"\xc0" + b"\x00" * 46 + b"\x01", None, gpu.DECODE_BAD_ENCODING)         # infinity flag with stray bits
+    put(b"\xe0" + b"\x00" * 47, None, gpu.DECODE_BAD_ENCODING)                   # infinity + sign flag
+    put(b"\x00" * 48, None, gpu.DECODE_BAD_ENCODING)                             # uncompressed form
+    put(bytes([0x9f]) + b"\xff" * 47, None, gpu.DECODE_BAD_ENCODING)             # x >= p
+    pb = bytearray(p.to_bytes(48, "big"))
+    pb[0] |= 0x80
+    put(bytes(pb), None, gpu.DECODE_BAD_ENCODING)                                # x == p
+    on_curve_not_g1 = 0
+    x = 5
+    while on_curve_not_g1 < 6:
+        x += 1
+        rhs = (x * x * x + 4) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        enc = bytearray(x.to_bytes(48, "big"))
+        enc[0] |= 0x80
+        if y * y % p != rhs:
+            put(bytes(enc), None, gpu.DECODE_NOT_ON_CURVE)
+            continue
+        pt = (x, y)
+        assert oracle.scalar_mul(r, pt) is not None
+        put(oracle.compress(pt), pt, gpu.DECODE_NOT_IN_SUBGROUP)
+        on_curve_not_g1 += 1
+    blob = b"".join(recs)
+    got_pt, got_st = gpu.g1_decompress_batch(blob, True)
+    assert list(got_st) == want_st
+    for g, w, st in zip(got_pt, want_pt, want_st):
+        if st == gpu.DECODE_OK:
+            assert oracle.affine_from_mont_limbs([int(v) for v in g]) == w
+        else:
+            assert not g.any()
+    # without the subgroup test, curve points outside G1 decode to themselves
+    got_pt, got_st = gpu.g1_decompress_batch(blob, False)
+    for g, w, st, st0 in zip(got_pt, want_pt, got_st, want_st):
+        if st0 == gpu.DECODE_NOT_IN_SUBGROUP:
+            assert st == gpu.DECODE_OK and oracle.affine_from_mont_limbs([int(v) for v in g]) == w
+        else:
+            assert st == st0
+    # agreement with the host decoder on every record
+    for enc, st in zip(recs, want_st):
+        if st in (gpu.DECODE_OK, gpu.DECODE_INFINITY):
+            gpu.g1_decompress(enc, True)
+        else:
+            with pytest.raises(gpu.CurdleError):
+                gpu.g1_decompress(enc, True)
+    assert gpu.g1_decompress_batch(b"", True)[0].shape == (0, 12)

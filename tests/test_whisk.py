@@ -1,0 +1,148 @@
+"""The reference's `whisk` package on this stack (go-curdleproofs_amd/host/whisk.cpp), mirroring
+/root/reference/whisk/whisk_test.go.  The tracker (opening) proofs need no MSM and run on the
+CPU; the shuffle proof and the full lifecycle run the curdleproof prover / verifier with every
+MSM on the GPU."""
+import numpy as np
+import pytest
+
+
+def fr_limbs(oracle, k):
+    return np.array(oracle.fr_to_mont_limbs(k), dtype=np.uint64)
+
+
+def fr_int(oracle, limbs):
+    return oracle.fr_from_mont_limbs([int(v) for v in limbs])
+
+
+def compute_tracker(oracle, k, r):
+    # whisk_test.go:98-104: rG = r*G, krG = k*rG, both in gnark's compressed form
+    rG = oracle.scalar_mul(r, oracle.G1)
+    return oracle.compress(rG) + oracle.compress(oracle.scalar_mul(k, rG))
+
+
+def k_comm(oracle, k):
+    return oracle.compress(oracle.scalar_mul(k, oracle.G1))  # whisk_test.go:106-109
+
+
+def test_tracker_proof(cm, oracle):
+    # TestWhiskTrackerProof, whisk_test.go:13-34
+    rand = cm.Rand(0)
+    k = fr_int(oracle, rand.get_fr())
+    tracker = compute_tracker(oracle, k, fr_int(oracle, rand.get_fr()))
+    proof = cm.whisk_generate_tracker_proof(tracker, fr_limbs(oracle, k), rand)
+    assert len(proof) == cm.WHISK_TRACKER_PROOF_SIZE == 128
+    assert cm.whisk_is_valid_tracker_proof(tracker, k_comm(oracle, k), proof) is True
+    # the proof binds k: another commitment, another tracker or a touched response are rejected
+    assert cm.whisk_is_valid_tracker_proof(tracker, k_comm(oracle, k + 1), proof) is False
+    other = compute_tracker(oracle, k + 1, 12345)
+    assert cm.whisk_is_valid_tracker_proof(other, k_comm(oracle, k), proof) is False
+    touched = bytearray(proof)
+    touched[127] ^= 1
+    assert cm.whisk_is_valid_tracker_proof(tracker, k_comm(oracle, k), bytes(touched)) is False
+    # (false, err): bytes that are not a compressed curve point / not in the subgroup / not a canonical scalar
+    with pytest.raises(cm.CurdleError) as e:
+        cm.whisk_is_valid_tracker_proof(tracker, k_comm(oracle, k), b"\x00" * 128)
+    assert "decoding proof" in e.value.msg
+    bad_s = proof[:96] + b"\xff" * 32
+    with pytest.raises(cm.CurdleError) as e:
+        cm.whisk_is_valid_tracker_proof(tracker, k_comm(oracle, k), bad_s)
+    assert "decoding proof" in e.value.msg
+    with pytest.raises(cm.CurdleError) as e:
+        cm.whisk_is_valid_tracker_proof(b"\x01" * 96, k_comm(oracle, k), proof)
+    assert "deserializing rG and krG" in e.value.msg
+
+
+def test_tracker_proof_matches_the_protocol_equations(cm, oracle):
+    """A = b*G, B = b*rG, s = b - c*k (whisk.go:156-172): recompute the verifier's two
+    equations with the oracle from the decoded proof."""
+    rand = cm.Rand(3)
+    k, r = fr_int(oracle, rand.get_fr()), fr_int(oracle, rand.get_fr())
+    tracker = compute_tracker(oracle, k, r)
+    proof = cm.whisk_generate_tracker_proof(tracker, fr_limbs(oracle, k), cm.Rand(9))
+    b = oracle.Rand(9).get_fr()                       # the blinder is the first draw of the proof's Rand
+    assert proof[:48] == oracle.compress(oracle.scalar_mul(b, oracle.G1))
+    rG = oracle.scalar_mul(r, oracle.G1)
+    assert proof[48:96] == oracle.compress(oracle.scalar_mul(b, rG))
+    s = int.from_bytes(proof[96:], "big")
+    c = (b - s) * pow(k, -1, oracle.R) % oracle.R     # the challenge implied by s
+    assert oracle.add(oracle.scalar_mul(s, oracle.G1), oracle.scalar_mul(c * k % oracle.R, oracle.G1)) == oracle.scalar_mul(b, oracle.G1)
+
+
+def shuffle_trackers(cm, oracle, rand, n):
+    # generateShuffleTrackers, whisk_test.go:111-119 (k then r drawn per tracker)
+    out = []
+    for _ in range(n):
+        k = fr_int(oracle, rand.get_fr())
+        r = fr_int(oracle, rand.get_fr())
+        out.append(compute_tracker(oracle, k, r))
+    return out
+
+
+@pytest.mark.gpu
+def test_shuffle_proof(gpu, oracle):
+    # TestWhiskShuffleProof, whisk_test.go:36-56
+    rand = gpu.Rand(0)
+    crs = gpu.CRS(gpu.WHISK_ELL, rand)
+    pre = shuffle_trackers(gpu, oracle, rand, gpu.WHISK_ELL)
+    post, proof = gpu.whisk_generate_shuffle_proof(crs, pre, rand)
+    assert len(proof) == gpu.WHISK_SHUFFLE_PROOF_SIZE == 4576 and len(post) == gpu.WHISK_ELL
+    assert proof[4536:] == b"\x00" * 40            # M (48) + curdleproof (4,488), zero padded (types.go:66-68)
+    assert gpu.whisk_is_valid_shuffle_proof(crs, pre, post, proof, rand) is True
+    # the post trackers are a permutation of k * pre trackers: none equals its pre tracker
+    assert all(a != b for a, b in zip(pre, post))
+    # rejected: trackers swapped, a post tracker replaced, proof body touched
+    assert gpu.whisk_is_valid_shuffle_proof(crs, post, pre, proof, gpu.Rand(1)) is False
+    post2 = list(post)
+    post2[5] = post[6]
+    assert gpu.whisk_is_valid_shuffle_proof(crs, pre, post2, proof, gpu.Rand(1)) is False
+    # (false, err) legs
+    with pytest.raises(gpu.CurdleError) as e:
+        gpu.whisk_is_valid_shuffle_proof(crs, pre, post[:-1], proof, gpu.Rand(1))
+    assert "same length" in e.value.msg
+    with pytest.raises(gpu.CurdleError) as e:
+        gpu.whisk_is_valid_shuffle_proof(crs, pre, post, b"\x00" * 4576, gpu.Rand(1))
+    assert "decoding proof" in e.value.msg
+    bad = list(pre)
+    bad[0] = b"\x01" * 96
+    with pytest.raises(gpu.CurdleError) as e:
+        gpu.whisk_is_valid_shuffle_proof(crs, bad, post, proof, gpu.Rand(1))
+    assert "getting pre shuffle points" in e.value.msg
+
+
+@pytest.mark.gpu
+def test_full_lifecycle(gpu, oracle):
+    # TestWhiskFullLifecycle, whisk_test.go:58-91 with produceBlock / processBlock (:137-209)
+    rand = gpu.Rand(0)
+    crs = gpu.CRS(gpu.WHISK_ELL, rand)
+    g1_gen_bytes = oracle.compress(oracle.G1)
+    proposer_index = 15400
+    state = {"tracker": compute_tracker(oracle, proposer_index, 1), "k_comm": k_comm(oracle, proposer_index),
+             "shuffled": shuffle_trackers(gpu, oracle, rand, gpu.WHISK_ELL)}
+    proposer_k = fr_int(oracle, rand.get_fr())
+
+    def produce_block():
+        r = gpu.Rand(0)
+        post, shuffle_proof = gpu.whisk_generate_shuffle_proof(crs, state["shuffled"], r)
+        first = state["tracker"][:48] == g1_gen_bytes
+        if first:
+            tracker = compute_tracker(oracle, proposer_k, fr_int(oracle, r.get_fr()))
+            kc = k_comm(oracle, proposer_k)
+            registration = gpu.whisk_generate_tracker_proof(tracker, fr_limbs(oracle, proposer_k), r)
+        else:
+            tracker, kc, registration = compute_tracker(oracle, 1, 1), k_comm(oracle, 1), b"\x00" * 128
+        k_prev = proposer_index if first else proposer_k
+        opening = gpu.whisk_generate_tracker_proof(state["tracker"], fr_limbs(oracle, k_prev), r)
+        return {"opening": opening, "post": post, "shuffle_proof": shuffle_proof, "registration": registration,
+                "tracker": tracker, "k_comm": kc}
+
+    def process_block(block):
+        r = gpu.Rand(0)
+        assert gpu.whisk_is_valid_tracker_proof(state["tracker"], state["k_comm"], block["opening"]) is True
+        assert gpu.whisk_is_valid_shuffle_proof(crs, state["shuffled"], block["post"], block["shuffle_proof"], r) is True
+        if state["tracker"][:48] == g1_gen_bytes:
+            assert gpu.whisk_is_valid_tracker_proof(block["tracker"], block["k_comm"], block["registration"]) is True
+            state["tracker"], state["k_comm"] = block["tracker"], block["k_comm"]
+
+    process_block(produce_block())   # first proposal: registers the validator's tracker
+    assert state["tracker"][:48] != g1_gen_bytes
+    process_block(produce_block())   # second proposal: opens the registered tracker
