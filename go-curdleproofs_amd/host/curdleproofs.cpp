@@ -136,10 +136,57 @@ void Writer::PutPoints(const std::vector<Point>& v) {
   buf.insert(buf.end(), len, len + 4);
   for (const auto& p : v) PutPoint(p);
 }
+size_t PointDecoder::Add(const uint8_t rec[48]) {
+  blob_.insert(blob_.end(), rec, rec + 48);
+  return n_++;
+}
+bool PointDecoder::OnDevice() {
+  static const bool host_only = [] {
+    const char* e = getenv("CURDLE_HOST_DECODE");
+    return e && *e && *e != '0';
+  }();
+  return !host_only && curdle_device_available() == 1;
+}
+void PointDecoder::Run() {
+  pts_.assign(n_, G1Affine{});
+  status_.assign(n_, CURDLE_DECODE_BAD_ENCODING);
+  if (n_ == 0) return;
+  // below a few dozen points one kernel launch (~2 ms: it is a 1,900-product serial chain per
+  // lane) is slower than the host's ~45 us per point
+  if (OnDevice() && n_ >= 48) {
+    int rc = curdle_g1_decompress_batch(blob_.data(), n_, subgroup_ ? 1 : 0, reinterpret_cast<uint64_t*>(pts_.data()),
+                                        status_.data());
+    if (rc != CURDLE_OK) {
+      char buf[256];
+      curdle_last_error(buf, sizeof(buf));
+      throw alg::MsmError(std::string("decoding points: ") + buf, rc);
+    }
+    return;
+  }
+  for (size_t i = 0; i < n_; i++) {
+    Point pt;
+    if (!Point::FromCompressed(&blob_[48 * i], &pt, subgroup_)) continue;
+    pts_[i] = pt.Affine();
+    status_[i] = g1_affine_is_inf(pts_[i]) ? CURDLE_DECODE_INFINITY : CURDLE_DECODE_OK;
+  }
+}
+bool PointDecoder::Get(size_t index, Point* out) const {
+  if (index >= n_ || status_[index] > CURDLE_DECODE_INFINITY) return false;
+  *out = status_[index] == CURDLE_DECODE_INFINITY ? Point::Infinity() : Point::FromAffine(pts_[index]);
+  return true;
+}
+
 Point Reader::GetPoint(const char* what) {
   if (left < 48) throw err(std::string("decoding ") + what + ": unexpected end of input");
   Point out;
-  if (!Point::FromCompressed(p, &out, subgroup_check)) throw err(std::string("decoding ") + what + ": invalid point");
+  if (collect) {
+    collect->Add(p);
+    out = Point::Infinity();
+  } else if (decoded) {
+    if (!decoded->Get(decoded_pos++, &out)) throw err(std::string("decoding ") + what + ": invalid point");
+  } else if (!Point::FromCompressed(p, &out, subgroup_check)) {
+    throw err(std::string("decoding ") + what + ": invalid point");
+  }
   p += 48;
   left -= 48;
   return out;
@@ -919,6 +966,29 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
   if (const char* e = getenv("CURDLE_BATCH_GROUP")) flush = (size_t)atoi(e);
   if (flush < 1) flush = 1;
 
+  // one batched GPU decode for every point of every proof: pass 1 walks each proof's wire
+  // format and registers its records (a proof that does not parse is rejected here)
+  PointDecoder dec(/*subgroup_check=*/true);
+  std::vector<size_t> first_point(k, 0);
+  std::vector<char> parses(k, 0);
+  for (size_t i = 0; i < k; i++) {
+    first_point[i] = dec.size();
+    try {
+      Reader scan(items[i].proof, items[i].proof_len, true);
+      scan.collect = &dec;
+      Proof::FromReader(scan);
+      parses[i] = 1;
+    } catch (const std::runtime_error&) {
+    }
+  }
+  dec.Run();
+  auto decode = [&](size_t i) {
+    Reader r(items[i].proof, items[i].proof_len, true);
+    r.decoded = &dec;
+    r.decoded_pos = first_point[i];
+    return Proof::FromReader(r);
+  };
+
   std::atomic<size_t> next(0);
   std::atomic<bool> failed(false);
   std::string first_error;
@@ -938,7 +1008,7 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
         }
         try {  // some accumulated check of the group failed: find out whose
           const BatchItem& it = items[i];
-          Proof p = Proof::FromBytes(it.proof, it.proof_len, /*subgroup_check=*/true);
+          Proof p = decode(i);
           common::Rand r(seeds[i]);
           oks[i] = Verify(p, crs, *it.Rs, *it.Ss, *it.Ts, *it.Us, it.M, r) ? 1 : 0;
         } catch (const alg::MsmError&) {
@@ -958,7 +1028,8 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
         MsmAccumulator mine;  // joins the group only if the proof's direct checks pass
         bool pre = false;
         try {
-          Proof p = Proof::FromBytes(it.proof, it.proof_len, /*subgroup_check=*/true);
+          if (!parses[i]) throw err("malformed proof");
+          Proof p = decode(i);
           common::Rand r(seeds[i]);
           pre = VerifyInto(p, crs, *it.Rs, *it.Ss, *it.Ts, *it.Us, it.M, r, mine);
         } catch (const alg::MsmError&) {
@@ -1006,7 +1077,15 @@ std::vector<uint8_t> Proof::Serialize() const {  // :358-387
   return w.buf;
 }
 Proof Proof::FromBytes(const uint8_t* data, size_t len, bool subgroup_check) {  // :320-356
+  // pass 1 walks the wire format and registers every point record, one GPU kernel decodes
+  // them (square roots, curve and subgroup tests), pass 2 builds the value
+  PointDecoder dec(subgroup_check);
+  Reader scan(data, len, subgroup_check);
+  scan.collect = &dec;
+  FromReader(scan);
+  dec.Run();
   Reader r(data, len, subgroup_check);
+  r.decoded = &dec;
   return FromReader(r);
 }
 Proof Proof::FromReader(Reader& r) {

@@ -40,10 +40,35 @@ struct Writer {
   void PutScalar(const Scalar& s);
   void PutPoints(const std::vector<Point>& v);  // uint32 big-endian length, then the points
 };
+// Batched decoding of compressed points on the GPU (curdle_g1_decompress_batch): callers
+// register the 48-byte records they will need, Run() decodes them all in one kernel, Get()
+// hands them out.  With no device visible (or CURDLE_HOST_DECODE=1) Run() decodes on the
+// host, point by point -- the same results, the reference's own order of operations.
+class PointDecoder {
+ public:
+  explicit PointDecoder(bool subgroup_check) : subgroup_(subgroup_check) {}
+  size_t Add(const uint8_t rec[48]);          // -> index for Get
+  void Run();
+  bool Get(size_t index, Point* out) const;   // false: not a valid encoding / not on the curve / not in G1
+  size_t size() const { return n_; }
+  static bool OnDevice();                     // would Run() use the GPU
+ private:
+  bool subgroup_;
+  size_t n_ = 0;
+  std::vector<uint8_t> blob_;
+  std::vector<G1Affine> pts_;
+  std::vector<uint8_t> status_;
+};
+
 struct Reader {
   const uint8_t* p;
   size_t left;
   bool subgroup_check;
+  // two-pass decoding: with `collect` set GetPoint only registers the record and returns
+  // infinity; with `decoded` set it hands out the records in the same order
+  PointDecoder* collect = nullptr;
+  const PointDecoder* decoded = nullptr;
+  size_t decoded_pos = 0;
   Reader(const uint8_t* data, size_t len, bool subgroup = false) : p(data), left(len), subgroup_check(subgroup) {}
   Point GetPoint(const char* what);
   Scalar GetScalar(const char* what);

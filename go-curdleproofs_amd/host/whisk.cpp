@@ -62,31 +62,54 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
                               common::Rand& rand) {
   if (preST.size() != postST.size()) throw err("pre and post shuffle trackers must be the same length");  // :21-23
 
-  // WhiskShuffleProof.FromReader, types.go:39-51: M, then the curdleproof; the fixed-size
-  // array's zero padding after the proof is never read
-  proto::Reader r(proof, WHISK_SHUFFLE_PROOF_SIZE, /*subgroup=*/true);
+  // Every point of the call -- M, the proof's ~90 points and the 4 n tracker points -- is
+  // decoded (square root, curve and subgroup tests) by ONE batched kernel on the GPU
+  // (proto::PointDecoder); the reference decodes them one by one (types.go:39-51, :85-95).
+  // Pass 1 registers the records, pass 2 reads the results in the reference's order, so
+  // the first error reported is the one the reference would report.
+  const size_t n = preST.size();
+  proto::PointDecoder dec(/*subgroup_check=*/true);
+  try {
+    // WhiskShuffleProof.FromReader: M, then the curdleproof; the fixed-size array's zero
+    // padding after the proof is never read
+    proto::Reader scan(proof, WHISK_SHUFFLE_PROOF_SIZE, true);
+    scan.collect = &dec;
+    scan.GetPoint("M");
+    proto::Proof::FromReader(scan);
+  } catch (const std::runtime_error& e) {
+    throw err(std::string("decoding proof: ") + e.what());
+  }
+  const size_t first_tracker = dec.size();
+  for (size_t i = 0; i < n; i++) {
+    dec.Add(preST[i].rG);
+    dec.Add(preST[i].krG);
+    dec.Add(postST[i].rG);
+    dec.Add(postST[i].krG);
+  }
+  dec.Run();
+
   Point M;
   proto::Proof p;
   try {
+    proto::Reader r(proof, WHISK_SHUFFLE_PROOF_SIZE, true);
+    r.decoded = &dec;
     M = r.GetPoint("M");
     p = proto::Proof::FromReader(r);
   } catch (const std::runtime_error& e) {
     throw err(std::string("decoding proof: ") + e.what());
   }
-
-  const size_t n = preST.size();
   std::vector<G1Affine> Rs(n), Ss(n), Ts(n), Us(n);
   for (size_t i = 0; i < n; i++) {  // :35-44
-    try {
-      GetPoints(preST[i], &Rs[i], &Ss[i]);
-    } catch (const std::runtime_error& e) {
-      throw err(std::string("getting pre shuffle points: ") + e.what());
-    }
-    try {
-      GetPoints(postST[i], &Ts[i], &Us[i]);
-    } catch (const std::runtime_error& e) {
-      throw err(std::string("getting post shuffle points: ") + e.what());
-    }
+    Point pt;
+    const size_t at = first_tracker + 4 * i;
+    if (!dec.Get(at, &pt)) throw err("getting pre shuffle points: failed to set rG");
+    Rs[i] = pt.Affine();
+    if (!dec.Get(at + 1, &pt)) throw err("getting pre shuffle points: failed to set krG");
+    Ss[i] = pt.Affine();
+    if (!dec.Get(at + 2, &pt)) throw err("getting post shuffle points: failed to set rG");
+    Ts[i] = pt.Affine();
+    if (!dec.Get(at + 3, &pt)) throw err("getting post shuffle points: failed to set krG");
+    Us[i] = pt.Affine();
   }
   try {
     return proto::Verify(p, crs, Rs, Ss, Ts, Us, M, rand);  // :46-58

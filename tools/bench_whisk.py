@@ -1,0 +1,62 @@
+"""The reference's whisk API end to end (whisk/whisk.go): IsValidWhiskShuffleProof on 124
+trackers -- 496 tracker points + 91 proof points decoded (square root, curve and subgroup
+tests), then curdleproof.Verify -- plus the tracker opening proofs.
+    python tools/bench_whisk.py                       # points decoded by one GPU kernel
+    CURDLE_HOST_DECODE=1 python tools/bench_whisk.py  # points decoded one by one on the host
+"""
+import os, sys, time, json, threading
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "go-curdleproofs_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import numpy as np
+import curdlemsm as cm
+
+cm.init(0)
+ONE = np.array([0x760900000002fffd, 0xebf4000bc40c0002, 0x5f48985753c758ba, 0x77ce585370525745, 0x5c071a97a256ec6d,
+                0x15f65ec3fa80e493], dtype=np.uint64)
+compress = lambda aff: cm.g1_compress(np.concatenate([aff, ONE]))
+rand = cm.Rand(0)
+crs = cm.CRS(cm.WHISK_ELL, rand)
+# trackers (rG, krG): any two subgroup points do for timing; take them from Rand
+pts = rand.get_g1_affines(2 * cm.WHISK_ELL)
+pre = [compress(pts[2 * i]) + compress(pts[2 * i + 1]) for i in range(cm.WHISK_ELL)]
+t0 = time.perf_counter()
+post, proof = cm.whisk_generate_shuffle_proof(crs, pre, rand)
+t_gen = time.perf_counter() - t0
+assert cm.whisk_is_valid_shuffle_proof(crs, pre, post, proof, cm.Rand(1))
+reps = 20
+t0 = time.perf_counter()
+for i in range(reps):
+    assert cm.whisk_is_valid_shuffle_proof(crs, pre, post, proof, cm.Rand(2 + i))
+t_valid = (time.perf_counter() - t0) / reps
+res = {}
+for nthreads in (4, 8, 16):
+    per = 8
+    def worker(tid):
+        for i in range(per):
+            assert cm.whisk_is_valid_shuffle_proof(crs, pre, post, proof, cm.Rand(1000 + 50 * tid + i))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    t0 = time.perf_counter()
+    [t.start() for t in th]
+    [t.join() for t in th]
+    res[nthreads] = nthreads * per / (time.perf_counter() - t0)
+# tracker opening proof
+import bls12381_ref as oracle
+k = 12345
+tracker = oracle.compress(oracle.scalar_mul(777, oracle.G1)) + oracle.compress(oracle.scalar_mul(777 * k % oracle.R, oracle.G1))
+kc = oracle.compress(oracle.scalar_mul(k, oracle.G1))
+kl = np.array(oracle.fr_to_mont_limbs(k), dtype=np.uint64)
+t0 = time.perf_counter()
+for i in range(50):
+    tp = cm.whisk_generate_tracker_proof(tracker, kl, cm.Rand(i))
+t_tgen = (time.perf_counter() - t0) / 50
+t0 = time.perf_counter()
+for i in range(50):
+    assert cm.whisk_is_valid_tracker_proof(tracker, kc, tp)
+t_tval = (time.perf_counter() - t0) / 50
+out = {"decode": "host" if os.environ.get("CURDLE_HOST_DECODE") else "gpu",
+       "generate_shuffle_proof_ms": t_gen * 1e3, "is_valid_shuffle_proof_ms": t_valid * 1e3,
+       "is_valid_shuffle_proof_per_s": 1 / t_valid, "is_valid_shuffle_proof_per_s_threads": res,
+       "generate_tracker_proof_ms": t_tgen * 1e3, "is_valid_tracker_proof_ms": t_tval * 1e3}
+print(json.dumps(out))
