@@ -79,6 +79,11 @@ __device__ __forceinline__ void to_canonical(u32* w, const F28& a) {
 
 }  // namespace
 
+// QUAD: four adjacent lanes per point.  They run the square root redundantly and share the
+// point operations of the subgroup test (fp28.h quad_dbl / quad_add: 3 and 4 product steps
+// instead of 9 and 14), which shortens the per-point chain from ~1,900 to ~1,050 products:
+// the launch is latency-bound until tens of thousands of points, so small batches use it.
+template <bool QUAD>
 __global__ void __launch_bounds__(kBlock, 2)
     k_g1_decompress(const uint8_t* __restrict__ in, u32 n, int subgroup_check, u32* __restrict__ out,
                     uint8_t* __restrict__ status) {
@@ -87,8 +92,10 @@ __global__ void __launch_bounds__(kBlock, 2)
   __shared__ u32 sh_x[d28::N][kBlock];
   __shared__ u32 sh_y[d28::N][kBlock];
   const u32 tid = threadIdx.x;
-  const u32 i = blockIdx.x * kBlock + tid;
-  if (i >= n) return;
+  const u32 lane = blockIdx.x * kBlock + tid;
+  const u32 i = QUAD ? lane >> 2 : lane;
+  const bool writer = !QUAD || (tid & 3u) == 0;
+  if (i >= n) return;  // whole quads leave together
   const uint8_t* b = in + (size_t)i * 48;
   u32* o = out + (size_t)i * 24;
   u32 xw[12];
@@ -98,6 +105,7 @@ __global__ void __launch_bounds__(kBlock, 2)
   const u32 flags = xw[11] >> 29;
   xw[11] &= 0x1fffffffu;
   auto fail = [&](uint8_t code) {
+    if (!writer) return;
 #pragma unroll
     for (int k = 0; k < 24; k++) o[k] = 0;
     status[i] = code;
@@ -162,24 +170,44 @@ __global__ void __launch_bounds__(kBlock, 2)
     d28::set_one(q.zz);
     d28::set_one(q.zzz);
     const unsigned long long zabs = 0xd201000000010000ull;
-    // first multiplication: the addend is affine (mixed additions)
     X28 acc = q;
-    for (int bit = 62; bit >= 0; bit--) {
-      d28::dbl(acc);
-      if ((zabs >> bit) & 1ull) d28::madd(acc, bx, y);
-    }
-    // second: the addend is the first result
-    q = acc;
-    for (int bit = 62; bit >= 0; bit--) {
-      d28::dbl(acc);
-      if ((zabs >> bit) & 1ull) d28::add(acc, q);
-    }
+    if constexpr (QUAD) {
+      for (int bit = 62; bit >= 0; bit--) {
+        d28::quad_dbl(acc);
+        if ((zabs >> bit) & 1ull) d28::quad_add(acc, q);
+      }
+      q = acc;
+      for (int bit = 62; bit >= 0; bit--) {
+        d28::quad_dbl(acc);
+        if ((zabs >> bit) & 1ull) d28::quad_add(acc, q);
+      }
 #pragma unroll
-    for (int k = 0; k < d28::N; k++) {
-      x.l[k] = sh_x[k][tid];
-      y.l[k] = sh_y[k][tid];
+      for (int k = 0; k < d28::N; k++) {
+        q.x.l[k] = sh_x[k][tid];
+        q.y.l[k] = sh_y[k][tid];
+      }
+      d28::set_one(q.zz);
+      d28::set_one(q.zzz);
+      d28::quad_add(acc, q);
+    } else {
+      // first multiplication: the addend is affine (mixed additions)
+      for (int bit = 62; bit >= 0; bit--) {
+        d28::dbl(acc);
+        if ((zabs >> bit) & 1ull) d28::madd(acc, bx, y);
+      }
+      // second: the addend is the first result
+      q = acc;
+      for (int bit = 62; bit >= 0; bit--) {
+        d28::dbl(acc);
+        if ((zabs >> bit) & 1ull) d28::add(acc, q);
+      }
+#pragma unroll
+      for (int k = 0; k < d28::N; k++) {
+        x.l[k] = sh_x[k][tid];
+        y.l[k] = sh_y[k][tid];
+      }
+      d28::madd(acc, x, y);
     }
-    d28::madd(acc, x, y);
     if (!d28::is_inf(acc)) return fail(CURDLE_DECODE_NOT_IN_SUBGROUP);
   }
 #pragma unroll
@@ -187,6 +215,7 @@ __global__ void __launch_bounds__(kBlock, 2)
     x.l[k] = sh_x[k][tid];
     y.l[k] = sh_y[k][tid];
   }
+  if (!writer) return;
   d28::to_gnark(o, x);
   d28::to_gnark(o + 12, y);
   status[i] = CURDLE_DECODE_OK;
@@ -195,8 +224,13 @@ __global__ void __launch_bounds__(kBlock, 2)
 hipError_t launch_g1_decompress(const uint8_t* in, uint32_t n, int subgroup_check, uint32_t* out, uint8_t* status,
                                 hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_g1_decompress, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n, subgroup_check, out,
-                     status);
+  // four lanes per point while even that is at most one round of the chip (2 waves per SIMD)
+  if (subgroup_check && (uint64_t)n * 4 <= 131072)
+    hipLaunchKernelGGL(k_g1_decompress<true>, dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n,
+                       subgroup_check, out, status);
+  else
+    hipLaunchKernelGGL(k_g1_decompress<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n,
+                       subgroup_check, out, status);
   return hipGetLastError();
 }
 

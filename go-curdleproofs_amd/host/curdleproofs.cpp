@@ -296,10 +296,32 @@ Proof Prove(const Point& Gt, const Point& Gu, const Point& H, const Point& R, co
 }
 
 bool Verify(const Proof& proof, const Point& Gt, const Point& Gu, const Point& H, const Point& R, const Point& S,
-            const GroupCommitment& T, const GroupCommitment& U, Transcript& tr) {
+            const GroupCommitment& T, const GroupCommitment& U, Transcript& tr, MsmAccumulator* acc,
+            common::Rand* rand) {
   // samescalarargument.go:83-100
   AppendStatement(tr, R, S, T, U, proof.A, proof.B);
   const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
+  if (acc && rand && !EagerChecks()) {
+    // The reference evaluates both sides of  A + alpha T == Com(Z_k R; Z_t)  and
+    // B + alpha U == Com(Z_k S; Z_u)  (ten scalar multiplications) and compares.  Each of
+    // the four coordinate equations is "a combination of known points equals an MSM", which
+    // is what the accumulator batches: hand them over like every other check, so they ride
+    // in the verification's one MSM.  Sound for the same reason the other checks are
+    // (a fresh random weight each); rejects surface at the final MSM instead of here.
+    auto check = [&](const Point& lhs0, const Point& lhs1, std::vector<Scalar> x, std::vector<G1Affine> v,
+                     const char* what) {
+      Terms c;
+      c.Add(Scalar::One(), lhs0);
+      c.Add(alpha, lhs1);
+      Accumulate(*acc, c, x, v, *rand, what);
+    };
+    const G1Affine h = H.Affine();
+    check(proof.A.T_1, T.T_1, {proof.Z_t}, {Gt.Affine()}, "same scalar check A.T_1");
+    check(proof.A.T_2, T.T_2, {proof.Z_k, proof.Z_t}, {R.Affine(), h}, "same scalar check A.T_2");
+    check(proof.B.T_1, U.T_1, {proof.Z_u}, {Gu.Affine()}, "same scalar check B.T_1");
+    check(proof.B.T_2, U.T_2, {proof.Z_k, proof.Z_u}, {S.Affine(), h}, "same scalar check B.T_2");
+    return true;
+  }
   const GroupCommitment e1 = GroupCommitment::New(Gt, H, R.Mul(proof.Z_k), proof.Z_t);
   const GroupCommitment e2 = GroupCommitment::New(Gu, H, S.Mul(proof.Z_k), proof.Z_u);
   return proof.A.Add(T.Mul(alpha)).Eq(e1) && proof.B.Add(U.Mul(alpha)).Eq(e2);
@@ -910,7 +932,8 @@ bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>&
   if (!sameperm::Verify(proof.proofSamePermutation, crs.Gs, crs.Hs, crs.H, crs.Gsum, crs.Hsum, proof.A, M, as,
                         N_BLINDERS, tr, acc, rand))
     return false;
-  if (!samescalar::Verify(proof.proofSameScalar, crs.Gt, crs.Gu, crs.H, proof.R, proof.S, proof.T, proof.U, tr))
+  if (!samescalar::Verify(proof.proofSameScalar, crs.Gt, crs.Gu, crs.H, proof.R, proof.S, proof.T, proof.U, tr, &acc,
+                          &rand))
     return false;
 
   const Point Aprime = proof.A + proof.T.T_1 + proof.U.T_1;

@@ -115,8 +115,11 @@ struct Proof {
 Proof Prove(const Point& Gt, const Point& Gu, const Point& H, const Point& R, const Point& S,
             const GroupCommitment& T, const GroupCommitment& U, const Scalar& k, const Scalar& r_t, const Scalar& r_u,
             transcript::Transcript& tr, common::Rand& rand);
+// With an accumulator (and not in eager mode) the two commitment equations join the batched
+// check instead of being evaluated on the spot; without one this is the reference's Verify.
 bool Verify(const Proof& proof, const Point& Gt, const Point& Gu, const Point& H, const Point& R, const Point& S,
-            const GroupCommitment& T, const GroupCommitment& U, transcript::Transcript& tr);
+            const GroupCommitment& T, const GroupCommitment& U, transcript::Transcript& tr,
+            msmaccumulator::MsmAccumulator* acc = nullptr, common::Rand* rand = nullptr);
 }  // namespace samescalar
 
 // ---- innerproductargument ----

@@ -191,3 +191,26 @@ def test_batched_point_decoding_on_the_gpu(gpu, oracle):
             with pytest.raises(gpu.CurdleError):
                 gpu.g1_decompress(enc, True)
     assert gpu.g1_decompress_batch(b"", True)[0].shape == (0, 12)
+
+
+def test_same_scalar_argument_is_enforced(gpu, check_mode):
+    """The same-scalar argument's responses (Z_k, Z_t, Z_u) and commitments (A, B) are bound by
+    two commitment equations (samescalarargument.go:83-100).  In the deferred mode those
+    ride in the accumulator's MSM instead of being compared on the spot: touching any of
+    them must still reject."""
+    n = 64
+    crs, Rs, Ss, Ts, Us, M, perm, k, rs_m = setup(gpu, n)
+    proof = gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(3))
+    assert gpu.verify(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(4)) is True
+    m = 6                                            # log2(n)
+    same_perm = 48 + (48 + 32) + (96 + 4 * (4 + 48 * m) + 64)
+    at = 48 + 96 + 96 + 48 + 48 + same_perm          # A, T, U, R, S, then proofSamePermutation
+    assert len(proof) == at + 288 + (3 * 48 + 6 * (4 + 48 * m) + 32)
+    for name, off in (("Z_k", at + 192 + 31), ("Z_t", at + 224 + 31), ("Z_u", at + 256 + 31)):
+        touched = bytearray(proof)
+        touched[off] ^= 1
+        assert gpu.verify(crs, bytes(touched), Rs, Ss, Ts, Us, M, gpu.Rand(4)) is False, name
+    # swap the argument's two commitments A and B (both valid points): rejected as well
+    swapped = bytearray(proof)
+    swapped[at:at + 96], swapped[at + 96:at + 192] = proof[at + 96:at + 192], proof[at:at + 96]
+    assert gpu.verify(crs, bytes(swapped), Rs, Ss, Ts, Us, M, gpu.Rand(4)) is False
