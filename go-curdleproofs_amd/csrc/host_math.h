@@ -68,6 +68,42 @@ inline bool g1_to_affine(G1Affine& out, const G1XYZZ& p) {
   return true;
 }
 
+// n XYZZ points -> affine with ONE inversion (Montgomery's trick over t_i = ZZ_i ZZZ_i:
+// 1/ZZ = ZZZ / t, 1/ZZZ = ZZ / t); infinities (ZZ = 0) become (0, 0).  ~8 products per point.
+inline void g1_batch_to_affine(G1Affine* out, const G1XYZZ* in, size_t n) {
+  if (n == 0) return;
+  Fp* prefix = new Fp[n];  // prefix[i] = prod of t_j over finite points j <= i
+  Fp run;
+  f_one(run);
+  for (size_t i = 0; i < n; i++) {
+    if (!g1_is_inf(in[i])) {
+      Fp t;
+      fp_mul(t, in[i].zz, in[i].zzz);
+      fp_mul(run, run, t);
+    }
+    prefix[i] = run;
+  }
+  Fp inv;
+  fp_inv(inv, run);  // run != 0: a product of non-zero field elements (or one)
+  for (size_t i = n; i-- > 0;) {
+    if (g1_is_inf(in[i])) {
+      f_zero(out[i].x);
+      f_zero(out[i].y);
+      continue;
+    }
+    Fp t, ti, izz, izzz, before;
+    if (i > 0) before = prefix[i - 1]; else f_one(before);
+    fp_mul(ti, inv, before);            // 1 / t_i
+    fp_mul(t, in[i].zz, in[i].zzz);
+    fp_mul(inv, inv, t);                // drop t_i from the running inverse
+    fp_mul(izz, ti, in[i].zzz);
+    fp_mul(izzz, ti, in[i].zz);
+    fp_mul(out[i].x, in[i].x, izz);
+    fp_mul(out[i].y, in[i].y, izzz);
+  }
+  delete[] prefix;
+}
+
 // gnark G1Jac (X, Y, Z), any representative -> XYZZ.
 inline void g1_from_jac(G1XYZZ& r, const G1Jac& j) {
   if (f_is_zero(j.z)) {

@@ -545,6 +545,44 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
 }
 
 // ---------------------------------------------------------------------------
+// Batched independent scalar multiplications (group_kernels.hip)
+// ---------------------------------------------------------------------------
+extern "C" void curdle_host_batch_to_affine(void* out_affine, const void* in_xyzz, size_t n);
+
+extern "C" int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t* scalars, size_t n_scalars,
+                                          const uint64_t* addends, size_t n, uint64_t* out_affine) {
+  if (n && (!points || !scalars || !out_affine)) return fail(CURDLE_EINVAL, "null argument");
+  if (n == 0) return CURDLE_OK;
+  if (n_scalars != n && n_scalars != 1) return fail(CURDLE_EINVAL, "n_scalars must be n or 1");
+  if (n > ((size_t)1 << 24)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^24 points", n);
+  int idx;
+  int rc = acquire_slot(true, &idx);
+  if (rc) return rc;
+  Slot& S = g_ctx.slots[idx];
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    int r;
+    if ((r = ensure(S.points, n * 96))) return r;
+    if ((r = ensure(S.scalars, n_scalars * 32))) return r;
+    if (addends && (r = ensure(S.digits, n * 96))) return r;
+    if ((r = ensure(S.sorted, n * sizeof(G1XYZZ)))) return r;
+    HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n_scalars * 32, hipMemcpyHostToDevice, S.stream));
+    if (addends) HIP_TRY(hipMemcpyAsync(S.digits.p, addends, n * 96, hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(launch_scalar_mul_batch(S.points.p, S.scalars.p, n_scalars == 1 ? 1 : 0, addends ? S.digits.p : nullptr,
+                                    (uint32_t)n, S.sorted.p, S.stream));
+    std::vector<G1XYZZ> res(n);
+    HIP_TRY(hipMemcpyAsync(res.data(), S.sorted.p, n * sizeof(G1XYZZ), hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    curdle_host_batch_to_affine(out_affine, res.data(), n);  // one shared inversion
+    return CURDLE_OK;
+  };
+  rc = body();
+  release_slot(idx);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
 // Life cycle
 // ---------------------------------------------------------------------------
 extern "C" int curdle_init(int device) {

@@ -56,7 +56,7 @@ SYMBOLS = [
     "curdle_prove", "curdle_verify", "curdle_proof_from_bytes", "curdle_proof_free", "curdle_verify_proof",
     "curdle_verify_batch", "curdle_verify_set_eager",
     "curdle_whisk_is_valid_shuffle_proof", "curdle_whisk_generate_shuffle_proof",
-    "curdle_whisk_is_valid_tracker_proof", "curdle_whisk_generate_tracker_proof", "curdle_proof_reencode", "curdle_merlin_test_vector", "curdle_g1_decompress_batch",
+    "curdle_whisk_is_valid_tracker_proof", "curdle_whisk_generate_tracker_proof", "curdle_proof_reencode", "curdle_merlin_test_vector", "curdle_g1_decompress_batch", "curdle_g1_scalar_mul_batch",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error",
 ]
 
@@ -590,6 +590,21 @@ def g1_decompress_batch(data: bytes, subgroup_check: bool = True):
     st = np.zeros(n, dtype=np.uint8)
     _check(_decompress_batch(_ptr(b), n, 1 if subgroup_check else 0, _ptr(out), _ptr(st)))
     return out, st
+
+
+_scalar_mul_batch = _sig("curdle_g1_scalar_mul_batch", C.c_int, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp)
+
+
+def g1_scalar_mul_batch(points, scalars, addends=None) -> np.ndarray:
+    """out[i] = addends[i] + scalars[i] * points[i] on the GPU; scalars (n, 4) or one shared (4,)."""
+    points = _as_u64(points, 12)
+    n = points.shape[0] if points.size else 0
+    sc = _as_u64(scalars, 4)
+    ns = (1 if sc.ndim == 1 else sc.shape[0]) if sc.size else 0
+    add = _as_u64(addends, 12) if addends is not None else None
+    out = np.zeros((n, 12), dtype=np.uint64)
+    _check(_scalar_mul_batch(_ptr(points), _ptr(sc), ns, _ptr(add) if add is not None else None, n, _ptr(out)))
+    return out
 
 
 def g1_compress(jac) -> bytes:

@@ -280,5 +280,28 @@ std::vector<Point> MultiExpBatch(const std::vector<const std::vector<G1Affine>*>
   return res;
 }
 
+std::vector<G1Affine> ScalarMulBatch(const std::vector<G1Affine>& points, const std::vector<Scalar>& scalars,
+                                     const std::vector<G1Affine>* addends) {
+  const size_t n = points.size();
+  if (scalars.size() != n && scalars.size() != 1) throw std::runtime_error("scalar mul batch: len(scalars) must be n or 1");
+  if (addends && addends->size() != n) throw std::runtime_error("scalar mul batch: len(addends) != len(points)");
+  std::vector<G1Affine> out(n);
+  if (n == 0) return out;
+  if (n >= kScalarMulBatchMin) {
+    int rc = curdle_g1_scalar_mul_batch(reinterpret_cast<const uint64_t*>(points.data()),
+                                        reinterpret_cast<const uint64_t*>(scalars.data()), scalars.size(),
+                                        addends ? reinterpret_cast<const uint64_t*>(addends->data()) : nullptr, n,
+                                        reinterpret_cast<uint64_t*>(out.data()));
+    if (rc != CURDLE_OK) throw msm_error(rc);
+    return out;
+  }
+  for (size_t i = 0; i < n; i++) {  // a handful of points: a kernel launch would cost more than it saves
+    Point r = Point::FromAffine(points[i]).Mul(scalars.size() == 1 ? scalars[0] : scalars[i]);
+    if (addends) r = r + Point::FromAffine((*addends)[i]);
+    out[i] = r.Affine();
+  }
+  return out;
+}
+
 }  // namespace alg
 }  // namespace curdle

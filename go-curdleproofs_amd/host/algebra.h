@@ -124,5 +124,13 @@ Point MultiExp(const std::vector<G1Affine>& points, const std::vector<Scalar>& s
 std::vector<Point> MultiExpBatch(const std::vector<const std::vector<G1Affine>*>& points,
                                  const std::vector<const std::vector<Scalar>*>& scalars);
 
+// out[i] = addends[i] + scalars[i] * points[i]; scalars.size() is points.size(), or 1 for one
+// scalar shared by all; addends may be null.  The independent scalar multiplications that
+// dominate the prover: a batch of at least kScalarMulBatchMin goes to
+// the GPU (curdle_g1_scalar_mul_batch), smaller ones run on the host one by one.
+static constexpr size_t kScalarMulBatchMin = 24;
+std::vector<G1Affine> ScalarMulBatch(const std::vector<G1Affine>& points, const std::vector<Scalar>& scalars,
+                                     const std::vector<G1Affine>* addends = nullptr);
+
 }  // namespace alg
 }  // namespace curdle

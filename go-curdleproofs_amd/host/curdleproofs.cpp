@@ -7,6 +7,7 @@
 
 #include "../../include/curdle_msm.h"
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -255,8 +256,11 @@ ShuffleCommit ShufflePermuteCommit(const std::vector<G1Affine>& crsGs, const std
                                    const std::vector<uint32_t>& perm, const Scalar& k, common::Rand& rand) {
   ShuffleCommit out;  // common/util.go:45-88
   std::vector<G1Affine> Ts(Rs.size()), Us(Ss.size());
-  for (size_t i = 0; i < Rs.size(); i++) Ts[i] = Point::FromAffine(Rs[i]).Mul(k).Affine();  // :55-58
-  for (size_t i = 0; i < Ss.size(); i++) Us[i] = Point::FromAffine(Ss[i]).Mul(k).Affine();  // :60-63
+  {
+    const std::vector<G1Affine> scaled = alg::ScalarMulBatch(Concat(Rs, Ss), {k});  // :55-63, 2 ell by one scalar
+    std::copy(scaled.begin(), scaled.begin() + Rs.size(), Ts.begin());
+    std::copy(scaled.begin() + Rs.size(), scaled.end(), Us.begin());
+  }
   out.Ts = Permute(Ts, perm);
   out.Us = Permute(Us, perm);
   std::vector<Scalar> range(crsGs.size(), Scalar::Zero());
@@ -431,8 +435,15 @@ Proof Prove(std::vector<G1Affine> Gs, std::vector<G1Affine> Gs_prime, const Poin
     for (size_t i = 0; i < n; i++) {  // fold, :155-166
       cs[i] = c_L[i] + gamma_inv * c_R[i];
       ds[i] = d_L[i] + gamma * d_R[i];
-      Gs[i] = (Point::FromAffine(G_L[i]) + Point::FromAffine(G_R[i]).Mul(gamma)).Affine();
-      Gs_prime[i] = (Point::FromAffine(Gp_L[i]) + Point::FromAffine(Gp_R[i]).Mul(gamma_inv)).Affine();
+    }
+    {
+      // G_L + gamma G_R and G'_L + gamma^-1 G'_R: 2n independent scalar multiplications, one batch
+      std::vector<G1Affine> pts = Concat(G_R, Gp_R), adds = Concat(G_L, Gp_L);
+      std::vector<Scalar> ks(2 * n, gamma);
+      std::fill(ks.begin() + n, ks.end(), gamma_inv);
+      const std::vector<G1Affine> folded = alg::ScalarMulBatch(pts, ks, &adds);
+      std::copy(folded.begin(), folded.begin() + n, Gs.begin());
+      std::copy(folded.begin() + n, folded.end(), Gs_prime.begin());
     }
     cs.resize(n);
     ds.resize(n);
@@ -564,12 +575,18 @@ Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, co
   // step 3: rescaled bases G'_i = beta^-(i+1) G_i, H'_i = beta^-(ell+1) H_i (:94-103)
   const Scalar betaInv = beta.Inverse();
   std::vector<G1Affine> Gs_prime(ell), Hs_prime(Hs.size());
-  Scalar bi = betaInv;
-  for (size_t i = 0; i < ell; i++) {
-    Gs_prime[i] = Point::FromAffine(Gs[i]).Mul(bi).Affine();
-    bi = bi * betaInv;
+  {
+    std::vector<Scalar> ks(ell + Hs.size());
+    Scalar bi = betaInv;
+    for (size_t i = 0; i < ell; i++) {
+      ks[i] = bi;
+      bi = bi * betaInv;
+    }
+    for (size_t i = 0; i < Hs.size(); i++) ks[ell + i] = bi;
+    const std::vector<G1Affine> scaled = alg::ScalarMulBatch(Concat(Gs, Hs), ks);  // ell + 4 in one batch
+    std::copy(scaled.begin(), scaled.begin() + ell, Gs_prime.begin());
+    std::copy(scaled.begin() + ell, scaled.end(), Hs_prime.begin());
   }
-  for (size_t i = 0; i < Hs.size(); i++) Hs_prime[i] = Point::FromAffine(Hs[i]).Mul(bi).Affine();
 
   std::vector<Scalar> betaPowers(ell), ds(ell);
   Scalar bp = Scalar::One();  // beta^i
@@ -755,11 +772,14 @@ Proof Prove(std::vector<G1Affine> G, const Point& A, const Point& Z_t, const Poi
     const Scalar gamma = tr.GetAndAppendChallenge(kGamma);
     if (gamma.IsZero()) throw err("gamma is zero");
     const Scalar gamma_inv = gamma.Inverse();
-    for (size_t i = 0; i < n; i++) {  // fold vectors and bases, :128-135
-      x[i] = x_L[i] + gamma_inv * x_R[i];
-      T[i] = (Point::FromAffine(T_L[i]) + Point::FromAffine(T_R[i]).Mul(gamma)).Affine();
-      U[i] = (Point::FromAffine(U_L[i]) + Point::FromAffine(U_R[i]).Mul(gamma)).Affine();
-      G[i] = (Point::FromAffine(G_L[i]) + Point::FromAffine(G_R[i]).Mul(gamma)).Affine();
+    for (size_t i = 0; i < n; i++) x[i] = x_L[i] + gamma_inv * x_R[i];  // fold vectors and bases, :128-135
+    {
+      // T_L + gamma T_R, U_L + gamma U_R, G_L + gamma G_R: 3n scalar multiplications by one scalar
+      const std::vector<G1Affine> pts = Concat(Concat(T_R, U_R), G_R), adds = Concat(Concat(T_L, U_L), G_L);
+      const std::vector<G1Affine> folded = alg::ScalarMulBatch(pts, {gamma}, &adds);
+      std::copy(folded.begin(), folded.begin() + n, T.begin());
+      std::copy(folded.begin() + n, folded.begin() + 2 * n, U.begin());
+      std::copy(folded.begin() + 2 * n, folded.end(), G.begin());
     }
     x.resize(n);
     T.resize(n);

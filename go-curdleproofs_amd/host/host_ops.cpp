@@ -12,6 +12,7 @@ void curdle_host_fp_pow_bmi2(void*, const void*, const uint32_t*);
 void curdle_host_fp_from_mont_bmi2(void*, const void*);
 int curdle_host_equal_bmi2(const void*, const void*);
 int curdle_host_in_subgroup_bmi2(const void*);
+void curdle_host_batch_to_affine_bmi2(void*, const void*, size_t);
 }
 
 static bool fast_isa() {
@@ -64,4 +65,11 @@ extern "C" int curdle_host_equal(const void* a_xyzz, const void* b_xyzz) {
 
 extern "C" int curdle_host_in_subgroup(const void* p_xyzz) {
   return fast_isa() ? curdle_host_in_subgroup_bmi2(p_xyzz) : curdle_host_in_subgroup_generic(p_xyzz);
+}
+
+extern "C" void curdle_host_batch_to_affine(void* out_affine, const void* in_xyzz, size_t n) {
+  if (fast_isa())
+    curdle_host_batch_to_affine_bmi2(out_affine, in_xyzz, n);
+  else
+    curdle_host_batch_to_affine_generic(out_affine, in_xyzz, n);
 }

@@ -1,5 +1,6 @@
 // Serial host-side group operations with run-time ISA dispatch (host_ops.cpp).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 extern "C" {
@@ -11,4 +12,5 @@ void curdle_host_fp_pow(void* r, const void* a, const uint32_t* e12);
 void curdle_host_fp_from_mont(void* r, const void* a);
 int curdle_host_equal(const void* a_xyzz, const void* b_xyzz);
 int curdle_host_in_subgroup(const void* p_xyzz);
+void curdle_host_batch_to_affine(void* out_affine, const void* in_xyzz, size_t n);
 }

@@ -75,3 +75,9 @@ extern "C" int CURDLE_FN(curdle_host_in_subgroup)(const void* p_xyzz) {
   using namespace curdle;
   return g1_in_subgroup(*static_cast<const G1XYZZ*>(p_xyzz)) ? 1 : 0;
 }
+
+// n XYZZ points -> n affine points with one shared inversion
+extern "C" void CURDLE_FN(curdle_host_batch_to_affine)(void* out_affine, const void* in_xyzz, size_t n) {
+  using namespace curdle;
+  g1_batch_to_affine(static_cast<G1Affine*>(out_affine), static_cast<const G1XYZZ*>(in_xyzz), n);
+}

@@ -260,6 +260,15 @@ int curdle_merlin_test_vector(const char* protocol, const char* label, const uin
                               const char* challenge_label, uint8_t* out, size_t out_len);
 int curdle_g1_compress(const uint64_t jac[18], uint8_t out[48]);
 int curdle_g1_decompress(const uint8_t in[48], int subgroup_check, uint64_t out_jac[18]);
+/* Batched independent scalar multiplications ON THE GPU:
+ *   out[i] = addends[i] + scalars[i] * points[i],   i < n
+ * points / addends / out gnark affine (addends may be NULL; (0,0) = infinity), scalars Montgomery
+ * fr.Elements; n_scalars = n, or 1 for one scalar shared by all points.  Replaces the loops of
+ * single ScalarMultiplication calls that dominate the reference's prover: the fold steps
+ * G_L[i] += gamma * G_R[i] (innerproductargument.go:155-166, samemultiscalarargument.go:129-135),
+ * grandproductargument.go:94-103 and common/util.go:55-63. */
+int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t* scalars, size_t n_scalars,
+                               const uint64_t* addends, size_t n, uint64_t* out_affine);
 /* Batched decoding of gnark's compressed G1 encoding ON THE GPU (one lane per point: square
  * root, curve check, sign selection, and with subgroup_check != 0 the endomorphism subgroup
  * test gnark's Decoder / SetBytes apply): n x 48 bytes in, n x 12 limbs of gnark affine

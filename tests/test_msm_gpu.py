@@ -437,3 +437,46 @@ def test_verifier_shaped_accumulation(gpu, oracle, coracle):
     pts, sc = ma.export()
     assert (gpu.msm_g1(pts, sc) == ma.A_c).all()
     assert (coracle.msm_pippenger(pts, sc, threads=8) == ma.A_c).all()
+
+
+def test_batched_scalar_multiplication(gpu, oracle):
+    """curdle_g1_scalar_mul_batch: out[i] = A[i] + s[i] * P[i] (the prover's fold step and its
+    plain scalar multiplications) against the oracle, incl. zero / one / r-1 scalars, infinity
+    operands, P + (-P) and doubling through the addend, one shared scalar, and a size that
+    takes the one-lane-per-point kernel."""
+    r = oracle.Rand(21)
+    n = 40
+    P = r.get_g1_affines(n)
+    A = r.get_g1_affines(n)
+    s = r.get_frs(n)
+    s[0], s[1], s[2], s[3] = 0, 1, oracle.R - 1, 2
+    P[4] = oracle.INF
+    A[5] = oracle.INF
+    A[6] = oracle.neg(oracle.scalar_mul(s[6], P[6]))   # result is infinity
+    A[7] = oracle.scalar_mul(s[7], P[7])                # addition of equal points
+    Pl = np.array([oracle.affine_to_mont_limbs(p) for p in P], dtype=np.uint64)
+    Al = np.array([oracle.affine_to_mont_limbs(p) for p in A], dtype=np.uint64)
+    sl = np.array([oracle.fr_to_mont_limbs(v) for v in s], dtype=np.uint64)
+    got = gpu.g1_scalar_mul_batch(Pl, sl, Al)
+    for i in range(n):
+        want = oracle.add(A[i], oracle.scalar_mul(s[i], P[i]))
+        assert oracle.affine_from_mont_limbs([int(v) for v in got[i]]) == want, i
+    got = gpu.g1_scalar_mul_batch(Pl, sl)               # no addend
+    for i in range(n):
+        assert oracle.affine_from_mont_limbs([int(v) for v in got[i]]) == oracle.scalar_mul(s[i], P[i]), i
+    got = gpu.g1_scalar_mul_batch(Pl, sl[9], Al)        # one scalar for all (the fold step)
+    for i in range(n):
+        assert oracle.affine_from_mont_limbs([int(v) for v in got[i]]) == oracle.add(A[i], oracle.scalar_mul(s[9], P[i])), i
+    assert gpu.g1_scalar_mul_batch(Pl[:0], sl[:0]).shape == (0, 12)
+    # 2^15 + 1 points: past the four-lanes-per-point limit; checked through linearity against the MSM
+    big = 32769
+    pts = gpu.Rand(4).get_g1_affines(64)
+    pts = np.concatenate([pts] * (big // 64 + 1))[:big]
+    k = np.array(oracle.fr_to_mont_limbs(0x1234567), dtype=np.uint64)
+    out = gpu.g1_scalar_mul_batch(pts, k)
+    ones = np.array([oracle.fr_to_mont_limbs(1)] * big, dtype=np.uint64)
+    lhs = gpu.msm_g1(out, ones)                                  # sum_i k P_i
+    rhs = gpu.msm_g1(pts, np.array([oracle.fr_to_mont_limbs(0x1234567)] * big, dtype=np.uint64))
+    assert (lhs == rhs).all()
+    assert oracle.affine_from_mont_limbs([int(v) for v in out[big - 1]]) == oracle.scalar_mul(
+        0x1234567, oracle.affine_from_mont_limbs([int(v) for v in pts[big - 1]]))
