@@ -114,3 +114,63 @@ func MultiExpBatch(dst []bls12381.G1Jac, points []bls12381.G1Affine, scalars []f
 	}
 	return nil
 }
+
+// ScalarMulBatch computes out[i] = addends[i] + scalars[i]*points[i] on the GPU
+// (curdle_g1_scalar_mul_batch): the prover's fold steps
+// (innerproductargument.go:155-166, samemultiscalarargument.go:129-135) with one
+// shared scalar (len(scalars) == 1) and its loops of plain scalar multiplications
+// (grandproductargument.go:94-103, common/util.go:55-63) with addends == nil.
+func ScalarMulBatch(out, points []bls12381.G1Affine, scalars []fr.Element, addends []bls12381.G1Affine) error {
+	n := len(points)
+	if len(out) != n || (len(scalars) != n && len(scalars) != 1) || (addends != nil && len(addends) != n) {
+		return errors.New("curdlemsm: ScalarMulBatch: mismatched lengths")
+	}
+	if n == 0 {
+		return nil
+	}
+	var ap unsafe.Pointer
+	if addends != nil {
+		ap = unsafe.Pointer(&addends[0])
+	}
+	rc := C.curdle_g1_scalar_mul_batch((*C.uint64_t)(unsafe.Pointer(&points[0])),
+		(*C.uint64_t)(unsafe.Pointer(&scalars[0])), C.size_t(len(scalars)), (*C.uint64_t)(ap), C.size_t(n),
+		(*C.uint64_t)(unsafe.Pointer(&out[0])))
+	if rc != 0 {
+		return lastError(rc)
+	}
+	return nil
+}
+
+// Status of one record decoded by DecompressBatch (CURDLE_DECODE_* in curdle_msm.h).
+const (
+	DecodeOK            = 0
+	DecodeInfinity      = 1
+	DecodeBadEncoding   = 2
+	DecodeNotOnCurve    = 3
+	DecodeNotInSubgroup = 4
+)
+
+// DecompressBatch decodes len(in)/48 compressed G1 points on the GPU
+// (curdle_g1_decompress_batch) -- what the per-point G1Affine.SetBytes loops of
+// whisk/types.go:85-95 and the Decoder calls of the FromReader methods do one at a
+// time, subgroup check included.  status[i] != DecodeOK / DecodeInfinity marks a
+// record SetBytes would have rejected.
+func DecompressBatch(out []bls12381.G1Affine, status []byte, in []byte, subgroupCheck bool) error {
+	n := len(in) / 48
+	if len(in)%48 != 0 || len(out) != n || len(status) != n {
+		return errors.New("curdlemsm: DecompressBatch: mismatched lengths")
+	}
+	if n == 0 {
+		return nil
+	}
+	sc := C.int(0)
+	if subgroupCheck {
+		sc = 1
+	}
+	rc := C.curdle_g1_decompress_batch((*C.uint8_t)(unsafe.Pointer(&in[0])), C.size_t(n), sc,
+		(*C.uint64_t)(unsafe.Pointer(&out[0])), (*C.uint8_t)(unsafe.Pointer(&status[0])))
+	if rc != 0 {
+		return lastError(rc)
+	}
+	return nil
+}
