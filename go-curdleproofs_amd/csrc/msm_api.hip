@@ -236,6 +236,9 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (const char* env = getenv("CURDLE_SEG_LEN")) L = (uint64_t)atoi(env);
   if (L < 8) L = 8;
   if (L > 128) L = 128;
+  // beyond ~2^25 pairs even 128 positions per lane leave more than 4M lanes and cut a bucket
+  // into more than max_small fragments (they would all take the merge_large detour): grow L
+  if (entries / L > ((uint64_t)1 << 22)) L = entries >> 22;
   p.L = (uint32_t)L;
   p.max_small = 16;
   // a bucket with more than max_small fragments holds more than (max_small - 1) * L entries
