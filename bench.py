@@ -73,8 +73,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=20, help="log2 of the MSM size (default: the headline 2^20)")
-    ap.add_argument("--in-flight", type=int, default=3,
-                    help="MSMs in flight (curdle_msm_g1_device_submit/wait); 1 = strictly one after the other")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="MSMs in flight (curdle_msm_g1_device_submit/wait); 1 = strictly one after the other; "
+                         "default: 4 for a whole MSM per GPU, 3 for a window-range partial (measured best)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: on ONE GPU, run only the window range rank 0 of an N-rank job would "
@@ -121,7 +122,8 @@ def main():
 
     c = cm.window_bits(n)
     W = cm.num_windows(n, c)
-    depth = max(1, min(args.in_flight, cm.MSM_SLOTS))
+    in_flight = args.in_flight or (4 if world == 1 and args.emulate_world <= 1 else 3)
+    depth = max(1, min(in_flight, cm.MSM_SLOTS - 1))
     if world > 1:
         from curdlemsm.distributed import gather_partials, window_partition
         wb, we = window_partition(W, world, rank)
@@ -170,7 +172,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    cm.profile_enable(True)
+    # timed region: HIP events around the dominant kernel only, on the stream it is launched
+    # on (bracketing all ten phases puts ten barrier packets per MSM into the hardware
+    # queues and costs the pipeline ~0.1 ms per step); the other phases are timed below
+    cm.profile_enable(2)
     result = run_steps(args.warmup)
     kernel_ms = {}
 
@@ -197,6 +202,7 @@ def main():
     # previous MSM's tail; those overlapped spans are what `roofline` uses)
     lat = []
     solo_ms = {}
+    cm.profile_enable(1)
     for _ in range(5):
         barrier()
         t1 = time.perf_counter()

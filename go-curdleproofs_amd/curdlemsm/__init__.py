@@ -366,8 +366,9 @@ class MsmAccumulator:
         return pts, sc
 
 
-def profile_enable(on: bool = True) -> None:
-    _check(_profile_enable(1 if on else 0))
+def profile_enable(on=True) -> None:
+    """True / 1: HIP events around every kernel; 2: around the dominant kernel only; False / 0: off."""
+    _check(_profile_enable(int(on)))
 
 
 def profile_last() -> dict:

@@ -296,8 +296,10 @@ typedef struct {
   int window_bits;
   int num_windows;
 } curdle_profile;
-/* When enabled, every MSM call brackets each kernel with hipEvents on the
- * stream it launches on and keeps the durations of the last call. */
+/* on = 1: every MSM call brackets each kernel with hipEvents on the stream it launches on
+ * and keeps the durations of the last call.  on = 2: only the dominant kernel (the bucket
+ * accumulation) is bracketed -- two events instead of ten, which a pipelined caller does
+ * not notice.  on = 0: off. */
 int curdle_profile_enable(int on);
 int curdle_profile_last(curdle_profile* out);
 
