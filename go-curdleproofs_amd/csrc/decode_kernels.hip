@@ -79,6 +79,63 @@ __device__ __forceinline__ void to_canonical(u32* w, const F28& a) {
 
 }  // namespace
 
+// [z^2] phi(P) + P == inf for the point whose internal-form coordinates are parked in
+// sh_x / sh_y [.][tid] (and passed in x, y); |z| = 0xd201000000010000, the sign cancels in
+// z^2.  QUAD: the four lanes of a quad hold the same point and share every point operation.
+template <bool QUAD>
+__device__ __forceinline__ bool in_subgroup(F28& x, F28& y, u32 (*sh_x)[kBlock], u32 (*sh_y)[kBlock], u32 tid) {
+  F28 c;
+  F28 bx;
+#pragma unroll
+  for (int k = 0; k < d28::N; k++) c.l[k] = kBeta(k);
+  d28::mul(bx, x, c);
+  X28 q;
+  q.x = bx;
+  q.y = y;
+  d28::set_one(q.zz);
+  d28::set_one(q.zzz);
+  const unsigned long long zabs = 0xd201000000010000ull;
+  X28 acc = q;
+  if constexpr (QUAD) {
+    for (int bit = 62; bit >= 0; bit--) {
+      d28::quad_dbl(acc);
+      if ((zabs >> bit) & 1ull) d28::quad_add(acc, q);
+    }
+    q = acc;
+    for (int bit = 62; bit >= 0; bit--) {
+      d28::quad_dbl(acc);
+      if ((zabs >> bit) & 1ull) d28::quad_add(acc, q);
+    }
+#pragma unroll
+    for (int k = 0; k < d28::N; k++) {
+      q.x.l[k] = sh_x[k][tid];
+      q.y.l[k] = sh_y[k][tid];
+    }
+    d28::set_one(q.zz);
+    d28::set_one(q.zzz);
+    d28::quad_add(acc, q);
+  } else {
+    // first multiplication: the addend is affine (mixed additions)
+    for (int bit = 62; bit >= 0; bit--) {
+      d28::dbl(acc);
+      if ((zabs >> bit) & 1ull) d28::madd(acc, bx, y);
+    }
+    // second: the addend is the first result
+    q = acc;
+    for (int bit = 62; bit >= 0; bit--) {
+      d28::dbl(acc);
+      if ((zabs >> bit) & 1ull) d28::add(acc, q);
+    }
+#pragma unroll
+    for (int k = 0; k < d28::N; k++) {
+      x.l[k] = sh_x[k][tid];
+      y.l[k] = sh_y[k][tid];
+    }
+    d28::madd(acc, x, y);
+  }
+  return d28::is_inf(acc);
+}
+
 // QUAD: four adjacent lanes per point.  They run the square root redundantly and share the
 // point operations of the subgroup test (fp28.h quad_dbl / quad_add: 3 and 4 product steps
 // instead of 9 and 14), which shortens the per-point chain from ~1,900 to ~1,050 products:
@@ -159,56 +216,7 @@ __global__ void __launch_bounds__(kBlock, 2)
   }
 
   if (subgroup_check) {
-    // [z^2] phi(P) + P == inf, |z| = 0xd201000000010000 (the sign cancels in z^2)
-    F28 bx;
-#pragma unroll
-    for (int k = 0; k < d28::N; k++) c.l[k] = kBeta(k);
-    d28::mul(bx, x, c);
-    X28 q;
-    q.x = bx;
-    q.y = y;
-    d28::set_one(q.zz);
-    d28::set_one(q.zzz);
-    const unsigned long long zabs = 0xd201000000010000ull;
-    X28 acc = q;
-    if constexpr (QUAD) {
-      for (int bit = 62; bit >= 0; bit--) {
-        d28::quad_dbl(acc);
-        if ((zabs >> bit) & 1ull) d28::quad_add(acc, q);
-      }
-      q = acc;
-      for (int bit = 62; bit >= 0; bit--) {
-        d28::quad_dbl(acc);
-        if ((zabs >> bit) & 1ull) d28::quad_add(acc, q);
-      }
-#pragma unroll
-      for (int k = 0; k < d28::N; k++) {
-        q.x.l[k] = sh_x[k][tid];
-        q.y.l[k] = sh_y[k][tid];
-      }
-      d28::set_one(q.zz);
-      d28::set_one(q.zzz);
-      d28::quad_add(acc, q);
-    } else {
-      // first multiplication: the addend is affine (mixed additions)
-      for (int bit = 62; bit >= 0; bit--) {
-        d28::dbl(acc);
-        if ((zabs >> bit) & 1ull) d28::madd(acc, bx, y);
-      }
-      // second: the addend is the first result
-      q = acc;
-      for (int bit = 62; bit >= 0; bit--) {
-        d28::dbl(acc);
-        if ((zabs >> bit) & 1ull) d28::add(acc, q);
-      }
-#pragma unroll
-      for (int k = 0; k < d28::N; k++) {
-        x.l[k] = sh_x[k][tid];
-        y.l[k] = sh_y[k][tid];
-      }
-      d28::madd(acc, x, y);
-    }
-    if (!d28::is_inf(acc)) return fail(CURDLE_DECODE_NOT_IN_SUBGROUP);
+    if (!in_subgroup<QUAD>(x, y, sh_x, sh_y, tid)) return fail(CURDLE_DECODE_NOT_IN_SUBGROUP);
   }
 #pragma unroll
   for (int k = 0; k < d28::N; k++) {
@@ -219,6 +227,45 @@ __global__ void __launch_bounds__(kBlock, 2)
   d28::to_gnark(o, x);
   d28::to_gnark(o + 12, y);
   status[i] = CURDLE_DECODE_OK;
+}
+
+// The subgroup test alone, on points decoded earlier (gnark affine, still in device memory):
+// lets a caller start working with the decoded points while this runs, and learn at the end
+// whether any of them has to be rejected.  Only entries with status OK are tested; a failure
+// overwrites the entry's status.
+template <bool QUAD>
+__global__ void __launch_bounds__(kBlock, 2)
+    k_g1_subgroup_check(const u32* __restrict__ points, u32 n, uint8_t* __restrict__ status) {
+  __shared__ u32 sh_x[d28::N][kBlock];
+  __shared__ u32 sh_y[d28::N][kBlock];
+  const u32 tid = threadIdx.x;
+  const u32 lane = blockIdx.x * kBlock + tid;
+  const u32 i = QUAD ? lane >> 2 : lane;
+  if (i >= n) return;
+  if (status[i] != CURDLE_DECODE_OK) return;  // uniform over a quad
+  u32 w[24];
+  d28::load_words<24>(w, reinterpret_cast<const uint4*>(points) + (size_t)i * 6);
+  F28 x, y;
+  d28::from_gnark(x, w);
+  d28::from_gnark(y, w + 12);
+#pragma unroll
+  for (int k = 0; k < d28::N; k++) {
+    sh_x[k][tid] = x.l[k];
+    sh_y[k][tid] = y.l[k];
+  }
+  const bool ok = in_subgroup<QUAD>(x, y, sh_x, sh_y, tid);
+  if (!ok && (!QUAD || (tid & 3u) == 0)) status[i] = CURDLE_DECODE_NOT_IN_SUBGROUP;
+}
+
+hipError_t launch_g1_subgroup_check(const uint32_t* points, uint32_t n, uint8_t* status, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  if ((uint64_t)n * 4 <= 131072)
+    hipLaunchKernelGGL(k_g1_subgroup_check<true>, dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, points, n,
+                       status);
+  else
+    hipLaunchKernelGGL(k_g1_subgroup_check<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, points, n,
+                       status);
+  return hipGetLastError();
 }
 
 hipError_t launch_g1_decompress(const uint8_t* in, uint32_t n, int subgroup_check, uint32_t* out, uint8_t* status,

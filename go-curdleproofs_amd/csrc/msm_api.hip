@@ -58,6 +58,7 @@ extern "C" int curdle_set_last_error(int code, const char* msg) { return fail(co
 namespace {
 
 static constexpr int kSlots = 8;
+static constexpr int kMaxDeferred = 2;          // two-step point decodings in flight (see curdle_g1_decompress_begin)
 static constexpr size_t kGpuCombineMin = 32;  // batches at least this large combine their window sums on the GPU
 
 struct Buf {
@@ -90,9 +91,21 @@ struct Slot {
   }
 };
 
+// A decode context: what a two-step point decoding (curdle_g1_decompress_begin / _finish)
+// holds between the two calls.  A pool of its own, NOT the MSM slots: the holder goes on to
+// call MSM entry points while the subgroup test runs, and eight such callers holding the
+// eight MSM slots would wait for each other forever.
+struct DSlot {
+  hipStream_t stream = nullptr;
+  Buf in, out, status;
+  bool busy = false;
+  uint32_t n = 0;
+};
+
 struct Ctx {
   std::mutex mu;
   std::condition_variable cv;
+  DSlot dslots[kMaxDeferred];
   bool inited = false;
   int device = 0;
   hipStream_t util_stream = nullptr;  // synthetic inputs, self-test
@@ -162,6 +175,7 @@ int init_locked(int device) {
     HIP_TRY(hipEventCreateWithFlags(&s.acc_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
   }
+  for (DSlot& d : g_ctx.dslots) HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
   g_ctx.device = device;
   g_ctx.inited = true;
   return CURDLE_OK;
@@ -573,6 +587,84 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
   return rc;
 }
 
+// Two-step form: begin decodes (square root, curve check, sign) and returns the points, and
+// leaves the subgroup test running on the slot's stream; finish waits for it and returns the
+// final status bytes.  The caller can work with the points in between.
+extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t* out_affine, uint8_t* status,
+                                          int* ticket) {
+  if (!ticket || (n && (!in || !out_affine || !status))) return fail(CURDLE_EINVAL, "null argument");
+  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 points", n);
+  int idx = -1;
+  {
+    std::unique_lock<std::mutex> g(g_ctx.mu);
+    int rc = init_default_locked();
+    if (rc) return rc;
+    // Deferring the subgroup test only pays for a caller that would otherwise wait for it;
+    // with several verifications in flight the GPU is busy anyway and every extra stream
+    // costs hardware-queue sharing: beyond kMaxDeferred the caller is told to use the
+    // one-shot form.
+    int busy = 0;
+    for (int i = 0; i < kMaxDeferred; i++) {
+      if (g_ctx.dslots[i].busy)
+        busy++;
+      else if (idx < 0)
+        idx = i;
+    }
+    if (idx < 0 || busy >= kMaxDeferred)
+      return fail(CURDLE_EBUSY, "%d deferred point decodings in flight; use curdle_g1_decompress_batch", busy);
+    g_ctx.dslots[idx].busy = true;
+  }
+  DSlot& D = g_ctx.dslots[idx];
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    D.n = (uint32_t)n;
+    if (n == 0) return CURDLE_OK;
+    int r;
+    if ((r = ensure(D.in, n * 48))) return r;
+    if ((r = ensure(D.out, n * 96))) return r;
+    if ((r = ensure(D.status, n))) return r;
+    HIP_TRY(hipMemcpyAsync(D.in.p, in, n * 48, hipMemcpyHostToDevice, D.stream));
+    HIP_TRY(launch_g1_decompress((const uint8_t*)D.in.p, (uint32_t)n, 0, (uint32_t*)D.out.p, (uint8_t*)D.status.p,
+                                 D.stream));
+    HIP_TRY(hipMemcpyAsync(out_affine, D.out.p, n * 96, hipMemcpyDeviceToHost, D.stream));
+    HIP_TRY(hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.stream));
+    HIP_TRY(hipStreamSynchronize(D.stream));
+    HIP_TRY(launch_g1_subgroup_check((const uint32_t*)D.out.p, (uint32_t)n, (uint8_t*)D.status.p, D.stream));
+    return CURDLE_OK;
+  };
+  int rc = body();
+  if (rc) {
+    (void)hipStreamSynchronize(D.stream);
+    {
+      std::lock_guard<std::mutex> g(g_ctx.mu);
+      D.busy = false;
+    }
+    return rc;
+  }
+  *ticket = idx;
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
+  if (ticket < 0 || ticket >= kMaxDeferred) return fail(CURDLE_EINVAL, "bad ticket");
+  DSlot& D = g_ctx.dslots[ticket];
+  {
+    std::lock_guard<std::mutex> g(g_ctx.mu);
+    if (!D.busy) return fail(CURDLE_EINVAL, "ticket %d is not in flight", ticket);
+  }
+  const size_t n = D.n;
+  int rc = CURDLE_OK;
+  hipError_t he = hipSetDevice(g_ctx.device);
+  if (he == hipSuccess && n && status) he = hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(D.stream);
+  if (he != hipSuccess) rc = fail(CURDLE_EHIP, "decompress finish: %s", hipGetErrorString(he));
+  {
+    std::lock_guard<std::mutex> g(g_ctx.mu);
+    D.busy = false;
+  }
+  return rc;
+}
+
 // ---------------------------------------------------------------------------
 // Batched independent scalar multiplications (group_kernels.hip)
 // ---------------------------------------------------------------------------
@@ -625,7 +717,19 @@ extern "C" int curdle_shutdown(void) {
   if (!C.inited) return CURDLE_OK;
   for (Slot& S : C.slots)
     if (S.busy) return fail(CURDLE_EBUSY, "an MSM is still in flight");
+  for (DSlot& d : C.dslots)
+    if (d.busy) return fail(CURDLE_EBUSY, "a point decoding is still in flight");
   (void)hipSetDevice(C.device);
+  for (DSlot& d : C.dslots) {
+    (void)hipStreamSynchronize(d.stream);
+    for (Buf* b : {&d.in, &d.out, &d.status}) {
+      if (b->p) (void)hipFree(b->p);
+      b->p = nullptr;
+      b->cap = 0;
+    }
+    (void)hipStreamDestroy(d.stream);
+    d.stream = nullptr;
+  }
   for (Slot& S : C.slots) {
     (void)hipStreamSynchronize(S.stream);
     for (int i = 0; Buf* b = S.all_bufs(i); i++) {

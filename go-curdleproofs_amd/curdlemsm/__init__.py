@@ -56,7 +56,8 @@ SYMBOLS = [
     "curdle_prove", "curdle_verify", "curdle_proof_from_bytes", "curdle_proof_free", "curdle_verify_proof",
     "curdle_verify_batch", "curdle_verify_set_eager",
     "curdle_whisk_is_valid_shuffle_proof", "curdle_whisk_generate_shuffle_proof",
-    "curdle_whisk_is_valid_tracker_proof", "curdle_whisk_generate_tracker_proof", "curdle_proof_reencode", "curdle_merlin_test_vector", "curdle_g1_decompress_batch", "curdle_g1_scalar_mul_batch",
+    "curdle_whisk_is_valid_tracker_proof", "curdle_whisk_generate_tracker_proof", "curdle_proof_reencode", "curdle_merlin_test_vector", "curdle_g1_decompress_batch", "curdle_g1_decompress_begin", "curdle_g1_decompress_finish",
+    "curdle_g1_scalar_mul_batch",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error",
 ]
 
@@ -579,6 +580,28 @@ def merlin_test_vector(protocol: bytes, label: bytes, msg: bytes, challenge_labe
 
 _decompress_batch = _sig("curdle_g1_decompress_batch", C.c_int, _vp, C.c_size_t, C.c_int, _vp, _vp)
 DECODE_OK, DECODE_INFINITY, DECODE_BAD_ENCODING, DECODE_NOT_ON_CURVE, DECODE_NOT_IN_SUBGROUP = range(5)
+
+
+_decompress_begin = _sig("curdle_g1_decompress_begin", C.c_int, _vp, C.c_size_t, _vp, _vp, C.POINTER(C.c_int))
+_decompress_finish = _sig("curdle_g1_decompress_finish", C.c_int, C.c_int, _vp)
+
+
+def g1_decompress_begin(data: bytes):
+    """Two-step decode: returns (points, preliminary status, ticket); the subgroup test keeps
+    running on the GPU until g1_decompress_finish(ticket, n) returns the final status bytes."""
+    b = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    n = len(b) // 48
+    out = np.zeros((n, 12), dtype=np.uint64)
+    st = np.zeros(n, dtype=np.uint8)
+    t = C.c_int(-1)
+    _check(_decompress_begin(_ptr(b), n, _ptr(out), _ptr(st), C.byref(t)))
+    return out, st, t.value
+
+
+def g1_decompress_finish(ticket: int, n: int) -> np.ndarray:
+    st = np.zeros(n, dtype=np.uint8)
+    _check(_decompress_finish(ticket, _ptr(st)))
+    return st
 
 
 def g1_decompress_batch(data: bytes, subgroup_check: bool = True):

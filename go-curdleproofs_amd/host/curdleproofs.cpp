@@ -148,16 +148,21 @@ bool PointDecoder::OnDevice() {
   }();
   return !host_only && curdle_device_available() == 1;
 }
-void PointDecoder::Run() {
+void PointDecoder::Run(bool defer_subgroup) {
   pts_.assign(n_, G1Affine{});
   status_.assign(n_, CURDLE_DECODE_BAD_ENCODING);
   if (n_ == 0) return;
-  // below a few dozen points one kernel launch (~2 ms: it is a 1,900-product serial chain per
-  // lane) is slower than the host's ~45 us per point
+  // below a few dozen points one kernel launch (~1.5 ms: it is a serial chain of a thousand
+  // products per point) is slower than the host's ~45 us per point
   if (OnDevice() && n_ >= 48) {
-    int rc = curdle_g1_decompress_batch(blob_.data(), n_, subgroup_ ? 1 : 0, reinterpret_cast<uint64_t*>(pts_.data()),
-                                        status_.data());
+    int rc = CURDLE_EBUSY;
+    if (subgroup_ && defer_subgroup)
+      rc = curdle_g1_decompress_begin(blob_.data(), n_, reinterpret_cast<uint64_t*>(pts_.data()), status_.data(), &ticket_);
+    if (rc == CURDLE_EBUSY)  // not deferring, or enough deferred decodings in flight already
+      rc = curdle_g1_decompress_batch(blob_.data(), n_, subgroup_ ? 1 : 0, reinterpret_cast<uint64_t*>(pts_.data()),
+                                      status_.data());
     if (rc != CURDLE_OK) {
+      ticket_ = -1;
       char buf[256];
       curdle_last_error(buf, sizeof(buf));
       throw alg::MsmError(std::string("decoding points: ") + buf, rc);
@@ -170,6 +175,23 @@ void PointDecoder::Run() {
     pts_[i] = pt.Affine();
     status_[i] = g1_affine_is_inf(pts_[i]) ? CURDLE_DECODE_INFINITY : CURDLE_DECODE_OK;
   }
+}
+bool PointDecoder::Finish() {
+  if (ticket_ < 0) return true;  // nothing deferred: Get() already told everything
+  const int t = ticket_;
+  ticket_ = -1;
+  int rc = curdle_g1_decompress_finish(t, status_.data());
+  if (rc != CURDLE_OK) {
+    char buf[256];
+    curdle_last_error(buf, sizeof(buf));
+    throw alg::MsmError(std::string("decoding points: ") + buf, rc);
+  }
+  for (uint8_t st : status_)
+    if (st == CURDLE_DECODE_NOT_IN_SUBGROUP) return false;
+  return true;
+}
+PointDecoder::~PointDecoder() {
+  if (ticket_ >= 0) (void)curdle_g1_decompress_finish(ticket_, nullptr);  // never leak the workspace slot
 }
 bool PointDecoder::Get(size_t index, Point* out) const {
   if (index >= n_ || status_[index] > CURDLE_DECODE_INFINITY) return false;
@@ -1128,6 +1150,15 @@ Proof Proof::FromBytes(const uint8_t* data, size_t len, bool subgroup_check) {  
   FromReader(scan);
   dec.Run();
   Reader r(data, len, subgroup_check);
+  r.decoded = &dec;
+  return FromReader(r);
+}
+Proof Proof::FromBytesDeferred(const uint8_t* data, size_t len, PointDecoder& dec) {
+  Reader scan(data, len, true);
+  scan.collect = &dec;
+  FromReader(scan);
+  dec.Run(/*defer_subgroup=*/true);
+  Reader r(data, len, true);
   r.decoded = &dec;
   return FromReader(r);
 }

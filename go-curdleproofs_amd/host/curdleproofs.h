@@ -47,8 +47,16 @@ struct Writer {
 class PointDecoder {
  public:
   explicit PointDecoder(bool subgroup_check) : subgroup_(subgroup_check) {}
+  ~PointDecoder();
+  PointDecoder(const PointDecoder&) = delete;
+  PointDecoder& operator=(const PointDecoder&) = delete;
   size_t Add(const uint8_t rec[48]);          // -> index for Get
-  void Run();
+  // Decodes every record.  With defer_subgroup the GPU's subgroup test keeps running after
+  // Run() returns (Get() then only reflects encoding / curve errors) and Finish() collects
+  // its verdict: the caller overlaps its own work with it and must not publish a result
+  // before Finish() has returned true.
+  void Run(bool defer_subgroup = false);
+  bool Finish();                              // true: no record failed the (deferred) subgroup test
   bool Get(size_t index, Point* out) const;   // false: not a valid encoding / not on the curve / not in G1
   size_t size() const { return n_; }
   static bool OnDevice();                     // would Run() use the GPU
@@ -58,6 +66,7 @@ class PointDecoder {
   std::vector<uint8_t> blob_;
   std::vector<G1Affine> pts_;
   std::vector<uint8_t> status_;
+  int ticket_ = -1;                           // >= 0: a deferred subgroup test is in flight
 };
 
 struct Reader {
@@ -202,6 +211,10 @@ struct Proof {
   std::vector<uint8_t> Serialize() const;                                    // curdleproof.go:358
   static Proof FromBytes(const uint8_t* data, size_t len, bool subgroup_check = false);  // :320
   static Proof FromReader(Reader& r);  // the same from a stream position (trailing bytes are left unread)
+  // Decoding with the GPU's subgroup test left running: the caller must call dec.Finish()
+  // and treat `false` as the decoding error it is before using any result derived from
+  // the proof.
+  static Proof FromBytesDeferred(const uint8_t* data, size_t len, PointDecoder& dec);
 };
 Proof Prove(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M,

@@ -112,10 +112,14 @@ extern "C" int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t
   *ok = 0;
   if (ell != crs->crs.Gs.size()) return curdle_set_last_error(CURDLE_EINVAL, "ell does not match the CRS");
   return Guard([&]() {
-    // gnark's Decoder checks curve and subgroup membership of every point (curdleproof.go:322)
-    proto::Proof p = proto::Proof::FromBytes(proof, proof_len, /*subgroup_check=*/true);
+    // gnark's Decoder checks curve and subgroup membership of every point (curdleproof.go:322).
+    // The subgroup half of that runs on the GPU while the host verifies; its verdict is
+    // collected before anything is reported.
+    proto::PointDecoder dec(/*subgroup_check=*/true);
+    proto::Proof p = proto::Proof::FromBytesDeferred(proof, proof_len, dec);
     bool accept = proto::Verify(p, crs->crs, Affines(Rs, ell), Affines(Ss, ell), Affines(Ts, ell), Affines(Us, ell),
                                 Point::FromJac(M), rand->r);
+    if (!dec.Finish()) throw std::runtime_error("decoding proof: invalid point (not in the prime-order subgroup)");
     *ok = accept ? 1 : 0;
     return CURDLE_OK;
   });

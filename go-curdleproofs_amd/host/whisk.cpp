@@ -86,7 +86,7 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
     dec.Add(postST[i].rG);
     dec.Add(postST[i].krG);
   }
-  dec.Run();
+  dec.Run(/*defer_subgroup=*/true);  // the subgroup test keeps running on the GPU; collected below
 
   Point M;
   proto::Proof p;
@@ -111,13 +111,30 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
     if (!dec.Get(at + 3, &pt)) throw err("getting post shuffle points: failed to set krG");
     Us[i] = pt.Affine();
   }
+  bool accept = false;
+  std::string verify_error;
   try {
-    return proto::Verify(p, crs, Rs, Ss, Ts, Us, M, rand);  // :46-58
+    accept = proto::Verify(p, crs, Rs, Ss, Ts, Us, M, rand);  // :46-58
   } catch (const alg::MsmError&) {
     throw;
   } catch (const std::runtime_error& e) {
-    throw err(std::string("verifying proof: ") + e.what());
+    verify_error = e.what();
   }
+  // the decoding verdict comes first, as in the reference (SetBytes / Decode fail before Verify runs)
+  if (!dec.Finish()) {
+    Point pt;
+    for (size_t i = 0; i < first_tracker; i++)
+      if (!dec.Get(i, &pt)) throw err("decoding proof: invalid point (not in the prime-order subgroup)");
+    for (size_t i = 0; i < n; i++) {
+      const size_t at = first_tracker + 4 * i;
+      if (!dec.Get(at, &pt)) throw err("getting pre shuffle points: failed to set rG");
+      if (!dec.Get(at + 1, &pt)) throw err("getting pre shuffle points: failed to set krG");
+      if (!dec.Get(at + 2, &pt)) throw err("getting post shuffle points: failed to set rG");
+      if (!dec.Get(at + 3, &pt)) throw err("getting post shuffle points: failed to set krG");
+    }
+  }
+  if (!verify_error.empty()) throw err("verifying proof: " + verify_error);
+  return accept;
 }
 
 std::vector<WhiskTracker> GenerateWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTracker>& preTrackers,

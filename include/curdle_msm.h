@@ -282,6 +282,14 @@ int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t* scalars, 
 #define CURDLE_DECODE_NOT_ON_CURVE 3
 #define CURDLE_DECODE_NOT_IN_SUBGROUP 4
 int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgroup_check, uint64_t* out_affine, uint8_t* status);
+/* The same in two steps, so the caller's host work overlaps the subgroup test (the longer half
+ * of the kernel): begin decodes -- square root, curve check, sign -- and returns the points
+ * with a preliminary status (0, 1, 2 or 3), leaving the subgroup test running on the GPU;
+ * finish waits for it and writes the final status bytes (now possibly 4).  Every begin must
+ * be matched by a finish.  At most two may be in flight: a third begin returns CURDLE_EBUSY (with
+ * several verifications in flight the GPU is busy anyway; use the one-shot form then). */
+int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t* out_affine, uint8_t* status, int* ticket);
+int curdle_g1_decompress_finish(int ticket, uint8_t* status);
 int curdle_set_last_error(int code, const char* msg);  /* internal: shared by the library's translation units */
 
 /* ------------------------------------------------------------------------- *

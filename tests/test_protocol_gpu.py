@@ -191,6 +191,14 @@ def test_batched_point_decoding_on_the_gpu(gpu, oracle):
             with pytest.raises(gpu.CurdleError):
                 gpu.g1_decompress(enc, True)
     assert gpu.g1_decompress_batch(b"", True)[0].shape == (0, 12)
+    # the two-step form: points and encoding / curve verdicts at once, the subgroup verdict at finish
+    pts2, st2, ticket = gpu.g1_decompress_begin(blob)
+    for g, w, st, st0 in zip(pts2, want_pt, st2, want_st):
+        if st0 in (gpu.DECODE_OK, gpu.DECODE_NOT_IN_SUBGROUP):
+            assert st == gpu.DECODE_OK and oracle.affine_from_mont_limbs([int(v) for v in g]) == w
+        else:
+            assert st == st0
+    assert list(gpu.g1_decompress_finish(ticket, len(want_st))) == want_st
 
 
 def test_same_scalar_argument_is_enforced(gpu, check_mode):

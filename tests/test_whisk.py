@@ -110,6 +110,28 @@ def test_shuffle_proof(gpu, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(180)
+def test_more_concurrent_verifications_than_workspace_slots(gpu, oracle):
+    """Each verification keeps a decode context while its subgroup test runs on the GPU and
+    takes an MSM workspace slot for its final check: twelve at once (more than either pool
+    holds) must all finish."""
+    import threading
+    rand = gpu.Rand(2)
+    crs = gpu.CRS(gpu.WHISK_ELL, rand)
+    pre = shuffle_trackers(gpu, oracle, rand, gpu.WHISK_ELL)
+    post, proof = gpu.whisk_generate_shuffle_proof(crs, pre, rand)
+    results = [None] * 12
+
+    def worker(t):
+        results[t] = all(gpu.whisk_is_valid_shuffle_proof(crs, pre, post, proof, gpu.Rand(50 + 7 * t + i)) for i in range(3))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert results == [True] * 12
+
+
+@pytest.mark.gpu
 def test_full_lifecycle(gpu, oracle):
     # TestWhiskFullLifecycle, whisk_test.go:58-91 with produceBlock / processBlock (:137-209)
     rand = gpu.Rand(0)
