@@ -45,7 +45,7 @@ struct MsmPlan {
 
 // Sizes of the internal (fp28.h) point formats, for workspace allocation.
 static constexpr size_t kX28Bytes = 224;
-static constexpr size_t kA28Bytes = 112;
+static constexpr size_t kA28Bytes = 128;  // stride of the internal point array: a 112-byte d28::A28 padded to one 128-byte line
 
 // Device workspace, laid out by msm_api.hip.  nb = k * NB bucket slots.
 struct MsmWorkspace {

@@ -241,6 +241,15 @@ __global__ void __launch_bounds__(kBlock) k_fix_foff(u32* __restrict__ foff, con
 
 // Phase 0: gnark points (R = 2^384, saturated limbs) -> internal form (fp28.h),
 // once per MSM: one Montgomery product per coordinate.  (0,0) stays (0,0).
+// element i of the internal point array (kA28Bytes apart: one 128-byte line per point, so a
+// gathered point never straddles two lines)
+__device__ __forceinline__ A28* a28_at(A28* base, size_t i) {
+  return reinterpret_cast<A28*>(reinterpret_cast<char*>(base) + i * kA28Bytes);
+}
+__device__ __forceinline__ const A28* a28_at(const A28* base, size_t i) {
+  return reinterpret_cast<const A28*>(reinterpret_cast<const char*>(base) + i * kA28Bytes);
+}
+
 __global__ void __launch_bounds__(kBlock, 2)
     k_convert_points(const uint4* __restrict__ points, u32 n, A28* __restrict__ out) {
   u32 i = blockIdx.x * kBlock + threadIdx.x;
@@ -250,7 +259,7 @@ __global__ void __launch_bounds__(kBlock, 2)
   A28 a;
   d28::from_gnark(a.x, w);
   d28::from_gnark(a.y, w + 12);
-  d28::store(&out[i], a);
+  d28::store(a28_at(out, i), a);
 }
 
 // Sum of `acc` over aligned groups of G lanes (G a power of two <= 256) of a
@@ -315,13 +324,13 @@ __global__ void __launch_bounds__(kBlock, WAVES)
   // the gather of position pos + 1 is issued before the addition of position pos
   u32 e_next = sorted[pos];
   A28 pt_next;
-  d28::load(pt_next, &points[e_next & 0x7fffffffu]);
+  d28::load(pt_next, a28_at(points, e_next & 0x7fffffffu));
   for (; pos < end; pos++) {
     const u32 e = e_next;
     A28 pt = pt_next;
     if (pos + 1 < end) {
       e_next = sorted[pos + 1];
-      d28::load(pt_next, &points[e_next & 0x7fffffffu]);
+      d28::load(pt_next, a28_at(points, e_next & 0x7fffffffu));
     }
     if (pos == gend) {
       d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
