@@ -44,6 +44,15 @@ def test_completeness(gpu, check_mode):
     assert gpu.verify_proof(crs, decoded, Ss, Rs, Ts, Us, M, gpu.Rand(43)) is False
     with pytest.raises(gpu.CurdleError):
         gpu.Proof(proof[:-1])
+    # a proof point on the curve but outside the subgroup (A is the first 48 bytes): the decoder
+    # rejects it, in the one-step and in the overlapped (curdle_verify) form alike
+    rogue = bytes.fromhex("80" + "00" * 46 + "05")       # x = 5: on the curve, not in G1
+    assert gpu.g1_decompress_batch(rogue, True)[1][0] == gpu.DECODE_NOT_IN_SUBGROUP
+    with pytest.raises(gpu.CurdleError):
+        gpu.Proof(rogue + proof[48:])
+    with pytest.raises(gpu.CurdleError) as e:
+        gpu.verify(crs, rogue + proof[48:], Rs, Ss, Ts, Us, M, gpu.Rand(43))
+    assert "decoding" in e.value.msg
 
 
 def test_soundness_and_encoding(gpu, oracle, check_mode):

@@ -107,6 +107,28 @@ def test_shuffle_proof(gpu, oracle):
     with pytest.raises(gpu.CurdleError) as e:
         gpu.whisk_is_valid_shuffle_proof(crs, bad, post, proof, gpu.Rand(1))
     assert "getting pre shuffle points" in e.value.msg
+    # a tracker point on the curve but outside the prime-order subgroup: SetBytes rejects it
+    # (types.go:85-95).  Here that verdict comes from the subgroup test that runs on the GPU
+    # while the host verifies, and must still surface as the decoding error.
+    p = oracle.P
+    x = 6
+    while True:
+        rhs = (x * x * x + 4) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p == rhs and oracle.scalar_mul(oracle.R, (x, y)) is not None:
+            break
+        x += 1
+    rogue = oracle.compress((x, y))
+    for which, msg in ((0, "getting pre shuffle points"), (1, "getting post shuffle points")):
+        trackers = [list(pre), list(post)]
+        trackers[which][7] = trackers[which][7][:48] + rogue        # krG replaced
+        with pytest.raises(gpu.CurdleError) as e:
+            gpu.whisk_is_valid_shuffle_proof(crs, trackers[0], trackers[1], proof, gpu.Rand(1))
+        assert msg in e.value.msg and "krG" in e.value.msg
+    # ... and a proof point outside the subgroup (M is the first 48 bytes of the proof)
+    with pytest.raises(gpu.CurdleError) as e:
+        gpu.whisk_is_valid_shuffle_proof(crs, pre, post, rogue + proof[48:], gpu.Rand(1))
+    assert "decoding proof" in e.value.msg
 
 
 @pytest.mark.gpu
