@@ -142,11 +142,14 @@ size_t PointDecoder::Add(const uint8_t rec[48]) {
   return n_++;
 }
 bool PointDecoder::OnDevice() {
+  // CURDLE_HOST_DECODE=1 is an explicit request (A/B measurements of the host decoder), not a
+  // fallback: without it a batch of kMinDeviceBatch or more records goes to the GPU and the
+  // call fails loudly if there is none.
   static const bool host_only = [] {
     const char* e = getenv("CURDLE_HOST_DECODE");
     return e && *e && *e != '0';
   }();
-  return !host_only && curdle_device_available() == 1;
+  return !host_only;
 }
 void PointDecoder::Run(bool defer_subgroup) {
   pts_.assign(n_, G1Affine{});
@@ -154,7 +157,7 @@ void PointDecoder::Run(bool defer_subgroup) {
   if (n_ == 0) return;
   // below a few dozen points one kernel launch (~1.5 ms: it is a serial chain of a thousand
   // products per point) is slower than the host's ~45 us per point
-  if (OnDevice() && n_ >= 48) {
+  if (OnDevice() && n_ >= kMinDeviceBatch) {
     int rc = CURDLE_EBUSY;
     if (subgroup_ && defer_subgroup)
       rc = curdle_g1_decompress_begin(blob_.data(), n_, reinterpret_cast<uint64_t*>(pts_.data()), status_.data(), &ticket_);

@@ -42,8 +42,10 @@ struct Writer {
 };
 // Batched decoding of compressed points on the GPU (curdle_g1_decompress_batch): callers
 // register the 48-byte records they will need, Run() decodes them all in one kernel, Get()
-// hands them out.  With no device visible (or CURDLE_HOST_DECODE=1) Run() decodes on the
-// host, point by point -- the same results, the reference's own order of operations.
+// hands them out.  Fewer than kMinDeviceBatch records are decoded on the host, point by
+// point (a kernel launch would cost more); larger batches need the GPU -- there is no
+// silent host fallback, a missing device is an alg::MsmError.  CURDLE_HOST_DECODE=1 forces
+// the host decoder for A/B measurements.
 class PointDecoder {
  public:
   explicit PointDecoder(bool subgroup_check) : subgroup_(subgroup_check) {}
@@ -59,7 +61,8 @@ class PointDecoder {
   bool Finish();                              // true: no record failed the (deferred) subgroup test
   bool Get(size_t index, Point* out) const;   // false: not a valid encoding / not on the curve / not in G1
   size_t size() const { return n_; }
-  static bool OnDevice();                     // would Run() use the GPU
+  static bool OnDevice();                     // false only under CURDLE_HOST_DECODE=1
+  static constexpr size_t kMinDeviceBatch = 48;
  private:
   bool subgroup_;
   size_t n_ = 0;
