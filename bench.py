@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--logn", type=int, default=20, help="log2 of the MSM size (default: the headline 2^20)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="MSMs in flight (curdle_msm_g1_device_submit/wait); 1 = strictly one after the other; "
-                         "default: 4 for a whole MSM per GPU, 3 for a window-range partial (measured best)")
+                         "default: 4 for a whole MSM per GPU, 5 for a window-range partial (measured best)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: on ONE GPU, run only the window range rank 0 of an N-rank job would "
@@ -122,7 +122,7 @@ def main():
 
     c = cm.window_bits(n)
     W = cm.num_windows(n, c)
-    in_flight = args.in_flight or (4 if world == 1 and args.emulate_world <= 1 else 3)
+    in_flight = args.in_flight or (4 if world == 1 and args.emulate_world <= 1 else 5)
     depth = max(1, min(in_flight, cm.MSM_SLOTS - 1))
     if world > 1:
         from curdlemsm.distributed import gather_partials, window_partition

@@ -124,6 +124,13 @@ struct Ctx {
   // Recoding + bucket sort of every MSM, in order; light, memory/LDS-bound phases that
   // overlap the previous MSM's accumulation.
   hipStream_t pre_stream = nullptr;
+  // Window-range partials (the multi-GPU split) alternate their sort phases over two streams:
+  // per partial the sort is no smaller than for a whole MSM (every rank converts and recodes
+  // all n pairs) while the accumulation is 1/world of it, so one in-order sort stream was the
+  // bottleneck of the pipeline (8 ranks: 1.06 -> 0.80 ms per step with 5 in flight).
+  // CURDLE_PRE_STREAMS=1 disables.
+  hipStream_t pre_stream2 = nullptr;
+  int pre_streams = 2;
   Slot slots[kSlots];
   int profile = 0;  // 0 off, 1 every phase, 2 the dominant kernel only
   curdle_profile last = {};
@@ -165,6 +172,8 @@ int init_locked(int device) {
     if (g_ctx.main_streams < 1 || g_ctx.main_streams > 4) g_ctx.main_streams = 1;
   }
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.pre_stream, hipStreamNonBlocking, prio_least));
+  HIP_TRY(hipStreamCreateWithPriority(&g_ctx.pre_stream2, hipStreamNonBlocking, prio_least));
+  if (const char* ps = getenv("CURDLE_PRE_STREAMS")) g_ctx.pre_streams = atoi(ps) == 1 ? 1 : 2;
   // Tail streams at normal priority by default: on ROCm 7.2 all high-priority streams of a
   // process appear to share one hardware queue, which serialises the tails of consecutive
   // MSMs (measured: 0.93 vs 0.84 ms per 2-window partial).  CURDLE_TAIL_PRIO=1 restores it.
@@ -500,6 +509,7 @@ int finish_slot(Slot& S, uint64_t* out) {
 
 void drain_slot(Slot& S) {
   (void)hipStreamSynchronize(g_ctx.pre_stream);
+  (void)hipStreamSynchronize(g_ctx.pre_stream2);
   (void)hipStreamSynchronize(g_ctx.main_stream);
   for (auto& st : g_ctx.main_extra) (void)hipStreamSynchronize(st);
   (void)hipStreamSynchronize(S.stream);
@@ -761,6 +771,9 @@ extern "C" int curdle_shutdown(void) {
   (void)hipStreamSynchronize(C.pre_stream);
   (void)hipStreamDestroy(C.pre_stream);
   C.pre_stream = nullptr;
+  (void)hipStreamSynchronize(C.pre_stream2);
+  (void)hipStreamDestroy(C.pre_stream2);
+  C.pre_stream2 = nullptr;
   (void)hipStreamDestroy(C.util_stream);
   C.util_stream = nullptr;
   C.inited = false;
@@ -842,7 +855,9 @@ extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_s
   const uint32_t off[2] = {0, (uint32_t)n};
   const unsigned turn = g_ctx.submit_count++ % (unsigned)g_ctx.main_streams;
   hipStream_t main = turn == 0 ? g_ctx.main_stream : g_ctx.main_extra[turn - 1];
-  rc = enqueue_slot(S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, g_ctx.pre_stream, main,
+  const bool partial = win_begin > 0 || (win_end >= 0 && win_end < curdle_msm_num_windows(n, window_bits));
+  hipStream_t pre = partial && g_ctx.pre_streams == 2 && (g_ctx.submit_count & 1u) ? g_ctx.pre_stream2 : g_ctx.pre_stream;
+  rc = enqueue_slot(S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, pre, main,
                     S.stream, /*latency_mode=*/false);
   if (rc) {
     drain_slot(S);
