@@ -1078,7 +1078,9 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
           const BatchItem& it = items[i];
           Proof p = decode(i);
           common::Rand r(seeds[i]);
-          oks[i] = Verify(p, crs, *it.Rs, *it.Ss, *it.Ts, *it.Us, it.M, r) ? 1 : 0;
+          const std::vector<G1Affine> Rs(it.Rs, it.Rs + it.ell), Ss(it.Ss, it.Ss + it.ell), Ts(it.Ts, it.Ts + it.ell),
+              Us(it.Us, it.Us + it.ell);
+          oks[i] = Verify(p, crs, Rs, Ss, Ts, Us, Point::FromJac(it.M), r) ? 1 : 0;
         } catch (const alg::MsmError&) {
           throw;  // device failure, not a verdict
         } catch (const std::runtime_error&) {
@@ -1099,7 +1101,10 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
           if (!parses[i]) throw err("malformed proof");
           Proof p = decode(i);
           common::Rand r(seeds[i]);
-          pre = VerifyInto(p, crs, *it.Rs, *it.Ss, *it.Ts, *it.Us, it.M, r, mine);
+          // the instance copies happen here, on the worker, not serially before the batch starts
+          const std::vector<G1Affine> Rs(it.Rs, it.Rs + it.ell), Ss(it.Ss, it.Ss + it.ell), Ts(it.Ts, it.Ts + it.ell),
+              Us(it.Us, it.Us + it.ell);
+          pre = VerifyInto(p, crs, Rs, Ss, Ts, Us, Point::FromJac(it.M), r, mine);
         } catch (const alg::MsmError&) {
           throw;  // device failure (eager mode computes MSMs here), not a verdict
         } catch (const std::runtime_error&) {

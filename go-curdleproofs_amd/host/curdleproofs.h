@@ -229,11 +229,12 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
 
 // Cross-proof batch verification over one CRS: one shared accumulator, one MSM (see the
 // definition).  Returns the per-proof accept bits.
-struct BatchItem {
+struct BatchItem {  // borrowed buffers: ell affine points each, M as 18 Jacobian limbs
   const uint8_t* proof;
   size_t proof_len;
-  const std::vector<G1Affine>*Rs, *Ss, *Ts, *Us;
-  Point M;
+  const G1Affine *Rs, *Ss, *Ts, *Us;
+  size_t ell;
+  const uint64_t* M;
 };
 std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items, common::Rand& rand, int nthreads);
 

@@ -165,15 +165,17 @@ extern "C" int curdle_verify_batch(const curdle_crs* crs, size_t k, const uint8_
     return curdle_set_last_error(CURDLE_EINVAL, "null argument");
   if (ell != crs->crs.Gs.size()) return curdle_set_last_error(CURDLE_EINVAL, "ell does not match the CRS");
   return Guard([&]() {
-    std::vector<std::vector<G1Affine>> r(k), s(k), t(k), u(k);
     std::vector<proto::BatchItem> items(k);
     for (size_t i = 0; i < k; i++) {
       if (!proofs[i] || !Rs[i] || !Ss[i] || !Ts[i] || !Us[i]) throw std::runtime_error("null argument in batch item");
-      r[i] = Affines(Rs[i], ell);
-      s[i] = Affines(Ss[i], ell);
-      t[i] = Affines(Ts[i], ell);
-      u[i] = Affines(Us[i], ell);
-      items[i] = proto::BatchItem{proofs[i], proof_lens[i], &r[i], &s[i], &t[i], &u[i], Point::FromJac(Ms + 18 * i)};
+      items[i] = proto::BatchItem{proofs[i],
+                                  proof_lens[i],
+                                  reinterpret_cast<const G1Affine*>(Rs[i]),
+                                  reinterpret_cast<const G1Affine*>(Ss[i]),
+                                  reinterpret_cast<const G1Affine*>(Ts[i]),
+                                  reinterpret_cast<const G1Affine*>(Us[i]),
+                                  ell,
+                                  Ms + 18 * i};
     }
     std::vector<int> res = proto::VerifyBatch(crs->crs, items, rand->r, nthreads);
     for (size_t i = 0; i < k; i++) oks[i] = res[i];
