@@ -55,7 +55,8 @@ SYMBOLS = [
     "curdle_crs_generate", "curdle_crs_free", "curdle_crs_size", "curdle_shuffle_permute_commit",
     "curdle_prove", "curdle_verify", "curdle_proof_from_bytes", "curdle_proof_free", "curdle_verify_proof",
     "curdle_verify_batch", "curdle_verify_set_eager",
-    "curdle_whisk_is_valid_shuffle_proof", "curdle_whisk_generate_shuffle_proof",
+    "curdle_whisk_is_valid_shuffle_proof", "curdle_whisk_is_valid_shuffle_proof_batch",
+    "curdle_whisk_generate_shuffle_proof",
     "curdle_whisk_is_valid_tracker_proof", "curdle_whisk_generate_tracker_proof", "curdle_proof_reencode", "curdle_merlin_test_vector", "curdle_g1_decompress_batch", "curdle_g1_decompress_begin", "curdle_g1_decompress_finish",
     "curdle_g1_scalar_mul_batch",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error",
@@ -130,6 +131,8 @@ _verify_batch = _sig("curdle_verify_batch", C.c_int, _vp, C.c_size_t, _vp, _vp, 
                      C.c_int, _vp)
 _whisk_valid_shuffle = _sig("curdle_whisk_is_valid_shuffle_proof", C.c_int, _vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp,
                             C.POINTER(C.c_int))
+_whisk_valid_shuffle_batch = _sig("curdle_whisk_is_valid_shuffle_proof_batch", C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_size_t,
+                                  _vp, _vp, C.c_int, _vp)
 _whisk_gen_shuffle = _sig("curdle_whisk_generate_shuffle_proof", C.c_int, _vp, _vp, C.c_size_t, _vp, _vp, _vp)
 _whisk_valid_tracker = _sig("curdle_whisk_is_valid_tracker_proof", C.c_int, _vp, _vp, _vp, C.POINTER(C.c_int))
 _whisk_gen_tracker = _sig("curdle_whisk_generate_tracker_proof", C.c_int, _vp, _vp, _vp, _vp)
@@ -527,6 +530,22 @@ def whisk_is_valid_shuffle_proof(crs: CRS, pre_trackers, post_trackers, proof: b
     _check(_whisk_valid_shuffle(crs._h, _ptr(pre), _ptr(post), len(pre_trackers), len(post_trackers), _ptr(pb), rand._h,
                                 C.byref(ok)))
     return bool(ok.value)
+
+
+def whisk_is_valid_shuffle_proof_batch(crs: CRS, pre_sets, post_sets, proofs, rand: Rand, nthreads: int = 16):
+    """k shuffle proofs at once: pre_sets / post_sets are lists of tracker lists (all the same
+    length), proofs a list of 4,576-byte strings.  Returns the list of accept bits."""
+    k = len(proofs)
+    n = len(pre_sets[0]) if k else 0
+    pre = [_bytes_arr(b"".join(s)) for s in pre_sets]
+    post = [_bytes_arr(b"".join(s)) for s in post_sets]
+    pb = [_bytes_arr(p) for p in proofs]
+    if any(len(a) != 96 * n for a in pre + post) or any(len(p) != WHISK_SHUFFLE_PROOF_SIZE for p in pb):
+        raise ValueError("every tracker set needs the same length; proofs are %d bytes" % WHISK_SHUFFLE_PROOF_SIZE)
+    arr = lambda bufs: (C.c_void_p * k)(*[b.ctypes.data for b in bufs])
+    oks = (C.c_int * k)()
+    _check(_whisk_valid_shuffle_batch(crs._h, k, arr(pre), arr(post), n, arr(pb), rand._h, int(nthreads), oks))
+    return [bool(v) for v in oks]
 
 
 def whisk_generate_shuffle_proof(crs: CRS, pre_trackers, rand: Rand):

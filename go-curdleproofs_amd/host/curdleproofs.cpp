@@ -2,6 +2,7 @@
 // Each function cites the reference lines it restates (paths relative to
 // /root/reference).  Transcript labels are those of SURVEY.md appendix A.
 #include "curdleproofs.h"
+#include "verify_batch_impl.h"
 
 #include <stdlib.h>
 
@@ -1020,121 +1021,43 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
 // joining a group.
 std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items, common::Rand& rand, int nthreads) {
   const size_t k = items.size();
-  std::vector<int> oks(k, 0);
-  if (k == 0) return oks;
-  std::vector<uint64_t> seeds(k);
-  for (size_t i = 0; i < k; i++) {
-    Fr f;
-    rand.GetFr(f);
-    seeds[i] = (uint64_t)f.l[0] | ((uint64_t)f.l[1] << 32);
-  }
-  if (nthreads < 1) nthreads = 1;
-  if ((size_t)nthreads > k) nthreads = (int)k;
-  size_t flush = 32;
-  if (const char* e = getenv("CURDLE_BATCH_GROUP")) flush = (size_t)atoi(e);
-  if (flush < 1) flush = 1;
-
   // one batched GPU decode for every point of every proof: pass 1 walks each proof's wire
   // format and registers its records (a proof that does not parse is rejected here)
-  PointDecoder dec(/*subgroup_check=*/true);
-  std::vector<size_t> first_point(k, 0);
-  std::vector<char> parses(k, 0);
+  struct BytesSource {
+    const std::vector<BatchItem>& items;
+    PointDecoder dec{/*subgroup_check=*/true};
+    std::vector<size_t> first_point;
+    std::vector<char> parses;
+    explicit BytesSource(const std::vector<BatchItem>& it) : items(it), first_point(it.size(), 0), parses(it.size(), 0) {}
+    bool Usable(size_t i) const { return parses[i] != 0; }
+    Proof DecodeProof(size_t i) const {
+      Reader r(items[i].proof, items[i].proof_len, true);
+      r.decoded = &dec;
+      r.decoded_pos = first_point[i];
+      return Proof::FromReader(r);
+    }
+    void Instance(size_t i, std::vector<G1Affine>& Rs, std::vector<G1Affine>& Ss, std::vector<G1Affine>& Ts,
+                  std::vector<G1Affine>& Us, Point& M) const {
+      const BatchItem& it = items[i];
+      Rs.assign(it.Rs, it.Rs + it.ell);
+      Ss.assign(it.Ss, it.Ss + it.ell);
+      Ts.assign(it.Ts, it.Ts + it.ell);
+      Us.assign(it.Us, it.Us + it.ell);
+      M = Point::FromJac(it.M);
+    }
+  } src(items);
   for (size_t i = 0; i < k; i++) {
-    first_point[i] = dec.size();
+    src.first_point[i] = src.dec.size();
     try {
       Reader scan(items[i].proof, items[i].proof_len, true);
-      scan.collect = &dec;
+      scan.collect = &src.dec;
       Proof::FromReader(scan);
-      parses[i] = 1;
+      src.parses[i] = 1;
     } catch (const std::runtime_error&) {
     }
   }
-  dec.Run();
-  auto decode = [&](size_t i) {
-    Reader r(items[i].proof, items[i].proof_len, true);
-    r.decoded = &dec;
-    r.decoded_pos = first_point[i];
-    return Proof::FromReader(r);
-  };
-
-  std::atomic<size_t> next(0);
-  std::atomic<bool> failed(false);
-  std::string first_error;
-  std::mutex err_mu;
-  auto worker = [&]() {
-    std::vector<G1Affine> bases;
-    std::vector<Scalar> scalars;
-    std::vector<size_t> members;
-    Point a_c = Point::Infinity();
-    auto settle = [&]() {
-      if (members.empty()) return;
-      const bool all = alg::MultiExp(bases, scalars) == a_c;  // the group's one MSM, on the GPU
-      for (size_t i : members) {
-        if (all) {
-          oks[i] = 1;
-          continue;
-        }
-        try {  // some accumulated check of the group failed: find out whose
-          const BatchItem& it = items[i];
-          Proof p = decode(i);
-          common::Rand r(seeds[i]);
-          const std::vector<G1Affine> Rs(it.Rs, it.Rs + it.ell), Ss(it.Ss, it.Ss + it.ell), Ts(it.Ts, it.Ts + it.ell),
-              Us(it.Us, it.Us + it.ell);
-          oks[i] = Verify(p, crs, Rs, Ss, Ts, Us, Point::FromJac(it.M), r) ? 1 : 0;
-        } catch (const alg::MsmError&) {
-          throw;  // device failure, not a verdict
-        } catch (const std::runtime_error&) {
-          oks[i] = 0;
-        }
-      }
-      bases.clear();
-      scalars.clear();
-      members.clear();
-      a_c = Point::Infinity();
-    };
-    try {
-      for (size_t i = next.fetch_add(1); i < k && !failed.load(); i = next.fetch_add(1)) {
-        const BatchItem& it = items[i];
-        MsmAccumulator mine;  // joins the group only if the proof's direct checks pass
-        bool pre = false;
-        try {
-          if (!parses[i]) throw err("malformed proof");
-          Proof p = decode(i);
-          common::Rand r(seeds[i]);
-          // the instance copies happen here, on the worker, not serially before the batch starts
-          const std::vector<G1Affine> Rs(it.Rs, it.Rs + it.ell), Ss(it.Ss, it.Ss + it.ell), Ts(it.Ts, it.Ts + it.ell),
-              Us(it.Us, it.Us + it.ell);
-          pre = VerifyInto(p, crs, Rs, Ss, Ts, Us, Point::FromJac(it.M), r, mine);
-        } catch (const alg::MsmError&) {
-          throw;  // device failure (eager mode computes MSMs here), not a verdict
-        } catch (const std::runtime_error&) {
-          pre = false;  // malformed proof / zero randomizer: rejected in a batch
-        }
-        if (!pre) continue;
-        bases.insert(bases.end(), mine.Bases().begin(), mine.Bases().end());
-        for (const Fr& f : mine.Scalars()) {
-          Scalar sc;
-          sc.v = f;
-          scalars.push_back(sc);
-        }
-        Point ac;
-        ac.p = mine.A_c;
-        a_c = a_c + ac;
-        members.push_back(i);
-        if (members.size() >= flush) settle();
-      }
-      settle();
-    } catch (const std::exception& e) {  // device failure inside an MSM: the whole call fails
-      std::lock_guard<std::mutex> g(err_mu);
-      if (!failed.exchange(true)) first_error = e.what();
-    }
-  };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nthreads; t++) th.emplace_back(worker);
-  worker();
-  for (auto& x : th) x.join();
-  if (failed.load()) throw alg::MsmError("batch verification: " + first_error, CURDLE_EHIP);
-  return oks;
+  src.dec.Run();
+  return VerifyBatchCore(crs, k, src, rand, nthreads);
 }
 
 std::vector<uint8_t> Proof::Serialize() const {  // :358-387

@@ -227,6 +227,12 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M,
             common::Rand& rand);                                            // :199
 
+// The body of Verify up to, but not including, the accumulator's final MSM (false: a direct,
+// non-accumulated check already failed); lets several proofs share one accumulator.
+bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
+                msmaccumulator::MsmAccumulator& acc);
+
 // Cross-proof batch verification over one CRS: one shared accumulator, one MSM (see the
 // definition).  Returns the per-proof accept bits.
 struct BatchItem {  // borrowed buffers: ell affine points each, M as 18 Jacobian limbs

@@ -206,6 +206,25 @@ extern "C" int curdle_whisk_is_valid_shuffle_proof(const curdle_crs* crs, const 
   });
 }
 
+extern "C" int curdle_whisk_is_valid_shuffle_proof_batch(const curdle_crs* crs, size_t k, const uint8_t* const* pre_trackers,
+                                                         const uint8_t* const* post_trackers, size_t n,
+                                                         const uint8_t* const* proofs, curdle_rand* rand, int nthreads,
+                                                         int* oks) {
+  if (!crs || !rand || !oks || (k && (!pre_trackers || !post_trackers || !proofs)))
+    return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  return Guard([&]() {
+    std::vector<whisk::ShuffleBatchItem> items(k);
+    for (size_t i = 0; i < k; i++) {
+      if (!pre_trackers[i] || !post_trackers[i] || !proofs[i]) throw std::runtime_error("null argument in batch item");
+      items[i] = whisk::ShuffleBatchItem{reinterpret_cast<const whisk::WhiskTracker*>(pre_trackers[i]),
+                                         reinterpret_cast<const whisk::WhiskTracker*>(post_trackers[i]), n, proofs[i]};
+    }
+    std::vector<int> res = whisk::IsValidWhiskShuffleProofBatch(crs->crs, items, rand->r, nthreads);
+    for (size_t i = 0; i < k; i++) oks[i] = res[i];
+    return CURDLE_OK;
+  });
+}
+
 extern "C" int curdle_whisk_generate_shuffle_proof(const curdle_crs* crs, const uint8_t* pre_trackers, size_t n,
                                                    curdle_rand* rand, uint8_t* post_trackers_out, uint8_t* proof_out) {
   if (!crs || !pre_trackers || !rand || !post_trackers_out || !proof_out)

@@ -1,6 +1,8 @@
 // whisk package restatement -- see whisk.h.  Reference: /root/reference/whisk/whisk.go, types.go.
 #include "whisk.h"
 
+#include "verify_batch_impl.h"
+
 #include <string.h>
 
 #include <stdexcept>
@@ -135,6 +137,65 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
   }
   if (!verify_error.empty()) throw err("verifying proof: " + verify_error);
   return accept;
+}
+
+std::vector<int> IsValidWhiskShuffleProofBatch(const proto::CRS& crs, const std::vector<ShuffleBatchItem>& items,
+                                               common::Rand& rand, int nthreads) {
+  const size_t k = items.size();
+  struct Source {
+    const std::vector<ShuffleBatchItem>& items;
+    proto::PointDecoder dec{/*subgroup_check=*/true};
+    std::vector<size_t> first_point, first_tracker;
+    std::vector<char> parses;
+    explicit Source(const std::vector<ShuffleBatchItem>& it)
+        : items(it), first_point(it.size(), 0), first_tracker(it.size(), 0), parses(it.size(), 0) {}
+    bool Usable(size_t i) const { return parses[i] != 0; }
+    proto::Proof DecodeProof(size_t i) const {
+      proto::Reader r(items[i].proof, WHISK_SHUFFLE_PROOF_SIZE, true);
+      r.decoded = &dec;
+      r.decoded_pos = first_point[i];
+      r.GetPoint("M");
+      return proto::Proof::FromReader(r);
+    }
+    void Instance(size_t i, std::vector<G1Affine>& Rs, std::vector<G1Affine>& Ss, std::vector<G1Affine>& Ts,
+                  std::vector<G1Affine>& Us, Point& M) const {
+      const size_t n = items[i].n;
+      Rs.resize(n);
+      Ss.resize(n);
+      Ts.resize(n);
+      Us.resize(n);
+      if (!dec.Get(first_point[i], &M)) throw err("decoding proof: invalid point");
+      Point pt;
+      for (size_t t = 0; t < n; t++) {
+        const size_t at = first_tracker[i] + 4 * t;
+        std::vector<G1Affine>* dst[4] = {&Rs, &Ss, &Ts, &Us};
+        for (int c = 0; c < 4; c++) {
+          if (!dec.Get(at + c, &pt)) throw err("getting shuffle points: invalid tracker point");
+          (*dst[c])[t] = pt.Affine();
+        }
+      }
+    }
+  } src(items);
+  for (size_t i = 0; i < k; i++) {
+    src.first_point[i] = src.dec.size();
+    try {
+      proto::Reader scan(items[i].proof, WHISK_SHUFFLE_PROOF_SIZE, true);
+      scan.collect = &src.dec;
+      scan.GetPoint("M");
+      proto::Proof::FromReader(scan);
+      src.parses[i] = 1;
+    } catch (const std::runtime_error&) {
+    }
+    src.first_tracker[i] = src.dec.size();
+    for (size_t t = 0; t < items[i].n; t++) {
+      src.dec.Add(items[i].preST[t].rG);
+      src.dec.Add(items[i].preST[t].krG);
+      src.dec.Add(items[i].postST[t].rG);
+      src.dec.Add(items[i].postST[t].krG);
+    }
+  }
+  src.dec.Run();
+  return proto::VerifyBatchCore(crs, k, src, rand, nthreads);
 }
 
 std::vector<WhiskTracker> GenerateWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTracker>& preTrackers,

@@ -37,6 +37,19 @@ struct TrackerProof {  // types.go:99-103
 bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTracker>& preST,
                               const std::vector<WhiskTracker>& postST, const uint8_t proof[WHISK_SHUFFLE_PROOF_SIZE],
                               common::Rand& rand);
+// Many shuffle proofs over one CRS at once (no reference counterpart; BASELINE config 5 is
+// "1024 Whisk proofs"): every point of every proof and tracker set decoded by one GPU
+// kernel, the proofs verified by proto::VerifyBatchCore (worker threads, one MSM per group
+// of 32 proofs).  Returns the accept bits; a proof or tracker set that does not decode is
+// rejected (bit 0) rather than raised.
+struct ShuffleBatchItem {
+  const WhiskTracker* preST;
+  const WhiskTracker* postST;
+  size_t n;
+  const uint8_t* proof;  // WHISK_SHUFFLE_PROOF_SIZE bytes
+};
+std::vector<int> IsValidWhiskShuffleProofBatch(const proto::CRS& crs, const std::vector<ShuffleBatchItem>& items,
+                                               common::Rand& rand, int nthreads);
 // whisk.go:63 -- returns the post-shuffle trackers, writes the 4,576-byte proof.
 std::vector<WhiskTracker> GenerateWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTracker>& preTrackers,
                                                     common::Rand& rand, uint8_t proof_out[WHISK_SHUFFLE_PROOF_SIZE]);

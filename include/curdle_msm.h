@@ -246,6 +246,13 @@ int curdle_proof_reencode(const uint8_t* proof, size_t proof_len, uint8_t* out, 
 int curdle_whisk_is_valid_shuffle_proof(const curdle_crs* crs, const uint8_t* pre_trackers, const uint8_t* post_trackers,
                                         size_t n_pre, size_t n_post,
                                         const uint8_t proof[CURDLE_WHISK_SHUFFLE_PROOF_SIZE], curdle_rand* rand, int* ok);
+/* k shuffle proofs over one CRS at once (no reference counterpart; BASELINE config 5): all
+ * points of all proofs and tracker sets decoded by one GPU kernel, the proofs verified like
+ * curdle_verify_batch.  pre / post: k pointers to n trackers each; proofs: k pointers to
+ * CURDLE_WHISK_SHUFFLE_PROOF_SIZE bytes.  oks[i] = accept bit; what does not decode is rejected. */
+int curdle_whisk_is_valid_shuffle_proof_batch(const curdle_crs* crs, size_t k, const uint8_t* const* pre_trackers,
+                                              const uint8_t* const* post_trackers, size_t n,
+                                              const uint8_t* const* proofs, curdle_rand* rand, int nthreads, int* oks);
 /* GenerateWhiskShuffleProof, whisk.go:63: n must be CURDLE_WHISK_ELL (the permutation length is fixed there) */
 int curdle_whisk_generate_shuffle_proof(const curdle_crs* crs, const uint8_t* pre_trackers, size_t n, curdle_rand* rand,
                                         uint8_t* post_trackers_out, uint8_t proof_out[CURDLE_WHISK_SHUFFLE_PROOF_SIZE]);

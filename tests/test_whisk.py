@@ -154,6 +154,28 @@ def test_more_concurrent_verifications_than_workspace_slots(gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_shuffle_proof_batch(gpu, oracle):
+    """curdle_whisk_is_valid_shuffle_proof_batch: several shuffles over one CRS, all points
+    decoded by one kernel, exact per-proof bits when some are bad."""
+    rand = gpu.Rand(4)
+    crs = gpu.CRS(gpu.WHISK_ELL, rand)
+    sets = []
+    for j in range(3):
+        pre = shuffle_trackers(gpu, oracle, gpu.Rand(30 + j), gpu.WHISK_ELL)
+        post, proof = gpu.whisk_generate_shuffle_proof(crs, pre, gpu.Rand(60 + j))
+        sets.append((pre, post, proof))
+    pres, posts, proofs = ([s[c] for s in sets] for c in range(3))
+    assert gpu.whisk_is_valid_shuffle_proof_batch(crs, pres, posts, proofs, gpu.Rand(1), nthreads=2) == [True] * 3
+    assert gpu.whisk_is_valid_shuffle_proof_batch(crs, [], [], [], gpu.Rand(1)) == []
+    # proof 0 against proof 1's post trackers; proof 2 with a tracker point that is not a curve point
+    bad_posts = [posts[1], posts[1], list(posts[2])]
+    bad_posts[2][3] = b"\x01" * 96
+    assert gpu.whisk_is_valid_shuffle_proof_batch(crs, pres, bad_posts, proofs, gpu.Rand(1), nthreads=3) == [False, True, False]
+    # a proof that does not parse
+    assert gpu.whisk_is_valid_shuffle_proof_batch(crs, pres[:2], posts[:2], [proofs[0], b"\x00" * 4576], gpu.Rand(1)) == [True, False]
+
+
+@pytest.mark.gpu
 def test_full_lifecycle(gpu, oracle):
     # TestWhiskFullLifecycle, whisk_test.go:58-91 with produceBlock / processBlock (:137-209)
     rand = gpu.Rand(0)
