@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <vector>
@@ -120,7 +121,7 @@ struct Ctx {
   // one in-order queue (measured at N = 2^20: 3.44 -> 3.30 ms per MSM with 4 in flight).
   hipStream_t main_extra[3] = {nullptr, nullptr, nullptr};
   int main_streams = 2;
-  unsigned submit_count = 0;
+  std::atomic<unsigned> submit_count{0};  // submits come from any thread
   // Recoding + bucket sort of every MSM, in order; light, memory/LDS-bound phases that
   // overlap the previous MSM's accumulation.
   hipStream_t pre_stream = nullptr;
@@ -853,10 +854,11 @@ extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_s
     return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
   }
   const uint32_t off[2] = {0, (uint32_t)n};
-  const unsigned turn = g_ctx.submit_count++ % (unsigned)g_ctx.main_streams;
+  const unsigned seq = g_ctx.submit_count.fetch_add(1, std::memory_order_relaxed);
+  const unsigned turn = seq % (unsigned)g_ctx.main_streams;
   hipStream_t main = turn == 0 ? g_ctx.main_stream : g_ctx.main_extra[turn - 1];
   const bool partial = win_begin > 0 || (win_end >= 0 && win_end < curdle_msm_num_windows(n, window_bits));
-  hipStream_t pre = partial && g_ctx.pre_streams == 2 && (g_ctx.submit_count & 1u) ? g_ctx.pre_stream2 : g_ctx.pre_stream;
+  hipStream_t pre = partial && g_ctx.pre_streams == 2 && (seq & 1u) ? g_ctx.pre_stream2 : g_ctx.pre_stream;
   rc = enqueue_slot(S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, pre, main,
                     S.stream, /*latency_mode=*/false);
   if (rc) {
