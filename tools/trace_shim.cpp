@@ -19,7 +19,8 @@ struct Stat {
   std::atomic<long> ns{0};
   explicit Stat(const char* n) : name(n) {}
 };
-Stat s_msm("curdle_msm_g1"), s_batch("curdle_msm_g1_batch"), s_smul("curdle_host_scalar_mul"),
+Stat s_msm("curdle_msm_g1"), s_batch("curdle_msm_g1_batch"), s_smb("curdle_g1_scalar_mul_batch"),
+    s_dec("curdle_g1_decompress_batch"), s_smul("curdle_host_scalar_mul"),
     s_add("curdle_host_add"), s_aff("curdle_host_to_affine"), s_pow("curdle_host_fp_pow");
 struct Timer {
   Stat& s;
@@ -32,7 +33,7 @@ struct Timer {
 };
 void report_and_reset(const char* what) {
   fprintf(stderr, "[trace] ---- %s\n", what);
-  for (Stat* s : {&s_msm, &s_batch, &s_smul, &s_add, &s_aff, &s_pow}) {
+  for (Stat* s : {&s_msm, &s_batch, &s_smb, &s_dec, &s_smul, &s_add, &s_aff, &s_pow}) {
     fprintf(stderr, "[trace] %-24s calls %8ld  total %10.2f ms  avg %9.2f us\n", s->name, s->calls.load(), s->ns / 1e6,
             s->calls ? s->ns / 1e3 / s->calls : 0.0);
     s->calls = 0;
@@ -69,6 +70,16 @@ int curdle_msm_g1_batch(const uint64_t* p, const uint64_t* s, const size_t* off,
   static auto f = next<int (*)(const uint64_t*, const uint64_t*, const size_t*, size_t, uint64_t*)>("curdle_msm_g1_batch");
   Timer t(s_batch);
   return f(p, s, off, k, out);
+}
+int curdle_g1_scalar_mul_batch(const uint64_t* p, const uint64_t* s, size_t ns, const uint64_t* a, size_t n, uint64_t* out) {
+  static auto f = next<int (*)(const uint64_t*, const uint64_t*, size_t, const uint64_t*, size_t, uint64_t*)>("curdle_g1_scalar_mul_batch");
+  Timer t(s_smb);
+  return f(p, s, ns, a, n, out);
+}
+int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int sub, uint64_t* out, uint8_t* st) {
+  static auto f = next<int (*)(const uint8_t*, size_t, int, uint64_t*, uint8_t*)>("curdle_g1_decompress_batch");
+  Timer t(s_dec);
+  return f(in, n, sub, out, st);
 }
 void curdle_host_scalar_mul(void* r, const void* p, const uint32_t* k) {
   static auto f = next<void (*)(void*, const void*, const uint32_t*)>("curdle_host_scalar_mul");
