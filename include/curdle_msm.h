@@ -1,7 +1,9 @@
 /*
  * curdle_msm.h -- C ABI of libcurdlemsm.so: BLS12-381 G1 multi-scalar
  * multiplication on MI355X (gfx950), the drop-in for the MSM path of
- * jsign/go-curdleproofs.
+ * jsign/go-curdleproofs -- plus, further down, the entry points of the layers either side of
+ * that path (batched point decoding, batched scalar multiplications, the protocol and Whisk
+ * restatements that funnel every MSM into the GPU).
  *
  * Every entry point replaces one reference interface (paths relative to
  * /root/reference); INTEGRATION.md shows the cgo binding for each.
