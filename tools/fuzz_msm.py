@@ -1,7 +1,7 @@
 """Randomised differential test of the GPU MSM against the C oracle: random sizes, repeated /
 negated / infinity points (doublings and cancellations inside buckets), scalars that are 0, 1,
 r-1, short, or share windows; single, batch and window-partial entry points.
-    python tools/fuzz_msm.py [seconds] [seed]
+    python tools/fuzz_msm.py [seconds] [seed]          (FUZZ_SIZES=65536,262144 for large inputs)
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,7 @@ import curdlemsm as cm
 import bls12381_ref as o
 import coracle as co
 
+SIZES = [int(x) for x in os.environ.get("FUZZ_SIZES", "1,2,3,7,33,64,257,1000,1268,4097,20000").split(",")]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
@@ -35,6 +36,15 @@ def neg_points(pts):
 
 def scalars(n):
     kind = rng.integers(0, 6)
+    if n > 50000:                                                                 # vectorised for large inputs
+        v = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+        v[:, 3] &= np.uint64((1 << 61) - 1)
+        if kind in (1, 3):
+            v[:, 1:] = 0
+            v[:, 0] &= np.uint64(511)
+        elif kind == 2:
+            v[:] = v[0]
+        return v                                                                  # any 4 limbs < r are a valid Montgomery element
     if kind == 0:
         v = [int.from_bytes(rng.bytes(32), "little") % R for _ in range(n)]
     elif kind == 1:
@@ -55,7 +65,7 @@ def scalars(n):
 t_end = time.time() + budget
 cases = 0
 while time.time() < t_end:
-    n = int(rng.choice([1, 2, 3, 7, 33, 64, 257, 1000, 1268, 4097, 20000]))
+    n = int(rng.choice(SIZES))
     idx = rng.integers(0, 4096 if rng.integers(0, 2) else 8, size=n)          # many repeats half of the time
     pts = pool[idx].copy()
     flip = rng.integers(0, 4, size=n) == 0
@@ -64,7 +74,7 @@ while time.time() < t_end:
     inf = rng.integers(0, 50, size=n) == 0
     pts[inf] = 0
     sc = scalars(n)
-    want = co.msm_pippenger(pts, sc, threads=8)
+    want = co.msm_pippenger(pts, sc, threads=16)
     mode = int(rng.integers(0, 3))
     if mode == 0:
         got = cm.msm_g1(pts, sc)
