@@ -231,3 +231,20 @@ def test_same_scalar_argument_is_enforced(gpu, check_mode):
     swapped = bytearray(proof)
     swapped[at:at + 96], swapped[at + 96:at + 192] = proof[at + 96:at + 192], proof[at:at + 96]
     assert gpu.verify(crs, bytes(swapped), Rs, Ss, Ts, Us, M, gpu.Rand(4)) is False
+
+
+def test_single_bit_changes_of_a_proof_are_never_accepted(gpu, check_mode):
+    """The transcript and the accumulated checks bind the whole proof: a changed bit anywhere in
+    its serialisation gives a reject or a decoding error, never an accept (a stride through
+    the proof here; tools/fuzz_proof_bits.py walks every byte)."""
+    crs, Rs, Ss, Ts, Us, M, perm, k, rs_m = setup(gpu, 32)
+    proof = gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(1))
+    assert gpu.verify(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(2)) is True
+    rng = np.random.default_rng(5)
+    for pos in range(3, len(proof), 41):
+        touched = bytearray(proof)
+        touched[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            assert gpu.verify(crs, bytes(touched), Rs, Ss, Ts, Us, M, gpu.Rand(3)) is False, pos
+        except gpu.CurdleError:
+            pass
