@@ -301,8 +301,8 @@ ShuffleCommit ShufflePermuteCommit(const std::vector<G1Affine>& crsGs, const std
 
 // ====================================================== samescalarargument =====
 namespace samescalar {
-static const char* kPoints = "sameexp_points";
-static const char* kAlpha = "sameexp_alpha";
+static const std::string kPoints = "sameexp_points";
+static const std::string kAlpha = "sameexp_alpha";
 
 static void AppendStatement(Transcript& tr, const Point& R, const Point& S, const GroupCommitment& T,
                             const GroupCommitment& U, const GroupCommitment& A, const GroupCommitment& B) {
@@ -375,11 +375,11 @@ void Proof::FromReader(Reader& r) {  // :102-120
 
 // ==================================================== innerproductargument =====
 namespace ipa {
-static const char* kStep1 = "ipa_step1";
-static const char* kAlpha = "ipa_alpha";
-static const char* kBeta = "ipa_beta";
-static const char* kLoop = "ipa_loop";
-static const char* kGamma = "ipa_gamma";
+static const std::string kStep1 = "ipa_step1";
+static const std::string kAlpha = "ipa_alpha";
+static const std::string kBeta = "ipa_beta";
+static const std::string kLoop = "ipa_loop";
+static const std::string kGamma = "ipa_gamma";
 
 // generateIPABlinders (innerproductargument.go:299-391): r, z with <r,d> + <z,c> = 0 and
 // <r,z> = 0; all but the last two z are random, the last two solve the 2x2 system.
@@ -565,10 +565,10 @@ void Proof::FromReader(Reader& r) {  // :393-426
 
 // ==================================================== grandproductargument =====
 namespace gprod {
-static const char* kStep1 = "gprod_step1";
-static const char* kStep2 = "gprod_step2";
-static const char* kAlpha = "gprod_alpha";
-static const char* kBeta = "gprod_beta";
+static const std::string kStep1 = "gprod_step1";
+static const std::string kStep2 = "gprod_step2";
+static const std::string kAlpha = "gprod_alpha";
+static const std::string kBeta = "gprod_beta";
 
 Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H, const Point& B,
             const Scalar& result, const std::vector<Scalar>& bs, const std::vector<Scalar>& r_bs, Transcript& tr,
@@ -688,9 +688,9 @@ void Proof::FromReader(Reader& r) {  // :288-302
 
 // ================================================= samepermutationargument =====
 namespace sameperm {
-static const char* kStep1 = "same_perm_step1";
-static const char* kAlpha = "same_perm_alpha";
-static const char* kBeta = "same_perm_beta";
+static const std::string kStep1 = "same_perm_step1";
+static const std::string kAlpha = "same_perm_alpha";
+static const std::string kBeta = "same_perm_beta";
 
 Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H, const Point& A,
             const Point& M, const std::vector<Scalar>& as, const std::vector<uint32_t>& permutation,
@@ -749,10 +749,10 @@ void Proof::FromReader(Reader& r) {  // :166-179
 
 // ================================================= samemultiscalarargument =====
 namespace samemsm {
-static const char* kStep1 = "same_msm_step1";
-static const char* kAlpha = "same_msm_alpha";
-static const char* kLoop = "same_msm_loop";
-static const char* kGamma = "same_msm_gamma";
+static const std::string kStep1 = "same_msm_step1";
+static const std::string kAlpha = "same_msm_alpha";
+static const std::string kLoop = "same_msm_loop";
+static const std::string kGamma = "same_msm_gamma";
 
 static void AppendStatement(Transcript& tr, const Point& A, const Point& Z_t, const Point& Z_u,
                             const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, const Point& B_a,
@@ -887,9 +887,9 @@ void Proof::FromReader(Reader& r) {  // :282-323
 }  // namespace samemsm
 
 // ============================================================= curdleproof =====
-static const char* kTranscript = "curdleproofs";
-static const char* kStep1 = "curdleproofs_step1";
-static const char* kVecA = "curdleproofs_vec_a";
+static const std::string kTranscript = "curdleproofs";
+static const std::string kStep1 = "curdleproofs_step1";
+static const std::string kVecA = "curdleproofs_vec_a";
 
 static void AppendInstance(Transcript& tr, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
                            const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M) {

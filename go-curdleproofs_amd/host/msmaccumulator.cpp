@@ -47,16 +47,52 @@ Status MsmAccumulator::AccumulateCheckXYZZ(const G1XYZZ& Cx, const std::vector<F
   return Status::OK();
 }
 
-void MsmAccumulator::AddTerm(const G1Affine& base, const Fr& scalar) {
-  std::string key(reinterpret_cast<const char*>(&base), sizeof(G1Affine));
-  auto it = index_.find(key);
-  if (it == index_.end()) {
-    index_.emplace(std::move(key), bases_.size());
-    bases_.push_back(base);
-    scalars_.push_back(scalar);
-  } else {
-    fr_add(scalars_[it->second], scalars_[it->second], scalar);
+static inline uint64_t KeyHash(const G1Affine& b) {
+  // the limbs of a point are uniformly distributed field elements already: mix two of them
+  uint64_t x0, y0;
+  memcpy(&x0, &b.x, 8);
+  memcpy(&y0, &b.y, 8);
+  uint64_t h = x0 ^ (y0 * 0x9e3779b97f4a7c15ull);
+  return h ^ (h >> 29);
+}
+
+void MsmAccumulator::Grow() {
+  size_t cap = table_.empty() ? 1024 : table_.size() * 2;
+  table_.assign(cap, 0);
+  for (size_t i = 0; i < bases_.size(); i++) {
+    size_t s = KeyHash(bases_[i]) & (cap - 1);
+    while (table_[s]) s = (s + 1) & (cap - 1);
+    table_[s] = (uint32_t)i + 1;
   }
+}
+
+// slot of `base` in table_: *found tells whether it holds the base already
+size_t MsmAccumulator::Find(const G1Affine& base, bool* found) {
+  if (table_.empty() || (bases_.size() + 1) * 2 > table_.size()) Grow();
+  const size_t mask = table_.size() - 1;
+  size_t s = KeyHash(base) & mask;
+  while (table_[s]) {
+    if (memcmp(&bases_[table_[s] - 1], &base, sizeof(G1Affine)) == 0) {
+      *found = true;
+      return s;
+    }
+    s = (s + 1) & mask;
+  }
+  *found = false;
+  return s;
+}
+
+void MsmAccumulator::AddTerm(const G1Affine& base, const Fr& scalar) {
+  bool found;
+  const size_t s = Find(base, &found);
+  if (found) {
+    Fr& acc = scalars_[table_[s] - 1];
+    fr_add(acc, acc, scalar);
+    return;
+  }
+  bases_.push_back(base);
+  scalars_.push_back(scalar);
+  table_[s] = (uint32_t)bases_.size();
 }
 
 Status MsmAccumulator::AccumulateCheckDeferred(const std::vector<Fr>& c_scalars, const std::vector<G1Affine>& c_points,

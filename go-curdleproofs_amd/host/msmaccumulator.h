@@ -7,7 +7,6 @@
 #include <stdint.h>
 
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "../csrc/bls12_381.h"
@@ -68,7 +67,11 @@ class MsmAccumulator {
   // a base shared by several checks merges; kept in insertion order (Go's map
   // order is random per run, :53-56, so only the group element is defined).
   void AddTerm(const G1Affine& base, const Fr& scalar);
-  std::unordered_map<std::string, size_t> index_;
+  size_t Find(const G1Affine& base, bool* found);
+  void Grow();
+  // open-addressing table over bases_ (slot = index + 1, 0 = empty), keyed by the 96 key
+  // bytes; a verification inserts ~1,400 keys, so no per-key allocation
+  std::vector<uint32_t> table_;
   std::vector<G1Affine> bases_;
   std::vector<Fr> scalars_;
 };
