@@ -150,3 +150,32 @@ def test_protocol_layer_has_no_cpu_msm_either(cm):
     with pytest.raises(cm.CurdleError) as e:
         cm.shuffle_permute_commit(crs, Rs, Ss, rand.generate_permutation(ell), rand.get_fr(), rand)
     assert e.value.code == cm.ENODEV
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "msm_from_c")
+    pkg = os.path.join(ROOT, "go-curdleproofs_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "msm_from_c.c"), "-L" + pkg, "-lcurdlemsm",
+                           "-Wl,-rpath," + pkg, "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_caller_links(cm, tmp_path):
+    """cgo parses include/curdle_msm.h as C: it must compile as strict C99 and a C program must
+    link against the library; without a device that program reports ENODEV (exit code 2)."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    if not cm.device_available():
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_caller_computes_three_g(gpu, oracle, tmp_path):
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, check=True)
+    want = oracle.jac_to_mont_limbs(oracle.scalar_mul(3, oracle.G1))
+    assert r.stdout.strip() == "3G x0=%016x y0=%016x z0=%016x" % (want[0], want[6], want[12])
