@@ -79,6 +79,8 @@ struct Slot {
   bool ev_made = false;
   // the call in flight
   bool busy = false;
+  bool claimed = false;   // a curdle_msm_wait is finishing this call (a second wait on the ticket is refused)
+  uint32_t gen = 0;       // bumped at every acquire: tickets carry it, stale ones are refused
   hipStream_t run_stream = nullptr;
   MsmPlan plan;
   bool profiled = false;
@@ -100,6 +102,8 @@ struct DSlot {
   hipStream_t stream = nullptr;
   Buf in, out, status;
   bool busy = false;
+  bool claimed = false;
+  uint32_t gen = 0;
   uint32_t n = 0;
 };
 
@@ -312,6 +316,8 @@ int acquire_slot(bool block, int* idx) {
     for (int i = 0; i < kSlots; i++) {
       if (!g_ctx.slots[i].busy) {
         g_ctx.slots[i].busy = true;
+        g_ctx.slots[i].claimed = false;
+        g_ctx.slots[i].gen++;
         *idx = i;
         return CURDLE_OK;
       }
@@ -328,6 +334,13 @@ void release_slot(int idx) {
   }
   g_ctx.cv.notify_one();
 }
+
+// A ticket names a slot AND the acquisition it was handed out for (slot index in the low
+// byte, the slot's generation above it), so a ticket that was already waited for, or one
+// kept across a later submit, is refused instead of touching another caller's workspace.
+inline int make_ticket(int idx, uint32_t gen) { return (int)(((gen & 0x7fffffu) << 8) | (uint32_t)idx); }
+inline int ticket_index(int ticket) { return ticket & 0xff; }
+inline uint32_t ticket_gen(int ticket) { return ((uint32_t)ticket >> 8) & 0x7fffffu; }
 
 // HIP-event bracketing of the phases of one call.  mode 1: an event after every phase (ten
 // timed events per MSM, on three streams).  mode 2: only the dominant kernel (accumulate) is
@@ -594,6 +607,7 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
     return CURDLE_OK;
   };
   rc = body();
+  if (rc) (void)hipStreamSynchronize(S.stream);  // queued copies into the caller's buffers must not outlive the call
   release_slot(idx);
   return rc;
 }
@@ -624,6 +638,8 @@ extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t*
     if (idx < 0 || busy >= kMaxDeferred)
       return fail(CURDLE_EBUSY, "%d deferred point decodings in flight; use curdle_g1_decompress_batch", busy);
     g_ctx.dslots[idx].busy = true;
+    g_ctx.dslots[idx].claimed = false;
+    g_ctx.dslots[idx].gen++;
   }
   DSlot& D = g_ctx.dslots[idx];
   auto body = [&]() -> int {
@@ -652,16 +668,18 @@ extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t*
     }
     return rc;
   }
-  *ticket = idx;
+  *ticket = make_ticket(idx, D.gen);
   return CURDLE_OK;
 }
 
 extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
-  if (ticket < 0 || ticket >= kMaxDeferred) return fail(CURDLE_EINVAL, "bad ticket");
-  DSlot& D = g_ctx.dslots[ticket];
+  if (ticket < 0 || ticket_index(ticket) >= kMaxDeferred) return fail(CURDLE_EINVAL, "bad ticket");
+  DSlot& D = g_ctx.dslots[ticket_index(ticket)];
   {
     std::lock_guard<std::mutex> g(g_ctx.mu);
-    if (!D.busy) return fail(CURDLE_EINVAL, "ticket %d is not in flight", ticket);
+    if (!D.busy || D.claimed || (D.gen & 0x7fffffu) != ticket_gen(ticket))
+      return fail(CURDLE_EINVAL, "ticket %d is not in flight (stale or already finished)", ticket);
+    D.claimed = true;
   }
   const size_t n = D.n;
   int rc = CURDLE_OK;
@@ -710,6 +728,7 @@ extern "C" int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t
     return CURDLE_OK;
   };
   rc = body();
+  if (rc) (void)hipStreamSynchronize(S.stream);  // `res` is a local: nothing may still be copying into it
   release_slot(idx);
   return rc;
 }
@@ -866,20 +885,29 @@ extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_s
     release_slot(idx);
     return rc;
   }
-  *ticket = idx;
+  *ticket = make_ticket(idx, S.gen);
   return CURDLE_OK;
 }
 
 extern "C" int curdle_msm_wait(int ticket, uint64_t out_jac[18]) {
-  if (ticket < 0 || ticket >= kSlots || !out_jac) return fail(CURDLE_EINVAL, "bad ticket or null output");
+  if (ticket < 0 || ticket_index(ticket) >= kSlots || !out_jac) return fail(CURDLE_EINVAL, "bad ticket or null output");
+  const int idx = ticket_index(ticket);
   {
     std::lock_guard<std::mutex> g(g_ctx.mu);
-    if (!g_ctx.inited || !g_ctx.slots[ticket].busy) return fail(CURDLE_EINVAL, "ticket %d is not in flight", ticket);
+    Slot& S = g_ctx.slots[idx];
+    if (!g_ctx.inited || !S.busy || S.claimed || (S.gen & 0x7fffffu) != ticket_gen(ticket))
+      return fail(CURDLE_EINVAL, "ticket %d is not in flight (stale or already waited for)", ticket);
+    S.claimed = true;
   }
   hipError_t he = hipSetDevice(g_ctx.device);
-  if (he != hipSuccess) return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
-  int rc = finish_slot(g_ctx.slots[ticket], out_jac);
-  release_slot(ticket);
+  if (he != hipSuccess) {
+    std::lock_guard<std::mutex> g(g_ctx.mu);
+    g_ctx.slots[idx].claimed = false;  // the call is still in flight: the caller may wait again
+    return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
+  }
+  int rc = finish_slot(g_ctx.slots[idx], out_jac);
+  if (rc) drain_slot(g_ctx.slots[idx]);
+  release_slot(idx);
   return rc;
 }
 
@@ -1164,7 +1192,7 @@ extern "C" int curdle_acc_verify(curdle_acc* a, int* ok) {
   if (!st.ok) {
     snprintf(saved, sizeof(saved), "%s", st.err.c_str());
     // keep the class of the underlying failure (no device vs HIP error) visible to the caller
-    return fail(strstr(saved, "no HIP device") ? CURDLE_ENODEV : CURDLE_EHIP, "%s", saved);
+    return fail(st.rc ? st.rc : CURDLE_EHIP, "%s", saved);
   }
   return CURDLE_OK;
 }

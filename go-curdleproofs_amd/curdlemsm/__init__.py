@@ -59,7 +59,7 @@ SYMBOLS = [
     "curdle_whisk_generate_shuffle_proof",
     "curdle_whisk_is_valid_tracker_proof", "curdle_whisk_generate_tracker_proof", "curdle_proof_reencode", "curdle_merlin_test_vector", "curdle_g1_decompress_batch", "curdle_g1_decompress_begin", "curdle_g1_decompress_finish",
     "curdle_g1_scalar_mul_batch",
-    "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error",
+    "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error", "curdle_fr_inner_product",
 ]
 
 _u64p = C.POINTER(C.c_uint64)
@@ -588,6 +588,18 @@ def proof_reencode(proof: bytes) -> bytes:
     n = C.c_size_t(0)
     _check(_reencode(_ptr(pb), len(pb), _ptr(out), len(out), C.byref(n)))
     return bytes(out[: n.value])
+
+
+_fr_ip = _sig("curdle_fr_inner_product", C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp)
+
+
+def fr_inner_product(a, b) -> np.ndarray:
+    """common.IPA (reference common/util.go:26): Montgomery-form Fr vectors in, Montgomery Fr out."""
+    a = _as_u64(a, 4)
+    b = _as_u64(b, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    _check(_fr_ip(_ptr(a), len(a), _ptr(b), len(b), _ptr(out)))
+    return out
 
 
 def merlin_test_vector(protocol: bytes, label: bytes, msg: bytes, challenge_label: bytes, n: int) -> bytes:

@@ -1004,7 +1004,7 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
   if (!VerifyInto(proof, crs, Rs, Ss, Ts, Us, M, rand, acc)) return false;
   bool ok = false;
   msmaccumulator::Status st = acc.Verify(&ok);                                // :313, the batched MSM on the GPU
-  if (!st.ok) throw alg::MsmError("verifying msm accumulator: " + st.err, CURDLE_EHIP);  // device failure
+  if (!st.ok) throw alg::MsmError("verifying msm accumulator: " + st.err, st.rc ? st.rc : CURDLE_EHIP);  // device failure
   return ok;
 }
 

@@ -128,7 +128,7 @@ Status MsmAccumulator::Verify(bool* ok) {
   if (rc != CURDLE_OK) {
     char buf[256];
     curdle_last_error(buf, sizeof(buf));
-    return Status::Error(std::string("computing msm: ") + buf);  // :60
+    return Status::Error(std::string("computing msm: ") + buf, rc);  // :60
   }
   G1Jac j;
   memcpy(&j, out, sizeof(j));

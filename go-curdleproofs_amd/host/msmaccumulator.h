@@ -18,8 +18,9 @@ namespace msmaccumulator {
 struct Status {
   bool ok;
   std::string err;  // text of the Go error ("x and v must have the same length", "computing msm: ...")
-  static Status OK() { return Status{true, ""}; }
-  static Status Error(const std::string& e) { return Status{false, e}; }
+  int rc;           // CURDLE_* code behind a failed MSM (0 for the structural errors of the Go API)
+  static Status OK() { return Status{true, "", 0}; }
+  static Status Error(const std::string& e, int code = 0) { return Status{false, e, code}; }
 };
 
 class MsmAccumulator {

@@ -42,10 +42,12 @@ static int Guard(F&& f) {
     return f();
   } catch (const std::bad_alloc&) {
     return curdle_set_last_error(CURDLE_ENOMEM, "out of memory");
+  } catch (const alg::MsmError& e) {
+    // a device-side failure (no device, HIP error, out of device memory) carries the code of
+    // the entry point that failed: "could not compute", never to be read as "reject"
+    return curdle_set_last_error(e.rc == CURDLE_OK || e.rc == CURDLE_EINVAL ? CURDLE_EHIP : e.rc, e.what());
   } catch (const std::exception& e) {
-    const char* m = e.what();
-    int code = strstr(m, "no HIP device") ? CURDLE_ENODEV : (strstr(m, "computing msm") ? CURDLE_EHIP : CURDLE_EINVAL);
-    return curdle_set_last_error(code, m);
+    return curdle_set_last_error(CURDLE_EINVAL, e.what());  // malformed input / structural error of the protocol
   }
 }
 
@@ -270,6 +272,22 @@ extern "C" int curdle_proof_reencode(const uint8_t* proof, size_t proof_len, uin
     *out_len = bytes.size();
     if (!out || cap < bytes.size()) return curdle_set_last_error(CURDLE_EINVAL, "buffer too small");
     memcpy(out, bytes.data(), bytes.size());
+    return CURDLE_OK;
+  });
+}
+
+// common.IPA (/root/reference/common/util.go:26-35): inner product of two Fr vectors, Montgomery
+// limbs in and out; the reference's own known answer (common/util_test.go:10-27) is asserted
+// against this entry point.
+extern "C" int curdle_fr_inner_product(const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len,
+                                       uint64_t out_fr[4]) {
+  if (!out_fr || (a_len && !a) || (b_len && !b)) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  return Guard([&]() {
+    std::vector<Scalar> va(a_len), vb(b_len);
+    for (size_t i = 0; i < a_len; i++) va[i] = Scalar::FromMont(a + 4 * i);
+    for (size_t i = 0; i < b_len; i++) vb[i] = Scalar::FromMont(b + 4 * i);
+    const Scalar r = alg::InnerProduct(va, vb);  // throws on a length mismatch, as util.go:27-29 errors
+    memcpy(out_fr, &r.v, 32);
     return CURDLE_OK;
   });
 }

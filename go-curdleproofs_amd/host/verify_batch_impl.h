@@ -38,6 +38,7 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
   std::atomic<size_t> next(0);
   std::atomic<bool> failed(false);
   std::string first_error;
+  int first_rc = CURDLE_EHIP;
   std::mutex err_mu;
   auto worker = [&]() {
     std::vector<G1Affine> bases;
@@ -102,7 +103,13 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
         if (members.size() >= flush) settle();
       }
       settle();
-    } catch (const std::exception& e) {  // device failure inside an MSM: the whole call fails
+    } catch (const alg::MsmError& e) {  // device failure inside an MSM: the whole call fails
+      std::lock_guard<std::mutex> g(err_mu);
+      if (!failed.exchange(true)) {
+        first_error = e.what();
+        first_rc = e.rc;
+      }
+    } catch (const std::exception& e) {
       std::lock_guard<std::mutex> g(err_mu);
       if (!failed.exchange(true)) first_error = e.what();
     }
@@ -111,7 +118,7 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
   for (int t = 1; t < nthreads; t++) th.emplace_back(worker);
   worker();
   for (auto& x : th) x.join();
-  if (failed.load()) throw alg::MsmError("batch verification: " + first_error, CURDLE_EHIP);
+  if (failed.load()) throw alg::MsmError("batch verification: " + first_error, first_rc);
   return oks;
 }
 

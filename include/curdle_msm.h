@@ -264,6 +264,9 @@ int curdle_whisk_is_valid_tracker_proof(const uint8_t tracker[CURDLE_WHISK_TRACK
 /* GenerateWhiskTrackerProof, whisk.go:149 */
 int curdle_whisk_generate_tracker_proof(const uint8_t tracker[CURDLE_WHISK_TRACKER_SIZE], const uint64_t k[4],
                                         curdle_rand* rand, uint8_t proof_out[CURDLE_WHISK_TRACKER_PROOF_SIZE]);
+/* common.IPA (reference common/util.go:26-35): out = sum_i a[i] * b[i] over Fr, Montgomery limbs
+ * in and out; CURDLE_EINVAL if the lengths differ (the reference returns an error). */
+int curdle_fr_inner_product(const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, uint64_t out_fr[4]);
 /* pieces exposed for known-answer tests */
 int curdle_merlin_test_vector(const char* protocol, const char* label, const uint8_t* msg, size_t msg_len,
                               const char* challenge_label, uint8_t* out, size_t out_len);

@@ -179,3 +179,52 @@ def test_c_caller_computes_three_g(gpu, oracle, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, check=True)
     want = oracle.jac_to_mont_limbs(oracle.scalar_mul(3, oracle.G1))
     assert r.stdout.strip() == "3G x0=%016x y0=%016x z0=%016x" % (want[0], want[6], want[12])
+
+
+def _zero_wire_proof(n):
+    """A syntactically complete curdleproof for n = ell + 4 (all-zero point and scalar
+    records, correct uint32 slice prefixes): it parses, so decoding
+    reaches the batched point decoder."""
+    m = n.bit_length() - 1
+    pt, fr = bytes(48), bytes(32)
+    vec = m.to_bytes(4, "big") + pt * m
+    ipa = pt * 2 + vec * 4 + fr * 2
+    sameperm = pt + (pt + fr + ipa)
+    samescalar = pt * 4 + fr * 3
+    samemsm = pt * 3 + vec * 6 + fr
+    return pt + pt * 2 + pt * 2 + pt + pt + sameperm + samescalar + samemsm
+
+
+def test_device_failure_in_point_decoding_is_not_reported_as_reject(cm):
+    """a device failure inside the batched point decoder ("decoding points: ...")
+    must surface with the failing entry point's code (ENODEV here), never as EINVAL -- the code
+    of a malformed proof -- so a caller mapping EINVAL to "reject" cannot drop a valid proof
+    because the GPU was unavailable."""
+    if cm.device_available():
+        pytest.skip("a device is visible")
+    ell = 60
+    rand = cm.Rand(3)
+    crs = cm.CRS(ell, rand)
+    pts = np.tile(rand.get_g1_affines(1), (ell, 1))
+    M = np.zeros(18, dtype=np.uint64)
+    with pytest.raises(cm.CurdleError) as e:
+        cm.verify(crs, _zero_wire_proof(ell + 4), pts, pts, pts, pts, M, cm.Rand(4))
+    assert e.value.code == cm.ENODEV, (e.value.code, e.value.msg)
+    assert "decoding points" in e.value.msg
+    # a proof that does not parse at all IS a malformed input
+    with pytest.raises(cm.CurdleError) as e:
+        cm.verify(crs, b"\x00" * 100, pts, pts, pts, pts, M, cm.Rand(4))
+    assert e.value.code == cm.EINVAL
+
+
+def test_stale_and_repeated_tickets_are_refused(cm):
+    """tickets carry the slot's generation; a made-up, stale or repeated ticket is
+    refused instead of releasing a slot owned by another caller.  (Needs no device: the checks
+    come before any HIP call.)"""
+    out = np.zeros(18, dtype=np.uint64)
+    for t in (0, 3, 7, (5 << 8) | 1):
+        with pytest.raises(cm.CurdleError) as e:
+            cm.msm_wait(t)
+        assert e.value.code == cm.EINVAL
+    with pytest.raises(cm.CurdleError):
+        cm.g1_decompress_finish(0, 1)

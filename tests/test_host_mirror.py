@@ -232,3 +232,21 @@ def test_subgroup_check_of_the_decoder(cm, oracle):
         small = oracle.scalar_mul(r, pt)
         with pytest.raises(cm.CurdleError):
             cm.g1_decompress(oracle.compress(small), True)
+
+
+def test_inner_product_known_answer_of_the_reference(cm, oracle):
+    """The one hard-coded expected value the reference's tests hold on this path:
+    common/util_test.go:10-27, IPA([1,2,3,4], [2,3,4,5]) == 40; plus the length-mismatch
+    error of util.go:27-29 and a random vector against Python integers."""
+    a = np.array([oracle.fr_to_mont_limbs(v) for v in (1, 2, 3, 4)], dtype=np.uint64)
+    b = np.array([oracle.fr_to_mont_limbs(v) for v in (2, 3, 4, 5)], dtype=np.uint64)
+    assert [int(v) for v in cm.fr_inner_product(a, b)] == oracle.fr_to_mont_limbs(40)
+    with pytest.raises(cm.CurdleError):
+        cm.fr_inner_product(a, b[:3])
+    r = oracle.Rand(9)
+    xs, ys = r.get_frs(17), r.get_frs(17)
+    exp = sum(x * y for x, y in zip(xs, ys)) % oracle.R
+    A = np.array([oracle.fr_to_mont_limbs(v) for v in xs], dtype=np.uint64)
+    B = np.array([oracle.fr_to_mont_limbs(v) for v in ys], dtype=np.uint64)
+    assert [int(v) for v in cm.fr_inner_product(A, B)] == oracle.fr_to_mont_limbs(exp)
+    assert [int(v) for v in cm.fr_inner_product(A[:0], B[:0])] == oracle.fr_to_mont_limbs(0)
