@@ -259,16 +259,29 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // and is better served by the smaller total work of 16-bucket segments (3.27 -> 3.13 ms
   // per MSM at N = 2^20); a synchronous caller waits for the chain (4.3 vs 5.0 ms).
   p.seg = nbk >= (1u << 19) ? (latency_mode ? 8 : 16) : (nbk >= (1u << 14) ? 4 : 2);
+  // Four lanes per point (quad28.h) in the latency-bound kernels when the caller waits for
+  // this very call (synchronous entry points): the segments are lengthened until the
+  // four-fold lane count is at most one round of the chip at two waves per SIMD (131,072
+  // lanes), because a quad's addition is 4 product steps against 14 and the chain
+  // (2.5 seg + log2(buckets) point operations) is what the caller waits for.  Pipelined
+  // (submit / wait) calls hide their tails behind other MSMs' accumulation and keep one lane
+  // per operation (a quad spends ~30 % more issue slots per addition), unless the call is
+  // small enough (a window-range partial, a small MSM) to leave most of the chip idle anyway.
+  p.quad = 0;
+  if (latency_mode) {
+    uint32_t seg = p.seg;
+    while (nbk / seg * 4 > 131072 && seg < 32) seg *= 2;
+    if (nbk / seg * 4 <= 131072) {
+      p.seg = seg;
+      p.quad = 1;
+    }
+  } else if (nbk / p.seg * 4 <= 65536) {
+    p.quad = 1;
+  }
   if (const char* env = getenv("CURDLE_REDUCE_SEG")) p.seg = (uint32_t)atoi(env);
   if (p.seg < 1) p.seg = 1;
   while (p.seg > min_nbkt || (p.seg & (p.seg - 1))) p.seg >>= 1;
   p.NS = p.NB / p.seg;
-  // Four lanes per point operation in the latency-bound kernels when the caller waits for
-  // this very call (synchronous entry points) and even the four-fold lane count is at most
-  // one round of the chip at two waves per SIMD.  It shortens the tail of an isolated call
-  // by ~0.4 ms but costs ~40 % more multiplier work, so pipelined (submit / wait) calls,
-  // whose tails overlap other MSMs' accumulation anyway, keep one lane per operation.
-  p.quad = latency_mode && (uint64_t)k * p.NS * 4 <= 131072 ? 1u : 0u;
   if (const char* env = getenv("CURDLE_QUAD")) p.quad = atoi(env) ? 1u : 0u;
   const uint32_t gmax = p.quad ? 64u : 256u;
   p.G = min_nbkt / p.seg < gmax ? min_nbkt / p.seg : gmax;
@@ -277,7 +290,11 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   const uint64_t entries = (uint64_t)(win_end - win_begin) * n_total;
   uint64_t L = (entries + 2 * 131072 - 1) / (2 * 131072);
   if (const char* env = getenv("CURDLE_SEG_LEN")) L = (uint64_t)atoi(env);
-  if (L < 8) L = 8;
+  // small MSMs are latency-bound on the lane's chain of L mixed additions: halve it while the
+  // launch stays far below one round of the chip (every lane emits at least one fragment,
+  // which the bucket reduce has to add, so not below 4)
+  const uint64_t Lmin = entries <= 8 * 65536 ? 4 : 8;
+  if (L < Lmin) L = Lmin;
   if (L > 128) L = 128;
   // beyond ~2^25 pairs even 128 positions per lane leave more than 4M lanes and cut a bucket
   // into more than max_small fragments (they would all take the merge_large detour): grow L
@@ -1057,7 +1074,7 @@ extern "C" int curdle_profile_last(curdle_profile* out) {
 }
 
 extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64_t* out64, int on_device) {
-  if (op < 0 || op > 7 || !in64 || !out64) return fail(CURDLE_EINVAL, "bad selftest arguments");
+  if (op < 0 || op > 10 || !in64 || !out64) return fail(CURDLE_EINVAL, "bad selftest arguments");
   const uint32_t* in = reinterpret_cast<const uint32_t*>(in64);
   uint32_t* out = reinterpret_cast<uint32_t*>(out64);
   const size_t in_w = op <= 3 ? 24 : (op == 4 ? 16 : 96);
@@ -1086,10 +1103,13 @@ extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64
         memcpy(&b, s + 48, 192);
         if (op == 5) {
           if (!(f_is_zero(b.x) && f_is_zero(b.y))) g1_madd(acc, b.x, b.y);
-        } else if (op == 6) {
+        } else if (op == 6 || op == 8) {
           g1_add(acc, b);
-        } else {
+        } else if (op == 7 || op == 9) {
           g1_dbl(acc);
+        } else {  // op 10: k * b with the kernel's 20-bit k (msm_kernels.hip k_selftest)
+          const u32 k = (u32)((u32)i * 2654435761u) >> 12;
+          g1_scalar_mul(acc, b, &k, 1);
         }
         memcpy(d, &acc, 192);
       }

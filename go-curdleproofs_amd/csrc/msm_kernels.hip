@@ -28,6 +28,7 @@
 #include "msm_kernels.h"
 
 #include "fp28.h"
+#include "quad28.h"
 
 namespace curdle {
 
@@ -425,69 +426,90 @@ __global__ void __launch_bounds__(kBlock, WAVES)
 }
 
 // ---------------------------------------------------------------------------
-// Quad variants of the latency-bound kernels (fp28.h "Lane-cooperative point
-// arithmetic"): four adjacent lanes per logical lane, so a 256-thread block carries
-// 64 logical lanes.  Used when the launch has few enough logical lanes that the
-// four-fold lane count still fits the chip in one round.
+// Quad variants of the latency-bound kernels (quad28.h): four adjacent lanes own ONE
+// point between them (X | Y | ZZ | ZZZ), so a 256-thread block carries 64 logical
+// lanes ("quads") and a point addition is 4 product steps instead of 14.  Used when the
+// launch has few enough logical lanes that the four-fold lane count still fits the chip
+// in one round.
 // ---------------------------------------------------------------------------
-// Sum over aligned groups of G logical lanes (G a power of two <= 64); valid in the
-// first quad of each group.
-__device__ __forceinline__ void group_sum_quad(X28& acc, u32 G, X28* wave_partials /* LDS, 4 entries */) {
+// Sum over aligned groups of G quads (G a power of two <= 64); valid in the first quad of
+// each group.  wave_partials: LDS, [4 waves][4 coordinates].
+__device__ __forceinline__ void group_sum_quad(F28& acc, u32 G, F28 (*wave_partials)[4]) {
   const u32 tid = threadIdx.x;
-  const u32 ll = (tid & 63u) >> 2;       // logical lane inside the wave, 0..15
+  const u32 ll = (tid & 63u) >> 2;       // quad inside the wave, 0..15
   const u32 gw = G < 16u ? G : 16u;
-  X28 b;
+  F28 b;
   for (u32 off = gw / 2; off > 0; off >>= 1) {
-    shfl_down_x28(b, acc, off * 4);      // all four copies move together
-    if ((ll & (gw - 1)) >= off) d28::set_inf(b);
-    d28::quad_add(acc, b);
+    q28::shfl_down(b, acc, off);
+    if ((ll & (gw - 1)) >= off) q28::set_inf(b);  // quads outside the live half contribute nothing
+    q28::add(acc, b);
   }
   if (G > 16u) {  // G = 32 or 64: combine the waves' results
-    if ((tid & 63u) == 0) wave_partials[tid >> 6] = acc;
+    if ((tid & 63u) < 4u) wave_partials[tid >> 6][tid & 3u] = acc;
     __syncthreads();
-    const u32 lt = tid >> 2;             // logical lane inside the block, 0..63
+    const u32 lt = tid >> 2;             // quad inside the block, 0..63
     if ((lt & (G - 1)) == 0) {           // whole quads take this branch
       for (u32 k = 1; k < G / 16u; k++) {
-        b = wave_partials[(tid >> 6) + k];
-        d28::quad_add(acc, b);
+        b = wave_partials[(tid >> 6) + k][tid & 3u];
+        q28::add(acc, b);
       }
     }
   }
 }
 
+// One quad per segment of `seg` consecutive buckets.  The running-sum recurrence is run as
+// ONE addition per step -- the next fragment of the current bucket into the running sum,
+// or, when the bucket is exhausted, the running sum into the segment sum -- so quads whose
+// buckets have different fragment counts do not wait for each other bucket by bucket, and
+// the kernel has a single copy of the addition in its main loop.
 __global__ void __launch_bounds__(kBlock, 2)
     k_bucket_reduce_quad(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
                          X28* __restrict__ partials, MsmPlan p) {
-  __shared__ X28 sh[4];
+  __shared__ F28 sh[4][4];
   const u32 tid = threadIdx.x;
   const u32 q = blockIdx.x * (kBlock / 4) + (tid >> 2);  // logical lane
-  X28 acc, b;
-  d28::set_inf(acc);
-  if (q < p.k * p.NS) {
+  const bool live = q < p.k * p.NS;
+  F28 acc, run, b;
+  q28::set_inf(acc);
+  q28::set_inf(run);
+  if (live) {
     const u32 j = q / p.NS;
     const u32 r = q - j * p.NS;
     int w = p.win_begin;
     while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
     const u32 lo = (r - p.base[w] / p.seg) * p.seg;
     const u32 g0 = j * p.NB + p.base[w] + lo;
-    X28 run;
-    d28::set_inf(run);
-    for (int u = (int)p.seg - 1; u >= 0; u--) {
-      const u32 m = fragcnt[g0 + u];
-      const X28* f = frags + foff[g0 + u];
-      for (u32 k = 0; k < m; k++) {
-        d28::load(b, &f[k]);
-        d28::quad_add(run, b);
+    int u = (int)p.seg - 1;
+    u32 m = fragcnt[g0 + u], k = 0;
+    const X28* f = frags + foff[g0 + u];
+    while (u >= 0) {
+      const bool take = k < m;  // uniform over the quad
+      if (take) {
+        q28::load(b, &f[k]);
+        k++;
       }
-      d28::quad_add(acc, run);
+      F28 dst, src;
+      q28::sel(dst, take, run, acc);
+      q28::sel(src, take, b, run);
+      q28::add(dst, src);
+      q28::sel(run, take, dst, run);
+      q28::sel(acc, take, acc, dst);
+      if (!take) {
+        u--;
+        if (u >= 0) {
+          m = fragcnt[g0 + u];
+          f = frags + foff[g0 + u];
+          k = 0;
+        }
+      }
     }
-    if (lo != 0) {
-      d28::quad_mul_small(b, run, lo);
-      d28::quad_add(acc, b);
-    }
+    // lo * (segment total): every quad of the window runs the same number of steps
+    const int top = 31 - __clz((int)(p.nbkt[w] | 1u));
+    q28::mul_small(b, run, lo, top);
+    q28::add(acc, b);
   }
   if (p.G > 1) group_sum_quad(acc, p.G, sh);
-  if (((tid >> 2) & (p.G - 1)) == 0 && (tid & 3u) == 0 && q < p.k * p.NS) d28::store(&partials[q / p.G], acc);
+  if (((tid >> 2) & (p.G - 1)) == 0 && live) q28::store(&partials[q / p.G], acc);
 }
 
 __device__ __forceinline__ void write_window_sum(const X28& acc, G1XYZZ* winsums, X28* winsums28, const MsmPlan& p,
@@ -541,24 +563,40 @@ __global__ void __launch_bounds__(64, 1)
   if (tid == 0) write_window_sum(acc, winsums, winsums28, p, j, lw);
 }
 
+// The quad's own coordinate of a window sum: gnark form for the host combine, internal form
+// for k_combine.
+__device__ __forceinline__ void write_window_sum_quad(const F28& c, G1XYZZ* winsums, X28* winsums28, const MsmPlan& p,
+                                                      u32 j, u32 lw) {
+  const u32 nw = p.win_end - p.win_begin;
+  if (!p.gpu_combine) {
+    u32 w12[12];
+    d28::to_gnark(w12, c);
+    u32* dst = reinterpret_cast<u32*>(&winsums[(size_t)j * nw + lw]) + 12u * q28::role();
+#pragma unroll
+    for (int i = 0; i < 12; i++) dst[i] = w12[i];
+  } else {
+    q28::store(&winsums28[(size_t)j * nw + lw], c);
+  }
+}
+
 __global__ void __launch_bounds__(kBlock, 2)
     k_window_sum_wide_quad(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28,
                            MsmPlan p) {
-  __shared__ X28 sh[4];
+  __shared__ F28 sh[4][4];
   const u32 lw = blockIdx.x, j = blockIdx.y;
   const u32 w = p.win_begin + lw;
   const u32 tid = threadIdx.x;
   const u32 lt = tid >> 2;  // logical lane 0..63
   const u32 np = p.nbkt[w] / p.seg / p.G;
   const X28* pw = partials + ((size_t)j * p.NS + p.base[w] / p.seg) / p.G;
-  X28 acc, b;
-  d28::set_inf(acc);
+  F28 acc, b;
+  q28::set_inf(acc);
   for (u32 k = lt; k < np; k += 64) {
-    d28::load(b, &pw[k]);
-    d28::quad_add(acc, b);
+    q28::load(b, &pw[k]);
+    q28::add(acc, b);
   }
   group_sum_quad(acc, 64, sh);
-  if (tid == 0) write_window_sum(acc, winsums, winsums28, p, j, lw);
+  if (tid < 4) write_window_sum_quad(acc, winsums, winsums28, p, j, lw);
 }
 
 __global__ void __launch_bounds__(kBlock, 2)
@@ -816,6 +854,34 @@ hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32
 // runs in the internal radix-2^28 form the MSM kernels use.
 __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __restrict__ in, size_t n, u32* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (op >= 8) {  // lane-distributed point operations (quad28.h): four lanes per element
+    i >>= 2;
+    if (i >= n) return;  // whole quads leave together
+    G1XYZZ ga, gb;
+    const u32* src = in + i * 96;
+    u32* a32 = reinterpret_cast<u32*>(&ga);
+    u32* b32 = reinterpret_cast<u32*>(&gb);
+    for (int k = 0; k < 48; k++) {
+      a32[k] = src[k];
+      b32[k] = src[48 + k];
+    }
+    X28 pa, pb;
+    d28::from_gnark(pa, ga);
+    d28::from_gnark(pb, gb);
+    F28 ca, cb;
+    q28::from_x28(ca, pa);
+    q28::from_x28(cb, pb);
+    if (op == 8) q28::add(ca, cb);
+    else if (op == 9) q28::dbl(ca);
+    else q28::mul_small(ca, cb, (u32)(i * 2654435761u) >> 12, 19);  // op 10: k * b, k = 20 bits of a hash of i
+    q28::to_x28(pa, ca);
+    if (threadIdx.x & 3u) return;
+    G1XYZZ o;
+    d28::to_gnark(o, pa);
+    const u32* o32 = reinterpret_cast<const u32*>(&o);
+    for (int k = 0; k < 48; k++) out[i * 48 + k] = o32[k];
+    return;
+  }
   if (i >= n) return;
   if (op <= 3) {
     u32 w[24];
@@ -863,7 +929,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __res
 }
 
 hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_selftest, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, op, d_in, n, d_out);
+  const size_t lanes = op >= 8 ? 4 * n : n;
+  hipLaunchKernelGGL(k_selftest, dim3(cdiv(lanes, kBlock)), dim3(kBlock), 0, stream, op, d_in, n, d_out);
   return hipGetLastError();
 }
 

@@ -385,7 +385,8 @@ def profile_last() -> dict:
     }
 
 
-_SELFTEST_W = {0: (24, 12), 1: (24, 12), 2: (24, 12), 3: (24, 12), 4: (16, 8), 5: (96, 48), 6: (96, 48), 7: (96, 48)}
+_SELFTEST_W = {0: (24, 12), 1: (24, 12), 2: (24, 12), 3: (24, 12), 4: (16, 8), 5: (96, 48), 6: (96, 48), 7: (96, 48),
+               8: (96, 48), 9: (96, 48), 10: (96, 48)}
 
 
 def selftest_op(op: int, inp: np.ndarray, on_device: bool) -> np.ndarray:

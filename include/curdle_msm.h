@@ -338,6 +338,9 @@ int curdle_synth_points_walk_device(const uint64_t k[4], const uint64_t q[4], si
  *   op 5: xyzz madd: in: n x (XYZZ acc | XYZZ whose X,Y hold the affine addend), out: n x XYZZ
  *   op 6: xyzz add : in: n x (XYZZ | XYZZ),            out: n x XYZZ
  *   op 7: xyzz dbl : in: n x (XYZZ | XYZZ ignored),    out: n x XYZZ
+ *   op 8 / 9: the same add / dbl through the lane-distributed ("quad") point operations the
+ *             latency-bound kernels use (csrc/quad28.h); op 10: k * (second point) with a
+ *             20-bit k derived from the element index, by the quads' double-and-add
  * (limbs are passed as uint32 little-endian; 24/16/96 in and 12/8/48 out per item)
  * on_device = 0 runs the same header code on the host CPU. */
 int curdle_selftest_op(int op, const uint64_t* in, size_t n, uint64_t* out, int on_device);

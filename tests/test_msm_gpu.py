@@ -56,6 +56,16 @@ def test_device_primitives_match_host(gpu, oracle):
     for op in (5, 6, 7):
         arr = group_inputs(oracle, op, cases)
         assert (gpu.selftest_op(op, arr, True) == gpu.selftest_op(op, arr, False)).all(), op
+    # the lane-distributed ("quad") point operations of the latency-bound kernels (quad28.h):
+    # same group elements as the single-lane formulas (coordinates may differ by the
+    # projective scale only where the exceptional branches differ, so compare affine points)
+    from test_host_mirror import xyzz_to_affine
+    cases = cases * 7                                   # several quads per wave, odd count
+    for op, host_op in ((8, 6), (9, 7), (10, 10)):
+        arr = group_inputs(oracle, 6, cases)
+        dev, host = gpu.selftest_op(op, arr, True), gpu.selftest_op(host_op, arr, False)
+        for i in range(len(cases)):
+            assert xyzz_to_affine(oracle, dev[i]) == xyzz_to_affine(oracle, host[i]), (op, i)
 
 
 # -------------------------------------------------------------- golden vectors ---
@@ -85,7 +95,7 @@ def test_segment_lengths(gpu, golden):
     """The accumulate kernel's lane segment length must not change results (fragment
     bookkeeping at every alignment)."""
     try:
-        for L in (8, 9, 13, 32, 128):
+        for L in (4, 5, 8, 9, 13, 32, 128):
             os.environ["CURDLE_SEG_LEN"] = str(L)
             for name in ("rand0_n257", "rand0_n1024", "edge_all_equal_scalars", "edge_small_scalars"):
                 got = gpu.msm_g1(golden[name + "_points"], golden[name + "_scalars"])
@@ -334,7 +344,7 @@ def test_async_submit_wait_and_concurrent_callers(gpu, oracle, coracle):
     for _ in range(3):
         ns = gpu.MSM_SLOTS
         tickets = [gpu.msm_g1_device_submit(d_p[i % 3].data_ptr(), d_s[i % 3].data_ptr(), sizes[i % 3]) for i in range(ns)]
-        assert sorted(tickets) == list(range(ns))
+        assert sorted(t & 0xFF for t in tickets) == list(range(ns))   # one slot each (slot index in the low byte)
         with pytest.raises(gpu.CurdleError) as e:
             gpu.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), sizes[0])
         assert e.value.code == gpu.EBUSY
@@ -342,6 +352,13 @@ def test_async_submit_wait_and_concurrent_callers(gpu, oracle, coracle):
             assert (gpu.msm_wait(tickets[i]) == exp[i % 3]).all(), i
         with pytest.raises(gpu.CurdleError):
             gpu.msm_wait(tickets[0])                # already collected
+        # a stale ticket stays refused when its slot is busy again for another caller
+        fresh = gpu.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), sizes[0])
+        stale = [t for t in tickets if (t & 0xFF) == (fresh & 0xFF)][0]
+        assert stale != fresh
+        with pytest.raises(gpu.CurdleError):
+            gpu.msm_wait(stale)
+        assert (gpu.msm_wait(fresh) == exp[0]).all()
     # a window-range partial submitted asynchronously
     W = gpu.num_windows(sizes[0], 12)
     t1 = gpu.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), sizes[0], window_bits=12, win_begin=0, win_end=W // 2)
