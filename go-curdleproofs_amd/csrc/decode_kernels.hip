@@ -12,6 +12,7 @@
 
 #include "../../include/curdle_msm.h"
 #include "fp28.h"
+#include "quad28.h"
 #include "msm_kernels.h"
 
 namespace curdle {
@@ -81,7 +82,7 @@ __device__ __forceinline__ void to_canonical(u32* w, const F28& a) {
 
 // [z^2] phi(P) + P == inf for the point whose internal-form coordinates are parked in
 // sh_x / sh_y [.][tid] (and passed in x, y); |z| = 0xd201000000010000, the sign cancels in
-// z^2.  QUAD: the four lanes of a quad hold the same point and share every point operation.
+// z^2.  QUAD: the four lanes of a quad hold one coordinate each of every point (quad28.h).
 template <bool QUAD>
 __device__ __forceinline__ bool in_subgroup(F28& x, F28& y, u32 (*sh_x)[kBlock], u32 (*sh_y)[kBlock], u32 tid) {
   F28 c;
@@ -89,32 +90,36 @@ __device__ __forceinline__ bool in_subgroup(F28& x, F28& y, u32 (*sh_x)[kBlock],
 #pragma unroll
   for (int k = 0; k < d28::N; k++) c.l[k] = kBeta(k);
   d28::mul(bx, x, c);
-  X28 q;
-  q.x = bx;
-  q.y = y;
-  d28::set_one(q.zz);
-  d28::set_one(q.zzz);
   const unsigned long long zabs = 0xd201000000010000ull;
-  X28 acc = q;
   if constexpr (QUAD) {
+    // the point lives spread over the quad's four lanes (quad28.h)
+    F28 q, acc;
+    q28::from_affine(q, bx, y);
+    acc = q;
     for (int bit = 62; bit >= 0; bit--) {
-      d28::quad_dbl(acc);
-      if ((zabs >> bit) & 1ull) d28::quad_add(acc, q);
+      q28::dbl(acc);
+      if ((zabs >> bit) & 1ull) q28::add(acc, q);
     }
     q = acc;
     for (int bit = 62; bit >= 0; bit--) {
-      d28::quad_dbl(acc);
-      if ((zabs >> bit) & 1ull) d28::quad_add(acc, q);
+      q28::dbl(acc);
+      if ((zabs >> bit) & 1ull) q28::add(acc, q);
     }
 #pragma unroll
     for (int k = 0; k < d28::N; k++) {
-      q.x.l[k] = sh_x[k][tid];
-      q.y.l[k] = sh_y[k][tid];
+      x.l[k] = sh_x[k][tid];
+      y.l[k] = sh_y[k][tid];
     }
+    q28::from_affine(q, x, y);
+    q28::add(acc, q);
+    return q28::is_inf(acc);
+  } else {
+    X28 q;
+    q.x = bx;
+    q.y = y;
     d28::set_one(q.zz);
     d28::set_one(q.zzz);
-    d28::quad_add(acc, q);
-  } else {
+    X28 acc = q;
     // first multiplication: the addend is affine (mixed additions)
     for (int bit = 62; bit >= 0; bit--) {
       d28::dbl(acc);
@@ -132,13 +137,13 @@ __device__ __forceinline__ bool in_subgroup(F28& x, F28& y, u32 (*sh_x)[kBlock],
       y.l[k] = sh_y[k][tid];
     }
     d28::madd(acc, x, y);
+    return d28::is_inf(acc);
   }
-  return d28::is_inf(acc);
 }
 
 // QUAD: four adjacent lanes per point.  They run the square root redundantly and share the
-// point operations of the subgroup test (fp28.h quad_dbl / quad_add: 3 and 4 product steps
-// instead of 9 and 14), which shortens the per-point chain from ~1,900 to ~1,050 products:
+// point operations of the subgroup test (quad28.h: 3 and 4 product steps per doubling /
+// addition instead of 9 and 14), which shortens the per-point chain from ~1,900 to ~1,050 products:
 // the launch is latency-bound until tens of thousands of points, so small batches use it.
 template <bool QUAD>
 __global__ void __launch_bounds__(kBlock, 2)

@@ -520,118 +520,6 @@ __device__ __forceinline__ void mul_small(X28& r, const X28& p, u32 k) {
 }
 
 // ---------------------------------------------------------------------------
-// Lane-cooperative point arithmetic for the latency-bound phases ("quads").
-//
-// One G1 addition is 14 dependent field products; a wave alone issues a multiply-add
-// only every ~10 cycles, so on one lane that is ~25 us, and the bucket reduction is
-// a chain of ~40 of them.  When a launch has far fewer lanes than the chip, four
-// adjacent lanes (a DPP quad) work on ONE point operation instead: all four hold
-// identical copies of the operands, each computes one of up to four independent
-// products of a step, and the results are exchanged with quad-permute DPP moves
-// (14 per field element, full rate, no LDS).  An addition becomes 4 product steps
-// instead of 14, a doubling 3 instead of 9.  The rare exceptional cases fall back
-// to the single-lane routines, run redundantly by the four lanes.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ u32 quad_rank() { return threadIdx.x & 3u; }
-
-template <int SRC>
-__device__ __forceinline__ void quad_bcast(F28& dst, const F28& src) {
-  constexpr int ctrl = SRC * 0x55;  // quad_perm: every lane of the quad reads lane SRC
-#pragma unroll
-  for (int i = 0; i < N; i++)
-    dst.l[i] = (u32)__builtin_amdgcn_update_dpp((int)src.l[i], (int)src.l[i], ctrl, 0xf, 0xf, true);
-}
-
-// Lane r of the quad computes a_r * b_r; the other three products are computed by
-// its neighbours at the same time.
-__device__ __forceinline__ void quad_mul4(F28& out, const F28& a0, const F28& b0, const F28& a1, const F28& b1,
-                                          const F28& a2, const F28& b2, const F28& a3, const F28& b3) {
-  const u32 r = quad_rank();
-  F28 a, b;
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    a.l[i] = r == 0 ? a0.l[i] : (r == 1 ? a1.l[i] : (r == 2 ? a2.l[i] : a3.l[i]));
-    b.l[i] = r == 0 ? b0.l[i] : (r == 1 ? b1.l[i] : (r == 2 ? b2.l[i] : b3.l[i]));
-  }
-  mul(out, a, b);
-}
-
-// acc += b; acc and b replicated over the quad.  add-2008-s in four product steps.
-__device__ __forceinline__ void quad_add(X28& acc, const X28& b) {
-  if (is_inf(b)) return;
-  if (is_inf(acc)) {
-    acc = b;
-    return;
-  }
-  F28 m, u1, u2, s1, s2, p, r, pp, rr, ppp, q, x3, t0, t1;
-  quad_mul4(m, acc.x, b.zz, b.x, acc.zz, acc.y, b.zzz, b.y, acc.zzz);  // U1 | U2 | S1 | S2
-  quad_bcast<0>(u1, m);
-  quad_bcast<1>(u2, m);
-  quad_bcast<2>(s1, m);
-  quad_bcast<3>(s2, m);
-  sub_raw<4>(p, u2, u1);  // < 6p
-  sub_raw<4>(r, s2, s1);  // < 6p
-  quad_mul4(m, p, p, r, r, acc.zz, b.zz, acc.zzz, b.zzz);  // PP | RR | ZZ1 ZZ2 | ZZZ1 ZZZ2
-  quad_bcast<0>(pp, m);
-  quad_bcast<1>(rr, m);
-  if (is_zero_lt2p(pp)) {  // uniform over the quad
-    add(acc, b);           // equal or opposite points: single-lane routine, four times over
-    return;
-  }
-  // lane 2 still holds ZZ1*ZZ2 in m, lane 3 ZZZ1*ZZZ2
-  F28 keep = m;
-  quad_mul4(m, p, pp, u1, pp, keep, pp, p, pp);  // PPP | Q | ZZ3 | (unused)
-  quad_bcast<0>(ppp, m);
-  quad_bcast<1>(q, m);
-  F28 zz3;
-  quad_bcast<2>(zz3, m);
-  x3_fused(x3, rr, ppp, q);  // X3 < 10p
-  sub_raw<16>(t0, q, x3);    // Q - X3 < 18p
-  quad_mul4(m, r, t0, s1, ppp, r, t0, keep, ppp);  // R (Q - X3) | S1 PPP | (unused) | ZZZ3
-  quad_bcast<0>(t0, m);
-  quad_bcast<1>(t1, m);
-  quad_bcast<3>(acc.zzz, m);
-  sub<4>(acc.y, t0, t1);  // Y3 < 6p
-  acc.x = x3;
-  acc.zz = zz3;
-}
-
-// p = 2p, replicated over the quad.  dbl-2008-s-1 in three product steps.
-__device__ __forceinline__ void quad_dbl(X28& p) {
-  if (is_inf(p)) return;
-  F28 m, u, v, xx, w, s, mm, m3, x3, z, t0, t1;
-  dbl_raw(u, p.y);  // < 12p
-  quad_mul4(m, u, u, p.x, p.x, u, u, p.x, p.x);  // V | XX | (dup) | (dup)
-  quad_bcast<0>(v, m);
-  quad_bcast<1>(xx, m);
-  triple_raw(m3, xx);  // M = 3 X^2 < 6p
-  quad_mul4(m, u, v, p.x, v, m3, m3, u, v);  // W | S | M^2 | (dup)
-  quad_bcast<0>(w, m);
-  quad_bcast<1>(s, m);
-  quad_bcast<2>(mm, m);
-  set_zero(z);
-  x3_fused(x3, mm, z, s);    // < 10p
-  sub_raw<16>(t0, s, x3);    // < 18p
-  quad_mul4(m, m3, t0, w, p.y, v, p.zz, w, p.zzz);  // M (S - X3) | W Y | ZZ3 | ZZZ3
-  quad_bcast<0>(t0, m);
-  quad_bcast<1>(t1, m);
-  quad_bcast<2>(p.zz, m);
-  quad_bcast<3>(p.zzz, m);
-  sub<4>(p.y, t0, t1);  // < 6p
-  p.x = x3;
-}
-
-__device__ __forceinline__ void quad_mul_small(X28& r, const X28& p, u32 k) {
-  set_inf(r);
-  if (k == 0) return;
-  const int top = 31 - __clz(k);
-  for (int bit = top; bit >= 0; bit--) {
-    quad_dbl(r);
-    if ((k >> bit) & 1u) quad_add(r, p);
-  }
-}
-
-// ---------------------------------------------------------------------------
 // Memory: 16-byte vector accesses (an F28 is 56 B, X28 224 B, A28 112 B; arrays
 // of X28 / A28 are 16-B aligned).
 // ---------------------------------------------------------------------------

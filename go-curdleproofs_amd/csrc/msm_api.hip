@@ -24,6 +24,7 @@
 using namespace curdle;
 
 extern "C" void curdle_window_combine(const void* winsums_xyzz, int nw, const int* dbls, uint64_t out[18]);
+extern "C" void curdle_host_batch_to_affine(void* out_affine, const void* in_xyzz, size_t n);
 
 // ---------------------------------------------------------------------------
 // Errors
@@ -425,9 +426,9 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
   if ((rc = ensure(S.winsums, k * (size_t)nw * sizeof(G1XYZZ)))) return rc;
   if (p.gpu_combine) {
     if ((rc = ensure(S.winsums28, k * (size_t)nw * kX28Bytes))) return rc;
-    if ((rc = ensure(S.results, k * 144))) return rc;
+    if ((rc = ensure(S.results, k * sizeof(G1XYZZ)))) return rc;
   }
-  const size_t host_need = (p.gpu_combine ? k * 144 : k * (size_t)nw * sizeof(G1XYZZ)) + (k + 1) * 4;
+  const size_t host_need = (p.gpu_combine ? k * sizeof(G1XYZZ) : k * (size_t)nw * sizeof(G1XYZZ)) + (k + 1) * 4;
   if (S.h_buf_cap < host_need) {
     if (S.h_buf) HIP_TRY(hipHostFree(S.h_buf));
     S.h_buf = nullptr;
@@ -452,7 +453,7 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
   ws.partials = S.partials.p;
   ws.winsums28 = S.winsums28.p;
   ws.winsums = (G1XYZZ*)S.winsums.p;
-  ws.results = (uint64_t*)S.results.p;
+  ws.results = (G1XYZZ*)S.results.p;
 
   // the offsets are staged in pinned memory (tail of h_buf) so the copy is truly asynchronous
   uint32_t* h_off_pinned = (uint32_t*)((char*)S.h_buf + host_need - (k + 1) * 4);
@@ -495,7 +496,7 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
   if (p.gpu_combine) {
     HIP_TRY(launch_combine(p, ws, stream));
     prof.mark("combine");
-    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.results, k * 144, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.results, k * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
   } else {
     HIP_TRY(hipMemcpyAsync(S.h_buf, ws.winsums, k * (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
   }
@@ -525,7 +526,22 @@ int finish_slot(Slot& S, uint64_t* out) {
     L.num_windows = p.W;
   }
   if (p.gpu_combine) {
-    memcpy(out, S.h_buf, k * 144);
+    // the GPU ran the Horner passes; one shared inversion normalises the whole batch
+    std::vector<G1Affine> aff(k);
+    curdle_host_batch_to_affine(aff.data(), S.h_buf, k);
+    for (size_t j = 0; j < k; j++) {
+      G1Jac r;
+      if (g1_affine_is_inf(aff[j])) {
+        f_one(r.x);
+        f_one(r.y);
+        f_zero(r.z);
+      } else {
+        r.x = aff[j].x;
+        r.y = aff[j].y;
+        f_one(r.z);
+      }
+      memcpy(out + 18 * j, &r, sizeof(r));
+    }
     return CURDLE_OK;
   }
   // Window combine on the host: Horner from the top window down, each step shifting
@@ -714,8 +730,6 @@ extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
 // ---------------------------------------------------------------------------
 // Batched independent scalar multiplications (group_kernels.hip)
 // ---------------------------------------------------------------------------
-extern "C" void curdle_host_batch_to_affine(void* out_affine, const void* in_xyzz, size_t n);
-
 extern "C" int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t* scalars, size_t n_scalars,
                                           const uint64_t* addends, size_t n, uint64_t* out_affine) {
   if (n && (!points || !scalars || !out_affine)) return fail(CURDLE_EINVAL, "null argument");

@@ -65,7 +65,7 @@ struct MsmWorkspace {
   void* partials;     // [k * NS / G]      d28::X28, one per group of G bucket-reduce lanes
   void* winsums28;    // [k][nw]           d28::X28 (large batches: combined on the GPU)
   G1XYZZ* winsums;    // [k][nw]   gnark-form XYZZ, canonical coordinates (host combine)
-  uint64_t* results;  // [k][18]   canonical Jacobian results of a batched call
+  G1XYZZ* results;    // [k]       XYZZ results of a batched call, gnark form (normalised by the host)
 };
 
 // Every launcher enqueues on `stream` and returns the launch status.
@@ -78,7 +78,7 @@ hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream
 hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
-// Batched calls only: Horner over each MSM's window sums + normalisation, one lane per MSM.
+// Batched calls only: Horner over each MSM's window sums, one quad per MSM.
 hipError_t launch_combine(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 
 // P_i = p0 + i*Q for i < n (n <= 2^27); d_table holds 27 affine points 2^j * Q.

@@ -618,52 +618,32 @@ __global__ void __launch_bounds__(kBlock, 2)
   write_window_sum(acc, winsums, winsums28, p, j, lw);
 }
 
-// Batched calls: one lane per MSM does what the host does for a single MSM --
-// Horner over the window sums, the 2^shift scaling of a partial, and the
-// normalisation to the canonical Jacobian (x, y, 1) / (1, 1, 0) in gnark form.
-// ~255 doublings + one Fermat inversion per lane; with hundreds of MSMs in
-// flight the serial chain is amortised over the batch.
+// Batched calls: one quad per MSM runs the Horner pass over its window sums (what the host
+// does for a single MSM) and the 2^shift scaling of a partial: ~255 doublings + one
+// addition per window, 3 and 4 product steps each (quad28.h); with hundreds of MSMs in
+// flight the serial chain is amortised over the batch.  The results leave as XYZZ in gnark
+// form; the host normalises the whole batch with ONE shared inversion
+// (curdle_host_batch_to_affine) -- a Fermat inversion here would be another 570-product
+// serial chain per MSM (round 1: 3.7 ms for this kernel, 1.2 ms of it the inversion).
 __global__ void __launch_bounds__(kBlock, 2)
-    k_combine(const X28* __restrict__ winsums28, u64* __restrict__ results, MsmPlan p) {
-  const u32 j = blockIdx.x * kBlock + threadIdx.x;
-  if (j >= p.k) return;
+    k_combine(const X28* __restrict__ winsums28, G1XYZZ* __restrict__ results, MsmPlan p) {
+  const u32 j = blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2);
+  if (j >= p.k) return;  // whole quads leave together
   const u32 nw = p.win_end - p.win_begin;
-  X28 acc, b;
-  d28::set_inf(acc);
+  F28 acc, b;
+  q28::set_inf(acc);
   for (int lw = (int)nw - 1; lw >= 0; lw--) {
-    d28::load(b, &winsums28[(size_t)j * nw + lw]);
-    d28::add(acc, b);
+    q28::load(b, &winsums28[(size_t)j * nw + lw]);
+    q28::add(acc, b);
     const int dbls = lw > 0 ? p.bits[p.win_begin + lw - 1] : p.shift[p.win_begin];
-    if (!d28::is_inf(acc))
-      for (int q = 0; q < dbls; q++) d28::dbl(acc);
+    if (!q28::is_inf(acc))
+      for (int q = 0; q < dbls; q++) q28::dbl(acc);
   }
-  u32 w[36];
-  F28 one;
-  d28::set_one(one);
-  if (d28::is_inf(acc)) {
-    d28::to_gnark(w, one);
-    for (int q = 0; q < 12; q++) {
-      w[12 + q] = w[q];
-      w[24 + q] = 0;
-    }
-  } else {
-    F28 t, inv, izz, izzz, x, y;
-    d28::mul(t, acc.zz, acc.zzz);
-    d28::set_one(inv);
-    for (int bit = 383; bit >= 0; bit--) {
-      d28::sqr(inv, inv);
-      if ((kPminus2[bit >> 5] >> (bit & 31)) & 1u) d28::mul(inv, inv, t);
-    }
-    d28::mul(izz, inv, acc.zzz);
-    d28::mul(izzz, inv, acc.zz);
-    d28::mul(x, acc.x, izz);
-    d28::mul(y, acc.y, izzz);
-    d28::to_gnark(w, x);
-    d28::to_gnark(w + 12, y);
-    d28::to_gnark(w + 24, one);
-  }
-  u32* dst = reinterpret_cast<u32*>(results + (size_t)j * 18);
-  for (int q = 0; q < 36; q++) dst[q] = w[q];
+  u32 w12[12];
+  d28::to_gnark(w12, acc);  // this lane's coordinate; ZZ = 0 (infinity) stays 0
+  u32* dst = reinterpret_cast<u32*>(&results[j]) + 12u * q28::role();
+#pragma unroll
+  for (int i = 0; i < 12; i++) dst[i] = w12[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -787,7 +767,7 @@ hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream
 }
 
 hipError_t launch_combine(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  hipLaunchKernelGGL(k_combine, dim3(cdiv(p.k, kBlock)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(k_combine, dim3(cdiv(p.k, kBlock / 4)), dim3(kBlock), 0, stream,
                      reinterpret_cast<const X28*>(ws.winsums28), ws.results, p);
   return hipGetLastError();
 }
