@@ -73,7 +73,9 @@ struct Slot {
   hipEvent_t acc_done = nullptr;
   hipEvent_t pre_done = nullptr;
   Buf points, scalars, offsets, points28, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials,
-      winsums, winsums28, results;
+      winsums, winsums28, results, job;
+  void* h_stage[2] = {nullptr, nullptr};  // pinned staging of the device accumulator (instance points; job)
+  size_t h_stage_cap[2] = {0, 0};
   void* h_buf = nullptr;  // pinned: window sums (host combine) or results (GPU combine)
   size_t h_buf_cap = 0;
   hipEvent_t ev[CURDLE_PROF_MAX_KERNELS + 1];
@@ -90,7 +92,7 @@ struct Slot {
 
   Buf* all_bufs(int i) {
     Buf* b[] = {&points, &scalars, &offsets, &points28, &counts, &starts, &cursor, &fragcnt, &foff, &small,
-                &digits, &sorted,  &frags,   &partials, &winsums, &winsums28, &results};
+                &digits, &sorted,  &frags,   &partials, &winsums, &winsums28, &results, &job};
     return i < (int)(sizeof(b) / sizeof(b[0])) ? b[i] : nullptr;
   }
 };
@@ -394,7 +396,7 @@ struct Prof {
 // and must stay valid until the matching finish_slot(); h_off has k + 1 entries.
 int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                  int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail,
-                 bool latency_mode = true) {
+                 bool latency_mode = true, bool points28_ready = false) {
   const size_t n = h_off[k];
   size_t n_max = 0;
   for (size_t j = 0; j < k; j++) {
@@ -462,8 +464,10 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
   HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, pre));
   HIP_TRY(hipMemsetAsync(ws.nlarge, 0, 4, pre));
   Prof prof(S, pre, g_ctx.profile);
-  HIP_TRY(launch_convert_points(p, ws, d_points, pre));
-  prof.mark("convert_points");
+  if (!points28_ready) {  // the device accumulator fills S.points28 itself (resident bases: no conversion here)
+    HIP_TRY(launch_convert_points(p, ws, d_points, pre));
+    prof.mark("convert_points");
+  }
   HIP_TRY(launch_digits(p, ws, d_scalars, pre));
   prof.mark("digits");
   HIP_TRY(launch_hist(p, ws, pre));
@@ -801,6 +805,11 @@ extern "C" int curdle_shutdown(void) {
     if (S.h_buf) (void)hipHostFree(S.h_buf);
     S.h_buf = nullptr;
     S.h_buf_cap = 0;
+    for (int q = 0; q < 2; q++) {
+      if (S.h_stage[q]) (void)hipHostFree(S.h_stage[q]);
+      S.h_stage[q] = nullptr;
+      S.h_stage_cap[q] = 0;
+    }
     if (S.ev_made)
       for (auto& e : S.ev) (void)hipEventDestroy(e);
     S.ev_made = false;
@@ -1036,6 +1045,201 @@ extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k,
   rc = body();
   if (rc) drain_slot(S);
   release_slot(idx);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// Accumulator on the device
+// ---------------------------------------------------------------------------
+struct curdle_dbases {
+  void* d28 = nullptr;  // n internal-form points, kA28Bytes apart
+  size_t n = 0;
+};
+struct curdle_dacc {
+  int slot = -1;
+  const curdle_dbases* crs = nullptr;
+  size_t n_inst = 0;
+};
+
+extern "C" int curdle_dbases_create(const uint64_t* points, size_t n, curdle_dbases** out) {
+  if (!out || (n && !points)) return fail(CURDLE_EINVAL, "null argument");
+  *out = nullptr;
+  if (n > ((size_t)1 << 24)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^24 resident bases", n);
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  int rc = init_default_locked();
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  curdle_dbases* b = new (std::nothrow) curdle_dbases();
+  if (!b) return fail(CURDLE_ENOMEM, "out of memory");
+  b->n = n;
+  if (n) {
+    void* tmp = nullptr;
+    hipError_t e = hipMalloc(&b->d28, n * kA28Bytes);
+    if (e == hipSuccess) e = hipMalloc(&tmp, n * 96);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp, points, n * 96, hipMemcpyHostToDevice, g_ctx.util_stream);
+    if (e == hipSuccess) e = launch_convert_points_raw(tmp, (uint32_t)n, b->d28, g_ctx.util_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.util_stream);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) {
+      if (b->d28) (void)hipFree(b->d28);
+      delete b;
+      return fail(e == hipErrorOutOfMemory ? CURDLE_ENOMEM : CURDLE_EHIP, "resident bases: %s", hipGetErrorString(e));
+    }
+  }
+  *out = b;
+  return CURDLE_OK;
+}
+
+extern "C" void curdle_dbases_free(curdle_dbases* b) {
+  if (!b) return;
+  if (b->d28) {
+    std::lock_guard<std::mutex> g(g_ctx.mu);
+    if (g_ctx.inited) {  // after curdle_shutdown the context's memory is gone with it
+      (void)hipSetDevice(g_ctx.device);
+      (void)hipFree(b->d28);
+    }
+  }
+  delete b;
+}
+
+extern "C" size_t curdle_dbases_size(const curdle_dbases* b) { return b ? b->n : 0; }
+
+namespace {
+int ensure_pinned(Slot& S, int which, size_t bytes) {
+  if (S.h_stage_cap[which] >= bytes) return CURDLE_OK;
+  if (S.h_stage[which]) HIP_TRY(hipHostFree(S.h_stage[which]));
+  S.h_stage[which] = nullptr;
+  S.h_stage_cap[which] = 0;
+  HIP_TRY(hipHostMalloc(&S.h_stage[which], bytes + bytes / 4 + 4096, hipHostMallocDefault));
+  S.h_stage_cap[which] = bytes + bytes / 4 + 4096;
+  return CURDLE_OK;
+}
+}  // namespace
+
+extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_points, size_t n_inst, curdle_dacc** out) {
+  if (!crs || !out || (n_inst && !inst_points)) return fail(CURDLE_EINVAL, "null argument");
+  *out = nullptr;
+  if (crs->n + n_inst + CURDLE_DACC_MAX_EXTRA > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "too many bases");
+  int idx;
+  int rc = acquire_slot(true, &idx);
+  if (rc) return rc;
+  Slot& S = g_ctx.slots[idx];
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    const size_t cap = crs->n + n_inst + CURDLE_DACC_MAX_EXTRA;
+    int r;
+    // sized for the whole accumulation now: the MSM pipeline's own ensure() must not move them later
+    if ((r = ensure(S.points28, cap * kA28Bytes))) return r;
+    if ((r = ensure(S.scalars, cap * 32))) return r;
+    if ((r = ensure(S.points, (n_inst + CURDLE_DACC_MAX_EXTRA) * 96))) return r;
+    if ((r = ensure_pinned(S, 0, n_inst * 96))) return r;
+    if (crs->n)
+      HIP_TRY(hipMemcpyAsync(S.points28.p, crs->d28, crs->n * kA28Bytes, hipMemcpyDeviceToDevice, S.stream));
+    if (n_inst) {
+      memcpy(S.h_stage[0], inst_points, n_inst * 96);  // pinned: the copy below is truly asynchronous
+      HIP_TRY(hipMemcpyAsync(S.points.p, S.h_stage[0], n_inst * 96, hipMemcpyHostToDevice, S.stream));
+      HIP_TRY(launch_convert_points_raw(S.points.p, (uint32_t)n_inst, (char*)S.points28.p + crs->n * kA28Bytes, S.stream));
+    }
+    return CURDLE_OK;
+  };
+  rc = body();
+  if (rc) {
+    (void)hipStreamSynchronize(S.stream);
+    release_slot(idx);
+    return rc;
+  }
+  curdle_dacc* a = new (std::nothrow) curdle_dacc();
+  if (!a) {
+    (void)hipStreamSynchronize(S.stream);
+    release_slot(idx);
+    return fail(CURDLE_ENOMEM, "out of memory");
+  }
+  a->slot = idx;
+  a->crs = crs;
+  a->n_inst = n_inst;
+  *out = a;
+  return CURDLE_OK;
+}
+
+extern "C" void curdle_dacc_abort(curdle_dacc* acc) {
+  if (!acc) return;
+  (void)hipSetDevice(g_ctx.device);
+  (void)hipStreamSynchronize(g_ctx.slots[acc->slot].stream);
+  release_slot(acc->slot);
+  delete acc;
+}
+
+extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
+                               size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars,
+                               size_t n_extra, uint64_t out_jac[18], uint64_t* export_scalars) {
+  if (!acc) return fail(CURDLE_EINVAL, "null accumulator");
+  const int idx = acc->slot;
+  Slot& S = g_ctx.slots[idx];
+  const size_t n_crs = acc->crs->n, n_inst = acc->n_inst, n_res = n_crs + n_inst, n = n_res + n_extra;
+  auto body = [&]() -> int {
+    if (!out_jac || (n_checks && !checks) || (pool_len && !pool) || (n_extra && (!extra_points || !extra_scalars)))
+      return fail(CURDLE_EINVAL, "null argument");
+    if (n_extra > CURDLE_DACC_MAX_EXTRA) return fail(CURDLE_EINVAL, "%zu loose bases exceed CURDLE_DACC_MAX_EXTRA", n_extra);
+    // the descriptions come from the caller: every offset is checked before a kernel reads through it
+    for (size_t c = 0; c < n_checks; c++) {
+      const curdle_dacc_check& k = checks[c];
+      if (k.kind > CURDLE_VEC_FOLD_POW || k.nseg > CURDLE_DACC_MAX_SEGS || k.m > 31)
+        return fail(CURDLE_EINVAL, "check %zu: malformed description", c);
+      if (k.weight_off >= pool_len || k.alpha_off >= pool_len || (size_t)k.tail_off + k.n_tail > pool_len ||
+          (k.kind >= CURDLE_VEC_FOLD && (size_t)k.gammas_off + k.m > pool_len) ||
+          (k.kind == CURDLE_VEC_FOLD_POW && k.q_off >= pool_len))
+        return fail(CURDLE_EINVAL, "check %zu: offset outside the pool", c);
+      if (k.kind >= CURDLE_VEC_FOLD && k.n_struct > ((uint64_t)1 << k.m))
+        return fail(CURDLE_EINVAL, "check %zu: more structured elements than 2^m", c);
+      for (uint32_t s = 0; s < k.nseg; s++) {
+        const size_t set_n = k.seg[s].set == CURDLE_SET_CRS ? n_crs : n_inst;
+        if (k.seg[s].set > CURDLE_SET_INST || (size_t)k.seg[s].first + k.seg[s].len > set_n ||
+            (size_t)k.seg[s].vec_first + k.seg[s].len > (size_t)k.n_struct + k.n_tail)
+          return fail(CURDLE_EINVAL, "check %zu: segment %u out of range", c, s);
+      }
+    }
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    if (n == 0) {
+      set_out_infinity(out_jac);
+      return CURDLE_OK;
+    }
+    // one pinned block: checks | pool | extra points | extra scalars
+    const size_t o_pool = (n_checks * sizeof(curdle_dacc_check) + 31) & ~(size_t)31;
+    const size_t o_xp = o_pool + pool_len * 32;
+    const size_t o_xs = o_xp + n_extra * 96;
+    const size_t bytes = o_xs + n_extra * 32;
+    int r;
+    if ((r = ensure_pinned(S, 1, bytes + n_res * 32))) return r;
+    if ((r = ensure(S.job, bytes))) return r;
+    char* h = (char*)S.h_stage[1];
+    if (n_checks) memcpy(h, checks, n_checks * sizeof(curdle_dacc_check));
+    if (pool_len) memcpy(h + o_pool, pool, pool_len * 32);
+    if (n_extra) {
+      memcpy(h + o_xp, extra_points, n_extra * 96);
+      memcpy(h + o_xs, extra_scalars, n_extra * 32);
+    }
+    hipStream_t st = S.stream;
+    HIP_TRY(hipMemcpyAsync(S.job.p, h, bytes, hipMemcpyHostToDevice, st));
+    char* dj = (char*)S.job.p;
+    if (n_extra) {
+      HIP_TRY(launch_convert_points_raw(dj + o_xp, (uint32_t)n_extra, (char*)S.points28.p + n_res * kA28Bytes, st));
+      HIP_TRY(hipMemcpyAsync((char*)S.scalars.p + n_res * 32, dj + o_xs, n_extra * 32, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(launch_dacc_scalars(dj, (uint32_t)n_checks, dj + o_pool, (uint32_t)n_crs, (uint32_t)n_inst, S.scalars.p, st));
+    if (export_scalars && n_res)
+      HIP_TRY(hipMemcpyAsync(h + bytes, S.scalars.p, n_res * 32, hipMemcpyDeviceToHost, st));
+    const uint32_t off[2] = {0, (uint32_t)n};
+    if ((r = enqueue_slot(S, nullptr, S.scalars.p, off, 1, 0, 0, -1, st, st, st, /*latency_mode=*/true,
+                          /*points28_ready=*/true)))
+      return r;
+    if ((r = finish_slot(S, out_jac))) return r;
+    if (export_scalars && n_res) memcpy(export_scalars, h + bytes, n_res * 32);
+    return CURDLE_OK;
+  };
+  int rc = body();
+  if (rc) (void)hipStreamSynchronize(S.stream);
+  release_slot(idx);
+  delete acc;
   return rc;
 }
 

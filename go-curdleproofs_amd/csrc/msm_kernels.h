@@ -70,6 +70,9 @@ struct MsmWorkspace {
 
 // Every launcher enqueues on `stream` and returns the launch status.
 hipError_t launch_convert_points(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream);
+// n gnark affine points -> internal form at d_out28 (kA28Bytes apart), outside a plan: the device accumulator
+// converts its resident base sets once and per-verification points as they arrive.
+hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_out28, hipStream_t stream);
 hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);
 hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
@@ -97,6 +100,10 @@ hipError_t launch_g1_subgroup_check(const uint32_t* points, uint32_t n, uint8_t*
 // group_kernels.hip: out[i] = addends[i] + scalars[i or 0] * points[i] as gnark-format XYZZ
 // (ZZ = 0 for infinity); points / addends gnark affine (addends may be null), scalars
 // Montgomery fr.Elements.
+// dacc_kernels.hip: the slot scalars of the device accumulator (checks: curdle_dacc_check[], pool: fr.Elements).
+hipError_t launch_dacc_scalars(const void* d_checks, uint32_t n_checks, const void* d_pool, uint32_t n_crs, uint32_t n_inst,
+                               void* d_out, hipStream_t stream);
+
 hipError_t launch_scalar_mul_batch(const void* points, const void* scalars, int shared_scalar, const void* addends,
                                    uint32_t n, void* out_xyzz, hipStream_t stream);
 

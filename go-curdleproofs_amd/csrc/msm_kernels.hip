@@ -714,6 +714,13 @@ hipError_t launch_convert_points(const MsmPlan& p, const MsmWorkspace& ws, const
   return hipGetLastError();
 }
 
+hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_out28, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_convert_points, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const uint4*>(d_points), n, reinterpret_cast<A28*>(d_out28));
+  return hipGetLastError();
+}
+
 hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
   const u32 nb = p.k * p.NB;

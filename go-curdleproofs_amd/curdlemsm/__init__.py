@@ -60,6 +60,9 @@ SYMBOLS = [
     "curdle_whisk_is_valid_tracker_proof", "curdle_whisk_generate_tracker_proof", "curdle_proof_reencode", "curdle_merlin_test_vector", "curdle_g1_decompress_batch", "curdle_g1_decompress_begin", "curdle_g1_decompress_finish",
     "curdle_g1_scalar_mul_batch",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error", "curdle_fr_inner_product",
+    "curdle_dbases_create", "curdle_dbases_free", "curdle_dbases_size",
+    "curdle_dacc_begin", "curdle_dacc_run", "curdle_dacc_abort",
+    "curdle_verify_set_device_acc", "curdle_verify_export_accumulator",
 ]
 
 _u64p = C.POINTER(C.c_uint64)
@@ -575,6 +578,31 @@ def whisk_generate_tracker_proof(tracker: bytes, k, rand: Rand) -> bytes:
     out = np.zeros(WHISK_TRACKER_PROOF_SIZE, dtype=np.uint8)
     _check(_whisk_gen_tracker(_ptr(t), _ptr(kk), rand._h, _ptr(out)))
     return out.tobytes()
+
+
+_set_dev_acc = _sig("curdle_verify_set_device_acc", C.c_int, C.c_int)
+_export_acc = _sig("curdle_verify_export_accumulator", C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_int,
+                   _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int))
+
+
+def verify_set_device_acc(on: bool) -> bool:
+    """Keep curdleproof.Verify's accumulator on the device (default) or on the host mirror;
+    returns the previous setting."""
+    return bool(_set_dev_acc(1 if on else 0))
+
+
+def verify_export_accumulator(crs: "CRS", proof: "Proof", Rs, Ss, Ts, Us, M, rand: "Rand", device: bool):
+    """(points[n, 12], scalars[n, 4], accept) accumulated by one verification before its final
+    MSM, from the host mirror (device=False) or the device accumulator (device=True)."""
+    Rs, Ss, Ts, Us = (_as_u64(a, 12) for a in (Rs, Ss, Ts, Us))
+    M = _as_u64(M)
+    cap = 6 * crs.ell + 8192
+    pts = np.zeros((cap, 12), dtype=np.uint64)
+    sc = np.zeros((cap, 4), dtype=np.uint64)
+    n, ok = C.c_size_t(0), C.c_int(0)
+    _check(_export_acc(crs._h, proof._h, _ptr(Rs), _ptr(Ss), _ptr(Ts), _ptr(Us), crs.ell, _ptr(M), rand._h,
+                       1 if device else 0, _ptr(pts), _ptr(sc), cap, C.byref(n), C.byref(ok)))
+    return pts[: n.value].copy(), sc[: n.value].copy(), bool(ok.value)
 
 
 def verify_set_eager(eager: bool) -> bool:

@@ -195,6 +195,34 @@ void Point::Compressed(uint8_t out[48]) const {
   if (y_is_larger(a.y)) out[0] |= 0x20;
 }
 
+void CompressAffine(const G1Affine& a, uint8_t out[48]) {
+  if (g1_affine_is_inf(a)) {
+    memset(out, 0, 48);
+    out[0] = 0xc0;
+    return;
+  }
+  Fp xc;
+  FpFromMontImpl(xc, a.x);
+  for (int i = 0; i < 12; i++) {
+    u32 w = xc.l[11 - i];
+    out[4 * i] = (uint8_t)(w >> 24);
+    out[4 * i + 1] = (uint8_t)(w >> 16);
+    out[4 * i + 2] = (uint8_t)(w >> 8);
+    out[4 * i + 3] = (uint8_t)w;
+  }
+  out[0] |= 0x80;
+  if (y_is_larger(a.y)) out[0] |= 0x20;
+}
+
+FixedBase::FixedBase(const G1Affine& p) : table_(32 * 255) { curdle_host_fixed_base_table(table_.data(), &p); }
+Point FixedBase::Mul(const Scalar& k) const {
+  u32 kc[8];
+  k.Canonical(kc);
+  Point r;
+  curdle_host_fixed_base_mul(&r.p, table_.data(), kc);
+  return r;
+}
+
 bool Point::FromCompressed(const uint8_t in[48], Point* out, bool subgroup_check) {
   const uint8_t flags = in[0] & 0xe0;
   if (!(flags & 0x80)) return false;  // only the compressed form is used on this wire

@@ -116,6 +116,20 @@ struct Point {
 
 std::vector<G1Affine> BatchToAffine(const std::vector<Point>& pts);   // BatchJacobianToAffineG1
 
+// gnark G1Affine.Bytes() of an affine point without the round trip through Point: two
+// Montgomery reductions (x to canonical bytes, y for the sign bit).
+void CompressAffine(const G1Affine& a, uint8_t out[48]);
+
+// k * P for a base that never changes (CRS points): 8-bit windows precomputed once, then at
+// most 32 mixed additions per multiplication instead of ~255 doublings + 64 additions.
+class FixedBase {
+ public:
+  explicit FixedBase(const G1Affine& p);
+  Point Mul(const Scalar& k) const;
+ private:
+  std::vector<G1Affine> table_;  // 32 x 255
+};
+
 // common.MultiExp: every MSM of the protocol code funnels through
 // here and runs on the GPU (curdle_msm_g1).  Throws std::runtime_error on a length
 // mismatch or a device error, with the Go error text.

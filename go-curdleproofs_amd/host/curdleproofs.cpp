@@ -2,6 +2,7 @@
 // Each function cites the reference lines it restates (paths relative to
 // /root/reference).  Transcript labels are those of SURVEY.md appendix A.
 #include "curdleproofs.h"
+#include "device_accumulator.h"
 #include "verify_batch_impl.h"
 
 #include <stdlib.h>
@@ -62,29 +63,8 @@ std::atomic<int>& EagerFlag() {
 }
 bool EagerChecks() { return EagerFlag().load(std::memory_order_relaxed) != 0; }
 
-struct Terms {
-  std::vector<Scalar> s;
-  std::vector<G1Affine> p;
-  void Add(const Scalar& k, const Point& pt) {
-    s.push_back(k);
-    p.push_back(pt.Affine());
-  }
-  void Add(const std::vector<Scalar>& ks, const std::vector<Point>& pts) {
-    for (size_t i = 0; i < pts.size(); i++) Add(ks[i], pts[i]);
-  }
-  // the eager value: one MSM on the GPU
-  Point Eval() const { return alg::MultiExp(p, s); }
-};
-
-void Accumulate(MsmAccumulator& acc, const Terms& C, const std::vector<Scalar>& x, const std::vector<G1Affine>& v,
-                common::Rand& rand, const char* what) {
-  if (EagerChecks()) return Accumulate(acc, C.Eval(), x, v, rand, what);
-  std::vector<Fr> xs(x.size()), cs(C.s.size());
-  for (size_t i = 0; i < x.size(); i++) xs[i] = x[i].v;
-  for (size_t i = 0; i < cs.size(); i++) cs[i] = C.s[i].v;
-  msmaccumulator::Status st = acc.AccumulateCheckDeferred(cs, C.p, xs, v, &rand);
-  if (!st.ok) throw err(std::string(what) + ": " + st.err);
-}
+// The eager value of a check point: one MSM on the GPU.
+Point EvalTerms(const Terms& t) { return alg::MultiExp(t.p, t.s); }
 
 template <class T>
 std::vector<T> Concat(const std::vector<T>& a, const std::vector<T>& b) {
@@ -120,6 +100,81 @@ const G1Affine kZeroPoint = [] {
 }  // namespace
 
 int SetEagerChecks(int eager) { return EagerFlag().exchange(eager ? 1 : 0); }
+
+// ================================================= deferred-check descriptions =====
+Scalar VecExpr::At(size_t i) const {
+  if (i >= n_struct) return tail.at(i - n_struct);
+  if (kind == kConst) return scale;
+  Scalar v = scale;
+  const size_t m = gammas.size();
+  for (size_t j = 0; j < m; j++)
+    if ((i >> j) & 1u) v = v * gammas[m - 1 - j];
+  if (kind == kFoldPow) v = v * q.Pow((i < q_cap ? i : q_cap) + 1);
+  return v;
+}
+
+std::vector<Scalar> VecExpr::Materialise() const {
+  std::vector<Scalar> out(size());
+  if (kind == kConst) {
+    for (size_t i = 0; i < n_struct; i++) out[i] = scale;
+  } else if (kind == kFold || kind == kFoldPow) {
+    // index i with top bit j extends index i - 2^j: n products instead of n m / 2
+    const size_t m = gammas.size();
+    if (n_struct) out[0] = scale;
+    for (size_t j = 0; j < m; j++)
+      for (size_t i = (size_t)1 << j; i < ((size_t)2 << j) && i < n_struct; i++)
+        out[i] = out[i - ((size_t)1 << j)] * gammas[m - j - 1];
+    if (kind == kFoldPow) {
+      Scalar qi = q;  // q^(i+1)
+      for (size_t i = 0; i < n_struct; i++) {
+        out[i] = out[i] * qi;
+        if (i < q_cap) qi = qi * q;
+      }
+    }
+  }
+  for (size_t i = 0; i < tail.size(); i++) out[n_struct + i] = tail[i];
+  return out;
+}
+
+MirrorSink::MirrorSink(MsmAccumulator& acc, const CRS& crs, const std::vector<G1Affine>& Rs,
+                       const std::vector<G1Affine>& Ss, const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us)
+    : acc_(acc), crs_(crs.Gs), inst_{&Rs, &Ss, &Ts, &Us}, ell_(crs.Gs.size()) {
+  crs_.insert(crs_.end(), crs.Hs.begin(), crs.Hs.end());
+  crs_.push_back(AffineOf(crs.H));
+  crs_.push_back(AffineOf(crs.Gt));
+  crs_.push_back(AffineOf(crs.Gu));
+}
+
+void MirrorSink::Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs,
+                       const std::vector<LooseBase>& loose, common::Rand& rand, const char* what) {
+  // rebuild the reference's (x, v) pair: v[i] is the base x[i] multiplies, the point at
+  // infinity where the description names none (curdleproof.go:281,285)
+  const std::vector<Scalar> xv = x.Materialise();
+  std::vector<G1Affine> v(xv.size(), kZeroPoint);
+  for (const BaseSeg& sg : segs)
+    for (uint32_t j = 0; j < sg.len; j++) {
+      const uint32_t slot = sg.first + j;
+      if (sg.vec_first + j >= v.size()) throw err(std::string(what) + ": base segment beyond the scalar vector");
+      if (sg.set == kSetCrs) {
+        v[sg.vec_first + j] = crs_.at(slot);
+      } else {
+        if (slot >= 4 * ell_) throw err(std::string(what) + ": instance slot out of range");
+        v[sg.vec_first + j] = inst_[slot / ell_]->at(slot % ell_);
+      }
+    }
+  for (const LooseBase& lb : loose) v.at(lb.index) = lb.point;
+  std::vector<Fr> xs(xv.size());
+  for (size_t i = 0; i < xv.size(); i++) xs[i] = xv[i].v;
+  msmaccumulator::Status st;
+  if (EagerChecks()) {
+    st = acc_.AccumulateCheckXYZZ(EvalTerms(C).p, xs, v, &rand);
+  } else {
+    std::vector<Fr> cs(C.s.size());
+    for (size_t i = 0; i < cs.size(); i++) cs[i] = C.s[i].v;
+    st = acc_.AccumulateCheckDeferred(cs, C.p, xs, v, &rand);
+  }
+  if (!st.ok) throw err(std::string(what) + ": " + st.err);
+}
 
 // =========================================================== wire format =====
 void Writer::PutPoint(const Point& p) {
@@ -274,6 +329,9 @@ CRS GenerateCRS(size_t size, common::Rand& rand) {
   for (const auto& h : crs.Hs) hs = hs + Point::FromAffine(h);
   crs.Gsum = gs.Affine();
   crs.Hsum = hs.Affine();
+  crs.GsumTable = std::make_shared<const alg::FixedBase>(crs.Gsum);
+  crs.HsumTable = std::make_shared<const alg::FixedBase>(crs.Hsum);
+  crs.device = std::make_shared<DeviceCrs>();
   return crs;
 }
 
@@ -326,30 +384,33 @@ Proof Prove(const Point& Gt, const Point& Gu, const Point& H, const Point& R, co
 }
 
 bool Verify(const Proof& proof, const Point& Gt, const Point& Gu, const Point& H, const Point& R, const Point& S,
-            const GroupCommitment& T, const GroupCommitment& U, Transcript& tr, MsmAccumulator* acc,
-            common::Rand* rand) {
+            const GroupCommitment& T, const GroupCommitment& U, Transcript& tr, CheckSink* sink, common::Rand* rand,
+            size_t ell) {
   // samescalarargument.go:83-100
   AppendStatement(tr, R, S, T, U, proof.A, proof.B);
   const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
-  if (acc && rand && !EagerChecks()) {
+  if (sink && rand && !EagerChecks()) {
     // The reference evaluates both sides of  A + alpha T == Com(Z_k R; Z_t)  and
     // B + alpha U == Com(Z_k S; Z_u)  (ten scalar multiplications) and compares.  Each of
     // the four coordinate equations is "a combination of known points equals an MSM", which
     // is what the accumulator batches: hand them over like every other check, so they ride
     // in the verification's one MSM.  Sound for the same reason the other checks are
     // (a fresh random weight each); rejects surface at the final MSM instead of here.
-    auto check = [&](const Point& lhs0, const Point& lhs1, std::vector<Scalar> x, std::vector<G1Affine> v,
-                     const char* what) {
+    // Gt, Gu and H are the CRS's (resident bases, addressed by index); R and S are proof points.
+    const CrsIndex ix{ell};
+    auto check = [&](const Point& lhs0, const Point& lhs1, std::vector<Scalar> x, std::vector<BaseSeg> segs,
+                     std::vector<LooseBase> loose, const char* what) {
       Terms c;
       c.Add(Scalar::One(), lhs0);
       c.Add(alpha, lhs1);
-      Accumulate(*acc, c, x, v, *rand, what);
+      sink->Check(c, VecExpr::Explicit(std::move(x)), segs, loose, *rand, what);
     };
-    const G1Affine h = H.Affine();
-    check(proof.A.T_1, T.T_1, {proof.Z_t}, {Gt.Affine()}, "same scalar check A.T_1");
-    check(proof.A.T_2, T.T_2, {proof.Z_k, proof.Z_t}, {R.Affine(), h}, "same scalar check A.T_2");
-    check(proof.B.T_1, U.T_1, {proof.Z_u}, {Gu.Affine()}, "same scalar check B.T_1");
-    check(proof.B.T_2, U.T_2, {proof.Z_k, proof.Z_u}, {S.Affine(), h}, "same scalar check B.T_2");
+    check(proof.A.T_1, T.T_1, {proof.Z_t}, {{kSetCrs, ix.Gt(), 1, 0}}, {}, "same scalar check A.T_1");
+    check(proof.A.T_2, T.T_2, {proof.Z_k, proof.Z_t}, {{kSetCrs, ix.H(), 1, 1}}, {{0, R.Affine()}},
+          "same scalar check A.T_2");
+    check(proof.B.T_1, U.T_1, {proof.Z_u}, {{kSetCrs, ix.Gu(), 1, 0}}, {}, "same scalar check B.T_1");
+    check(proof.B.T_2, U.T_2, {proof.Z_k, proof.Z_u}, {{kSetCrs, ix.H(), 1, 1}}, {{0, S.Affine()}},
+          "same scalar check B.T_2");
     return true;
   }
   const GroupCommitment e1 = GroupCommitment::New(Gt, H, R.Mul(proof.Z_k), proof.Z_t);
@@ -481,22 +542,22 @@ Proof Prove(std::vector<G1Affine> Gs, std::vector<G1Affine> Gs_prime, const Poin
   return proof;
 }
 
-bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const Point& Hcrs, const Point& C, const Point& D,
-            const Scalar& z, const std::vector<Scalar>& us, Transcript& tr, MsmAccumulator& acc,
-            common::Rand& rand) {
-  // innerproductargument.go:190-297
+bool Verify(const Proof& proof, size_t ell, const Point& Hcrs, const Point& C, const Point& D, const Scalar& z,
+            const Scalar& u_q, Transcript& tr, CheckSink& sink, common::Rand& rand) {
+  // innerproductargument.go:190-297.  The bases are the CRS's Gs | Hs (n = ell + 4 of them,
+  // resident, addressed by index) and H; the vector us of the reference is u_i = u_q^(min(i,
+  // ell) + 1) (grandproductargument.go:234-242), handed over as that description.
   tr.AppendPoints(kStep1, {C, D});
   tr.AppendScalar(kStep1, z);
   tr.AppendPoints(kStep1, {proof.B_c, proof.B_d});
   const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
   Scalar beta = tr.GetAndAppendChallenge(kBeta);
 
-  const size_t n = Gs.size();
+  const size_t n = ell + N_BLINDERS;
   const int m = Log2Exact(n, "ipa n");
   if ((int)proof.L_Cs.size() != m || (int)proof.R_Cs.size() != m || (int)proof.L_Ds.size() != m ||
       (int)proof.R_Ds.size() != m)
     throw err("ipa proof has the wrong number of rounds");
-  if (us.size() != n) throw err("ipa us has the wrong length");
 
   std::vector<Scalar> gamma;
   for (int i = 0; i < m; i++) {  // :215-219
@@ -504,15 +565,10 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const Point& Hc
     gamma.push_back(tr.GetAndAppendChallenge(kGamma));
   }
   const std::vector<Scalar> gamma_inv = alg::BatchInvert(gamma);
+  const CrsIndex ix{ell};
 
-  // s_i = prod_{j : bit j of i set} gamma_{m-j-1}, s'_i likewise over the inverses (:223-234);
-  // built by doubling -- index i with top bit j extends index i - 2^j -- n products instead of n m / 2
-  std::vector<Scalar> s(n, Scalar::One()), s_prime(n, Scalar::One());
-  for (int j = 0; j < m; j++)
-    for (size_t i = (size_t)1 << j; i < ((size_t)2 << j); i++) {
-      s[i] = s[i - ((size_t)1 << j)] * gamma[m - j - 1];
-      s_prime[i] = s_prime[i - ((size_t)1 << j)] * gamma_inv[m - j - 1];
-    }
+  // s_i = prod_{j : bit j of i set} gamma_{m-j-1}, s'_i likewise over the inverses (:223-234):
+  // VecExpr::Fold -- n products by doubling on the host mirror, one lane per i on the device.
 
   // accumulate check 1 (:237-271): AC1 = <gamma, L_C> + B_c + alpha C + (beta alpha^2 z) H + <gamma^-1, R_C>
   Terms AC1;
@@ -521,13 +577,14 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const Point& Hc
   AC1.Add(alpha, C);
   AC1.Add(beta * alpha * alpha * z, Hcrs);
   AC1.Add(gamma_inv, proof.R_Cs);
-  std::vector<G1Affine> GplusH(Gs);
-  GplusH.push_back(AffineOf(Hcrs));
-  std::vector<Scalar> scalars(n + 1);
-  for (size_t i = 0; i < n; i++) scalars[i] = s[i] * proof.c0;
   beta = beta * proof.d0 * proof.c0;
-  scalars[n] = beta;
-  Accumulate(acc, AC1, scalars, GplusH, rand, "accumulate check 1");
+  {
+    // x = (s_0 c0, ..., s_{n-1} c0, beta d0 c0) against Gs | Hs | H
+    VecExpr x = VecExpr::Fold(gamma, proof.c0, n + 1);
+    x.tail.push_back(beta);
+    sink.Check(AC1, x, {{kSetCrs, ix.G(0), (uint32_t)n, 0}, {kSetCrs, ix.H(), 1, (uint32_t)n}}, {}, rand,
+               "accumulate check 1");
+  }
 
   // accumulate check 2 (:273-294)
   Terms AC2;  // <gamma, L_D> + B_d + alpha D + <gamma^-1, R_D>
@@ -535,9 +592,9 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const Point& Hc
   AC2.Add(Scalar::One(), proof.B_d);
   AC2.Add(alpha, D);
   AC2.Add(gamma_inv, proof.R_Ds);
-  std::vector<Scalar> scalars2(n);
-  for (size_t i = 0; i < n; i++) scalars2[i] = s_prime[i] * us[i] * proof.d0;
-  Accumulate(acc, AC2, scalars2, Gs, rand, "accumulate check 2");
+  // x_i = s'_i u_i d0 against Gs | Hs
+  sink.Check(AC2, VecExpr::FoldPow(gamma_inv, proof.d0, u_q, ell, n), {{kSetCrs, ix.G(0), (uint32_t)n, 0}}, {}, rand,
+             "accumulate check 2");
   return true;
 }
 
@@ -645,11 +702,10 @@ Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, co
   return proof;
 }
 
-bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H,
-            const G1Affine& Gsum, const G1Affine& Hsum, const Point& B, const Scalar& result, int numBlinders,
-            Transcript& tr, MsmAccumulator& acc, common::Rand& rand) {
+bool Verify(const Proof& proof, const CRS& crs, const Point& B, const Scalar& result, Transcript& tr, CheckSink& sink,
+            common::Rand& rand) {
   // grandproductargument.go:206-286
-  const size_t ell = Gs.size();
+  const size_t ell = crs.Gs.size();
   tr.AppendPoint(kStep1, B);
   tr.AppendScalar(kStep1, result);
   const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
@@ -658,20 +714,18 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const std::vect
   const Scalar beta = tr.GetAndAppendChallenge(kBeta);
   if (beta.IsZero()) throw err("beta is zero");
 
+  // us_i = beta^-(i+1) for i < ell, beta^-(ell+1) for the blinder positions (:234-242): the
+  // inner-product verifier takes the description (u_q = beta^-1), not the vector.
   const Scalar betaInv = beta.Inverse();
-  std::vector<Scalar> us(ell + numBlinders);
-  Scalar bi = betaInv;
-  for (size_t i = 0; i < ell; i++) {  // :234-242
-    us[i] = bi;
-    bi = bi * betaInv;
-  }
-  for (size_t i = ell; i < us.size(); i++) us[i] = bi;
-  const Point D = B - Point::FromAffine(Gsum).Mul(betaInv) + Point::FromAffine(Hsum).Mul(alpha);  // :243-246
+  // D = B - beta^-1 Gsum + alpha Hsum (:243-246): Gsum and Hsum never change, so the two scalar
+  // multiplications go through the CRS's fixed-base tables (32 mixed additions each)
+  const Point gs = crs.GsumTable ? crs.GsumTable->Mul(betaInv) : Point::FromAffine(crs.Gsum).Mul(betaInv);
+  const Point hs = crs.HsumTable ? crs.HsumTable->Mul(alpha) : Point::FromAffine(crs.Hsum).Mul(alpha);
+  const Point D = B - gs + hs;
 
-  const std::vector<G1Affine> G_full = Concat(Gs, Hs);
   const Scalar betaExpL = beta.Pow(ell);
   const Scalar z = result * betaExpL + proof.Rp * (betaExpL * beta) - Scalar::One();  // :253-260
-  return ipa::Verify(proof.IPAProof, G_full, H, proof.C, D, z, us, tr, acc, rand);
+  return ipa::Verify(proof.IPAProof, ell, crs.H, proof.C, D, z, betaInv, tr, sink, rand);
 }
 
 void Proof::Serialize(Writer& w) const {  // :304-318
@@ -717,10 +771,10 @@ Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, co
   return proof;
 }
 
-bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H,
-            const G1Affine& Gsum, const G1Affine& Hsum, const Point& A, const Point& M, const std::vector<Scalar>& as,
-            int numBlinders, Transcript& tr, MsmAccumulator& acc, common::Rand& rand) {
+bool Verify(const Proof& proof, const CRS& crs, const Point& A, const Point& M, const std::vector<Scalar>& as,
+            Transcript& tr, CheckSink& sink, common::Rand& rand) {
   // samepermutationargument.go:103-164
+  const size_t ell = crs.Gs.size();
   tr.AppendPoints(kStep1, {A, M});
   tr.AppendScalars(kStep1, as);
   const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
@@ -728,13 +782,14 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const std::vect
 
   Scalar p = Scalar::One();
   for (size_t i = 0; i < as.size(); i++) p = p * (Scalar::FromU64(i) * alpha + beta + as[i]);  // :125-130
-  const std::vector<Scalar> betas(Gs.size(), beta);
   Terms C;  // proof.B - A - alpha M, :136-139
   C.Add(Scalar::One(), proof.B);
   C.Add(-Scalar::One(), A);
   C.Add(-alpha, M);
-  Accumulate(acc, C, betas, Gs, rand, "failed to accumulate check");  // :140
-  return gprod::Verify(proof.gpaProof, Gs, Hs, H, Gsum, Hsum, proof.B, p, numBlinders, tr, acc, rand);
+  const CrsIndex ix{ell};
+  sink.Check(C, VecExpr::Const(beta, ell), {{kSetCrs, ix.G(0), (uint32_t)ell, 0}}, {}, rand,
+             "failed to accumulate check");  // :140, betas against Gs
+  return gprod::Verify(proof.gpaProof, crs, proof.B, p, tr, sink, rand);
 }
 
 void Proof::Serialize(Writer& w) const {  // :181-192
@@ -816,10 +871,13 @@ Proof Prove(std::vector<G1Affine> G, const Point& A, const Point& Z_t, const Poi
   return proof;
 }
 
-bool Verify(const Proof& proof, const std::vector<G1Affine>& G, const Point& A, const Point& Z_t, const Point& Z_u,
-            const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, Transcript& tr, MsmAccumulator& acc,
+bool Verify(const Proof& proof, size_t ell, const Point& A, const Point& Z_t, const Point& Z_u,
+            const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, Transcript& tr, CheckSink& sink,
             common::Rand& rand) {
-  // samemultiscalarargument.go:159-236 and unfoldedScalars :239-280
+  // samemultiscalarargument.go:159-236 and unfoldedScalars :239-280.  T and U (the padded
+  // vectors T', U' of curdleproof.go:271-285) are passed for the transcript; as bases they are
+  // the instance's Ts / Us (resident, by index) followed by 0 | 0 | H | 0 and 0 | 0 | 0 | H, and
+  // G is the CRS's Gs | Hs[:2] | Gt | Gu.
   const size_t n = T.size();
   AppendStatement(tr, A, Z_t, Z_u, T, U, proof.B_a, proof.B_t, proof.B_u);
   const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
@@ -827,6 +885,7 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& G, const Point& A, 
   const size_t lg_n = proof.L_A.size();
   if (lg_n >= 32) throw err("recursive steps greater than expected");
   if (n != ((size_t)1 << lg_n)) throw err("must by log2(L_a)");
+  if (n != ell + N_BLINDERS) throw err("same msm vectors do not match the CRS");
   if (proof.L_T.size() != lg_n || proof.L_U.size() != lg_n || proof.R_A.size() != lg_n || proof.R_T.size() != lg_n ||
       proof.R_U.size() != lg_n)
     throw err("same msm proof vectors differ in length");
@@ -835,11 +894,8 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& G, const Point& A, 
     tr.AppendPoints(kLoop, {proof.L_A[i], proof.L_T[i], proof.L_U[i], proof.R_A[i], proof.R_T[i], proof.R_U[i]});
     gamma.push_back(tr.GetAndAppendChallenge(kGamma));
   }
-  // unfoldedScalars (:267-277): s_i = prod_{b : bit b of i set} gamma_{lg_n-b-1}, by doubling
-  std::vector<Scalar> xs(n, Scalar::One());
-  for (size_t b = 0; b < lg_n; b++)
-    for (size_t i = (size_t)1 << b; i < ((size_t)2 << b); i++) xs[i] = xs[i - ((size_t)1 << b)] * gamma[lg_n - b - 1];
-  for (size_t i = 0; i < n; i++) xs[i] = proof.x * xs[i];  // x * s_i, :184-187
+  // unfoldedScalars (:267-277): x * s_i with s_i = prod_{b : bit b of i set} gamma_{lg_n-b-1}
+  const VecExpr xs = VecExpr::Fold(gamma, proof.x, n);  // :184-187
   const std::vector<Scalar> gamma_inv = alg::BatchInvert(gamma);
 
   // the three check points (:196-231): B + alpha Z + <gamma, L> + <gamma^-1, R>
@@ -851,12 +907,16 @@ bool Verify(const Proof& proof, const std::vector<G1Affine>& G, const Point& A, 
     t.Add(gamma_inv, R);
     return t;
   };
+  const CrsIndex ix{ell};
+  const InstIndex in{ell};
+  const uint32_t e = (uint32_t)ell;
   const Terms pA = check_point(proof.B_a, A, proof.L_A, proof.R_A);
-  Accumulate(acc, pA, xs, G, rand, "accumulating msm 1");  // :206
+  sink.Check(pA, xs, {{kSetCrs, ix.G(0), e + 2, 0}, {kSetCrs, ix.Gt(), 1, e + 2}, {kSetCrs, ix.Gu(), 1, e + 3}}, {}, rand,
+             "accumulating msm 1");  // :206
   const Terms pT = check_point(proof.B_t, Z_t, proof.L_T, proof.R_T);
-  Accumulate(acc, pT, xs, T, rand, "accumulating msm 2");  // :218
+  sink.Check(pT, xs, {{kSetInst, in.T(0), e, 0}, {kSetCrs, ix.H(), 1, e + 2}}, {}, rand, "accumulating msm 2");  // :218
   const Terms pU = check_point(proof.B_u, Z_u, proof.L_U, proof.R_U);
-  Accumulate(acc, pU, xs, U, rand, "accumulating msm 3");  // :231
+  sink.Check(pU, xs, {{kSetInst, in.U(0), e, 0}, {kSetCrs, ix.H(), 1, e + 3}}, {}, rand, "accumulating msm 3");  // :231
   return true;
 }
 
@@ -963,43 +1023,64 @@ Proof Prove(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G
 }
 
 // The body of curdleproof.Verify up to, but not including, the accumulator's final MSM:
-// false = a direct (non-accumulated) check already failed.  Split out so several proofs
-// can share one accumulator (VerifyBatch).
-bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
-                const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
-                MsmAccumulator& acc) {
+// false = a direct (non-accumulated) check already failed.  Every AccumulateCheck of the
+// sub-arguments goes to `sink`.
+bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                    const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
+                    CheckSink& sink) {
   // curdleproof.go:199-311
+  const size_t ell = crs.Gs.size();
+  if (Rs.size() != ell || Ss.size() != ell || Ts.size() != ell || Us.size() != ell)
+    throw err("instance vectors do not match the CRS");
   Transcript tr(kTranscript);
   if (Ts.empty() || g1_affine_is_inf(Ts[0])) throw err("randomizer is zero");  // :213-215
 
   AppendInstance(tr, Rs, Ss, Ts, Us, M);
   const std::vector<Scalar> as = tr.GetAndAppendChallenges(kVecA, Rs.size());
 
-  if (!sameperm::Verify(proof.proofSamePermutation, crs.Gs, crs.Hs, crs.H, crs.Gsum, crs.Hsum, proof.A, M, as,
-                        N_BLINDERS, tr, acc, rand))
-    return false;
-  if (!samescalar::Verify(proof.proofSameScalar, crs.Gt, crs.Gu, crs.H, proof.R, proof.S, proof.T, proof.U, tr, &acc,
-                          &rand))
+  if (!sameperm::Verify(proof.proofSamePermutation, crs, proof.A, M, as, tr, sink, rand)) return false;
+  if (!samescalar::Verify(proof.proofSameScalar, crs.Gt, crs.Gu, crs.H, proof.R, proof.S, proof.T, proof.U, tr, &sink,
+                          &rand, ell))
     return false;
 
   const Point Aprime = proof.A + proof.T.T_1 + proof.U.T_1;
-  std::vector<G1Affine> G, Tp, Up;
-  MultiscalarBases(crs, Ts, Us, &G, &Tp, &Up);
-  if (!samemsm::Verify(proof.proofSameMultiscalar, G, Aprime, proof.T.T_2, proof.U.T_2, Tp, Up, tr, acc, rand))
+  // T' = Ts | 0 | 0 | H | 0 and U' = Us | 0 | 0 | 0 | H for the transcript (curdleproof.go:271-285)
+  const G1Affine Haff = AffineOf(crs.H);
+  std::vector<G1Affine> Tp(Ts), Up(Us);
+  Tp.insert(Tp.end(), {kZeroPoint, kZeroPoint, Haff, kZeroPoint});
+  Up.insert(Up.end(), {kZeroPoint, kZeroPoint, kZeroPoint, Haff});
+  if (!samemsm::Verify(proof.proofSameMultiscalar, ell, Aprime, proof.T.T_2, proof.U.T_2, Tp, Up, tr, sink, rand))
     return false;
 
   Terms R, S;
   R.Add(Scalar::One(), proof.R);
   S.Add(Scalar::One(), proof.S);
-  Accumulate(acc, R, as, Rs, rand, "msm accumulator check R, as, Rs");  // :306
-  Accumulate(acc, S, as, Ss, rand, "msm accumulator check S, as, Ss");  // :309
+  const InstIndex in{ell};
+  VecExpr xa = VecExpr::Explicit(as);
+  sink.Check(R, xa, {{kSetInst, in.R(0), (uint32_t)ell, 0}}, {}, rand, "msm accumulator check R, as, Rs");  // :306
+  sink.Check(S, xa, {{kSetInst, in.S(0), (uint32_t)ell, 0}}, {}, rand, "msm accumulator check S, as, Ss");  // :309
   return true;
+}
+
+bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
+                MsmAccumulator& acc) {
+  MirrorSink sink(acc, crs, Rs, Ss, Ts, Us);
+  return VerifyWithSink(proof, crs, Rs, Ss, Ts, Us, M, rand, sink);
 }
 
 bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand) {
-  // curdleproof.go:199-318: every sub-argument folds its checks into one accumulator,
-  // whose single MSM (:313) decides
+  // curdleproof.go:199-318: every sub-argument folds its checks into one accumulator, whose
+  // single MSM (:313) decides.  By default that accumulator lives on the GPU
+  // (device_accumulator.h: CRS bases resident, scalars built by index in an Fr kernel, MSM
+  // fed directly); the host mirror does the same job in eager mode and under
+  // CURDLE_DEVICE_ACC=0.
+  if (!EagerChecks() && DeviceAccumulatorEnabled()) {
+    DeviceSink sink(crs, Rs, Ss, Ts, Us);
+    if (!VerifyWithSink(proof, crs, Rs, Ss, Ts, Us, M, rand, sink)) return false;
+    return sink.Verify();  // the batched MSM on the GPU, == A_c
+  }
   MsmAccumulator acc;
   if (!VerifyInto(proof, crs, Rs, Ss, Ts, Us, M, rand, acc)) return false;
   bool ok = false;

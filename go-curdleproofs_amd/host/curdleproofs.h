@@ -17,6 +17,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -103,6 +104,12 @@ struct CRS {
   std::vector<G1Affine> Gs, Hs;
   Point H, Gt, Gu;
   G1Affine Gsum, Hsum;
+  // Derived, never serialised: fixed-base tables of Gsum and Hsum (the two points every
+  // verification rescales, grandproductargument.go:243-246), built by GenerateCRS.
+  std::shared_ptr<const alg::FixedBase> GsumTable, HsumTable;
+  // ... and the holder of the device-resident copy of Gs | Hs | H | Gt | Gu
+  // (device_accumulator.h), filled on the first verification that uses it.
+  std::shared_ptr<class DeviceCrs> device;
 };
 CRS GenerateCRS(size_t size, common::Rand& rand);  // crs.go:20
 
@@ -115,6 +122,128 @@ struct ShuffleCommit {
 ShuffleCommit ShufflePermuteCommit(const std::vector<G1Affine>& crsGs, const std::vector<G1Affine>& crsHs,
                                    const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
                                    const std::vector<uint32_t>& perm, const Scalar& k, common::Rand& rand);
+
+// ---- the verifier's deferred checks, described rather than materialised ----
+// Every sub-argument ends in msmAccumulator.AccumulateCheck(C, x, v, rand)
+// (msmaccumulator.go:23): "sum_i x_i v_i == C".  Here C is handed over as the linear
+// combination it is (Terms), x as a description (VecExpr) and v as index ranges of the two base
+// sets that are resident on the GPU (the CRS and the instance) plus the odd loose point, so
+// that a sink can either rebuild the reference's call on the host mirror (MirrorSink) or
+// ship the description to the device accumulator (DeviceSink, device_accumulator.h), which
+// evaluates x, multiplies by the check's random weight and adds into the base's scalar slot
+// by index -- SURVEY.md section 8f-3.
+struct Terms {
+  std::vector<Scalar> s;
+  std::vector<G1Affine> p;
+  void Add(const Scalar& k, const Point& pt) {
+    s.push_back(k);
+    p.push_back(pt.Affine());
+  }
+  void Add(const std::vector<Scalar>& ks, const std::vector<Point>& pts) {
+    for (size_t i = 0; i < pts.size(); i++) Add(ks[i], pts[i]);
+  }
+};
+
+struct VecExpr {
+  enum Kind : uint32_t {
+    kExplicit = 0,  // the tail only
+    kConst = 1,     // x_i = scale
+    kFold = 2,      // x_i = scale * prod_{j : bit j of i set} gammas[m-1-j]   (innerproductargument.go:223-234,
+                    //                                                         samemultiscalarargument.go:267-277)
+    kFoldPow = 3,   // ... * q^(min(i, q_cap) + 1)                             (grandproductargument.go:234-242)
+  };
+  Kind kind = kExplicit;
+  size_t n_struct = 0;          // elements given by the rule above
+  Scalar scale = Scalar::One();
+  std::vector<Scalar> gammas;
+  Scalar q = Scalar::One();
+  size_t q_cap = 0;
+  std::vector<Scalar> tail;     // explicit elements after the structured ones
+  size_t size() const { return n_struct + tail.size(); }
+  Scalar At(size_t i) const;
+  std::vector<Scalar> Materialise() const;  // n products for the folds (doubling), not n log n
+  static VecExpr Explicit(std::vector<Scalar> v) {
+    VecExpr e;
+    e.tail = std::move(v);
+    return e;
+  }
+  static VecExpr Const(const Scalar& c, size_t n) {
+    VecExpr e;
+    e.kind = kConst;
+    e.n_struct = n;
+    e.scale = c;
+    return e;
+  }
+  // n may exceed 2^m only through the tail: n_struct = min(n, 2^m)
+  static VecExpr Fold(const std::vector<Scalar>& gammas, const Scalar& scale, size_t n) {
+    VecExpr e;
+    e.kind = kFold;
+    e.gammas = gammas;
+    e.scale = scale;
+    const size_t full = (size_t)1 << gammas.size();
+    e.n_struct = n < full ? n : full;
+    return e;
+  }
+  static VecExpr FoldPow(const std::vector<Scalar>& gammas, const Scalar& scale, const Scalar& q, size_t q_cap, size_t n) {
+    VecExpr e = Fold(gammas, scale, n);
+    e.kind = kFoldPow;
+    e.q = q;
+    e.q_cap = q_cap;
+    return e;
+  }
+};
+
+// Resident base sets and their index layouts.
+enum : uint32_t { kSetCrs = 0, kSetInst = 1 };
+struct CrsIndex {  // Gs | Hs | H | Gt | Gu
+  size_t ell;
+  uint32_t G(size_t i) const { return (uint32_t)i; }  // Gs[i] for i < ell, Hs[i - ell] after
+  uint32_t H() const { return (uint32_t)(ell + N_BLINDERS); }
+  uint32_t Gt() const { return (uint32_t)(ell + N_BLINDERS + 1); }
+  uint32_t Gu() const { return (uint32_t)(ell + N_BLINDERS + 2); }
+  size_t size() const { return ell + N_BLINDERS + 3; }
+};
+struct InstIndex {  // Rs | Ss | Ts | Us
+  size_t ell;
+  uint32_t R(size_t i) const { return (uint32_t)i; }
+  uint32_t S(size_t i) const { return (uint32_t)(ell + i); }
+  uint32_t T(size_t i) const { return (uint32_t)(2 * ell + i); }
+  uint32_t U(size_t i) const { return (uint32_t)(3 * ell + i); }
+  size_t size() const { return 4 * ell; }
+};
+struct BaseSeg {  // slots [first, first + len) of resident set `set` take x[vec_first + j]
+  uint32_t set, first, len, vec_first;
+};
+struct LooseBase {  // a base outside the resident sets takes x[index]
+  uint32_t index;
+  G1Affine point;
+};
+
+class CheckSink {
+ public:
+  virtual ~CheckSink() {}
+  // msmAccumulator.AccumulateCheck(C, x, v, rand); indices of x covered by neither a segment
+  // nor a loose base pair with the point at infinity (the zero entries of T' and U',
+  // curdleproof.go:271-285).
+  virtual void Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs,
+                     const std::vector<LooseBase>& loose, common::Rand& rand, const char* what) = 0;
+};
+
+// The reference's behaviour: every check goes to the msmaccumulator mirror (deferred or,
+// under curdle_verify_set_eager, with C evaluated on the spot).
+class MirrorSink : public CheckSink {
+ public:
+  MirrorSink(msmaccumulator::MsmAccumulator& acc, const struct CRS& crs, const std::vector<G1Affine>& Rs,
+             const std::vector<G1Affine>& Ss, const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us);
+  void Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs, const std::vector<LooseBase>& loose,
+             common::Rand& rand, const char* what) override;
+
+ private:
+  msmaccumulator::MsmAccumulator& acc_;
+  std::vector<G1Affine> crs_;  // Gs | Hs | H | Gt | Gu
+  const std::vector<G1Affine>*inst_[4];
+  size_t ell_;
+};
 
 // ---- samescalarargument ----
 namespace samescalar {
@@ -131,7 +260,7 @@ Proof Prove(const Point& Gt, const Point& Gu, const Point& H, const Point& R, co
 // check instead of being evaluated on the spot; without one this is the reference's Verify.
 bool Verify(const Proof& proof, const Point& Gt, const Point& Gu, const Point& H, const Point& R, const Point& S,
             const GroupCommitment& T, const GroupCommitment& U, transcript::Transcript& tr,
-            msmaccumulator::MsmAccumulator* acc = nullptr, common::Rand* rand = nullptr);
+            CheckSink* sink = nullptr, common::Rand* rand = nullptr, size_t ell = 0);
 }  // namespace samescalar
 
 // ---- innerproductargument ----
@@ -147,9 +276,9 @@ struct Proof {
 Proof Prove(std::vector<G1Affine> Gs, std::vector<G1Affine> Gs_prime, const Point& H, const Point& C, const Point& D,
             const Scalar& z, std::vector<Scalar> cs, std::vector<Scalar> ds, transcript::Transcript& tr,
             common::Rand& rand);
-bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const Point& H, const Point& C, const Point& D,
-            const Scalar& z, const std::vector<Scalar>& us, transcript::Transcript& tr,
-            msmaccumulator::MsmAccumulator& acc, common::Rand& rand);
+// Bases Gs | Hs (n = ell + 4, the CRS's, by index) and H; us_i = u_q^(min(i, ell) + 1).
+bool Verify(const Proof& proof, size_t ell, const Point& H, const Point& C, const Point& D, const Scalar& z,
+            const Scalar& u_q, transcript::Transcript& tr, CheckSink& sink, common::Rand& rand);
 }  // namespace ipa
 
 // ---- grandproductargument ----
@@ -164,9 +293,8 @@ struct Proof {
 Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H, const Point& B,
             const Scalar& result, const std::vector<Scalar>& bs, const std::vector<Scalar>& r_bs,
             transcript::Transcript& tr, common::Rand& rand);
-bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H,
-            const G1Affine& Gsum, const G1Affine& Hsum, const Point& B, const Scalar& result, int numBlinders,
-            transcript::Transcript& tr, msmaccumulator::MsmAccumulator& acc, common::Rand& rand);
+bool Verify(const Proof& proof, const struct CRS& crs, const Point& B, const Scalar& result, transcript::Transcript& tr,
+            CheckSink& sink, common::Rand& rand);
 }  // namespace gprod
 
 // ---- samepermutationargument ----
@@ -181,9 +309,8 @@ Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, co
             const Point& M, const std::vector<Scalar>& as, const std::vector<uint32_t>& permutation,
             const std::vector<Scalar>& rs_a, const std::vector<Scalar>& rs_m, transcript::Transcript& tr,
             common::Rand& rand);
-bool Verify(const Proof& proof, const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, const Point& H,
-            const G1Affine& Gsum, const G1Affine& Hsum, const Point& A, const Point& M, const std::vector<Scalar>& as,
-            int numBlinders, transcript::Transcript& tr, msmaccumulator::MsmAccumulator& acc, common::Rand& rand);
+bool Verify(const Proof& proof, const struct CRS& crs, const Point& A, const Point& M, const std::vector<Scalar>& as,
+            transcript::Transcript& tr, CheckSink& sink, common::Rand& rand);
 }  // namespace sameperm
 
 // ---- samemultiscalarargument ----
@@ -198,9 +325,10 @@ struct Proof {
 // G, T, U, x by value: folded in place by the prover.
 Proof Prove(std::vector<G1Affine> G, const Point& A, const Point& Z_t, const Point& Z_u, std::vector<G1Affine> T,
             std::vector<G1Affine> U, std::vector<Scalar> x, transcript::Transcript& tr, common::Rand& rand);
-bool Verify(const Proof& proof, const std::vector<G1Affine>& G, const Point& A, const Point& Z_t, const Point& Z_u,
-            const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, transcript::Transcript& tr,
-            msmaccumulator::MsmAccumulator& acc, common::Rand& rand);
+// T, U: the padded vectors T', U' (for the transcript); as bases they are addressed by index.
+bool Verify(const Proof& proof, size_t ell, const Point& A, const Point& Z_t, const Point& Z_u,
+            const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, transcript::Transcript& tr, CheckSink& sink,
+            common::Rand& rand);
 }  // namespace samemsm
 
 // ---- curdleproof.go ----
@@ -232,6 +360,10 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
 bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
                 const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
                 msmaccumulator::MsmAccumulator& acc);
+// The same into any sink.
+bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                    const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
+                    CheckSink& sink);
 
 // Cross-proof batch verification over one CRS: one shared accumulator, one MSM (see the
 // definition).  Returns the per-proof accept bits.

@@ -1,0 +1,146 @@
+// DeviceSink -- see device_accumulator.h.
+#include "device_accumulator.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+#include <stdexcept>
+
+namespace curdle {
+namespace proto {
+
+namespace {
+alg::MsmError device_error(const char* what, int rc) {
+  char buf[256];
+  curdle_last_error(buf, sizeof(buf));
+  return alg::MsmError(std::string(what) + ": " + buf + " (rc " + std::to_string(rc) + ")", rc);
+}
+std::atomic<int>& Flag() {
+  static std::atomic<int> on([] {
+    const char* e = getenv("CURDLE_DEVICE_ACC");
+    return (e && *e == '0') ? 0 : 1;
+  }());
+  return on;
+}
+}  // namespace
+
+bool DeviceAccumulatorEnabled() { return Flag().load(std::memory_order_relaxed) != 0; }
+int SetDeviceAccumulator(int on) { return Flag().exchange(on ? 1 : 0); }
+
+DeviceCrs::~DeviceCrs() { curdle_dbases_free(h_); }
+
+const curdle_dbases* DeviceCrs::Get(const CRS& crs) {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!h_) {
+    std::vector<G1Affine> pts(crs.Gs);  // Gs | Hs | H | Gt | Gu  (CrsIndex)
+    pts.insert(pts.end(), crs.Hs.begin(), crs.Hs.end());
+    pts.push_back(crs.H.Affine());
+    pts.push_back(crs.Gt.Affine());
+    pts.push_back(crs.Gu.Affine());
+    int rc = curdle_dbases_create(reinterpret_cast<const uint64_t*>(pts.data()), pts.size(), &h_);
+    if (rc != CURDLE_OK) throw device_error("making the CRS resident", rc);
+  }
+  return h_;
+}
+
+DeviceSink::DeviceSink(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                       const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us)
+    : ell_(crs.Gs.size()), n_crs_(CrsIndex{crs.Gs.size()}.size()), n_inst_(4 * crs.Gs.size()), crs_(crs),
+      inst_{&Rs, &Ss, &Ts, &Us} {
+  if (!crs.device) throw std::runtime_error("CRS without a device holder");
+  if (Rs.size() != ell_ || Ss.size() != ell_ || Ts.size() != ell_ || Us.size() != ell_)
+    throw std::runtime_error("instance vectors do not match the CRS");
+  const curdle_dbases* bases = crs.device->Get(crs);
+  // Rs | Ss | Ts | Us (InstIndex), uploaded now: converted on the GPU while the host hashes
+  std::vector<G1Affine> inst;
+  inst.reserve(n_inst_);
+  for (const auto* v : inst_) inst.insert(inst.end(), v->begin(), v->end());
+  int rc = curdle_dacc_begin(bases, reinterpret_cast<const uint64_t*>(inst.data()), inst.size(), &acc_);
+  if (rc != CURDLE_OK) throw device_error("starting the device accumulator", rc);
+}
+
+DeviceSink::~DeviceSink() {
+  if (acc_) curdle_dacc_abort(acc_);
+}
+
+uint32_t DeviceSink::Put(const Scalar& s) {
+  pool_.push_back(s);
+  return (uint32_t)(pool_.size() - 1);
+}
+
+void DeviceSink::Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs,
+                       const std::vector<LooseBase>& loose, common::Rand& rand, const char* what) {
+  if (segs.size() > CURDLE_DACC_MAX_SEGS) throw std::runtime_error(std::string(what) + ": too many base segments");
+  Scalar alpha;
+  rand.GetFr(alpha.v);  // msmaccumulator.go:32 -- the same draw, in the same order, as the host mirror
+  curdle_dacc_check ck;
+  memset(&ck, 0, sizeof(ck));
+  ck.kind = (uint32_t)x.kind;
+  ck.n_struct = (uint32_t)x.n_struct;
+  ck.m = (uint32_t)x.gammas.size();
+  ck.q_cap = (uint32_t)x.q_cap;
+  ck.alpha_off = Put(alpha);
+  ck.weight_off = Put(alpha * x.scale);
+  ck.gammas_off = (uint32_t)pool_.size();
+  for (const Scalar& g : x.gammas) Put(g);
+  ck.q_off = Put(x.q);
+  ck.tail_off = (uint32_t)pool_.size();
+  ck.n_tail = (uint32_t)x.tail.size();
+  for (const Scalar& t : x.tail) Put(t);
+  ck.nseg = (uint32_t)segs.size();
+  for (size_t s = 0; s < segs.size(); s++) {
+    ck.seg[s].set = segs[s].set;
+    ck.seg[s].first = segs[s].first;
+    ck.seg[s].len = segs[s].len;
+    ck.seg[s].vec_first = segs[s].vec_first;
+  }
+  checks_.push_back(ck);
+  // bases outside the resident sets: the proof points of the same-scalar argument
+  for (const LooseBase& lb : loose) {
+    if (g1_affine_is_inf(lb.point)) continue;
+    extra_points_.push_back(lb.point);
+    extra_scalars_.push_back(alpha * x.At(lb.index));
+  }
+  // C moves to the base side: - alpha c_j P_j  (MsmAccumulator::AccumulateCheckDeferred)
+  for (size_t j = 0; j < C.p.size(); j++) {
+    if (g1_affine_is_inf(C.p[j])) continue;
+    extra_points_.push_back(C.p[j]);
+    extra_scalars_.push_back(-(alpha * C.s[j]));
+  }
+}
+
+bool DeviceSink::Run(std::vector<Scalar>* slot_scalars) {
+  if (!acc_) throw std::runtime_error("device accumulator already consumed");
+  uint64_t out[18];
+  if (slot_scalars) slot_scalars->assign(n_crs_ + n_inst_, Scalar::Zero());
+  curdle_dacc* a = acc_;
+  acc_ = nullptr;  // run() ends the accumulation whatever happens
+  int rc = curdle_dacc_run(a, checks_.data(), checks_.size(), reinterpret_cast<const uint64_t*>(pool_.data()), pool_.size(),
+                           reinterpret_cast<const uint64_t*>(extra_points_.data()),
+                           reinterpret_cast<const uint64_t*>(extra_scalars_.data()), extra_points_.size(), out,
+                           slot_scalars ? reinterpret_cast<uint64_t*>(slot_scalars->data()) : nullptr);
+  if (rc != CURDLE_OK) throw device_error("verifying msm accumulator: computing msm", rc);  // msmaccumulator.go:60
+  return Point::FromJac(out).IsInfinity();  // :63, A_c is the point at infinity here
+}
+
+bool DeviceSink::Verify() { return Run(nullptr); }
+
+bool DeviceSink::VerifyAndExport(std::vector<G1Affine>* bases, std::vector<Scalar>* scalars) {
+  std::vector<Scalar> slots;
+  const bool ok = Run(&slots);
+  bases->assign(crs_.Gs.begin(), crs_.Gs.end());
+  bases->insert(bases->end(), crs_.Hs.begin(), crs_.Hs.end());
+  bases->push_back(crs_.H.Affine());
+  bases->push_back(crs_.Gt.Affine());
+  bases->push_back(crs_.Gu.Affine());
+  for (const auto* v : inst_) bases->insert(bases->end(), v->begin(), v->end());
+  bases->insert(bases->end(), extra_points_.begin(), extra_points_.end());
+  *scalars = slots;
+  scalars->insert(scalars->end(), extra_scalars_.begin(), extra_scalars_.end());
+  return ok;
+}
+
+}  // namespace proto
+}  // namespace curdle

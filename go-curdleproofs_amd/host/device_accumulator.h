@@ -1,0 +1,74 @@
+// The verifier's accumulator on the GPU: a CheckSink that ships the
+// sub-arguments' checks, as descriptions, to the device accumulator of include/curdle_msm.h
+// (curdle_dacc_*).  Replaces, for curdleproof.Verify, the host map of
+// /root/reference/msmaccumulator/msmaccumulator.go:11-64:
+//   * the CRS bases Gs | Hs | H | Gt | Gu (crs.go:10-18) are converted once and stay resident
+//     (proto::CRS carries the handle); the 4 ell instance points are uploaded when the
+//     verification STARTS and are converted while the host hashes the transcript;
+//   * AccumulateCheck's `map[v_i] += alpha x_i` (:38-43) becomes an index-addressed add in an
+//     Fr kernel, which also evaluates the verifier's s_i / s'_i / x s_i vectors
+//     (innerproductargument.go:223-234, samemultiscalarargument.go:267-277) from the log n
+//     challenges -- the host only draws alpha (same order, same values as the mirror);
+//   * the check points C and the loose bases (proof points) travel as ~100 (point, scalar)
+//     pairs; Verify()'s MultiExp (:59) runs over the slots in place.
+// The accept bit equals the host mirror's for every input (tests/test_device_accumulator.py
+// compares the exported base / scalar lists of both).
+#pragma once
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "../../include/curdle_msm.h"
+#include "curdleproofs.h"
+
+namespace curdle {
+namespace proto {
+
+// The CRS's device-resident bases; created on first use, shared by copies of the CRS.
+class DeviceCrs {
+ public:
+  DeviceCrs() = default;
+  ~DeviceCrs();
+  DeviceCrs(const DeviceCrs&) = delete;
+  DeviceCrs& operator=(const DeviceCrs&) = delete;
+  const curdle_dbases* Get(const CRS& crs);  // throws alg::MsmError without a device
+
+ private:
+  std::mutex mu_;
+  curdle_dbases* h_ = nullptr;
+};
+
+// CURDLE_DEVICE_ACC=0 (or SetDeviceAccumulator(0)) keeps curdleproof.Verify on the host mirror.
+bool DeviceAccumulatorEnabled();
+int SetDeviceAccumulator(int on);  // returns the previous setting
+
+class DeviceSink : public CheckSink {
+ public:
+  DeviceSink(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us);
+  ~DeviceSink() override;
+  void Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs, const std::vector<LooseBase>& loose,
+             common::Rand& rand, const char* what) override;
+  // msmAccumulator.Verify(): the MSM over every slot, compared with A_c (the point at infinity:
+  // every C was moved to the base side).  Ends the accumulation.
+  bool Verify();
+  // The same, also handing back what the device accumulated: bases (CRS | instance | loose) and
+  // their scalars (Montgomery), for the parity tests.
+  bool VerifyAndExport(std::vector<G1Affine>* bases, std::vector<Scalar>* scalars);
+
+ private:
+  bool Run(std::vector<Scalar>* slot_scalars);
+  uint32_t Put(const Scalar& s);
+  curdle_dacc* acc_ = nullptr;
+  size_t ell_, n_crs_, n_inst_;
+  std::vector<G1Affine> resident_;  // for VerifyAndExport only (filled lazily)
+  const CRS& crs_;
+  const std::vector<G1Affine>*inst_[4];
+  std::vector<curdle_dacc_check> checks_;
+  std::vector<Scalar> pool_;
+  std::vector<G1Affine> extra_points_;
+  std::vector<Scalar> extra_scalars_;
+};
+
+}  // namespace proto
+}  // namespace curdle

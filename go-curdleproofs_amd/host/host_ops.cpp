@@ -13,6 +13,8 @@ void curdle_host_fp_from_mont_bmi2(void*, const void*);
 int curdle_host_equal_bmi2(const void*, const void*);
 int curdle_host_in_subgroup_bmi2(const void*);
 void curdle_host_batch_to_affine_bmi2(void*, const void*, size_t);
+void curdle_host_fixed_base_table_bmi2(void*, const void*);
+void curdle_host_fixed_base_mul_bmi2(void*, const void*, const uint32_t*);
 }
 
 static bool fast_isa() {
@@ -72,4 +74,18 @@ extern "C" void curdle_host_batch_to_affine(void* out_affine, const void* in_xyz
     curdle_host_batch_to_affine_bmi2(out_affine, in_xyzz, n);
   else
     curdle_host_batch_to_affine_generic(out_affine, in_xyzz, n);
+}
+
+extern "C" void curdle_host_fixed_base_table(void* table_affine, const void* p_affine) {
+  if (fast_isa())
+    curdle_host_fixed_base_table_bmi2(table_affine, p_affine);
+  else
+    curdle_host_fixed_base_table_generic(table_affine, p_affine);
+}
+
+extern "C" void curdle_host_fixed_base_mul(void* r_xyzz, const void* table_affine, const uint32_t* k) {
+  if (fast_isa())
+    curdle_host_fixed_base_mul_bmi2(r_xyzz, table_affine, k);
+  else
+    curdle_host_fixed_base_mul_generic(r_xyzz, table_affine, k);
 }

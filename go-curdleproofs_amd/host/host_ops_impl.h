@@ -81,3 +81,40 @@ extern "C" void CURDLE_FN(curdle_host_batch_to_affine)(void* out_affine, const v
   using namespace curdle;
   g1_batch_to_affine(static_cast<G1Affine*>(out_affine), static_cast<const G1XYZZ*>(in_xyzz), n);
 }
+
+// Fixed-base scalar multiplication (8-bit windows, no doublings) for bases that never change
+// -- the CRS points Gsum and Hsum the grand-product verifier rescales in every verification
+// (grandproductargument.go:243-246): table[w * 255 + (d - 1)] = d * 2^(8 w) * P, affine, for
+// w < 32, d in 1..255; k * P is then at most 32 mixed additions.
+extern "C" void CURDLE_FN(curdle_host_fixed_base_table)(void* table_affine, const void* p_affine) {
+  using namespace curdle;
+  const G1Affine& p = *static_cast<const G1Affine*>(p_affine);
+  G1XYZZ* tmp = new G1XYZZ[32 * 255];
+  G1XYZZ base;
+  g1_from_affine(base, p);
+  for (int w = 0; w < 32; w++) {
+    G1XYZZ acc = base;
+    for (int d = 1; d <= 255; d++) {
+      tmp[w * 255 + d - 1] = acc;
+      g1_add(acc, base);      // (d + 1) * base; base + base takes the doubling branch
+    }
+    base = acc;               // 256 * base = 2^(8 (w + 1)) * P
+  }
+  g1_batch_to_affine(static_cast<G1Affine*>(table_affine), tmp, 32 * 255);
+  delete[] tmp;
+}
+
+// r = k * P from the table above; k = 8 canonical little-endian 32-bit limbs.
+extern "C" void CURDLE_FN(curdle_host_fixed_base_mul)(void* r_xyzz, const void* table_affine, const uint32_t* k) {
+  using namespace curdle;
+  const G1Affine* tab = static_cast<const G1Affine*>(table_affine);
+  G1XYZZ acc;
+  g1_set_inf(acc);
+  for (int w = 0; w < 32; w++) {
+    const uint32_t d = (k[w >> 2] >> (8 * (w & 3))) & 0xffu;
+    if (!d) continue;
+    const G1Affine& t = tab[w * 255 + d - 1];
+    if (!g1_affine_is_inf(t)) g1_madd(acc, t.x, t.y);
+  }
+  *static_cast<G1XYZZ*>(r_xyzz) = acc;
+}

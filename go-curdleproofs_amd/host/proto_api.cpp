@@ -10,6 +10,7 @@
 
 #include "../../include/curdle_msm.h"
 #include "curdleproofs.h"
+#include "device_accumulator.h"
 #include "whisk.h"
 
 using namespace curdle;
@@ -155,6 +156,50 @@ extern "C" int curdle_verify_proof(const curdle_crs* crs, const curdle_proof* pr
     bool accept = proto::Verify(proof->p, crs->crs, Affines(Rs, ell), Affines(Ss, ell), Affines(Ts, ell), Affines(Us, ell),
                                 Point::FromJac(M), rand->r);
     *ok = accept ? 1 : 0;
+    return CURDLE_OK;
+  });
+}
+
+// Where the verifier's accumulator lives: 1 (default) on the device, 0 on the host mirror.
+extern "C" int curdle_verify_set_device_acc(int on) { return proto::SetDeviceAccumulator(on); }
+
+// The accumulated (base, scalar) list of one verification, before the final MSM, from the host
+// mirror (device = 0) or from the device accumulator (device = 1), and the accept bit: what
+// the parity test of the two accumulators compares (tests/test_device_accumulator.py).
+extern "C" int curdle_verify_export_accumulator(const curdle_crs* crs, const curdle_proof* proof, const uint64_t* Rs,
+                                                const uint64_t* Ss, const uint64_t* Ts, const uint64_t* Us, size_t ell,
+                                                const uint64_t M[18], curdle_rand* rand, int device, uint64_t* points,
+                                                uint64_t* scalars, size_t cap, size_t* n_out, int* ok) {
+  if (!crs || !proof || !Rs || !Ss || !Ts || !Us || !M || !rand || !n_out || !ok)
+    return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  if (ell != crs->crs.Gs.size()) return curdle_set_last_error(CURDLE_EINVAL, "ell does not match the CRS");
+  return Guard([&]() {
+    const std::vector<G1Affine> R = Affines(Rs, ell), S = Affines(Ss, ell), T = Affines(Ts, ell), U = Affines(Us, ell);
+    std::vector<G1Affine> bases;
+    std::vector<Scalar> sc;
+    bool accept = false;
+    if (device) {
+      proto::DeviceSink sink(crs->crs, R, S, T, U);
+      if (proto::VerifyWithSink(proof->p, crs->crs, R, S, T, U, Point::FromJac(M), rand->r, sink))
+        accept = sink.VerifyAndExport(&bases, &sc);
+    } else {
+      msmaccumulator::MsmAccumulator acc;
+      if (proto::VerifyInto(proof->p, crs->crs, R, S, T, U, Point::FromJac(M), rand->r, acc)) {
+        bases = acc.Bases();
+        sc.resize(acc.Scalars().size());
+        for (size_t i = 0; i < sc.size(); i++) sc[i].v = acc.Scalars()[i];
+        msmaccumulator::Status st = acc.Verify(&accept);
+        if (!st.ok) throw alg::MsmError("verifying msm accumulator: " + st.err, st.rc ? st.rc : CURDLE_EHIP);
+      }
+    }
+    *n_out = bases.size();
+    *ok = accept ? 1 : 0;
+    if (bases.size() > cap || (bases.size() && (!points || !scalars)))
+      return curdle_set_last_error(CURDLE_EINVAL, "export buffers too small");
+    if (!bases.empty()) {
+      memcpy(points, bases.data(), bases.size() * 96);
+      memcpy(scalars, sc.data(), sc.size() * 32);
+    }
     return CURDLE_OK;
   });
 }

@@ -117,7 +117,11 @@ void Transcript::AppendPoints(const std::string& label, const std::vector<alg::P
   for (const auto& p : points) AppendPoint(label, p);  // :25-30 (normalise, then one message per point)
 }
 void Transcript::AppendPointsAffine(const std::string& label, const std::vector<G1Affine>& points) {
-  for (const auto& a : points) AppendPoint(label, alg::Point::FromAffine(a));
+  for (const auto& a : points) {
+    uint8_t b[48];
+    alg::CompressAffine(a, b);
+    inner_.AppendMessage(label, b, 48);
+  }
 }
 void Transcript::AppendScalar(const std::string& label, const alg::Scalar& s) {
   uint8_t b[32];

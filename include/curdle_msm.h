@@ -264,6 +264,72 @@ int curdle_whisk_is_valid_tracker_proof(const uint8_t tracker[CURDLE_WHISK_TRACK
 /* GenerateWhiskTrackerProof, whisk.go:149 */
 int curdle_whisk_generate_tracker_proof(const uint8_t tracker[CURDLE_WHISK_TRACKER_SIZE], const uint64_t k[4],
                                         curdle_rand* rand, uint8_t proof_out[CURDLE_WHISK_TRACKER_PROOF_SIZE]);
+/* ------------------------------------------------------------------------- *
+ * Accumulator on the device
+ *   msmaccumulator.AccumulateCheck / Verify (msmaccumulator/msmaccumulator.go:23-64) with
+ *   the base -> scalar map kept on the GPU as an array of scalar slots indexed by base, for
+ *   callers whose bases come from sets that stay resident: the CRS (crs.go:10-18: Gs | Hs |
+ *   H | Gt | Gu never change) and the per-verification instance points.  Instead of hashing
+ *   96-byte keys on the host (msmaccumulator.go:38-43) and re-uploading and re-converting every
+ *   base for the final MultiExp (:59), a check names slot ranges of the resident sets and
+ *   describes its scalar vector; an Fr kernel evaluates the vectors -- including the
+ *   verifier's O(n) products s_i, s'_i (innerproductargument.go:223-234,
+ *   samemultiscalarargument.go:267-277) -- weights them with the check's random alpha and
+ *   adds them into the slots; the result feeds the MSM's digit kernel directly.
+ * ------------------------------------------------------------------------- */
+typedef struct curdle_dbases curdle_dbases; /* a base set on the device, in the kernels' internal form */
+int curdle_dbases_create(const uint64_t* points /* n x 12, gnark G1Affine */, size_t n, curdle_dbases** out);
+void curdle_dbases_free(curdle_dbases* b);
+size_t curdle_dbases_size(const curdle_dbases* b);
+
+#define CURDLE_VEC_EXPLICIT 0 /* x_i = tail[i]                                                        */
+#define CURDLE_VEC_CONST 1    /* x_i = scale                                                          */
+#define CURDLE_VEC_FOLD 2     /* x_i = scale * prod_{j : bit j of i set} gammas[m-1-j]                */
+#define CURDLE_VEC_FOLD_POW 3 /* ... * q^(min(i, q_cap) + 1)                                          */
+#define CURDLE_DACC_MAX_SEGS 6
+#define CURDLE_DACC_MAX_EXTRA 4096
+#define CURDLE_SET_CRS 0
+#define CURDLE_SET_INST 1
+/* One AccumulateCheck: sum_i x_i v_i (== C, which the caller moves to the other side as extra
+ * terms).  Offsets index `pool`, an array of Montgomery fr.Elements; the first n_struct
+ * elements of x follow the rule of `kind` with weight = alpha * scale folded in by the caller,
+ * the n_tail elements after them are explicit and are multiplied by alpha on the device.
+ * Segment s says: slots [first, first + len) of resident set `set` take x[vec_first + j]. */
+typedef struct {
+  uint32_t kind, n_struct, m, q_cap;
+  uint32_t weight_off, alpha_off, gammas_off, q_off, tail_off, n_tail;
+  uint32_t nseg;
+  struct {
+    uint32_t set, first, len, vec_first;
+  } seg[CURDLE_DACC_MAX_SEGS];
+} curdle_dacc_check;
+
+typedef struct curdle_dacc curdle_dacc;
+/* Starts an accumulation over `crs` and n_inst instance points (host memory, gnark affine):
+ * takes a workspace slot and begins copying / converting the bases, then returns; the caller
+ * computes its challenges meanwhile. */
+int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_points, size_t n_inst, curdle_dacc** out);
+/* Applies the checks, appends the n_extra loose (point, scalar) pairs and runs the MSM over
+ * all slots: out_jac = sum over CRS, instance and extra bases (canonical Jacobian), i.e. what
+ * msmaccumulator.Verify compares with A_c.  export_scalars (optional, (n_crs + n_inst) x 4)
+ * receives the slot scalars the device built, for parity tests.  Ends the accumulation. */
+int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
+                    size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars, size_t n_extra,
+                    uint64_t out_jac[CURDLE_G1_JAC_U64], uint64_t* export_scalars);
+void curdle_dacc_abort(curdle_dacc* acc); /* ends an accumulation without running it */
+
+/* curdleproof.Verify keeps its accumulator on the device by default (the section above);
+ * 0 moves it back to the host mirror of msmaccumulator (same accept bit).  Returns the
+ * previous setting.  Environment: CURDLE_DEVICE_ACC=0. */
+int curdle_verify_set_device_acc(int on);
+/* Test hook: the accumulated (base, scalar) list of one verification of a decoded proof,
+ * taken before the final MSM from the host mirror (device = 0) or the device accumulator
+ * (device = 1), plus the accept bit.  points: cap x 12, scalars: cap x 4 (Montgomery);
+ * *n_out entries are written.  Bases may repeat (the device keeps loose points apart). */
+int curdle_verify_export_accumulator(const curdle_crs* crs, const curdle_proof* proof, const uint64_t* Rs,
+                                     const uint64_t* Ss, const uint64_t* Ts, const uint64_t* Us, size_t ell,
+                                     const uint64_t M[CURDLE_G1_JAC_U64], curdle_rand* rand, int device,
+                                     uint64_t* points, uint64_t* scalars, size_t cap, size_t* n_out, int* ok);
 /* common.IPA (reference common/util.go:26-35): out = sum_i a[i] * b[i] over Fr, Montgomery limbs
  * in and out; CURDLE_EINVAL if the lengths differ (the reference returns an error). */
 int curdle_fr_inner_product(const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, uint64_t out_fr[4]);

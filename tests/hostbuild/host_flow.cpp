@@ -1,0 +1,304 @@
+// TEST INFRASTRUCTURE ONLY.  Drives the host layer of libcurdlemsm.so (everything under
+// go-curdleproofs_amd/host/: wire-format readers, PointDecoder, MsmAccumulator table,
+// transcript, the five arguments, curdleproof Prove / Verify) over the naive host backend of
+// stub_backend.cpp, so it can run under AddressSanitizer + UBSan on a machine without a GPU
+// -- the counterpart of the reference CI's `go test -race`
+// (.github/workflows/buildlintcheck.yml:21).  Modes:
+//   host_flow flow <ell>          Prove -> serialise -> Verify (deferred and eager), soundness
+//                                 flips of curdleproof_test.go:48-182, encode/decode round trip
+//   host_flow fuzz <ell> <iters>  attacker-controlled bytes into every parser: bit flips,
+//                                 truncations, random slice prefixes, random blobs
+//   host_flow time <ell> <reps>   host share of Verify (everything but the final MSM), for gprof
+//   host_flow emit <ell> <file>   the serialised proof + instance as a fixture file
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <map>
+
+#include "../../go-curdleproofs_amd/host/curdleproofs.h"
+#include "../../go-curdleproofs_amd/host/device_accumulator.h"
+#include "../../go-curdleproofs_amd/host/whisk.h"
+
+using namespace curdle;
+using alg::Point;
+using alg::Scalar;
+
+struct Instance {
+  proto::CRS crs;
+  std::vector<G1Affine> Rs, Ss, Ts, Us;
+  Point M;
+  std::vector<uint32_t> perm;
+  Scalar k;
+  std::vector<Scalar> rs_m;
+  std::vector<uint8_t> proof;
+};
+
+static Instance Make(size_t ell, uint64_t seed) {
+  Instance in;
+  common::Rand rand(seed);
+  in.crs = proto::GenerateCRS(ell, rand);
+  common::Rand prand(seed + 42);
+  prand.GeneratePermutation(ell, in.perm);
+  rand.GetFr(in.k.v);
+  rand.GetG1Affines(ell, in.Rs);
+  rand.GetG1Affines(ell, in.Ss);
+  proto::ShuffleCommit sc = proto::ShufflePermuteCommit(in.crs.Gs, in.crs.Hs, in.Rs, in.Ss, in.perm, in.k, rand);
+  in.Ts = sc.Ts;
+  in.Us = sc.Us;
+  in.M = sc.M;
+  in.rs_m = sc.rs_m;
+  common::Rand pr(seed + 1000);
+  in.proof = proto::Prove(in.crs, in.Rs, in.Ss, in.Ts, in.Us, in.M, in.perm, in.k, in.rs_m, pr).Serialize();
+  return in;
+}
+
+static bool VerifyBytes(const Instance& in, const std::vector<uint8_t>& bytes, uint64_t seed) {
+  proto::Proof p = proto::Proof::FromBytes(bytes.data(), bytes.size(), true);
+  common::Rand vr(seed);
+  return proto::Verify(p, in.crs, in.Rs, in.Ss, in.Ts, in.Us, in.M, vr);
+}
+
+#define CHECK(cond)                                                          \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      fprintf(stderr, "host_flow: check failed at line %d: %s\n", __LINE__, #cond); \
+      exit(1);                                                               \
+    }                                                                        \
+  } while (0)
+
+static int Flow(size_t ell) {
+  Instance in = Make(ell, 7);
+  for (int eager = 0; eager < 2; eager++) {
+    proto::SetEagerChecks(eager);
+    CHECK(VerifyBytes(in, in.proof, 43));  // TestCompleteness, curdleproof_test.go:14-46
+    // encode / decode round trip
+    proto::Proof p = proto::Proof::FromBytes(in.proof.data(), in.proof.size(), true);
+    CHECK(p.Serialize() == in.proof);
+    // TestSoundness (:48-182): swapped R/S, another permutation, wrong commitment, other randomiser
+    {
+      Instance bad = in;
+      std::swap(bad.Rs, bad.Ss);
+      CHECK(!VerifyBytes(bad, in.proof, 44));
+    }
+    {
+      Instance bad = in;
+      std::swap(bad.Ts[0], bad.Ts[1]);
+      CHECK(!VerifyBytes(bad, in.proof, 45));
+    }
+    {
+      Instance bad = in;
+      bad.M = bad.M + Point::Generator();
+      CHECK(!VerifyBytes(bad, in.proof, 46));
+    }
+    {
+      Instance bad = in;
+      for (auto& t : bad.Ts) t = (Point::FromAffine(t) + Point::FromAffine(t)).Affine();
+      CHECK(!VerifyBytes(bad, in.proof, 47));
+    }
+    {  // zero randomiser is a structural error (curdleproof.go:213-215)
+      Instance bad = in;
+      memset(&bad.Ts[0], 0, sizeof(G1Affine));
+      bool threw = false;
+      try {
+        VerifyBytes(bad, in.proof, 48);
+      } catch (const std::runtime_error&) {
+        threw = true;
+      }
+      CHECK(threw);
+    }
+  }
+  proto::SetEagerChecks(0);
+  // msmaccumulator table: merge of shared bases, growth past the initial capacity
+  {
+    msmaccumulator::MsmAccumulator acc;
+    common::Rand r(5);
+    std::vector<G1Affine> v;
+    r.GetG1Affines(40, v);
+    for (int round = 0; round < 60; round++) {
+      std::vector<Fr> x(v.size());
+      for (auto& f : x) r.GetFr(f);
+      std::vector<alg::Scalar> xs(x.size());
+      for (size_t i = 0; i < x.size(); i++) xs[i].v = x[i];
+      Point C = alg::MultiExp(v, xs);
+      uint64_t j[18];
+      C.Jac(j);
+      G1Jac cj;
+      memcpy(&cj, j, sizeof(cj));
+      CHECK(acc.AccumulateCheck(cj, x, v, &r).ok);
+      if (round % 7 == 0) {  // a fresh base now and then: the table grows
+        G1Affine extra;
+        r.GetG1Affine(extra);
+        v.push_back(extra);
+      }
+    }
+    CHECK(acc.NumBases() == v.size());
+    bool ok = false;
+    CHECK(acc.Verify(&ok).ok && ok);
+  }
+  // The two accumulators -- host mirror and the device accumulator's description path (here over
+  // the stub's host evaluation of the same descriptions) -- hold the same base -> scalar map.
+  {
+    proto::Proof p = proto::Proof::FromBytes(in.proof.data(), in.proof.size(), true);
+    auto key = [](const G1Affine& a) { return std::string(reinterpret_cast<const char*>(&a), sizeof(a)); };
+    std::map<std::string, Scalar> mirror, device;
+    {
+      msmaccumulator::MsmAccumulator acc;
+      common::Rand vr(99);
+      CHECK(proto::VerifyInto(p, in.crs, in.Rs, in.Ss, in.Ts, in.Us, in.M, vr, acc));
+      for (size_t i = 0; i < acc.NumBases(); i++) {
+        Scalar sc;
+        sc.v = acc.Scalars()[i];
+        if (!g1_affine_is_inf(acc.Bases()[i])) mirror[key(acc.Bases()[i])] = sc;
+      }
+    }
+    {
+      proto::DeviceSink sink(in.crs, in.Rs, in.Ss, in.Ts, in.Us);
+      common::Rand vr(99);
+      CHECK(proto::VerifyWithSink(p, in.crs, in.Rs, in.Ss, in.Ts, in.Us, in.M, vr, sink));
+      std::vector<G1Affine> bases;
+      std::vector<Scalar> sc;
+      CHECK(sink.VerifyAndExport(&bases, &sc));
+      for (size_t i = 0; i < bases.size(); i++) {
+        auto it = device.find(key(bases[i]));
+        if (it == device.end()) device[key(bases[i])] = sc[i];
+        else it->second = it->second + sc[i];
+      }
+    }
+    for (auto it = mirror.begin(); it != mirror.end();) it = it->second.IsZero() ? mirror.erase(it) : std::next(it);
+    for (auto it = device.begin(); it != device.end();) it = it->second.IsZero() ? device.erase(it) : std::next(it);
+    CHECK(mirror.size() == device.size());
+    for (const auto& kv : mirror) {
+      auto it = device.find(kv.first);
+      CHECK(it != device.end() && it->second == kv.second);
+    }
+    // and the default Verify (device accumulator) agrees with the mirror on accept and reject
+    CHECK(proto::SetDeviceAccumulator(1) == 1);
+    CHECK(VerifyBytes(in, in.proof, 50));
+    Instance bad = in;
+    std::swap(bad.Us[0], bad.Us[1]);
+    CHECK(!VerifyBytes(bad, in.proof, 51));
+    proto::SetDeviceAccumulator(0);
+    CHECK(VerifyBytes(in, in.proof, 50));
+    CHECK(!VerifyBytes(bad, in.proof, 51));
+    proto::SetDeviceAccumulator(1);
+  }
+  printf("flow ell=%zu: completeness, round trip, soundness flips, accumulator table, mirror == device accumulator: ok\n", ell);
+  return 0;
+}
+
+static uint64_t g_rng = 0x9e3779b97f4a7c15ull;
+static uint64_t Rng() {
+  g_rng ^= g_rng << 13;
+  g_rng ^= g_rng >> 7;
+  g_rng ^= g_rng << 17;
+  return g_rng;
+}
+
+static int Fuzz(size_t ell, int iters) {
+  Instance in = Make(ell, 9);
+  long accepted = 0, rejected = 0, errors = 0;
+  auto attempt = [&](const std::vector<uint8_t>& bytes) {
+    try {
+      if (VerifyBytes(in, bytes, 77))
+        accepted++;
+      else
+        rejected++;
+    } catch (const std::runtime_error&) {
+      errors++;
+    }
+  };
+  for (int it = 0; it < iters; it++) {
+    std::vector<uint8_t> b = in.proof;
+    switch (it % 5) {
+      case 0:  // one flipped bit
+        b[Rng() % b.size()] ^= (uint8_t)(1u << (Rng() % 8));
+        break;
+      case 1:  // truncation
+        b.resize(Rng() % b.size());
+        break;
+      case 2: {  // a slice prefix replaced by an arbitrary 32-bit value
+        size_t at = Rng() % (b.size() - 4);
+        uint32_t v = (uint32_t)Rng();
+        if (it % 2) v &= 0xff;
+        memcpy(&b[at], &v, 4);
+        break;
+      }
+      case 3:  // random tail
+        for (size_t i = Rng() % b.size(); i < b.size(); i++) b[i] = (uint8_t)Rng();
+        break;
+      default:  // random blob of random length
+        b.resize(Rng() % (2 * b.size()));
+        for (auto& c : b) c = (uint8_t)Rng();
+    }
+    attempt(b);
+  }
+  // whisk byte API: tracker proofs and shuffle proofs from arbitrary bytes
+  for (int it = 0; it < iters / 4 + 1; it++) {
+    whisk::WhiskTracker t;
+    uint8_t kc[48], tp[128];
+    for (auto& c : t.rG) c = (uint8_t)Rng();
+    for (auto& c : t.krG) c = (uint8_t)Rng();
+    for (auto& c : kc) c = (uint8_t)Rng();
+    for (auto& c : tp) c = (uint8_t)Rng();
+    try {
+      if (whisk::IsValidWhiskTrackerProof(t, kc, tp)) accepted++;
+    } catch (const std::runtime_error&) {
+      errors++;
+    }
+  }
+  CHECK(accepted == 0);
+  printf("fuzz ell=%zu: %d mutated proofs + tracker proofs: %ld rejected, %ld decode errors, 0 accepted\n", ell, iters,
+         rejected, errors);
+  return 0;
+}
+
+static int Time(size_t ell, int reps) {
+  Instance in = Make(ell, 11);
+  proto::Proof p = proto::Proof::FromBytes(in.proof.data(), in.proof.size(), true);
+  auto t0 = std::chrono::steady_clock::now();
+  size_t bases = 0;
+  for (int r = 0; r < reps; r++) {
+    msmaccumulator::MsmAccumulator acc;
+    common::Rand vr(100 + r);
+    CHECK(proto::VerifyInto(p, in.crs, in.Rs, in.Ss, in.Ts, in.Us, in.M, vr, acc));
+    bases = acc.NumBases();
+  }
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+  printf("time ell=%zu: host share of Verify (all but the final MSM of %zu bases): %.3f ms\n", ell, bases, ms);
+  return 0;
+}
+
+static int Emit(size_t ell, const char* path) {
+  Instance in = Make(ell, 7);
+  FILE* f = fopen(path, "wb");
+  if (!f) return 1;
+  fwrite(in.proof.data(), 1, in.proof.size(), f);
+  fclose(f);
+  printf("emit ell=%zu: %zu proof bytes\n", ell, in.proof.size());
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    fprintf(stderr, "usage: host_flow flow|fuzz|time|emit <ell> [arg]\n");
+    return 2;
+  }
+  const std::string mode = argv[1];
+  const size_t ell = (size_t)atoi(argv[2]);
+  try {
+    if (mode == "flow") return Flow(ell);
+    if (mode == "fuzz") return Fuzz(ell, argc > 3 ? atoi(argv[3]) : 200);
+    if (mode == "time") return Time(ell, argc > 3 ? atoi(argv[3]) : 20);
+    if (mode == "emit") return Emit(ell, argc > 3 ? argv[3] : "proof.bin");
+  } catch (const std::exception& e) {
+    fprintf(stderr, "host_flow: unexpected exception: %s\n", e.what());
+    return 1;
+  }
+  return 2;
+}

@@ -1,0 +1,215 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into libcurdlemsm.so.
+//
+// A naive host stand-in for the device entry points the host-side protocol code calls
+// (curdle_msm_g1, curdle_msm_g1_batch, curdle_g1_scalar_mul_batch, curdle_g1_decompress_*),
+// so that the host layer (wire-format readers, PointDecoder, MsmAccumulator table, transcript,
+// the five arguments, Whisk) can be built with -fsanitize=address,undefined and run on a
+// machine without a GPU (tests/test_host_sanitize.py), and profiled with gprof.  The product
+// has no CPU MSM: libcurdlemsm.so's entry points fail with CURDLE_ENODEV without a device
+// (tests/test_abi.py).  The sums below are textbook double-and-add over host_math.h.
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/curdle_msm.h"
+#include "../../go-curdleproofs_amd/csrc/host_math.h"
+#include "../../go-curdleproofs_amd/host/algebra.h"
+
+using namespace curdle;
+
+static thread_local char g_err[256] = "";
+
+extern "C" int curdle_set_last_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+extern "C" int curdle_last_error(char* buf, size_t len) {
+  if (!buf || !len) return CURDLE_EINVAL;
+  snprintf(buf, len, "%s", g_err);
+  return CURDLE_OK;
+}
+
+static void msm_naive(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out[18]) {
+  G1XYZZ acc;
+  g1_set_inf(acc);
+  for (size_t i = 0; i < n; i++) {
+    G1Affine p;
+    memcpy(&p, points + 12 * i, 96);
+    if (g1_affine_is_inf(p)) continue;
+    Fr m, k;
+    memcpy(&m, scalars + 4 * i, 32);
+    f_from_mont<FrParams>(k, m);
+    G1XYZZ px, t;
+    g1_from_affine(px, p);
+    g1_scalar_mul(t, px, k.l, 8);
+    g1_add(acc, t);
+  }
+  g1_to_canonical_jac(out, acc);
+}
+
+extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
+  if (!out_jac || (n && (!points || !scalars))) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  msm_naive(points, scalars, n, out_jac);
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scalars, const size_t* offsets, size_t k,
+                                   uint64_t* out_jac) {
+  if (!offsets || (k && !out_jac)) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  for (size_t j = 0; j < k; j++)
+    msm_naive(points + 12 * offsets[j], scalars + 4 * offsets[j], offsets[j + 1] - offsets[j], out_jac + 18 * j);
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t* scalars, size_t n_scalars,
+                                          const uint64_t* addends, size_t n, uint64_t* out_affine) {
+  if (n_scalars != n && n_scalars != 1) return curdle_set_last_error(CURDLE_EINVAL, "n_scalars must be n or 1");
+  for (size_t i = 0; i < n; i++) {
+    uint64_t jac[18];
+    msm_naive(points + 12 * i, scalars + 4 * (n_scalars == 1 ? 0 : i), 1, jac);
+    alg::Point r = alg::Point::FromJac(jac);
+    if (addends) {
+      G1Affine a;
+      memcpy(&a, addends + 12 * i, 96);
+      r = r + alg::Point::FromAffine(a);
+    }
+    G1Affine o = r.Affine();
+    memcpy(out_affine + 12 * i, &o, 96);
+  }
+  return CURDLE_OK;
+}
+
+static void decode_all(const uint8_t* in, size_t n, int subgroup_check, uint64_t* out_affine, uint8_t* status) {
+  for (size_t i = 0; i < n; i++) {
+    alg::Point p;
+    G1Affine a;
+    memset(&a, 0, sizeof(a));
+    status[i] = CURDLE_DECODE_BAD_ENCODING;
+    if (alg::Point::FromCompressed(in + 48 * i, &p, subgroup_check != 0)) {
+      a = p.Affine();
+      status[i] = g1_affine_is_inf(a) ? CURDLE_DECODE_INFINITY : CURDLE_DECODE_OK;
+    } else if (subgroup_check && alg::Point::FromCompressed(in + 48 * i, &p, false)) {
+      status[i] = CURDLE_DECODE_NOT_IN_SUBGROUP;
+    }
+    memcpy(out_affine + 12 * i, &a, 96);
+  }
+}
+
+extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgroup_check, uint64_t* out_affine,
+                                          uint8_t* status) {
+  decode_all(in, n, subgroup_check, out_affine, status);
+  return CURDLE_OK;
+}
+
+// two-step form: everything happens in begin; finish hands the final status bytes back
+static std::vector<uint8_t> g_deferred[2];
+static bool g_busy[2] = {false, false};
+extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t* out_affine, uint8_t* status, int* ticket) {
+  for (int t = 0; t < 2; t++) {
+    if (g_busy[t]) continue;
+    g_busy[t] = true;
+    g_deferred[t].assign(n, 0);
+    decode_all(in, n, 1, out_affine, g_deferred[t].data());
+    // like the device: the first step reports curve membership only
+    for (size_t i = 0; i < n; i++) status[i] = g_deferred[t][i] == CURDLE_DECODE_NOT_IN_SUBGROUP ? CURDLE_DECODE_OK : g_deferred[t][i];
+    for (size_t i = 0; i < n; i++)
+      if (g_deferred[t][i] == CURDLE_DECODE_NOT_IN_SUBGROUP) {
+        alg::Point p;
+        alg::Point::FromCompressed(in + 48 * i, &p, false);
+        G1Affine a = p.Affine();
+        memcpy(out_affine + 12 * i, &a, 96);
+      }
+    *ticket = t;
+    return CURDLE_OK;
+  }
+  return curdle_set_last_error(CURDLE_EBUSY, "deferred decodings in flight");
+}
+extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
+  if (ticket < 0 || ticket > 1 || !g_busy[ticket]) return curdle_set_last_error(CURDLE_EINVAL, "bad ticket");
+  if (status) memcpy(status, g_deferred[ticket].data(), g_deferred[ticket].size());
+  g_busy[ticket] = false;
+  return CURDLE_OK;
+}
+
+// ---- device accumulator (curdle_dbases_* / curdle_dacc_*), evaluated naively on the host ----
+struct curdle_dbases {
+  std::vector<G1Affine> pts;
+};
+struct curdle_dacc {
+  const curdle_dbases* crs;
+  std::vector<G1Affine> inst;
+};
+extern "C" int curdle_dbases_create(const uint64_t* points, size_t n, curdle_dbases** out) {
+  curdle_dbases* b = new curdle_dbases();
+  b->pts.resize(n);
+  if (n) memcpy(b->pts.data(), points, n * 96);
+  *out = b;
+  return CURDLE_OK;
+}
+extern "C" void curdle_dbases_free(curdle_dbases* b) { delete b; }
+extern "C" size_t curdle_dbases_size(const curdle_dbases* b) { return b ? b->pts.size() : 0; }
+extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_points, size_t n_inst, curdle_dacc** out) {
+  curdle_dacc* a = new curdle_dacc();
+  a->crs = crs;
+  a->inst.resize(n_inst);
+  if (n_inst) memcpy(a->inst.data(), inst_points, n_inst * 96);
+  *out = a;
+  return CURDLE_OK;
+}
+extern "C" void curdle_dacc_abort(curdle_dacc* acc) { delete acc; }
+extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
+                               size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars,
+                               size_t n_extra, uint64_t out_jac[18], uint64_t* export_scalars) {
+  const size_t n_crs = acc->crs->pts.size(), n_inst = acc->inst.size(), n_res = n_crs + n_inst;
+  auto P = [&](uint32_t off) {
+    alg::Scalar s;
+    if (off >= pool_len) throw 1;
+    memcpy(&s.v, pool + 4 * (size_t)off, 32);
+    return s;
+  };
+  std::vector<alg::Scalar> slots(n_res, alg::Scalar::Zero());
+  int rc = CURDLE_OK;
+  try {
+    for (size_t slot = 0; slot < n_res; slot++) {
+      const uint32_t set = slot < n_crs ? CURDLE_SET_CRS : CURDLE_SET_INST;
+      const uint32_t idx = (uint32_t)(slot < n_crs ? slot : slot - n_crs);
+      for (size_t c = 0; c < n_checks; c++) {
+        const curdle_dacc_check& ck = checks[c];
+        for (uint32_t s = 0; s < ck.nseg; s++) {
+          if (ck.seg[s].set != set || idx < ck.seg[s].first || idx - ck.seg[s].first >= ck.seg[s].len) continue;
+          const uint32_t i = ck.seg[s].vec_first + (idx - ck.seg[s].first);
+          alg::Scalar v;
+          if (i >= ck.n_struct) {
+            if (i - ck.n_struct >= ck.n_tail) continue;
+            v = P(ck.alpha_off) * P(ck.tail_off + (i - ck.n_struct));
+          } else {
+            v = P(ck.weight_off);
+            if (ck.kind >= CURDLE_VEC_FOLD)
+              for (uint32_t j = 0; j < ck.m; j++)
+                if ((i >> j) & 1u) v = v * P(ck.gammas_off + (ck.m - 1 - j));
+            if (ck.kind == CURDLE_VEC_FOLD_POW) v = v * P(ck.q_off).Pow((i < ck.q_cap ? i : ck.q_cap) + 1);
+          }
+          slots[slot] = slots[slot] + v;
+        }
+      }
+    }
+  } catch (int) {
+    rc = curdle_set_last_error(CURDLE_EINVAL, "offset outside the pool");
+  }
+  if (rc == CURDLE_OK) {
+    std::vector<G1Affine> pts(acc->crs->pts);
+    pts.insert(pts.end(), acc->inst.begin(), acc->inst.end());
+    std::vector<uint64_t> sc(4 * (n_res + n_extra));
+    if (n_res) memcpy(sc.data(), slots.data(), n_res * 32);
+    pts.resize(n_res + n_extra);
+    if (n_extra) {
+      memcpy(pts.data() + n_res, extra_points, n_extra * 96);
+      memcpy(sc.data() + 4 * n_res, extra_scalars, n_extra * 32);
+    }
+    msm_naive(reinterpret_cast<const uint64_t*>(pts.data()), sc.data(), pts.size(), out_jac);
+    if (export_scalars && n_res) memcpy(export_scalars, slots.data(), n_res * 32);
+  }
+  delete acc;
+  return rc;
+}
