@@ -9,8 +9,11 @@
 
 #include "../../include/curdle_msm.h"
 
+#include <stdio.h>
+
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 
@@ -721,7 +724,8 @@ bool Verify(const Proof& proof, const CRS& crs, const Point& B, const Scalar& re
   // multiplications go through the CRS's fixed-base tables (32 mixed additions each)
   const Point gs = crs.GsumTable ? crs.GsumTable->Mul(betaInv) : Point::FromAffine(crs.Gsum).Mul(betaInv);
   const Point hs = crs.HsumTable ? crs.HsumTable->Mul(alpha) : Point::FromAffine(crs.Hsum).Mul(alpha);
-  const Point D = B - gs + hs;
+  // normalised once: D is hashed into the transcript AND rides in the accumulator as a base
+  const Point D = Point::FromAffine((B - gs + hs).Affine());
 
   const Scalar betaExpL = beta.Pow(ell);
   const Scalar z = result * betaExpL + proof.Rp * (betaExpL * beta) - Scalar::One();  // :253-260
@@ -1043,7 +1047,7 @@ bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affi
                           &rand, ell))
     return false;
 
-  const Point Aprime = proof.A + proof.T.T_1 + proof.U.T_1;
+  const Point Aprime = Point::FromAffine((proof.A + proof.T.T_1 + proof.U.T_1).Affine());  // hashed and accumulated
   // T' = Ts | 0 | 0 | H | 0 and U' = Us | 0 | 0 | 0 | H for the transcript (curdleproof.go:271-285)
   const G1Affine Haff = AffineOf(crs.H);
   std::vector<G1Affine> Tp(Ts), Up(Us);
@@ -1077,9 +1081,26 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
   // fed directly); the host mirror does the same job in eager mode and under
   // CURDLE_DEVICE_ACC=0.
   if (!EagerChecks() && DeviceAccumulatorEnabled()) {
+    // CURDLE_VERIFY_TRACE=1: where one verification's time goes (stderr), for the host-share
+    // figure of DESIGN.md: starting the accumulation (instance upload), the host's transcript
+    // and challenge algebra, the device part (scalars kernel + MSM + wait)
+    static const bool trace = [] {
+      const char* e = getenv("CURDLE_VERIFY_TRACE");
+      return e && *e && *e != '0';
+    }();
+    const auto t0 = std::chrono::steady_clock::now();
     DeviceSink sink(crs, Rs, Ss, Ts, Us);
+    const auto t1 = std::chrono::steady_clock::now();
     if (!VerifyWithSink(proof, crs, Rs, Ss, Ts, Us, M, rand, sink)) return false;
-    return sink.Verify();  // the batched MSM on the GPU, == A_c
+    const auto t2 = std::chrono::steady_clock::now();
+    const bool ok = sink.Verify();  // the batched MSM on the GPU, == A_c
+    if (trace) {
+      const auto t3 = std::chrono::steady_clock::now();
+      auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      fprintf(stderr, "[verify] begin %.0f us, host transcript+algebra %.0f us, device run %.0f us\n", us(t0, t1), us(t1, t2),
+              us(t2, t3));
+    }
+    return ok;
   }
   MsmAccumulator acc;
   if (!VerifyInto(proof, crs, Rs, Ss, Ts, Us, M, rand, acc)) return false;

@@ -12,7 +12,7 @@ namespace curdle {
 static inline uint64_t keccak_rotl(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 
 // st: 25 lanes, lane (x, y) at st[x + 5 y], little-endian lanes.
-static inline void keccak_f1600(uint64_t st[25]) {
+static inline __attribute__((always_inline)) void keccak_f1600(uint64_t st[25]) {
   static const uint64_t RC[24] = {
       0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
       0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
@@ -96,5 +96,21 @@ static inline void keccak_f1600(uint64_t st[25]) {
   st[15] = a03, st[16] = a13, st[17] = a23, st[18] = a33, st[19] = a43;
   st[20] = a04, st[21] = a14, st[22] = a24, st[23] = a34, st[24] = a44;
 }
+
+// The same round function compiled for BMI1 + BMI2 (andn for chi, rorx for rho) and picked at
+// run time; the generic build is the fallback.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("bmi,bmi2"))) static inline void keccak_f1600_bmi(uint64_t st[25]) { keccak_f1600(st); }
+static inline void keccak_f1600_generic(uint64_t st[25]) { keccak_f1600(st); }
+static inline void keccak_f1600_dispatch(uint64_t st[25]) {
+  static const bool fast = __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
+  if (fast)
+    keccak_f1600_bmi(st);
+  else
+    keccak_f1600_generic(st);
+}
+#else
+static inline void keccak_f1600_dispatch(uint64_t st[25]) { keccak_f1600(st); }
+#endif
 
 }  // namespace curdle

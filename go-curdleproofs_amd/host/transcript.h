@@ -32,7 +32,7 @@ class Strobe128 {
   void Absorb(const uint8_t* data, size_t len);
   void Squeeze(uint8_t* out, size_t len);
   void BeginOp(uint8_t flags, bool more);
-  uint8_t st_[200];
+  alignas(8) uint8_t st_[200];
   uint8_t pos_, pos_begin_, cur_flags_;
 };
 

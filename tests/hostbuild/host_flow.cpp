@@ -274,6 +274,21 @@ static int Time(size_t ell, int reps) {
   return 0;
 }
 
+// host share of the default Verify: the device accumulator's description path (no MSM)
+static int TimeDevicePath(size_t ell, int reps) {
+  Instance in = Make(ell, 11);
+  proto::Proof p = proto::Proof::FromBytes(in.proof.data(), in.proof.size(), true);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < reps; r++) {
+    proto::DeviceSink sink(in.crs, in.Rs, in.Ss, in.Ts, in.Us);
+    common::Rand vr(100 + r);
+    CHECK(proto::VerifyWithSink(p, in.crs, in.Rs, in.Ss, in.Ts, in.Us, in.M, vr, sink));
+  }
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+  printf("time ell=%zu: host share of Verify on the device-accumulator path: %.3f ms\n", ell, ms);
+  return 0;
+}
+
 static int Emit(size_t ell, const char* path) {
   Instance in = Make(ell, 7);
   FILE* f = fopen(path, "wb");
@@ -295,6 +310,7 @@ int main(int argc, char** argv) {
     if (mode == "flow") return Flow(ell);
     if (mode == "fuzz") return Fuzz(ell, argc > 3 ? atoi(argv[3]) : 200);
     if (mode == "time") return Time(ell, argc > 3 ? atoi(argv[3]) : 20);
+    if (mode == "timedev") return TimeDevicePath(ell, argc > 3 ? atoi(argv[3]) : 20);
     if (mode == "emit") return Emit(ell, argc > 3 ? argv[3] : "proof.bin");
   } catch (const std::exception& e) {
     fprintf(stderr, "host_flow: unexpected exception: %s\n", e.what());
