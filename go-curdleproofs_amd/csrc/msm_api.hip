@@ -528,6 +528,15 @@ int finish_slot(Slot& S, uint64_t* out) {
     }
     L.window_bits = p.c;
     L.num_windows = p.W;
+    L.entries = L.fragments = 0;
+    if (g_ctx.profile == 1) {  // two 4-byte reads after the call has drained: diagnostics only
+      const size_t nb = (size_t)p.k * p.NB;
+      uint32_t v[2] = {0, 0};
+      (void)hipMemcpy(&v[0], (const char*)S.starts.p + nb * 4, 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&v[1], (const char*)S.foff.p + nb * 4, 4, hipMemcpyDeviceToHost);
+      L.entries = v[0];
+      L.fragments = v[1];
+    }
   }
   if (p.gpu_combine) {
     // the GPU ran the Horner passes; one shared inversion normalises the whole batch

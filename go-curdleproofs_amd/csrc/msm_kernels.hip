@@ -322,15 +322,34 @@ __global__ void __launch_bounds__(kBlock, WAVES)
   u32 gend = starts[lo];
   X28 acc;
   d28::set_inf(acc);
-  // the gather of position pos + 1 is issued before the addition of position pos
-  u32 e_next = sorted[pos];
+  // The lane's indices are read eight at a time into a register queue: between two of its
+  // iterations the XCD's other lanes gather megabytes of points through the 4 MiB L2, so a
+  // 4-byte read per iteration fetched a whole 128-byte line of `sorted` from memory every time
+  // (2.1 GB of the launch's 4.3 GB, profiles/r02_fetch_calibration.txt); eight reads issued
+  // back to back share one line fetch.  The gather of position pos + 1 is issued before the
+  // addition of position pos.
+  u32 q[8];
+  auto refill = [&](u32 from) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = from + j < end ? sorted[from + j] : 0u;
+  };
+  refill(pos);
+  u32 queued = 0;
+  u32 e_next = q[0];
   A28 pt_next;
   d28::load(pt_next, a28_at(points, e_next & 0x7fffffffu));
   for (; pos < end; pos++) {
     const u32 e = e_next;
     A28 pt = pt_next;
+    if (++queued == 8) {
+      refill(pos + 1);
+      queued = 0;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; j++) q[j] = q[j + 1];
+    }
     if (pos + 1 < end) {
-      e_next = sorted[pos + 1];
+      e_next = q[0];
       d28::load(pt_next, a28_at(points, e_next & 0x7fffffffu));
     }
     if (pos == gend) {

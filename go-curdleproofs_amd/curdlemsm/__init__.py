@@ -71,7 +71,8 @@ _vp = C.c_void_p
 
 class _Profile(C.Structure):
     _fields_ = [("n_kernels", C.c_int), ("name", C.c_char_p * 16), ("ms", C.c_float * 16),
-                ("window_bits", C.c_int), ("num_windows", C.c_int)]
+                ("window_bits", C.c_int), ("num_windows", C.c_int), ("entries", C.c_ulonglong),
+                ("fragments", C.c_ulonglong)]
 
 
 def _sig(name, restype, *argtypes):
@@ -385,6 +386,8 @@ def profile_last() -> dict:
         "kernels": {p.name[i].decode(): float(p.ms[i]) for i in range(p.n_kernels)},
         "window_bits": p.window_bits,
         "num_windows": p.num_windows,
+        "entries": int(p.entries),
+        "fragments": int(p.fragments),
     }
 
 

@@ -29,6 +29,13 @@ def window_partition(n_windows: int, world_size: int, rank: int) -> Tuple[int, i
     return begin, end
 
 
+def point_partition(n: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """The reserve partition of SURVEY.md section 8e: contiguous point ranges [begin, end) --
+    every rank runs ALL windows over n / world_size pairs (its own window width), so the
+    per-rank recoding, sort and conversion shrink with the rank count too."""
+    return window_partition(n, world_size, rank)
+
+
 def gather_partials(partial: np.ndarray, group=None, device=None) -> np.ndarray:
     """all_gather of one uint64[18] Jacobian point per rank -> uint64[world, 18]."""
     import torch
@@ -45,24 +52,72 @@ def gather_partials(partial: np.ndarray, group=None, device=None) -> np.ndarray:
 
 
 def msm_g1_distributed(d_points: int, d_scalars: int, n: int, group=None, device=None, stream: int = 0,
-                       c: int = 0,
+                       c: int = 0, split: str = "windows",
                        partial_fn: Optional[Callable[[int, int, int], np.ndarray]] = None) -> np.ndarray:
     """Full MSM result (uint64[18]) on every rank.
 
-    partial_fn(c, win_begin, win_end) -> uint64[18] replaces the GPU partial; it
-    exists so the collective plumbing can be exercised by the world_size-2 gloo
-    tests on a machine without a GPU.  The product default is the HIP path.
+    split = "windows": every rank runs its window range over all n pairs (north_star).
+    split = "points":  every rank runs all windows over its point range (DESIGN.md section 5
+    says which one pays at which size).
+
+    partial_fn(c, begin, end) -> uint64[18] replaces the GPU partial (begin / end are the
+    window range or the point range); it exists so the collective plumbing can be exercised
+    by the world_size-2 gloo tests on a machine without a GPU.  The product default is the
+    HIP path.
     """
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    c = c or window_bits(n)
-    W = num_windows(n, c)
-    begin, end = window_partition(W, world, rank)
-    if partial_fn is not None:
-        partial = partial_fn(c, begin, end)
+    if split == "points":
+        begin, end = point_partition(n, world, rank)
+        if partial_fn is not None:
+            partial = partial_fn(0, begin, end)
+        else:
+            partial = msm_g1_device(d_points + 96 * begin, d_scalars + 32 * begin, end - begin, stream=stream)
     else:
-        partial = msm_g1_device(d_points, d_scalars, n, stream=stream, window_bits=c, win_begin=begin, win_end=end)
+        c = c or window_bits(n)
+        W = num_windows(n, c)
+        begin, end = window_partition(W, world, rank)
+        if partial_fn is not None:
+            partial = partial_fn(c, begin, end)
+        else:
+            partial = msm_g1_device(d_points, d_scalars, n, stream=stream, window_bits=c, win_begin=begin, win_end=end)
     allp = gather_partials(np.ascontiguousarray(partial, dtype=np.uint64), group=group, device=device)
     return g1_sum(allp)
+
+
+def replica_shard(k: int, world_size: int, rank: int) -> np.ndarray:
+    """BASELINE config 5 (many independent verifications) is replicas, not a partitioned
+    kernel: rank r takes items r, r + world, r + 2 world, ...."""
+    return np.arange(rank, k, world_size)
+
+
+def verify_replicas(k: int, verify_shard: Callable[[np.ndarray], np.ndarray], group=None, device=None) -> np.ndarray:
+    """Accept bits of k independent verifications, computed round-robin by the ranks of the
+    group -- rank r calls verify_shard(indices) for its shard (e.g. a
+    curdle_whisk_is_valid_shuffle_proof_batch over those proofs on its GPU) -- and exchanged
+    with ONE all_gather of ceil(k / world) bytes per rank; every rank returns all k bits.
+    There is no data-path collective: the verifications do not depend on each other."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = replica_shard(k, world, rank)
+    bits = np.asarray(verify_shard(mine), dtype=np.uint8)
+    if bits.shape != mine.shape:
+        raise ValueError("verify_shard must return one bit per index of its shard")
+    per = -(-k // world)
+    buf = np.full(per, 2, dtype=np.uint8)          # 2 = padding
+    buf[:len(bits)] = bits
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    res = np.zeros(k, dtype=np.uint8)
+    for r, o in enumerate(out):
+        idx = replica_shard(k, world, r)
+        res[idx] = o.cpu().numpy()[:len(idx)]
+    return res

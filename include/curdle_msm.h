@@ -381,6 +381,11 @@ typedef struct {
   float ms[CURDLE_PROF_MAX_KERNELS]; /* HIP-event time of each kernel, last MSM call */
   int window_bits;
   int num_windows;
+  /* mode 1 only: sorted (pair, window) entries of the last call (zero digits dropped) and the
+   * fragments the accumulate kernel emitted -- every fragment's first addition is a copy, so
+   * the launch did entries - fragments real mixed additions */
+  unsigned long long entries;
+  unsigned long long fragments;
 } curdle_profile;
 /* on = 1: every MSM call brackets each kernel with hipEvents on the stream it launches on
  * and keeps the durations of the last call.  on = 2: only the dominant kernel (the bucket

@@ -84,3 +84,31 @@ def fr_from_mont(a) -> np.ndarray:
     out = np.zeros(4, dtype=np.uint64)
     _lib.oracle_fr_from_mont(_p(_u64(a)), _p(out))
     return out
+
+
+# ---- the multi-threaded CPU baseline (oracle/cpu_msm_fast.c) ----
+def _load_fast(native: bool = False):
+    name = "libcurdle_cpufast_native.so" if native else "libcurdle_cpufast.so"
+    path = os.path.join(_DIR, name)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: run `make -C oracle`" + (" native" if native else ""))
+    lib = C.CDLL(path)
+    lib.fast_msm_g1.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp]
+    lib.fast_msm_g1.restype = C.c_int
+    return lib
+
+
+_fast = {}
+
+
+def msm_fast(points, scalars, threads: int = 1, c: int = 0, native: bool = False) -> np.ndarray:
+    """Bucket-method MSM on `threads` host cores: mulx/adx field products, signed digits, XYZZ
+    buckets, every window split over several tasks (oracle/cpu_msm_fast.c)."""
+    if native not in _fast:
+        _fast[native] = _load_fast(native)
+    points, scalars = _u64(points), _u64(scalars)
+    n = points.shape[0] if points.size else 0
+    out = np.zeros(18, dtype=np.uint64)
+    if _fast[native].fast_msm_g1(_p(points), _p(scalars), n, threads, c, _p(out)) != 0:
+        raise MemoryError("fast_msm_g1: allocation failed")
+    return out

@@ -27,7 +27,7 @@ def _ensure_built():
     ora = os.path.join(ROOT, "oracle", "libcurdle_oracle.so")
     if not os.path.exists(lib):
         subprocess.check_call(["make", "-C", PKG, "-j4"])
-    if not os.path.exists(ora):
+    if not os.path.exists(ora) or not os.path.exists(os.path.join(ROOT, "oracle", "libcurdle_cpufast.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 

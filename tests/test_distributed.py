@@ -54,8 +54,22 @@ def _worker(rank, world, port, n, result_dir):
         res = {}
         for c in (16, 15, 7):
             res[c] = msm_g1_distributed(0, 0, n, c=c, partial_fn=partial_fn)
+        # the reserve partition: point ranges, all windows per rank
+        res["points"] = msm_g1_distributed(
+            0, 0, n, split="points", partial_fn=lambda c, lo, hi: co.msm_pippenger(pts[lo:hi], sc[lo:hi], threads=2))
         full = co.msm_pippenger(pts, sc, threads=2)
         ok = all((res[c] == full).all() for c in res)
+        # config 5 replicas: 11 independent "verifications", round-robin, one all_gather of bits
+        from curdlemsm.distributed import replica_shard, verify_replicas
+        truth = np.array([(i * 7 + 3) % 5 != 0 for i in range(11)], dtype=np.uint8)
+        seen = []
+
+        def verify_shard(idx):
+            seen.extend(int(i) for i in idx)
+            return truth[idx]
+        bits = verify_replicas(11, verify_shard)
+        ok = ok and (bits == truth).all() and seen == [int(i) for i in replica_shard(11, world, rank)]
+        ok = ok and len(verify_replicas(0, lambda idx: np.zeros(0, dtype=np.uint8))) == 0
         np.save(os.path.join(result_dir, f"rank{rank}.npy"), np.array([int(ok)]))
     finally:
         dist.destroy_process_group()
@@ -68,6 +82,16 @@ def test_window_split_allgather_sum_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, port, 48, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert np.load(tmp_path / f"rank{r}.npy")[0] == 1
+
+
+def test_replica_shards_cover_every_item_once():
+    sys.path.insert(0, PKG)
+    from curdlemsm.distributed import replica_shard
+    for k in (0, 1, 7, 8, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            got = np.sort(np.concatenate([replica_shard(k, world, r) for r in range(world)]))
+            assert (got == np.arange(k)).all()
+            assert max(len(replica_shard(k, world, r)) for r in range(world)) == -(-k // world)
 
 
 def test_window_partition_properties():

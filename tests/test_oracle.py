@@ -121,3 +121,30 @@ def test_accumulator_merges_shared_bases(oracle):
     ma.accumulate_check(oracle.msm(A, x), x, A, r)
     ma.accumulate_check(oracle.msm(A, y), y, A, r)
     assert len(ma.base_scalar_map) == 3 and ma.verify()
+
+
+def test_fast_cpu_baseline_matches_the_oracle(oracle, coracle):
+    """oracle/cpu_msm_fast.c (bench.py's timed CPU baseline: mulx/adx products, signed digits,
+    XYZZ buckets, windows split over tasks) against the independent C / Python oracle: sizes
+    0..5000, every window width class, skewed scalar sets, infinity bases, thread counts that
+    do and do not divide the windows."""
+    k, q = oracle.Rand(1).get_frs(2)
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 3, 64, 257, 5000):
+        pts = coracle.points_walk(k, q, n)
+        sc = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+        if n:
+            sc[:, 3] &= np.uint64((1 << 62) - 1)
+        if n > 10:
+            pts[3] = 0            # an infinity base with a non-zero scalar (curdleproof.go:281)
+            sc[5] = 0
+        exp = coracle.msm_pippenger(pts, sc, threads=4)
+        for c, threads in ((0, 1), (4, 3), (7, 8), (13, 5), (16, 40)):
+            assert (coracle.msm_fast(pts, sc, threads=threads, c=c) == exp).all(), (n, c, threads)
+    n = 300
+    pts = coracle.points_walk(k, q, n)
+    assert (coracle.msm_fast(pts[:4], np.array([oracle.fr_to_mont_limbs(v) for v in (1, 2, 3, 4)], dtype=np.uint64))
+            == coracle.msm_naive(pts[:4], np.array([oracle.fr_to_mont_limbs(v) for v in (1, 2, 3, 4)], dtype=np.uint64))).all()
+    for fam in ([123456789] * n, [i % 7 for i in range(n)], [oracle.R - 1 - i for i in range(n)], [1 << 254] * n):
+        sc = np.array([oracle.fr_to_mont_limbs(v % oracle.R) for v in fam], dtype=np.uint64)
+        assert (coracle.msm_fast(pts, sc, threads=6) == coracle.msm_pippenger(pts, sc, threads=4)).all()
