@@ -1,0 +1,104 @@
+"""BASELINE.json's configurations at their REAL sizes (configs 3 and 5 were only
+exercised at reduced size in -m gpu): the full Prove -> Verify at n = 256 (ell = 252, config 3,
+curdleproof_test.go:184-237 benches exactly this size) and n = 512 in both check modes with
+the soundness flips of curdleproof_test.go:48-182; the 1,024 x 628-pair MSM batch of config 5
+against the C oracle; cross-proof batch verification at k = 256 with planted bad proofs."""
+import numpy as np
+import pytest
+
+from test_protocol_gpu import setup
+from test_msm_gpu import rand_scalars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_full_verify_at_baseline_size(gpu, oracle, n):
+    crs, Rs, Ss, Ts, Us, M, perm, k, rs_m = setup(gpu, n)
+    ell = n - 4
+    proof = gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(42))
+    m = n.bit_length() - 1
+    # wire size: 18 single points, 10 vectors of m points behind a 4-byte prefix, 7 scalars
+    assert len(proof) == 48 * 18 + 10 * (4 + 48 * m) + 32 * 7
+    other = gpu.Rand(1234).generate_permutation(ell)
+    r2 = gpu.Rand(99)
+    T2, U2, _, _ = gpu.shuffle_permute_commit(crs, Rs, Ss, perm, r2.get_fr(), r2)
+    aff = gpu.g1_decompress(gpu.g1_compress(M), False)
+    k_int = oracle.fr_from_mont_limbs([int(v) for v in k])
+    Mk = np.array(oracle.jac_to_mont_limbs(oracle.scalar_mul(k_int, oracle.jac_from_mont_limbs([int(v) for v in aff]))),
+                  dtype=np.uint64)
+    try:
+        for eager in (False, True):
+            gpu.verify_set_eager(eager)
+            assert gpu.verify(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(43)) is True                      # completeness
+            assert gpu.verify(crs, proof, Ss, Rs, Ts, Us, M, gpu.Rand(43)) is False                     # flips Ss and Rs
+            assert gpu.verify(crs, proof, Rs, Ss, Ts[other], Us[other], M, gpu.Rand(43)) is False       # another permutation
+            assert gpu.verify(crs, proof, Rs, Ss, Ts, Us, Mk, gpu.Rand(43)) is False                    # wrong commitment
+            assert gpu.verify(crs, proof, Rs, Ss, T2, U2, M, gpu.Rand(43)) is False                     # another randomizer
+    finally:
+        gpu.verify_set_eager(False)
+    assert gpu.proof_reencode(proof) == proof
+
+
+def test_config5_msm_batch_1024_x_628(gpu, oracle, coracle):
+    """1,024 independent 628-pair MSMs (the Whisk verifier's final MSM, ell = 124) in ONE call:
+    sampled members, the empty one and the all-infinity one against the C oracle, all members
+    against a second (device-resident) run, and the batch total against one big MSM."""
+    import torch
+    k, q = oracle.Rand(21).get_frs(2)
+    sizes = [628] * 1024
+    sizes[17], sizes[400] = 0, 3
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(offs[-1])
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    pts = d_pts.cpu().numpy().view(np.uint64).copy()
+    pts[offs[33]:offs[34]] = 0                                   # MSM 33: every base is the point at infinity
+    sc = rand_scalars(np.random.default_rng(21), n, oracle)
+    out = gpu.msm_g1_batch(pts, sc, offs)
+    assert out.shape == (1024, 18)
+    rng = np.random.default_rng(5)
+    sample = sorted(set([0, 1, 17, 33, 400, 511, 1022, 1023]) | set(int(v) for v in rng.integers(0, 1024, 28)))
+    assert len(sample) >= 32
+    for j in sample:
+        lo, hi = int(offs[j]), int(offs[j + 1])
+        assert (out[j] == coracle.msm_fast(pts[lo:hi], sc[lo:hi], threads=4)).all(), j
+    inf = coracle.msm_fast(pts[:0], sc[:0])
+    assert (out[17] == inf).all() and (out[33] == inf).all()
+    d_p = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
+    d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    assert (gpu.msm_g1_batch_device(d_p.data_ptr(), d_s.data_ptr(), offs) == out).all()
+    # checksum of checksums: the sum of all 1,024 results is the MSM over all pairs at once
+    assert (gpu.g1_sum(out) == gpu.msm_g1_device(d_p.data_ptr(), d_s.data_ptr(), n)).all()
+
+
+def test_cross_proof_batch_verification_at_k_256(gpu):
+    """curdle_verify_batch at k = 256 over one CRS (ell = 60) with planted bad members: a proof
+    checked against another proof's instance, a truncated proof, a proof with one flipped bit --
+    the accept bits stay exact."""
+    n = 64
+    ell = n - 4
+    rand = gpu.Rand(0)
+    crs = gpu.CRS(ell, rand)
+    base = []
+    for j in range(4):                                           # four distinct honest (proof, instance) pairs
+        perm = gpu.Rand(100 + j).generate_permutation(ell)
+        k = rand.get_fr()
+        Rs, Ss = rand.get_g1_affines(ell), rand.get_g1_affines(ell)
+        Ts, Us, M, rs_m = gpu.shuffle_permute_commit(crs, Rs, Ss, perm, k, rand)
+        base.append([gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(42 + j)), Rs, Ss, Ts, Us, M])
+    items = [list(base[i % 4]) for i in range(256)]
+    expect = [True] * 256
+    items[5][1], items[5][2] = base[2][1], base[2][2]            # instance of another proof
+    expect[5] = False
+    items[77][0] = items[77][0][:-9]                             # truncated
+    expect[77] = False
+    flipped = bytearray(items[200][0])
+    flipped[len(flipped) - 20] ^= 0x10                           # inside the last scalar
+    items[200][0] = bytes(flipped)
+    expect[200] = False
+    items[255][3] = base[(255 + 1) % 4][3]                       # Ts of another instance
+    expect[255] = False
+    cols = [list(c) for c in zip(*items)]
+    got = gpu.verify_batch(crs, *cols, gpu.Rand(9), nthreads=8)
+    assert got == expect
