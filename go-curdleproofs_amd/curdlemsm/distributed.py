@@ -51,14 +51,23 @@ def gather_partials(partial: np.ndarray, group=None, device=None) -> np.ndarray:
     return np.stack([o.cpu().numpy().view(np.uint64) for o in out])
 
 
+def choose_split(n: int, world_size: int) -> str:
+    """Which partition pays at which size (per-rank step times measured on one MI355X with
+    bench.py --emulate-world, profiles/r02_multi_gpu_emulation.jsonl): with
+    a window range every rank still converts and recodes all n pairs, with a point range it
+    runs its own, narrower Pippenger (more windows per pair); the window range is ahead up to
+    N = 2^22, the point range from 2^23 on (8 ranks, N = 2^24: 5.8 ms against 6.9 ms per step)."""
+    return "points" if n >= (1 << 23) and world_size > 1 else "windows"
+
+
 def msm_g1_distributed(d_points: int, d_scalars: int, n: int, group=None, device=None, stream: int = 0,
                        c: int = 0, split: str = "windows",
                        partial_fn: Optional[Callable[[int, int, int], np.ndarray]] = None) -> np.ndarray:
     """Full MSM result (uint64[18]) on every rank.
 
     split = "windows": every rank runs its window range over all n pairs (north_star).
-    split = "points":  every rank runs all windows over its point range (DESIGN.md section 5
-    says which one pays at which size).
+    split = "points":  every rank runs all windows over its point range.
+    split = "auto":    choose_split(n, world).
 
     partial_fn(c, begin, end) -> uint64[18] replaces the GPU partial (begin / end are the
     window range or the point range); it exists so the collective plumbing can be exercised
@@ -69,6 +78,8 @@ def msm_g1_distributed(d_points: int, d_scalars: int, n: int, group=None, device
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if split == "auto":
+        split = choose_split(n, world)
     if split == "points":
         begin, end = point_partition(n, world, rank)
         if partial_fn is not None:

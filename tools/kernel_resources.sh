@@ -7,8 +7,8 @@ import sys,re
 for l in sys.stdin:
     m=re.search(r'Function Name: (\S+)',l)
     if m: print(); print(m.group(1)[:70],end=' ')
-    for k in ['VGPRs:','AGPRs:','VGPRs Spill','SGPRs Spill','ScratchSize','Occupancy','LDS Size']:
-        m=re.search(r'remark: +'+k+r'[^:]*: *(\d+)',l)
-        if m: print(k.replace(' ','').replace(':','')+'='+m.group(1),end=' ')
+    for k in [' VGPRs',' AGPRs','VGPRs Spill','SGPRs Spill','ScratchSize','Occupancy','LDS Size']:
+        m=re.search(r'remark: +'+k.strip()+r'[^:]*: *(\d+)',l) if k.strip() not in ('VGPRs','AGPRs') else re.search(r'remark: +'+k.strip()+r': *(\d+)',l)
+        if m: print(k.strip().replace(' ','')+'='+m.group(1),end=' ')
 print()
 "
