@@ -209,6 +209,10 @@ int choose_window_bits(size_t n) {
   int lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
   int c = lg - 2;
+  // measured (tools/sweep.py n,c): from a few hundred to a few thousand pairs 8-bit windows win --
+  // 32 windows of 128 buckets reduce in two-bucket segments whose 64 results are one tree, and
+  // narrower windows only lengthen the host's Horner pass
+  if (n >= 300 && c < 8) c = 8;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
   return c;
@@ -226,13 +230,15 @@ int window_widths(int c, uint8_t bits[kMaxWindows]) {
 
 // Plan for k MSMs of n_total pairs in all, the largest having n_max pairs.
 int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end,
-              bool latency_mode) {
+              bool latency_mode, size_t sets = 1) {
   if (n_total > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n_total);
   if (c == 0) c = choose_window_bits(n_max);
   if (c < 4 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", c);
   memset(&p, 0, sizeof(p));
   p.n = (uint32_t)n_total;
   p.k = (uint32_t)k;
+  p.sets = (uint32_t)sets;
+  p.kr = (uint32_t)(k * sets);
   p.n_max = (uint32_t)n_max;
   p.c = c;
   p.W = window_widths(c, p.bits);
@@ -255,7 +261,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   }
   if (p.max_nbkt > 32768) return fail(CURDLE_EINVAL, "window of %u buckets exceeds the LDS histogram", p.max_nbkt);
   if (win_begin == win_end) return CURDLE_OK;
-  const uint64_t nbk = (uint64_t)k * p.NB;
+  const uint64_t nbk = (uint64_t)k * sets * p.NB;  // bucket slots the reduce kernels walk
   // Buckets per running-sum segment: long segments amortise the per-segment scalar
   // multiple, short ones keep the serial chain short when there are few buckets.
   // A pipelined caller (submit / wait) hides the chain behind the next MSM's accumulation
@@ -315,7 +321,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (const char* env = getenv("CURDLE_SORT_CHUNK")) ch = (uint64_t)atoll(env);
   if (ch > n_max) ch = n_max ? n_max : 1;
   p.chunk = (uint32_t)ch;
-  p.gpu_combine = k >= kGpuCombineMin ? 1u : 0u;
+  p.gpu_combine = k * sets >= kGpuCombineMin ? 1u : 0u;
   return CURDLE_OK;
 }
 
@@ -396,7 +402,9 @@ struct Prof {
 // and must stay valid until the matching finish_slot(); h_off has k + 1 entries.
 int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                  int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail,
-                 bool latency_mode = true, bool points28_ready = false) {
+                 bool latency_mode = true, bool points28_ready = false, size_t sets = 1) {
+  // sets > 1 (curdle_msm_g1_multi): d_points holds `sets` base sets of h_off[k] points each, all
+  // multiplied by the SAME scalars: recoded and sorted once, accumulated per set
   const size_t n = h_off[k];
   size_t n_max = 0;
   for (size_t j = 0; j < k; j++) {
@@ -404,8 +412,9 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
     if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
   }
   MsmPlan& p = S.plan;
-  int rc = make_plan(p, n, k, n_max, c, win_begin, win_end, latency_mode);
+  int rc = make_plan(p, n, k, n_max, c, win_begin, win_end, latency_mode, sets);
   if (rc) return rc;
+  const size_t kr = k * sets;
   S.run_stream = tail;
   S.profiled = false;
   const uint32_t nw = p.win_end - p.win_begin;
@@ -422,15 +431,16 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
   if ((rc = ensure(S.small, (1024 + 1 + (size_t)p.max_large) * 4))) return rc;
   if ((rc = ensure(S.digits, (size_t)nw * n * 4))) return rc;
   if ((rc = ensure(S.sorted, (size_t)nw * n * 4))) return rc;
-  if ((rc = ensure(S.points28, n * kA28Bytes))) return rc;
-  if ((rc = ensure(S.frags, (nb + nlanes + 1) * kX28Bytes))) return rc;
-  if ((rc = ensure(S.partials, (k * (size_t)p.NS / p.G + 1) * kX28Bytes))) return rc;
-  if ((rc = ensure(S.winsums, k * (size_t)nw * sizeof(G1XYZZ)))) return rc;
+  p.frag_stride = (uint32_t)(nb + nlanes + 1);
+  if ((rc = ensure(S.points28, sets * n * kA28Bytes))) return rc;
+  if ((rc = ensure(S.frags, sets * (size_t)p.frag_stride * kX28Bytes))) return rc;
+  if ((rc = ensure(S.partials, (kr * (size_t)p.NS / p.G + 1) * kX28Bytes))) return rc;
+  if ((rc = ensure(S.winsums, kr * (size_t)nw * sizeof(G1XYZZ)))) return rc;
   if (p.gpu_combine) {
-    if ((rc = ensure(S.winsums28, k * (size_t)nw * kX28Bytes))) return rc;
-    if ((rc = ensure(S.results, k * sizeof(G1XYZZ)))) return rc;
+    if ((rc = ensure(S.winsums28, kr * (size_t)nw * kX28Bytes))) return rc;
+    if ((rc = ensure(S.results, kr * sizeof(G1XYZZ)))) return rc;
   }
-  const size_t host_need = (p.gpu_combine ? k * sizeof(G1XYZZ) : k * (size_t)nw * sizeof(G1XYZZ)) + (k + 1) * 4;
+  const size_t host_need = (p.gpu_combine ? kr * sizeof(G1XYZZ) : kr * (size_t)nw * sizeof(G1XYZZ)) + (k + 1) * 4;
   if (S.h_buf_cap < host_need) {
     if (S.h_buf) HIP_TRY(hipHostFree(S.h_buf));
     S.h_buf = nullptr;
@@ -459,13 +469,14 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
 
   // the offsets are staged in pinned memory (tail of h_buf) so the copy is truly asynchronous
   uint32_t* h_off_pinned = (uint32_t*)((char*)S.h_buf + host_need - (k + 1) * 4);
-  memcpy(h_off_pinned, h_off, (k + 1) * 4);
-  HIP_TRY(hipMemcpyAsync(S.offsets.p, h_off_pinned, (k + 1) * 4, hipMemcpyHostToDevice, pre));
-  HIP_TRY(hipMemsetAsync(ws.counts, 0, nb * 4, pre));
-  HIP_TRY(hipMemsetAsync(ws.nlarge, 0, 4, pre));
+  if (k > 1) {  // a single MSM's kernels take [0, n) from the plan
+    memcpy(h_off_pinned, h_off, (k + 1) * 4);
+    HIP_TRY(hipMemcpyAsync(S.offsets.p, h_off_pinned, (k + 1) * 4, hipMemcpyHostToDevice, pre));
+  }
+  // counts are cleared by k_digits, the large-bucket counter by the scan
   Prof prof(S, pre, g_ctx.profile);
   if (!points28_ready) {  // the device accumulator fills S.points28 itself (resident bases: no conversion here)
-    HIP_TRY(launch_convert_points(p, ws, d_points, pre));
+    HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n), ws.points28, pre));
     prof.mark("convert_points");
   }
   HIP_TRY(launch_digits(p, ws, d_scalars, pre));
@@ -500,9 +511,9 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
   if (p.gpu_combine) {
     HIP_TRY(launch_combine(p, ws, stream));
     prof.mark("combine");
-    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.results, k * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.results, kr * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
   } else {
-    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.winsums, k * (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.winsums, kr * (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
   }
   return CURDLE_OK;
 }
@@ -511,7 +522,7 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
 // batch combined on the GPU).
 int finish_slot(Slot& S, uint64_t* out) {
   const MsmPlan& p = S.plan;
-  const size_t k = p.k;
+  const size_t k = p.kr;  // results
   const uint32_t nw = p.win_end - p.win_begin;
   if (p.n == 0 || nw == 0) {
     for (size_t j = 0; j < k; j++) set_out_infinity(out + 18 * j);
@@ -575,6 +586,23 @@ void drain_slot(Slot& S) {
   (void)hipStreamSynchronize(S.stream);
 }
 
+// Streams of a synchronous call.  The caller waits for this very call, so every phase goes to
+// the slot's own stream: no event hops between streams (each costs a cross-queue dependency,
+// ~10 us with 16 hardware queues: 0.58 -> 0.50 ms for a 1,268-pair MSM), and concurrent callers
+// still overlap, each on its slot's stream.  CURDLE_SYNC_STREAMS=3 restores the three-stream
+// layout of the pipelined entry points.
+struct SyncStreams {
+  hipStream_t pre, main, tail;
+};
+SyncStreams sync_streams(Slot& S) {
+  static const bool three = [] {
+    const char* e = getenv("CURDLE_SYNC_STREAMS");
+    return e && atoi(e) == 3;
+  }();
+  if (three) return {g_ctx.pre_stream, g_ctx.main_stream, S.stream};
+  return {S.stream, S.stream, S.stream};
+}
+
 // Synchronous run of k MSMs with inputs on the device.
 int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c, int win_begin,
                int win_end, uint64_t* out, void* user_stream) {
@@ -587,12 +615,13 @@ int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_of
     release_slot(idx);
     return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
   }
-  if (user_stream)
+  if (user_stream) {
     rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, (hipStream_t)user_stream,
                       (hipStream_t)user_stream, (hipStream_t)user_stream);
-  else
-    rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, g_ctx.pre_stream, g_ctx.main_stream,
-                      S.stream);
+  } else {
+    const SyncStreams st = sync_streams(S);
+    rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, st.pre, st.main, st.tail);
+  }
   if (!rc) rc = finish_slot(S, out);
   else drain_slot(S);
   release_slot(idx);
@@ -611,10 +640,10 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
     int r;
     if ((r = ensure(S.points, n * 96))) return r;
     if ((r = ensure(S.scalars, n * 32))) return r;
-    HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, g_ctx.pre_stream));
-    HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.pre_stream));
-    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, g_ctx.pre_stream, g_ctx.main_stream, S.stream)))
-      return r;
+    const SyncStreams st = sync_streams(S);
+    HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, st.pre));
+    HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st.pre));
+    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, st.pre, st.main, st.tail))) return r;
     return finish_slot(S, out);
   };
   rc = body();
@@ -1010,9 +1039,10 @@ extern "C" int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scala
   return run_host(points + 12 * lo, scalars + 4 * lo, off.data(), k, out_jac);
 }
 
-// k base sets against one scalar vector: run as a batch of k MSMs whose scalar
-// segments are k device copies of the same n scalars (the recoding is a few
-// percent of an MSM; sharing it is a later refinement).
+// k base sets against ONE scalar vector (samemultiscalarargument.go:64-70: the same r against
+// G, T, U; curdleproof.go:110,:114): the scalars are uploaded, recoded and bucket-sorted once;
+// the accumulate kernel walks the one sorted index list once per base set (grid.y), and the
+// reduce kernels read the shared fragment bookkeeping with a per-set fragment offset.
 extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k, const uint64_t* scalars, size_t n,
                                    uint64_t* out_jac) {
   if ((k && !out_jac) || (k && !points_sets)) return fail(CURDLE_EINVAL, "null argument");
@@ -1033,21 +1063,14 @@ extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k,
     HIP_TRY(hipSetDevice(g_ctx.device));
     int r;
     if ((r = ensure(S.points, k * n * 96))) return r;
-    if ((r = ensure(S.scalars, k * n * 32))) return r;
-    std::vector<uint32_t> off(k + 1);
-    for (size_t j = 0; j < k; j++) {
-      off[j] = (uint32_t)(j * n);
-      HIP_TRY(hipMemcpyAsync((char*)S.points.p + j * n * 96, points_sets[j], n * 96, hipMemcpyHostToDevice,
-                             g_ctx.pre_stream));
-      if (j == 0)
-        HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.pre_stream));
-      else
-        HIP_TRY(hipMemcpyAsync((char*)S.scalars.p + j * n * 32, S.scalars.p, n * 32, hipMemcpyDeviceToDevice,
-                               g_ctx.pre_stream));
-    }
-    off[k] = (uint32_t)(k * n);
-    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, off.data(), k, 0, 0, -1, g_ctx.pre_stream, g_ctx.main_stream,
-                          S.stream)))
+    if ((r = ensure(S.scalars, n * 32))) return r;
+    const SyncStreams st = sync_streams(S);
+    for (size_t j = 0; j < k; j++)
+      HIP_TRY(hipMemcpyAsync((char*)S.points.p + j * n * 96, points_sets[j], n * 96, hipMemcpyHostToDevice, st.pre));
+    HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st.pre));
+    const uint32_t off[2] = {0, (uint32_t)n};
+    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, st.pre, st.main, st.tail,
+                          /*latency_mode=*/true, /*points28_ready=*/false, /*sets=*/k)))
       return r;
     return finish_slot(S, out_jac);
   };

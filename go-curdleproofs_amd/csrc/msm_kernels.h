@@ -20,7 +20,10 @@ static constexpr int kMaxWindows = 64;
 // is m; the MSMs' slot ranges follow each other (NB slots each).
 struct MsmPlan {
   uint32_t n;          // pairs of all MSMs of the call
-  uint32_t k;          // MSMs in the call
+  uint32_t k;          // scalar vectors (sorted MSMs) in the call
+  uint32_t sets;       // base sets sharing every scalar vector's recoding and sort (1 but for curdle_msm_g1_multi)
+  uint32_t kr;         // results = k * sets; result r = set * k + j
+  uint32_t frag_stride;  // fragments reserved per base set
   uint32_t n_max;      // pairs of the largest MSM
   int c;               // requested maximum window width
   int W;               // windows of the full decomposition

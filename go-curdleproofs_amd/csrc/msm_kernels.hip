@@ -81,8 +81,11 @@ __device__ __forceinline__ Fr load_scalar_canonical(const uint4* scalars, u32 i)
 // Phase 1: recode every scalar once.  digits[lw][i] = |d| | sign << 31 (0 = no
 // contribution), window-major so the sort passes below read them coalesced.
 __global__ void __launch_bounds__(kBlock) k_digits(const uint4* __restrict__ scalars, MsmPlan p,
-                                                   u32* __restrict__ digits) {
+                                                   u32* __restrict__ digits, u32* __restrict__ counts, u32 nb) {
   u32 i = blockIdx.x * kBlock + threadIdx.x;
+  // the histogram's counters start from zero: cleared here, one launch before k_hist adds into
+  // them, instead of by a memset node of their own
+  for (u32 b = i; b < nb; b += gridDim.x * kBlock) counts[b] = 0;
   if (i >= p.n) return;
   Fr s = load_scalar_canonical(scalars, i);
   for_each_digit(s, p, [&](int w, u32 mag, u32 neg) {
@@ -101,8 +104,9 @@ __global__ void __launch_bounds__(kSortThreads) k_hist(const u32* __restrict__ d
                                                       const u32* __restrict__ offsets, u32* __restrict__ counts) {
   extern __shared__ u32 lds_cnt[];
   const u32 lw = blockIdx.y, j = blockIdx.z;
-  const u32 i0 = offsets[j] + blockIdx.x * p.chunk;
-  const u32 i1 = min(i0 + p.chunk, offsets[j + 1]);
+  // a single MSM covers pairs [0, n): no offsets array to wait for
+  const u32 i0 = (p.k == 1 ? 0u : offsets[j]) + blockIdx.x * p.chunk;
+  const u32 i1 = min(i0 + p.chunk, p.k == 1 ? p.n : offsets[j + 1]);
   if (i0 >= i1) return;  // block-uniform
   const u32 nb = p.nbkt[p.win_begin + lw];
   for (u32 b = threadIdx.x; b < nb; b += kSortThreads) lds_cnt[b] = 0;
@@ -128,8 +132,8 @@ __global__ void __launch_bounds__(kSortThreads) k_scatter(const u32* __restrict_
                                                          u32* __restrict__ sorted) {
   extern __shared__ u32 lds_cnt[];
   const u32 lw = blockIdx.y, j = blockIdx.z;
-  const u32 i0 = offsets[j] + blockIdx.x * p.chunk;
-  const u32 i1 = min(i0 + p.chunk, offsets[j + 1]);
+  const u32 i0 = (p.k == 1 ? 0u : offsets[j]) + blockIdx.x * p.chunk;
+  const u32 i1 = min(i0 + p.chunk, p.k == 1 ? p.n : offsets[j + 1]);
   if (i0 >= i1) return;  // block-uniform
   const u32 nb = p.nbkt[p.win_begin + lw];
   for (u32 b = threadIdx.x; b < nb; b += kSortThreads) lds_cnt[b] = 0;
@@ -240,6 +244,57 @@ __global__ void __launch_bounds__(kBlock) k_fix_foff(u32* __restrict__ foff, con
   }
 }
 
+// All of the above in ONE single-block launch for calls with at most 16,384 bucket slots
+// (small MSMs are launch-latency-bound: six dependent launches were ~30 us of a 0.4 ms call).
+static constexpr u32 kScanFusedMax = 16 * kScanThreads;
+__global__ void __launch_bounds__(kScanThreads)
+    k_scan_fused(const u32* __restrict__ counts, u32 nb, u32* __restrict__ starts, u32* __restrict__ cursor,
+                 u32* __restrict__ fragcnt, u32* __restrict__ foff, u32* __restrict__ large, u32* __restrict__ nlarge, u32 L,
+                 u32 max_small, u32 max_large) {
+  __shared__ u32 sh[kScanThreads];
+  const u32 tid = threadIdx.x;
+  const u32 per = (nb + kScanThreads - 1) / kScanThreads;  // <= 16
+  const u32 base = tid * per;
+  if (tid == 0) *nlarge = 0;
+  u32 v[16], fc[16], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    v[k] = ((u32)k < per && base + k < nb) ? counts[base + k] : 0u;
+    sum += v[k];
+  }
+  u32 total;
+  u32 run = block_exclusive_scan_1024(sum, sh, total);
+  u32 fsum = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    fc[k] = 0;
+    if ((u32)k < per && base + k < nb) {
+      starts[base + k] = run;
+      cursor[base + k] = run;
+      fc[k] = v[k] ? ((run + v[k] - 1) / L - run / L + 1) : 0u;
+      fragcnt[base + k] = fc[k];
+      fsum += fc[k];
+      run += v[k];
+    }
+  }
+  if (tid == 0) starts[nb] = total;
+  __syncthreads();  // sh is reused; nlarge = 0 is visible to the block
+  u32 ftotal;
+  u32 frun = block_exclusive_scan_1024(fsum, sh, ftotal);
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    if ((u32)k < per && base + k < nb) {
+      foff[base + k] = frun;
+      if (fc[k] > max_small) {
+        u32 q = atomicAdd(nlarge, 1u);
+        if (q < max_large) large[q] = base + k;
+      }
+      frun += fc[k];
+    }
+  }
+  if (tid == 0) foff[nb] = ftotal;
+}
+
 // Phase 0: gnark points (R = 2^384, saturated limbs) -> internal form (fp28.h),
 // once per MSM: one Montgomery product per coordinate.  (0,0) stays (0,0).
 // element i of the internal point array (kA28Bytes apart: one 128-byte line per point, so a
@@ -305,8 +360,11 @@ __device__ __forceinline__ void group_sum(X28& acc, u32 G, X28* wave_partials /*
 template <int WAVES>
 __global__ void __launch_bounds__(kBlock, WAVES)
     k_accumulate(const A28* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ starts,
-                 const u32* __restrict__ foff, X28* __restrict__ frags, u32 nb, u32 L) {
+                 const u32* __restrict__ foff, X28* __restrict__ frags, u32 nb, u32 L, u32 set_points, u32 frag_stride) {
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  // base set blockIdx.y of a shared-scalar call: its own points and fragments, the one sorted list
+  points = a28_at(points, (size_t)blockIdx.y * set_points);
+  frags += (size_t)blockIdx.y * frag_stride;
   const u32 total = starts[nb];
   u32 pos = t * L;
   if (pos >= total) return;
@@ -372,13 +430,15 @@ __global__ void __launch_bounds__(kBlock, WAVES)
 }
 
 // One block per queued bucket (more than max_small fragments): tree-sum of the
-// fragments into the bucket's first fragment slot, fragcnt := 1.
+// fragments into the bucket's first fragment slot; the reduce kernels read ONE fragment for
+// such a bucket (fragcnt itself stays as scanned: base sets of a shared-scalar call share it).
 __global__ void __launch_bounds__(kBlock, 2)
     k_merge_large(const u32* __restrict__ large, const u32* __restrict__ nlarge, const u32* __restrict__ foff,
-                  u32* __restrict__ fragcnt, X28* __restrict__ frags, u32 max_large) {
+                  const u32* __restrict__ fragcnt, X28* __restrict__ frags, u32 max_large, u32 frag_stride) {
   __shared__ X28 sh[4];
   const u32 nl = min(*nlarge, max_large);
   const u32 tid = threadIdx.x;
+  frags += (size_t)blockIdx.y * frag_stride;
   for (u32 q = blockIdx.x; q < nl; q += gridDim.x) {  // block-uniform trip count
     const u32 g = large[q];
     const u32 m = fragcnt[g];
@@ -390,10 +450,7 @@ __global__ void __launch_bounds__(kBlock, 2)
       d28::add(acc, b);
     }
     group_sum(acc, kBlock, sh);
-    if (tid == 0) {
-      d28::store(&f[0], acc);
-      fragcnt[g] = 1;
-    }
+    if (tid == 0) d28::store(&f[0], acc);
     __syncthreads();
   }
 }
@@ -417,9 +474,11 @@ __global__ void __launch_bounds__(kBlock, WAVES)
   const u32 q = blockIdx.x * kBlock + tid;
   X28 acc, b;
   d28::set_inf(acc);
-  if (q < p.k * p.NS) {
-    const u32 j = q / p.NS;
-    const u32 r = q - j * p.NS;
+  if (q < p.kr * p.NS) {
+    const u32 jr = q / p.NS;            // result index = set * k + j
+    const u32 r = q - jr * p.NS;
+    const u32 set = jr / p.k, j = jr - set * p.k;
+    frags += (size_t)set * p.frag_stride;
     int w = p.win_begin;
     while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
     const u32 lo = (r - p.base[w] / p.seg) * p.seg;
@@ -427,7 +486,8 @@ __global__ void __launch_bounds__(kBlock, WAVES)
     X28 run;
     d28::set_inf(run);
     for (int u = (int)p.seg - 1; u >= 0; u--) {
-      const u32 m = fragcnt[g0 + u];
+      u32 m = fragcnt[g0 + u];
+      if (m > p.max_small) m = 1;  // pre-merged by k_merge_large into its first slot
       const X28* f = frags + foff[g0 + u];
       for (u32 k = 0; k < m; k++) {
         d28::load(b, &f[k]);
@@ -441,7 +501,7 @@ __global__ void __launch_bounds__(kBlock, WAVES)
     }
   }
   if (p.G > 1) group_sum(acc, p.G, sh);
-  if ((tid & (p.G - 1)) == 0 && q < p.k * p.NS) d28::store(&partials[q / p.G], acc);
+  if ((tid & (p.G - 1)) == 0 && q < p.kr * p.NS) d28::store(&partials[q / p.G], acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -487,19 +547,22 @@ __global__ void __launch_bounds__(kBlock, 2)
   __shared__ F28 sh[4][4];
   const u32 tid = threadIdx.x;
   const u32 q = blockIdx.x * (kBlock / 4) + (tid >> 2);  // logical lane
-  const bool live = q < p.k * p.NS;
+  const bool live = q < p.kr * p.NS;
   F28 acc, run, b;
   q28::set_inf(acc);
   q28::set_inf(run);
   if (live) {
-    const u32 j = q / p.NS;
-    const u32 r = q - j * p.NS;
+    const u32 jr = q / p.NS;            // result index = set * k + j
+    const u32 r = q - jr * p.NS;
+    const u32 set = jr / p.k, j = jr - set * p.k;
+    frags += (size_t)set * p.frag_stride;
     int w = p.win_begin;
     while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
     const u32 lo = (r - p.base[w] / p.seg) * p.seg;
     const u32 g0 = j * p.NB + p.base[w] + lo;
     int u = (int)p.seg - 1;
     u32 m = fragcnt[g0 + u], k = 0;
+    if (m > p.max_small) m = 1;  // pre-merged by k_merge_large into its first slot
     const X28* f = frags + foff[g0 + u];
     while (u >= 0) {
       const bool take = k < m;  // uniform over the quad
@@ -517,6 +580,7 @@ __global__ void __launch_bounds__(kBlock, 2)
         u--;
         if (u >= 0) {
           m = fragcnt[g0 + u];
+          if (m > p.max_small) m = 1;
           f = frags + foff[g0 + u];
           k = 0;
         }
@@ -623,7 +687,7 @@ __global__ void __launch_bounds__(kBlock, 2)
                       MsmPlan p) {
   const u32 nw = p.win_end - p.win_begin;
   const u32 gw = blockIdx.x * kBlock + threadIdx.x;
-  if (gw >= p.k * nw) return;
+  if (gw >= p.kr * nw) return;
   const u32 j = gw / nw, lw = gw - j * nw;
   const u32 w = p.win_begin + lw;
   const u32 np = p.nbkt[w] / p.seg / p.G;
@@ -647,7 +711,7 @@ __global__ void __launch_bounds__(kBlock, 2)
 __global__ void __launch_bounds__(kBlock, 2)
     k_combine(const X28* __restrict__ winsums28, G1XYZZ* __restrict__ results, MsmPlan p) {
   const u32 j = blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2);
-  if (j >= p.k) return;  // whole quads leave together
+  if (j >= p.kr) return;  // whole quads leave together
   const u32 nw = p.win_end - p.win_begin;
   F28 acc, b;
   q28::set_inf(acc);
@@ -684,7 +748,7 @@ static hipError_t sort_lds_optin() {
 
 hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream) {
   hipLaunchKernelGGL(k_digits, dim3(cdiv(p.n, kBlock)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const uint4*>(d_scalars), p, ws.digits);
+                     reinterpret_cast<const uint4*>(d_scalars), p, ws.digits, ws.counts, p.k * p.NB);
   return hipGetLastError();
 }
 
@@ -707,6 +771,13 @@ static hipError_t scan_u32(const u32* in, u32 len, u32* out, u32* blocksum, hipS
 
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nb = p.k * p.NB;
+  if (nb <= kScanFusedMax) {
+    hipLaunchKernelGGL(k_scan_fused, dim3(1), dim3(kScanThreads), 0, stream, ws.counts, nb, ws.starts, ws.cursor,
+                       ws.fragcnt, ws.foff, ws.large, ws.nlarge, p.L, p.max_small, p.max_large);
+    return hipGetLastError();
+  }
+  hipError_t e0 = hipMemsetAsync(ws.nlarge, 0, 4, stream);
+  if (e0 != hipSuccess) return e0;
   hipError_t e = scan_u32(ws.counts, nb, ws.starts, ws.blocksum, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fix_starts, dim3(cdiv(nb, kBlock)), dim3(kBlock), 0, stream, ws.starts, ws.blocksum, ws.counts,
@@ -749,26 +820,26 @@ hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream
     return e ? atoi(e) : 2;
   }();
   if (waves == 3)
-    hipLaunchKernelGGL(k_accumulate<3>, dim3(cdiv(nlanes, kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(k_accumulate<3>, dim3(cdiv(nlanes, kBlock), p.sets), dim3(kBlock), 0, stream,
                        reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
-                       reinterpret_cast<X28*>(ws.frags), nb, p.L);
+                       reinterpret_cast<X28*>(ws.frags), nb, p.L, p.n, p.frag_stride);
   else
-    hipLaunchKernelGGL(k_accumulate<2>, dim3(cdiv(nlanes, kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(k_accumulate<2>, dim3(cdiv(nlanes, kBlock), p.sets), dim3(kBlock), 0, stream,
                        reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
-                       reinterpret_cast<X28*>(ws.frags), nb, p.L);
+                       reinterpret_cast<X28*>(ws.frags), nb, p.L, p.n, p.frag_stride);
   return hipGetLastError();
 }
 
 hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  hipLaunchKernelGGL(k_merge_large, dim3(p.max_large < 1024u ? p.max_large : 1024u), dim3(kBlock), 0, stream, ws.large, ws.nlarge, ws.foff,
-                     ws.fragcnt, reinterpret_cast<X28*>(ws.frags), p.max_large);
+  hipLaunchKernelGGL(k_merge_large, dim3(p.max_large < 1024u ? p.max_large : 1024u, p.sets), dim3(kBlock), 0, stream,
+                     ws.large, ws.nlarge, ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.frags), p.max_large, p.frag_stride);
   return hipGetLastError();
 }
 
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   // The 256-register build (2 waves per SIMD) even when the launch has one wave per SIMD:
   // it leaves room for an accumulate wave of the next MSM on the same SIMD.
-  const u64 lanes = (u64)p.k * p.NS;
+  const u64 lanes = (u64)p.kr * p.NS;
   if (p.quad)
     hipLaunchKernelGGL(k_bucket_reduce_quad, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream,
                        reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
@@ -781,19 +852,19 @@ hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStr
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
   if (p.max_nbkt / p.seg / p.G > 4 && p.quad)
-    hipLaunchKernelGGL(k_window_sum_wide_quad, dim3(nw, p.k), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(k_window_sum_wide_quad, dim3(nw, p.kr), dim3(kBlock), 0, stream,
                        reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
   else if (p.max_nbkt / p.seg / p.G > 4)
-    hipLaunchKernelGGL(k_window_sum_wide, dim3(nw, p.k), dim3(64), 0, stream, reinterpret_cast<const X28*>(ws.partials),
+    hipLaunchKernelGGL(k_window_sum_wide, dim3(nw, p.kr), dim3(64), 0, stream, reinterpret_cast<const X28*>(ws.partials),
                        ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
   else
-    hipLaunchKernelGGL(k_window_sum_flat, dim3(cdiv((u64)p.k * nw, kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(k_window_sum_flat, dim3(cdiv((u64)p.kr * nw, kBlock)), dim3(kBlock), 0, stream,
                        reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
   return hipGetLastError();
 }
 
 hipError_t launch_combine(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  hipLaunchKernelGGL(k_combine, dim3(cdiv(p.k, kBlock / 4)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(k_combine, dim3(cdiv(p.kr, kBlock / 4)), dim3(kBlock), 0, stream,
                      reinterpret_cast<const X28*>(ws.winsums28), ws.results, p);
   return hipGetLastError();
 }

@@ -1,0 +1,124 @@
+// Benchmarks for whoever has a Go toolchain next to an MI355X (BASELINE.md section 3 /
+// SURVEY.md section 8d): the numbers this pipeline cannot produce itself.
+//
+//	BenchmarkMultiExp/cpu/N=2^k   gnark-crypto's (*G1Jac).MultiExp with the reference's own
+//	                              configuration, common.MultiExpConf = {NbTasks: NumCPU}
+//	                              (/root/reference/common/util.go:14) -- the CPU baseline that
+//	                              bench.py can only approximate with oracle/cpu_msm_fast.c
+//	BenchmarkMultiExp/gpu/N=2^k   the same inputs through the cgo shim (host buffers, so the
+//	                              PCIe copy is inside the timed region: compare with bench.py's
+//	                              device-resident figure knowingly)
+//	BenchmarkParity               dst.Equal() between the two for every N, plus the sizes the
+//	                              protocol meets (6..9, 60..2548): the bit-exactness check
+//	                              against the REAL reference arithmetic that this repository's
+//	                              tests cannot make (parity is pinned on an in-house oracle)
+//
+// The reference's own BenchmarkVerifier / BenchmarkProver (curdleproof_test.go:184-237) need no
+// copy here: with the 39 MultiExp call sites routed through common.MultiExp (INTEGRATION.md
+// section 2) `go test -bench 'Verifier|Prover' .` in the reference tree measures the GPU path,
+// and `CURDLE_DISABLE=1` (see the dispatch function there) measures the unmodified CPU path.
+//
+// UNVERIFIED: never compiled (no Go toolchain in the build image).
+//
+//	cd go-curdleproofs_amd/go && go mod init curdlemsm-bench && go mod tidy
+//	go test -bench . -benchtime 5x ./bench
+package bench
+
+import (
+	"fmt"
+	"math/big"
+	"runtime"
+	"testing"
+
+	"github.com/consensys/gnark-crypto/ecc"
+	bls12381 "github.com/consensys/gnark-crypto/ecc/bls12-381"
+	"github.com/consensys/gnark-crypto/ecc/bls12-381/fr"
+
+	"curdlemsm-bench/curdlemsm"
+)
+
+// The synthetic inputs of SURVEY.md section 8d: P_i = P_0 + i*Q (distinct points with known
+// discrete logs), uniform scalars.  Deterministic, so runs are comparable.
+func inputs(n int) ([]bls12381.G1Affine, []fr.Element) {
+	_, _, g, _ := bls12381.Generators()
+	var p0, q bls12381.G1Jac
+	p0.FromAffine(&g)
+	p0.ScalarMultiplication(&p0, big.NewInt(0x1234567))
+	q.FromAffine(&g)
+	q.ScalarMultiplication(&q, big.NewInt(0x7654321))
+	jac := make([]bls12381.G1Jac, n)
+	acc := p0
+	for i := range jac {
+		jac[i] = acc
+		acc.AddAssign(&q)
+	}
+	points := bls12381.BatchJacobianToAffineG1(jac)
+	scalars := make([]fr.Element, n)
+	var s fr.Element
+	s.SetUint64(0x9e3779b97f4a7c15)
+	for i := range scalars {
+		s.Square(&s)
+		s.Add(&s, &scalars[(i+n-1)%n])
+		var one fr.Element
+		one.SetOne()
+		s.Add(&s, &one)
+		scalars[i] = s
+	}
+	return points, scalars
+}
+
+var sizes = []int{10, 12, 14, 16, 18, 20}
+
+func BenchmarkMultiExp(b *testing.B) {
+	if err := curdlemsm.Init(0); err != nil {
+		b.Skipf("no MI355X: %v", err)
+	}
+	for _, lg := range sizes {
+		points, scalars := inputs(1 << lg)
+		b.Run(fmt.Sprintf("cpu/N=2^%d", lg), func(b *testing.B) {
+			cfg := ecc.MultiExpConfig{NbTasks: runtime.NumCPU()} // common.MultiExpConf
+			var dst bls12381.G1Jac
+			b.ResetTimer()
+			for i := 0; i < b.N; i++ {
+				if _, err := dst.MultiExp(points, scalars, cfg); err != nil {
+					b.Fatal(err)
+				}
+			}
+			b.ReportMetric(float64(len(points))*float64(b.N)/b.Elapsed().Seconds(), "pairs/s")
+		})
+		b.Run(fmt.Sprintf("gpu/N=2^%d", lg), func(b *testing.B) {
+			var dst bls12381.G1Jac
+			b.ResetTimer()
+			for i := 0; i < b.N; i++ {
+				if _, err := curdlemsm.MultiExp(&dst, points, scalars); err != nil {
+					b.Fatal(err)
+				}
+			}
+			b.ReportMetric(float64(len(points))*float64(b.N)/b.Elapsed().Seconds(), "pairs/s")
+		})
+	}
+}
+
+func TestParity(t *testing.T) {
+	if err := curdlemsm.Init(0); err != nil {
+		t.Skipf("no MI355X: %v", err)
+	}
+	cfg := ecc.MultiExpConfig{NbTasks: runtime.NumCPU()}
+	ns := []int{0, 1, 2, 3, 6, 7, 8, 9, 60, 64, 124, 128, 252, 256, 308, 628, 1268, 2548, 1 << 12, 1 << 16}
+	for _, n := range ns {
+		points, scalars := inputs(n)
+		if n > 4 {
+			points[3] = bls12381.G1Affine{} // the (0,0) infinity base with a non-zero scalar (curdleproof.go:281)
+		}
+		var cpu, gpu bls12381.G1Jac
+		if _, err := cpu.MultiExp(points, scalars, cfg); err != nil {
+			t.Fatal(err)
+		}
+		if _, err := curdlemsm.MultiExp(&gpu, points, scalars); err != nil {
+			t.Fatal(err)
+		}
+		if !cpu.Equal(&gpu) {
+			t.Fatalf("n = %d: GPU MultiExp differs from gnark-crypto", n)
+		}
+	}
+}

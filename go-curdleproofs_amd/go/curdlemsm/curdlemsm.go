@@ -4,7 +4,7 @@
 // through one function (INTEGRATION.md).
 //
 // UNVERIFIED: there is no Go toolchain in the build image, so this file has
-// never been compiled.  It is deliberately small: one cgo call per entry point,
+// never been compiled (needs Go >= 1.21 for runtime.Pinner).  It is deliberately small: one cgo call per entry point,
 // zero-copy (gnark's fp.Element / fr.Element / G1Affine / G1Jac are
 // pointer-free [k]uint64 arrays, so &s[0] can be handed to C directly and the
 // cgo pointer rules hold: the library keeps no pointer after returning).
@@ -21,13 +21,23 @@ import "C"
 import (
 	"errors"
 	"fmt"
+	"runtime"
 	"unsafe"
 
 	bls12381 "github.com/consensys/gnark-crypto/ecc/bls12-381"
 	"github.com/consensys/gnark-crypto/ecc/bls12-381/fr"
 )
 
-func lastError(rc C.int) error {
+// The library keeps the text of the last error per OS THREAD; a goroutine can migrate between
+// two cgo calls, so every entry point below runs `call` and the error fetch under
+// runtime.LockOSThread (ADVICE r1).
+func locked(call func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	rc := call()
+	if rc == 0 {
+		return nil
+	}
 	var buf [256]C.char
 	C.curdle_last_error(&buf[0], C.size_t(len(buf)))
 	return fmt.Errorf("curdlemsm: rc=%d: %s", int(rc), C.GoString(&buf[0]))
@@ -35,10 +45,7 @@ func lastError(rc C.int) error {
 
 // Init selects the HIP device of this process (one process per GPU).
 func Init(device int) error {
-	if rc := C.curdle_init(C.int(device)); rc != 0 {
-		return lastError(rc)
-	}
-	return nil
+	return locked(func() C.int { return C.curdle_init(C.int(device)) })
 }
 
 // MultiExp is the drop-in for (*bls12381.G1Jac).MultiExp(points, scalars, cfg):
@@ -53,10 +60,12 @@ func MultiExp(dst *bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Elem
 		pp = unsafe.Pointer(&points[0])
 		sp = unsafe.Pointer(&scalars[0])
 	}
-	rc := C.curdle_msm_g1((*C.uint64_t)(pp), (*C.uint64_t)(sp), C.size_t(len(points)),
-		(*C.uint64_t)(unsafe.Pointer(dst)))
-	if rc != 0 {
-		return nil, lastError(rc)
+	err := locked(func() C.int {
+		return C.curdle_msm_g1((*C.uint64_t)(pp), (*C.uint64_t)(sp), C.size_t(len(points)),
+			(*C.uint64_t)(unsafe.Pointer(dst)))
+	})
+	if err != nil {
+		return nil, err
 	}
 	return dst, nil
 }
@@ -70,27 +79,37 @@ func MultiExpShared(dst []bls12381.G1Jac, sets [][]bls12381.G1Affine, scalars []
 	if len(sets) == 0 {
 		return nil
 	}
-	// C array of base-set pointers, allocated in C memory (cgo forbids Go pointers to Go pointers)
-	arr := (*[1 << 20]*C.uint64_t)(C.malloc(C.size_t(len(sets)) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-	defer C.free(unsafe.Pointer(arr))
-	for i, s := range sets {
+	for _, s := range sets {
 		if len(s) != len(scalars) {
 			return errors.New("len(points) != len(scalars)")
 		}
-		if len(s) > 0 {
-			arr[i] = (*C.uint64_t)(unsafe.Pointer(&s[0]))
+	}
+	if len(scalars) == 0 { // k empty MSMs: infinity each, nothing to hand to C
+		for i := range dst {
+			dst[i] = bls12381.G1Jac{}
+			dst[i].X.SetOne()
+			dst[i].Y.SetOne()
 		}
+		return nil
 	}
-	var sp unsafe.Pointer
-	if len(scalars) > 0 {
-		sp = unsafe.Pointer(&scalars[0])
+	// The C side takes an array of base-set pointers.  It lives in C memory, zeroed (calloc), and
+	// the Go slices it points to are pinned for the duration of the call (runtime.Pinner,
+	// Go >= 1.21): storing unpinned Go pointers in C memory is what the cgo rules forbid.
+	arr := (*[1 << 20]*C.uint64_t)(C.calloc(C.size_t(len(sets)), C.size_t(unsafe.Sizeof(uintptr(0)))))
+	if arr == nil {
+		return errors.New("curdlemsm: out of memory")
 	}
-	rc := C.curdle_msm_g1_multi((**C.uint64_t)(unsafe.Pointer(arr)), C.size_t(len(sets)),
-		(*C.uint64_t)(sp), C.size_t(len(scalars)), (*C.uint64_t)(unsafe.Pointer(&dst[0])))
-	if rc != 0 {
-		return lastError(rc)
+	defer C.free(unsafe.Pointer(arr))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	for i, s := range sets {
+		pin.Pin(&s[0])
+		arr[i] = (*C.uint64_t)(unsafe.Pointer(&s[0]))
 	}
-	return nil
+	return locked(func() C.int {
+		return C.curdle_msm_g1_multi((**C.uint64_t)(unsafe.Pointer(arr)), C.size_t(len(sets)),
+			(*C.uint64_t)(unsafe.Pointer(&scalars[0])), C.size_t(len(scalars)), (*C.uint64_t)(unsafe.Pointer(&dst[0])))
+	})
 }
 
 // MultiExpBatch runs independent MSMs in one call (many concurrent
@@ -107,12 +126,10 @@ func MultiExpBatch(dst []bls12381.G1Jac, points []bls12381.G1Affine, scalars []f
 		pp = unsafe.Pointer(&points[0])
 		sp = unsafe.Pointer(&scalars[0])
 	}
-	rc := C.curdle_msm_g1_batch((*C.uint64_t)(pp), (*C.uint64_t)(sp),
-		(*C.size_t)(unsafe.Pointer(&offsets[0])), C.size_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&dst[0])))
-	if rc != 0 {
-		return lastError(rc)
-	}
-	return nil
+	return locked(func() C.int {
+		return C.curdle_msm_g1_batch((*C.uint64_t)(pp), (*C.uint64_t)(sp),
+			(*C.size_t)(unsafe.Pointer(&offsets[0])), C.size_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&dst[0])))
+	})
 }
 
 // ScalarMulBatch computes out[i] = addends[i] + scalars[i]*points[i] on the GPU
@@ -132,13 +149,11 @@ func ScalarMulBatch(out, points []bls12381.G1Affine, scalars []fr.Element, adden
 	if addends != nil {
 		ap = unsafe.Pointer(&addends[0])
 	}
-	rc := C.curdle_g1_scalar_mul_batch((*C.uint64_t)(unsafe.Pointer(&points[0])),
-		(*C.uint64_t)(unsafe.Pointer(&scalars[0])), C.size_t(len(scalars)), (*C.uint64_t)(ap), C.size_t(n),
-		(*C.uint64_t)(unsafe.Pointer(&out[0])))
-	if rc != 0 {
-		return lastError(rc)
-	}
-	return nil
+	return locked(func() C.int {
+		return C.curdle_g1_scalar_mul_batch((*C.uint64_t)(unsafe.Pointer(&points[0])),
+			(*C.uint64_t)(unsafe.Pointer(&scalars[0])), C.size_t(len(scalars)), (*C.uint64_t)(ap), C.size_t(n),
+			(*C.uint64_t)(unsafe.Pointer(&out[0])))
+	})
 }
 
 // Status of one record decoded by DecompressBatch (CURDLE_DECODE_* in curdle_msm.h).
@@ -167,10 +182,8 @@ func DecompressBatch(out []bls12381.G1Affine, status []byte, in []byte, subgroup
 	if subgroupCheck {
 		sc = 1
 	}
-	rc := C.curdle_g1_decompress_batch((*C.uint8_t)(unsafe.Pointer(&in[0])), C.size_t(n), sc,
-		(*C.uint64_t)(unsafe.Pointer(&out[0])), (*C.uint8_t)(unsafe.Pointer(&status[0])))
-	if rc != 0 {
-		return lastError(rc)
-	}
-	return nil
+	return locked(func() C.int {
+		return C.curdle_g1_decompress_batch((*C.uint8_t)(unsafe.Pointer(&in[0])), C.size_t(n), sc,
+			(*C.uint64_t)(unsafe.Pointer(&out[0])), (*C.uint8_t)(unsafe.Pointer(&status[0])))
+	})
 }

@@ -308,6 +308,26 @@ std::vector<Point> MultiExpBatch(const std::vector<const std::vector<G1Affine>*>
   return res;
 }
 
+std::vector<Point> MultiExpShared(const std::vector<const std::vector<G1Affine>*>& sets,
+                                  const std::vector<Scalar>& scalars) {
+  const size_t k = sets.size();
+  std::vector<const uint64_t*> ptrs(k);
+  for (size_t j = 0; j < k; j++) {
+    if (sets[j]->size() != scalars.size()) throw std::runtime_error("computing msm: len(points) != len(scalars)");
+    ptrs[j] = reinterpret_cast<const uint64_t*>(sets[j]->data());
+  }
+  std::vector<uint64_t> out(18 * k);
+  if (scalars.empty()) {
+    std::vector<Point> res(k, Point::Infinity());
+    return res;
+  }
+  int rc = curdle_msm_g1_multi(ptrs.data(), k, reinterpret_cast<const uint64_t*>(scalars.data()), scalars.size(), out.data());
+  if (rc != CURDLE_OK) throw msm_error(rc);
+  std::vector<Point> res(k);
+  for (size_t j = 0; j < k; j++) res[j] = Point::FromJac(out.data() + 18 * j);
+  return res;
+}
+
 std::vector<G1Affine> ScalarMulBatch(const std::vector<G1Affine>& points, const std::vector<Scalar>& scalars,
                                      const std::vector<G1Affine>* addends) {
   const size_t n = points.size();

@@ -138,6 +138,12 @@ Point MultiExp(const std::vector<G1Affine>& points, const std::vector<Scalar>& s
 std::vector<Point> MultiExpBatch(const std::vector<const std::vector<G1Affine>*>& points,
                                  const std::vector<const std::vector<Scalar>*>& scalars);
 
+// One scalar vector against several base sets (curdle_msm_g1_multi): results[i] = MultiExp(*sets[i],
+// scalars), with the scalars uploaded, recoded and bucket-sorted once for all sets
+// (samemultiscalarargument.go:64-70; curdleproof.go:110,:114).
+std::vector<Point> MultiExpShared(const std::vector<const std::vector<G1Affine>*>& sets,
+                                  const std::vector<Scalar>& scalars);
+
 // out[i] = addends[i] + scalars[i] * points[i]; scalars.size() is points.size(), or 1 for one
 // scalar shared by all; addends may be null.  The independent scalar multiplications that
 // dominate the prover: a batch of at least kScalarMulBatchMin goes to

@@ -830,7 +830,7 @@ Proof Prove(std::vector<G1Affine> G, const Point& A, const Point& Z_t, const Poi
   const std::vector<Scalar> r = GetFrs(rand, n);
   Proof proof;
   {
-    std::vector<Point> b = alg::MultiExpBatch({&G, &T, &U}, {&r, &r, &r});  // :64-70, one scalar vector, three base sets
+    std::vector<Point> b = alg::MultiExpShared({&G, &T, &U}, r);  // :64-70, one scalar vector, three base sets: recoded once
     proof.B_a = b[0];
     proof.B_t = b[1];
     proof.B_u = b[2];
@@ -1005,7 +1005,7 @@ Proof Prove(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G
   // step 3 (:105-146)
   const Scalar r_t = GetFr(rand), r_u = GetFr(rand);
   {
-    std::vector<Point> rs = alg::MultiExpBatch({&Rs, &Ss}, {&as, &as});  // :110, :114, shared scalars
+    std::vector<Point> rs = alg::MultiExpShared({&Rs, &Ss}, as);  // :110, :114, shared scalars: recoded once
     proof.R = rs[0];
     proof.S = rs[1];
   }

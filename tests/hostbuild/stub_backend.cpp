@@ -62,6 +62,12 @@ extern "C" int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scala
   return CURDLE_OK;
 }
 
+extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k, const uint64_t* scalars, size_t n,
+                                   uint64_t* out_jac) {
+  for (size_t j = 0; j < k; j++) msm_naive(points_sets[j], scalars, n, out_jac + 18 * j);
+  return CURDLE_OK;
+}
+
 extern "C" int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t* scalars, size_t n_scalars,
                                           const uint64_t* addends, size_t n, uint64_t* out_affine) {
   if (n_scalars != n && n_scalars != 1) return curdle_set_last_error(CURDLE_EINVAL, "n_scalars must be n or 1");

@@ -302,6 +302,31 @@ def test_batch_and_multi_entry_points(gpu, oracle, coracle):
     out = gpu.msm_g1_multi(sets, s)
     for j in range(3):
         assert (out[j] == coracle.msm_pippenger(sets[j], s, threads=4)).all()
+    # the scalars are recoded and sorted ONCE for all base sets: sizes of the prover (2,548 = 5 ell + 8 at
+    # ell = 508), many sets (one takes the GPU window combine), every window width, and the scalar families that
+    # route buckets through the block-per-bucket pre-merge (shared fragment bookkeeping) or leave windows empty
+    for n, nsets in ((2548, 3), (5, 2), (700, 40)):
+        sets = [coracle.points_walk(k + 11 * j, q + j, n) for j in range(nsets)]
+        sets[1][n // 2] = 0                                       # an infinity base in one set only
+        s = rand_scalars(np.random.default_rng(n), n, oracle)
+        out = gpu.msm_g1_multi(sets, s)
+        for j in range(nsets):
+            assert (out[j] == coracle.msm_fast(sets[j], s, threads=4)).all(), (n, j)
+    n = 3000
+    sets = [coracle.points_walk(k + 5 * j, q, n) for j in range(3)]
+    fams = {"all_equal": [123456789123456789] * n, "small": [i % 300 for i in range(n)],
+            "hot_window": [(7 << 130) + i for i in range(n)], "zero": [0] * n}
+    try:
+        for name, fam in fams.items():
+            s = np.array([oracle.fr_to_mont_limbs(v % oracle.R) for v in fam], dtype=np.uint64)
+            for c in (0, 6, 13):
+                if c:
+                    os.environ["CURDLE_WINDOW_BITS"] = str(c)
+                out = gpu.msm_g1_multi(sets, s)
+                for j in range(3):
+                    assert (out[j] == coracle.msm_fast(sets[j], s, threads=4)).all(), (name, c, j)
+    finally:
+        os.environ.pop("CURDLE_WINDOW_BITS", None)
 
 
 def test_large_batch_runs_in_one_pass(gpu, oracle, coracle):
