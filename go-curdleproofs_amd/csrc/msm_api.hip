@@ -200,7 +200,7 @@ int init_locked(int device) {
 
 int init_default_locked() { return init_locked(g_ctx.inited ? g_ctx.device : 0); }
 
-int choose_window_bits(size_t n) {
+int choose_window_bits(size_t n, bool many = false) {
   const char* env = getenv("CURDLE_WINDOW_BITS");
   if (env) {
     int c = atoi(env);
@@ -212,7 +212,8 @@ int choose_window_bits(size_t n) {
   // measured (tools/sweep.py n,c): from a few hundred to a few thousand pairs 8-bit windows win --
   // 32 windows of 128 buckets reduce in two-bucket segments whose 64 results are one tree, and
   // narrower windows only lengthen the host's Horner pass
-  if (n >= 300 && c < 8) c = 8;
+  // (a large batch of small MSMs is throughput-bound instead: wider windows double its bucket-reduce work)
+  if (n >= 300 && c < 8 && !many) c = 8;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
   return c;
@@ -232,7 +233,7 @@ int window_widths(int c, uint8_t bits[kMaxWindows]) {
 int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end,
               bool latency_mode, size_t sets = 1) {
   if (n_total > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n_total);
-  if (c == 0) c = choose_window_bits(n_max);
+  if (c == 0) c = choose_window_bits(n_max, k * sets >= kGpuCombineMin);
   if (c < 4 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", c);
   memset(&p, 0, sizeof(p));
   p.n = (uint32_t)n_total;
