@@ -193,10 +193,36 @@ __global__ void __launch_bounds__(kBlock, 2)
   d28::add(rhs, t, c);  // x^3 + 4 < 4p
 
   // y = rhs^((p+1)/4), left to right; the top set bit is bit 378
-  y = rhs;
-  for (int bit = 377; bit >= 0; bit--) {
-    d28::sqr(y, y);
-    if ((kSqrtExp(bit >> 5) >> (bit & 31)) & 1u) d28::mul(y, y, rhs);
+  // 3-bit fixed windows over the 379-bit exponent (the same for every point, so the window
+  // digit is wave-uniform and picks one of seven call sites): 378 squarings + 6 + ~110 products
+  // instead of the 378 + ~190 of the bit-by-bit ladder
+  {
+    F28 t2, t3, t4, t5, t6, t7;
+    d28::sqr(t2, rhs);
+    d28::mul(t3, t2, rhs);
+    d28::sqr(t4, t2);
+    d28::mul(t5, t4, rhs);
+    d28::sqr(t6, t3);
+    d28::mul(t7, t6, rhs);
+    y = rhs;  // bit 378
+    for (int w = 125; w >= 0; w--) {
+      d28::sqr(y, y);
+      d28::sqr(y, y);
+      d28::sqr(y, y);
+      const int bit = 3 * w;
+      u32 d = kSqrtExp(bit >> 5) >> (bit & 31);
+      if ((bit & 31) > 29) d |= kSqrtExp((bit >> 5) + 1) << (32 - (bit & 31));
+      switch (d & 7u) {
+        case 1: d28::mul(y, y, rhs); break;
+        case 2: d28::mul(y, y, t2); break;
+        case 3: d28::mul(y, y, t3); break;
+        case 4: d28::mul(y, y, t4); break;
+        case 5: d28::mul(y, y, t5); break;
+        case 6: d28::mul(y, y, t6); break;
+        case 7: d28::mul(y, y, t7); break;
+        default: break;
+      }
+    }
   }
   u32 yc[12], want[12], got[12];
   d28::sqr(t, y);
