@@ -104,6 +104,8 @@ struct Slot {
 struct DSlot {
   hipStream_t stream = nullptr;
   Buf in, out, status;
+  void* h_in = nullptr;  // pinned staging of the compressed records
+  size_t h_in_cap = 0;
   bool busy = false;
   bool claimed = false;
   uint32_t gen = 0;
@@ -691,9 +693,15 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
 // Two-step form: begin decodes (square root, curve check, sign) and returns the points, and
 // leaves the subgroup test running on the slot's stream; finish waits for it and returns the
 // final status bytes.  The caller can work with the points in between.
-extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t* out_affine, uint8_t* status,
-                                          int* ticket) {
-  if (!ticket || (n && (!in || !out_affine || !status))) return fail(CURDLE_EINVAL, "null argument");
+extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status);
+
+// Three-step form: start launches the decoding (square root, curve check, sign) and returns at
+// once; points waits for that half and hands the points back, leaving the subgroup test running
+// on the context's stream; finish waits for it and returns the final status bytes.  The caller
+// can hash its transcript between start and points, and verify between points and finish.
+// begin = start + points.
+extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* ticket) {
+  if (!ticket || (n && !in)) return fail(CURDLE_EINVAL, "null argument");
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 points", n);
   int idx = -1;
   {
@@ -726,13 +734,18 @@ extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t*
     if ((r = ensure(D.in, n * 48))) return r;
     if ((r = ensure(D.out, n * 96))) return r;
     if ((r = ensure(D.status, n))) return r;
-    HIP_TRY(hipMemcpyAsync(D.in.p, in, n * 48, hipMemcpyHostToDevice, D.stream));
+    // pinned staging: the copy must not block the caller, who wants to hash meanwhile
+    if (D.h_in_cap < n * 48) {
+      if (D.h_in) HIP_TRY(hipHostFree(D.h_in));
+      D.h_in = nullptr;
+      D.h_in_cap = 0;
+      HIP_TRY(hipHostMalloc(&D.h_in, n * 48 + 4096, hipHostMallocDefault));
+      D.h_in_cap = n * 48 + 4096;
+    }
+    memcpy(D.h_in, in, n * 48);
+    HIP_TRY(hipMemcpyAsync(D.in.p, D.h_in, n * 48, hipMemcpyHostToDevice, D.stream));
     HIP_TRY(launch_g1_decompress((const uint8_t*)D.in.p, (uint32_t)n, 0, (uint32_t*)D.out.p, (uint8_t*)D.status.p,
                                  D.stream));
-    HIP_TRY(hipMemcpyAsync(out_affine, D.out.p, n * 96, hipMemcpyDeviceToHost, D.stream));
-    HIP_TRY(hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.stream));
-    HIP_TRY(hipStreamSynchronize(D.stream));
-    HIP_TRY(launch_g1_subgroup_check((const uint32_t*)D.out.p, (uint32_t)n, (uint8_t*)D.status.p, D.stream));
     return CURDLE_OK;
   };
   int rc = body();
@@ -745,6 +758,53 @@ extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t*
     return rc;
   }
   *ticket = make_ticket(idx, D.gen);
+  return CURDLE_OK;
+}
+
+namespace {
+// the decode context behind a ticket that is in flight and not being finished; nullptr otherwise
+DSlot* dslot_of(int ticket) {
+  if (ticket < 0 || ticket_index(ticket) >= kMaxDeferred) return nullptr;
+  DSlot& D = g_ctx.dslots[ticket_index(ticket)];
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  if (!D.busy || D.claimed || (D.gen & 0x7fffffu) != ticket_gen(ticket)) return nullptr;
+  return &D;
+}
+}  // namespace
+
+extern "C" int curdle_g1_decompress_points(int ticket, uint64_t* out_affine, uint8_t* status) {
+  DSlot* Dp = dslot_of(ticket);
+  if (!Dp) return fail(CURDLE_EINVAL, "ticket %d is not in flight (stale or already finished)", ticket);
+  DSlot& D = *Dp;
+  const size_t n = D.n;
+  if (n && (!out_affine || !status)) return fail(CURDLE_EINVAL, "null argument");
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    if (n == 0) return CURDLE_OK;
+    HIP_TRY(hipMemcpyAsync(out_affine, D.out.p, n * 96, hipMemcpyDeviceToHost, D.stream));
+    HIP_TRY(hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.stream));
+    HIP_TRY(hipStreamSynchronize(D.stream));
+    HIP_TRY(launch_g1_subgroup_check((const uint32_t*)D.out.p, (uint32_t)n, (uint8_t*)D.status.p, D.stream));
+    return CURDLE_OK;
+  };
+  int rc = body();
+  if (rc) (void)hipStreamSynchronize(D.stream);  // the ticket stays valid: the caller still has to finish it
+  return rc;
+}
+
+extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t* out_affine, uint8_t* status,
+                                          int* ticket) {
+  if (!ticket || (n && (!in || !out_affine || !status))) return fail(CURDLE_EINVAL, "null argument");
+  int rc = curdle_g1_decompress_start(in, n, ticket);
+  if (rc) return rc;
+  rc = curdle_g1_decompress_points(*ticket, out_affine, status);
+  if (rc) {
+    char saved[256];
+    snprintf(saved, sizeof(saved), "%s", g_err);
+    (void)curdle_g1_decompress_finish(*ticket, nullptr);
+    *ticket = -1;
+    return fail(rc, "%s", saved);
+  }
   return CURDLE_OK;
 }
 
@@ -831,6 +891,9 @@ extern "C" int curdle_shutdown(void) {
       b->p = nullptr;
       b->cap = 0;
     }
+    if (d.h_in) (void)hipHostFree(d.h_in);
+    d.h_in = nullptr;
+    d.h_in_cap = 0;
     (void)hipStreamDestroy(d.stream);
     d.stream = nullptr;
   }

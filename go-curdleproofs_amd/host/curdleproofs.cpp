@@ -210,10 +210,37 @@ bool PointDecoder::OnDevice() {
   }();
   return !host_only;
 }
+void PointDecoder::Start() {
+  if (started_ || n_ == 0 || !subgroup_ || !OnDevice() || n_ < kMinDeviceBatch) return;
+  int rc = curdle_g1_decompress_start(blob_.data(), n_, &ticket_);
+  if (rc == CURDLE_EBUSY) {  // enough deferred decodings in flight: Run() takes the one-shot form
+    ticket_ = -1;
+    return;
+  }
+  if (rc != CURDLE_OK) {
+    ticket_ = -1;
+    char buf[256];
+    curdle_last_error(buf, sizeof(buf));
+    throw alg::MsmError(std::string("decoding points: ") + buf, rc);
+  }
+  started_ = true;
+}
 void PointDecoder::Run(bool defer_subgroup) {
   pts_.assign(n_, G1Affine{});
   status_.assign(n_, CURDLE_DECODE_BAD_ENCODING);
   if (n_ == 0) return;
+  if (started_) {  // Start() launched it: collect the points; the subgroup test keeps running
+    started_ = false;
+    int rc = curdle_g1_decompress_points(ticket_, reinterpret_cast<uint64_t*>(pts_.data()), status_.data());
+    if (rc != CURDLE_OK) {
+      char buf[256];
+      curdle_last_error(buf, sizeof(buf));
+      (void)curdle_g1_decompress_finish(ticket_, nullptr);
+      ticket_ = -1;
+      throw alg::MsmError(std::string("decoding points: ") + buf, rc);
+    }
+    return;
+  }
   // below a few dozen points one kernel launch (~1.5 ms: it is a serial chain of a thousand
   // products per point) is slower than the host's ~45 us per point
   if (OnDevice() && n_ >= kMinDeviceBatch) {
@@ -815,10 +842,16 @@ static const std::string kGamma = "same_msm_gamma";
 
 static void AppendStatement(Transcript& tr, const Point& A, const Point& Z_t, const Point& Z_u,
                             const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, const Point& B_a,
-                            const Point& B_t, const Point& B_u) {
+                            const Point& B_t, const Point& B_u, const std::vector<uint8_t>* Tb = nullptr,
+                            const std::vector<uint8_t>* Ub = nullptr) {
   tr.AppendPoints(kStep1, {A, Z_t, Z_u});
-  tr.AppendPointsAffine(kStep1, T);
-  tr.AppendPointsAffine(kStep1, U);
+  if (Tb && Ub && Tb->size() == 48 * T.size() && Ub->size() == 48 * U.size()) {  // encodings kept by the caller
+    tr.AppendCompressed(kStep1, Tb->data(), T.size());
+    tr.AppendCompressed(kStep1, Ub->data(), U.size());
+  } else {
+    tr.AppendPointsAffine(kStep1, T);
+    tr.AppendPointsAffine(kStep1, U);
+  }
   tr.AppendPoints(kStep1, {B_a, B_t, B_u});
 }
 
@@ -877,13 +910,13 @@ Proof Prove(std::vector<G1Affine> G, const Point& A, const Point& Z_t, const Poi
 
 bool Verify(const Proof& proof, size_t ell, const Point& A, const Point& Z_t, const Point& Z_u,
             const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, Transcript& tr, CheckSink& sink,
-            common::Rand& rand) {
+            common::Rand& rand, const std::vector<uint8_t>* Tbytes, const std::vector<uint8_t>* Ubytes) {
   // samemultiscalarargument.go:159-236 and unfoldedScalars :239-280.  T and U (the padded
   // vectors T', U' of curdleproof.go:271-285) are passed for the transcript; as bases they are
   // the instance's Ts / Us (resident, by index) followed by 0 | 0 | H | 0 and 0 | 0 | 0 | H, and
   // G is the CRS's Gs | Hs[:2] | Gt | Gu.
   const size_t n = T.size();
-  AppendStatement(tr, A, Z_t, Z_u, T, U, proof.B_a, proof.B_t, proof.B_u);
+  AppendStatement(tr, A, Z_t, Z_u, T, U, proof.B_a, proof.B_t, proof.B_u, Tbytes, Ubytes);
   const Scalar alpha = tr.GetAndAppendChallenge(kAlpha);
 
   const size_t lg_n = proof.L_A.size();
@@ -1029,18 +1062,49 @@ Proof Prove(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G
 // The body of curdleproof.Verify up to, but not including, the accumulator's final MSM:
 // false = a direct (non-accumulated) check already failed.  Every AccumulateCheck of the
 // sub-arguments goes to `sink`.
+VerifyPrelude::VerifyPrelude() : tr(kTranscript) {}
+
+void StartVerify(VerifyPrelude& pre, size_t ell, const uint8_t* Rb, const uint8_t* Sb, const uint8_t* Tb, const uint8_t* Ub,
+                 const uint8_t Mb[48]) {
+  // curdleproof.go:217-224: Rs, Ss, Ts, Us, M under "curdleproofs_step1", then the vector a
+  pre.tr.AppendCompressed(kStep1, Rb, ell);
+  pre.tr.AppendCompressed(kStep1, Sb, ell);
+  pre.tr.AppendCompressed(kStep1, Tb, ell);
+  pre.tr.AppendCompressed(kStep1, Ub, ell);
+  pre.tr.AppendCompressed(kStep1, Mb, 1);
+  pre.as = pre.tr.GetAndAppendChallenges(kVecA, ell);
+  pre.Tb.assign(Tb, Tb + 48 * ell);
+  pre.Ub.assign(Ub, Ub + 48 * ell);
+}
+
+void StartVerify(VerifyPrelude& pre, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                 const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M) {
+  const size_t ell = Rs.size();
+  if (Ss.size() != ell || Ts.size() != ell || Us.size() != ell) throw err("instance vectors differ in length");
+  std::vector<uint8_t> b(48 * (4 * ell + 1));
+  const std::vector<G1Affine>* v[4] = {&Rs, &Ss, &Ts, &Us};
+  for (int k = 0; k < 4; k++)
+    for (size_t i = 0; i < ell; i++) alg::CompressAffine((*v[k])[i], &b[48 * (k * ell + i)]);
+  M.Compressed(&b[48 * 4 * ell]);
+  StartVerify(pre, ell, &b[0], &b[48 * ell], &b[96 * ell], &b[144 * ell], &b[192 * ell]);
+}
+
 bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
                     const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
-                    CheckSink& sink) {
+                    CheckSink& sink, VerifyPrelude* started) {
   // curdleproof.go:199-311
   const size_t ell = crs.Gs.size();
   if (Rs.size() != ell || Ss.size() != ell || Ts.size() != ell || Us.size() != ell)
     throw err("instance vectors do not match the CRS");
-  Transcript tr(kTranscript);
   if (Ts.empty() || g1_affine_is_inf(Ts[0])) throw err("randomizer is zero");  // :213-215
-
-  AppendInstance(tr, Rs, Ss, Ts, Us, M);
-  const std::vector<Scalar> as = tr.GetAndAppendChallenges(kVecA, Rs.size());
+  VerifyPrelude own;
+  if (!started) {
+    StartVerify(own, Rs, Ss, Ts, Us, M);
+    started = &own;
+  }
+  if (started->as.size() != ell) throw err("verification prelude does not match the CRS");
+  Transcript& tr = started->tr;
+  const std::vector<Scalar>& as = started->as;
 
   if (!sameperm::Verify(proof.proofSamePermutation, crs, proof.A, M, as, tr, sink, rand)) return false;
   if (!samescalar::Verify(proof.proofSameScalar, crs.Gt, crs.Gu, crs.H, proof.R, proof.S, proof.T, proof.U, tr, &sink,
@@ -1053,7 +1117,21 @@ bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affi
   std::vector<G1Affine> Tp(Ts), Up(Us);
   Tp.insert(Tp.end(), {kZeroPoint, kZeroPoint, Haff, kZeroPoint});
   Up.insert(Up.end(), {kZeroPoint, kZeroPoint, kZeroPoint, Haff});
-  if (!samemsm::Verify(proof.proofSameMultiscalar, ell, Aprime, proof.T.T_2, proof.U.T_2, Tp, Up, tr, sink, rand))
+  // ... and their encodings: the instance's, kept by the prelude, plus the four padding points
+  std::vector<uint8_t> Tpb(started->Tb), Upb(started->Ub);
+  {
+    uint8_t zero[48], h[48];
+    alg::CompressAffine(kZeroPoint, zero);
+    alg::CompressAffine(Haff, h);
+    const uint8_t* tpad[4] = {zero, zero, h, zero};
+    const uint8_t* upad[4] = {zero, zero, zero, h};
+    for (int k = 0; k < 4; k++) {
+      Tpb.insert(Tpb.end(), tpad[k], tpad[k] + 48);
+      Upb.insert(Upb.end(), upad[k], upad[k] + 48);
+    }
+  }
+  if (!samemsm::Verify(proof.proofSameMultiscalar, ell, Aprime, proof.T.T_2, proof.U.T_2, Tp, Up, tr, sink, rand, &Tpb,
+                       &Upb))
     return false;
 
   Terms R, S;
@@ -1075,6 +1153,14 @@ bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>&
 
 bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand) {
+  VerifyPrelude pre;
+  StartVerify(pre, Rs, Ss, Ts, Us, M);
+  return VerifyStarted(pre, proof, crs, Rs, Ss, Ts, Us, M, rand);
+}
+
+bool VerifyStarted(VerifyPrelude& pre, const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
+                   const std::vector<G1Affine>& Ss, const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us,
+                   const Point& M, common::Rand& rand) {
   // curdleproof.go:199-318: every sub-argument folds its checks into one accumulator, whose
   // single MSM (:313) decides.  By default that accumulator lives on the GPU
   // (device_accumulator.h: CRS bases resident, scalars built by index in an Fr kernel, MSM
@@ -1091,7 +1177,7 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
     const auto t0 = std::chrono::steady_clock::now();
     DeviceSink sink(crs, Rs, Ss, Ts, Us);
     const auto t1 = std::chrono::steady_clock::now();
-    if (!VerifyWithSink(proof, crs, Rs, Ss, Ts, Us, M, rand, sink)) return false;
+    if (!VerifyWithSink(proof, crs, Rs, Ss, Ts, Us, M, rand, sink, &pre)) return false;
     const auto t2 = std::chrono::steady_clock::now();
     const bool ok = sink.Verify();  // the batched MSM on the GPU, == A_c
     if (trace) {
@@ -1103,7 +1189,10 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
     return ok;
   }
   MsmAccumulator acc;
-  if (!VerifyInto(proof, crs, Rs, Ss, Ts, Us, M, rand, acc)) return false;
+  {
+    MirrorSink sink(acc, crs, Rs, Ss, Ts, Us);
+    if (!VerifyWithSink(proof, crs, Rs, Ss, Ts, Us, M, rand, sink, &pre)) return false;
+  }
   bool ok = false;
   msmaccumulator::Status st = acc.Verify(&ok);                                // :313, the batched MSM on the GPU
   if (!st.ok) throw alg::MsmError("verifying msm accumulator: " + st.err, st.rc ? st.rc : CURDLE_EHIP);  // device failure
@@ -1187,9 +1276,16 @@ Proof Proof::FromBytes(const uint8_t* data, size_t len, bool subgroup_check) {  
   return FromReader(r);
 }
 Proof Proof::FromBytesDeferred(const uint8_t* data, size_t len, PointDecoder& dec) {
+  ScanAndStart(data, len, dec);
+  return FromStarted(data, len, dec);
+}
+void Proof::ScanAndStart(const uint8_t* data, size_t len, PointDecoder& dec) {
   Reader scan(data, len, true);
   scan.collect = &dec;
   FromReader(scan);
+  dec.Start();
+}
+Proof Proof::FromStarted(const uint8_t* data, size_t len, PointDecoder& dec) {
   dec.Run(/*defer_subgroup=*/true);
   Reader r(data, len, true);
   r.decoded = &dec;

@@ -59,6 +59,10 @@ class PointDecoder {
   // its verdict: the caller overlaps its own work with it and must not publish a result
   // before Finish() has returned true.
   void Run(bool defer_subgroup = false);
+  // Optional first step of a deferred Run(true): launches the GPU decoding and returns, so the
+  // caller can hash its transcript from the raw bytes until it calls Run(true), which then only
+  // waits for the points.  A no-op when the batch would not go to the GPU's deferred form.
+  void Start();
   bool Finish();                              // true: no record failed the (deferred) subgroup test
   bool Get(size_t index, Point* out) const;   // false: not a valid encoding / not on the curve / not in G1
   size_t size() const { return n_; }
@@ -71,6 +75,7 @@ class PointDecoder {
   std::vector<G1Affine> pts_;
   std::vector<uint8_t> status_;
   int ticket_ = -1;                           // >= 0: a deferred subgroup test is in flight
+  bool started_ = false;                      // Start() launched the decoding; Run() collects the points
 };
 
 struct Reader {
@@ -328,7 +333,7 @@ Proof Prove(std::vector<G1Affine> G, const Point& A, const Point& Z_t, const Poi
 // T, U: the padded vectors T', U' (for the transcript); as bases they are addressed by index.
 bool Verify(const Proof& proof, size_t ell, const Point& A, const Point& Z_t, const Point& Z_u,
             const std::vector<G1Affine>& T, const std::vector<G1Affine>& U, transcript::Transcript& tr, CheckSink& sink,
-            common::Rand& rand);
+            common::Rand& rand, const std::vector<uint8_t>* Tbytes = nullptr, const std::vector<uint8_t>* Ubytes = nullptr);
 }  // namespace samemsm
 
 // ---- curdleproof.go ----
@@ -346,6 +351,11 @@ struct Proof {
   // and treat `false` as the decoding error it is before using any result derived from
   // the proof.
   static Proof FromBytesDeferred(const uint8_t* data, size_t len, PointDecoder& dec);
+  // The same in two steps, for callers with work to do while the GPU decodes: ScanAndStart
+  // registers the proof's point records with `dec` and launches the decoding; FromStarted waits
+  // for the points and builds the value (the subgroup verdict still comes from dec.Finish()).
+  static void ScanAndStart(const uint8_t* data, size_t len, PointDecoder& dec);
+  static Proof FromStarted(const uint8_t* data, size_t len, PointDecoder& dec);
 };
 Proof Prove(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M,
@@ -355,6 +365,24 @@ bool Verify(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M,
             common::Rand& rand);                                            // :199
 
+// The first steps of Verify (curdleproof.go:199-224) -- absorbing the instance and drawing the
+// challenge vector `as` -- need only the instance's compressed encodings, not the proof: a
+// caller that still waits for the GPU to decode the proof runs them meanwhile
+// (curdle_verify, IsValidWhiskShuffleProof).  The encodings are kept: the same-multiscalar
+// argument absorbs Ts and Us a second time.
+struct VerifyPrelude {
+  transcript::Transcript tr;
+  std::vector<Scalar> as;
+  std::vector<uint8_t> Tb, Ub;  // 48 bytes per point
+  VerifyPrelude();
+};
+// from compressed encodings (ell records each, M one record) ...
+void StartVerify(VerifyPrelude& pre, size_t ell, const uint8_t* Rb, const uint8_t* Sb, const uint8_t* Tb, const uint8_t* Ub,
+                 const uint8_t Mb[48]);
+// ... or from the decoded instance
+void StartVerify(VerifyPrelude& pre, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                 const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M);
+
 // The body of Verify up to, but not including, the accumulator's final MSM (false: a direct,
 // non-accumulated check already failed); lets several proofs share one accumulator.
 bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
@@ -363,7 +391,11 @@ bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>&
 // The same into any sink.
 bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
                     const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
-                    CheckSink& sink);
+                    CheckSink& sink, VerifyPrelude* started = nullptr);
+// curdleproof.Verify continued from a prelude the caller started earlier
+bool VerifyStarted(VerifyPrelude& pre, const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
+                   const std::vector<G1Affine>& Ss, const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us,
+                   const Point& M, common::Rand& rand);
 
 // Cross-proof batch verification over one CRS: one shared accumulator, one MSM (see the
 // definition).  Returns the per-proof accept bits.

@@ -119,9 +119,13 @@ extern "C" int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t
     // The subgroup half of that runs on the GPU while the host verifies; its verdict is
     // collected before anything is reported.
     proto::PointDecoder dec(/*subgroup_check=*/true);
-    proto::Proof p = proto::Proof::FromBytesDeferred(proof, proof_len, dec);
-    bool accept = proto::Verify(p, crs->crs, Affines(Rs, ell), Affines(Ss, ell), Affines(Ts, ell), Affines(Us, ell),
-                                Point::FromJac(M), rand->r);
+    proto::Proof::ScanAndStart(proof, proof_len, dec);  // the GPU takes the square roots ...
+    const std::vector<G1Affine> R = Affines(Rs, ell), S = Affines(Ss, ell), T = Affines(Ts, ell), U = Affines(Us, ell);
+    const Point Mp = Point::FromJac(M);
+    proto::VerifyPrelude pre;
+    proto::StartVerify(pre, R, S, T, U, Mp);            // ... while the host absorbs the instance and draws `as`
+    proto::Proof p = proto::Proof::FromStarted(proof, proof_len, dec);
+    bool accept = proto::VerifyStarted(pre, p, crs->crs, R, S, T, U, Mp, rand->r);
     if (!dec.Finish()) throw std::runtime_error("decoding proof: invalid point (not in the prime-order subgroup)");
     *ok = accept ? 1 : 0;
     return CURDLE_OK;

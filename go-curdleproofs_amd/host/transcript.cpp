@@ -129,6 +129,9 @@ void Transcript::AppendPointsAffine(const std::string& label, const std::vector<
     inner_.AppendMessage(label, b, 48);
   }
 }
+void Transcript::AppendCompressed(const std::string& label, const uint8_t* records, size_t count) {
+  for (size_t i = 0; i < count; i++) inner_.AppendMessage(label, records + 48 * i, 48);
+}
 void Transcript::AppendScalar(const std::string& label, const alg::Scalar& s) {
   uint8_t b[32];
   s.Bytes(b);

@@ -54,6 +54,9 @@ class Transcript {
   void AppendPoints(const std::string& label, const std::vector<alg::Point>& points);  // :25
   void AppendPoint(const std::string& label, const alg::Point& p);
   void AppendPointsAffine(const std::string& label, const std::vector<G1Affine>& points);  // :32
+  // the same from the points' 48-byte compressed encodings (count records, back to back): what
+  // AppendPointsAffine would produce for the decoded points, without compressing them again
+  void AppendCompressed(const std::string& label, const uint8_t* records, size_t count);
   void AppendScalars(const std::string& label, const std::vector<alg::Scalar>& scalars);   // :41
   void AppendScalar(const std::string& label, const alg::Scalar& s);
   alg::Scalar GetAndAppendChallenge(const std::string& label);                              // :48

@@ -88,7 +88,22 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
     dec.Add(postST[i].rG);
     dec.Add(postST[i].krG);
   }
-  dec.Run(/*defer_subgroup=*/true);  // the subgroup test keeps running on the GPU; collected below
+  dec.Start();  // the GPU takes the 4 n + ~100 square roots ...
+  // ... while the host runs the first steps of Verify from the RAW encodings: the transcript
+  // absorbs a point as its 48-byte compressed form, which for a valid record is the record
+  // itself (an invalid one fails the call below whatever was hashed).  curdleproof.go:217-224.
+  proto::VerifyPrelude pre;
+  {
+    std::vector<uint8_t> b(4 * n * G1POINT_SIZE);
+    for (size_t i = 0; i < n; i++) {
+      memcpy(&b[48 * i], preST[i].rG, 48);
+      memcpy(&b[48 * (n + i)], preST[i].krG, 48);
+      memcpy(&b[48 * (2 * n + i)], postST[i].rG, 48);
+      memcpy(&b[48 * (3 * n + i)], postST[i].krG, 48);
+    }
+    proto::StartVerify(pre, n, &b[0], &b[48 * n], &b[96 * n], &b[144 * n], proof);  // M is the proof's first record
+  }
+  dec.Run(/*defer_subgroup=*/true);  // the points; the subgroup test keeps running on the GPU, collected below
 
   Point M;
   proto::Proof p;
@@ -116,7 +131,7 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
   bool accept = false;
   std::string verify_error;
   try {
-    accept = proto::Verify(p, crs, Rs, Ss, Ts, Us, M, rand);  // :46-58
+    accept = proto::VerifyStarted(pre, p, crs, Rs, Ss, Ts, Us, M, rand);  // :46-58
   } catch (const alg::MsmError&) {
     throw;
   } catch (const std::runtime_error& e) {

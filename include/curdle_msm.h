@@ -367,6 +367,11 @@ int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgroup_check, 
  * be matched by a finish.  At most two may be in flight: a third begin returns CURDLE_EBUSY (with
  * several verifications in flight the GPU is busy anyway; use the one-shot form then). */
 int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t* out_affine, uint8_t* status, int* ticket);
+/* begin, split once more: start only launches the decoding and returns (the caller hashes its
+ * transcript from the raw bytes meanwhile); points waits for the square-root half, hands back
+ * the points and leaves the subgroup test running; finish as above.  begin = start + points. */
+int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* ticket);
+int curdle_g1_decompress_points(int ticket, uint64_t* out_affine, uint8_t* status);
 int curdle_g1_decompress_finish(int ticket, uint8_t* status);
 int curdle_set_last_error(int code, const char* msg);  /* internal: shared by the library's translation units */
 

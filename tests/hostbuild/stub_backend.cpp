@@ -131,6 +131,25 @@ extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t*
   }
   return curdle_set_last_error(CURDLE_EBUSY, "deferred decodings in flight");
 }
+// three-step form: start decodes into a parked copy, points hands it out
+static std::vector<uint64_t> g_parked_pts[2];
+static std::vector<uint8_t> g_parked_st[2];
+extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* ticket) {
+  std::vector<uint64_t> pts(12 * (n ? n : 1));
+  std::vector<uint8_t> st(n ? n : 1);
+  int rc = curdle_g1_decompress_begin(in, n, pts.data(), st.data(), ticket);
+  if (rc) return rc;
+  g_parked_pts[*ticket] = pts;
+  g_parked_st[*ticket] = st;
+  return CURDLE_OK;
+}
+extern "C" int curdle_g1_decompress_points(int ticket, uint64_t* out_affine, uint8_t* status) {
+  if (ticket < 0 || ticket > 1 || !g_busy[ticket]) return curdle_set_last_error(CURDLE_EINVAL, "bad ticket");
+  const size_t n = g_deferred[ticket].size();
+  memcpy(out_affine, g_parked_pts[ticket].data(), n * 96);
+  memcpy(status, g_parked_st[ticket].data(), n);
+  return CURDLE_OK;
+}
 extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
   if (ticket < 0 || ticket > 1 || !g_busy[ticket]) return curdle_set_last_error(CURDLE_EINVAL, "bad ticket");
   if (status) memcpy(status, g_deferred[ticket].data(), g_deferred[ticket].size());
