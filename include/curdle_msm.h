@@ -184,6 +184,15 @@ int curdle_acc_export(const curdle_acc* a, uint64_t* points, uint64_t* scalars);
  * Go-produced proofs.
  * Points are gnark G1Affine arrays (ell x 12 u64), M a G1Jac, scalars fr.Elements.
  * ------------------------------------------------------------------------- */
+/* BYTE COMPATIBILITY WITH THE GO IMPLEMENTATION IS UNVERIFIED for every entry point of this
+ * section that produces or consumes serialised proofs (curdle_prove, curdle_verify,
+ * curdle_proof_from_bytes, curdle_verify_batch, curdle_whisk_*): no Go toolchain and no
+ * Go-produced proof exist in the build environment.  The transcript labels, challenge order,
+ * gnark Encoder framing and verifier equations were checked against the reference source by
+ * reading; what the tests pin is Merlin's published vector, the common.Rand known answers, the
+ * reference's size constants (48 / 128 / 4576 bytes) and this implementation's own proof bytes
+ * for fixed seeds (tests/golden/proof_vectors.npz).  The MSM entry points above do not depend
+ * on any of this. */
 typedef struct curdle_crs curdle_crs;
 curdle_crs* curdle_crs_generate(size_t ell, curdle_rand* rand);   /* GenerateCRS, crs.go:20           */
 void curdle_crs_free(curdle_crs* crs);
