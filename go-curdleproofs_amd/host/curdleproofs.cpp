@@ -103,6 +103,7 @@ const G1Affine kZeroPoint = [] {
 }  // namespace
 
 int SetEagerChecks(int eager) { return EagerFlag().exchange(eager ? 1 : 0); }
+bool EagerChecksEnabled() { return EagerChecks(); }
 
 // ================================================= deferred-check descriptions =====
 Scalar VecExpr::At(size_t i) const {

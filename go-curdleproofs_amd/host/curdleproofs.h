@@ -411,6 +411,7 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
 // Deferred (default) or eager evaluation of the verifier's check points; see
 // curdle_verify_set_eager in include/curdle_msm.h.  Returns the previous setting.
 int SetEagerChecks(int eager);
+bool EagerChecksEnabled();
 
 }  // namespace proto
 }  // namespace curdle

@@ -65,13 +65,13 @@ DeviceSink::~DeviceSink() {
   if (acc_) curdle_dacc_abort(acc_);
 }
 
-uint32_t DeviceSink::Put(const Scalar& s) {
-  pool_.push_back(s);
-  return (uint32_t)(pool_.size() - 1);
+uint32_t CheckRecorder::Put(const Scalar& s) {
+  pool.push_back(s);
+  return (uint32_t)(pool.size() - 1);
 }
 
-void DeviceSink::Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs,
-                       const std::vector<LooseBase>& loose, common::Rand& rand, const char* what) {
+void CheckRecorder::Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs,
+                          const std::vector<LooseBase>& loose, common::Rand& rand, const char* what) {
   if (segs.size() > CURDLE_DACC_MAX_SEGS) throw std::runtime_error(std::string(what) + ": too many base segments");
   Scalar alpha;
   rand.GetFr(alpha.v);  // msmaccumulator.go:32 -- the same draw, in the same order, as the host mirror
@@ -83,10 +83,10 @@ void DeviceSink::Check(const Terms& C, const VecExpr& x, const std::vector<BaseS
   ck.q_cap = (uint32_t)x.q_cap;
   ck.alpha_off = Put(alpha);
   ck.weight_off = Put(alpha * x.scale);
-  ck.gammas_off = (uint32_t)pool_.size();
+  ck.gammas_off = (uint32_t)pool.size();
   for (const Scalar& g : x.gammas) Put(g);
   ck.q_off = Put(x.q);
-  ck.tail_off = (uint32_t)pool_.size();
+  ck.tail_off = (uint32_t)pool.size();
   ck.n_tail = (uint32_t)x.tail.size();
   for (const Scalar& t : x.tail) Put(t);
   ck.nseg = (uint32_t)segs.size();
@@ -96,19 +96,58 @@ void DeviceSink::Check(const Terms& C, const VecExpr& x, const std::vector<BaseS
     ck.seg[s].len = segs[s].len;
     ck.seg[s].vec_first = segs[s].vec_first;
   }
-  checks_.push_back(ck);
+  checks.push_back(ck);
   // bases outside the resident sets: the proof points of the same-scalar argument
   for (const LooseBase& lb : loose) {
     if (g1_affine_is_inf(lb.point)) continue;
-    extra_points_.push_back(lb.point);
-    extra_scalars_.push_back(alpha * x.At(lb.index));
+    extra_points.push_back(lb.point);
+    extra_scalars.push_back(alpha * x.At(lb.index));
   }
   // C moves to the base side: - alpha c_j P_j  (MsmAccumulator::AccumulateCheckDeferred)
   for (size_t j = 0; j < C.p.size(); j++) {
     if (g1_affine_is_inf(C.p[j])) continue;
-    extra_points_.push_back(C.p[j]);
-    extra_scalars_.push_back(-(alpha * C.s[j]));
+    extra_points.push_back(C.p[j]);
+    extra_scalars.push_back(-(alpha * C.s[j]));
   }
+}
+
+void CheckRecorder::AppendTo(size_t inst_base, std::vector<curdle_dacc_check>* group_checks, std::vector<Scalar>* group_pool,
+                             std::vector<G1Affine>* group_extra_points, std::vector<Scalar>* group_extra_scalars) const {
+  const uint32_t pb = (uint32_t)group_pool->size();
+  for (curdle_dacc_check ck : checks) {
+    ck.weight_off += pb;
+    ck.alpha_off += pb;
+    ck.gammas_off += pb;
+    ck.q_off += pb;
+    ck.tail_off += pb;
+    for (uint32_t s = 0; s < ck.nseg; s++)
+      if (ck.seg[s].set == kSetInst) ck.seg[s].first += (uint32_t)inst_base;
+    group_checks->push_back(ck);
+  }
+  group_pool->insert(group_pool->end(), pool.begin(), pool.end());
+  group_extra_points->insert(group_extra_points->end(), extra_points.begin(), extra_points.end());
+  group_extra_scalars->insert(group_extra_scalars->end(), extra_scalars.begin(), extra_scalars.end());
+}
+
+bool RunRecordedChecks(const CRS& crs, const std::vector<G1Affine>& inst, const std::vector<curdle_dacc_check>& checks,
+                       const std::vector<Scalar>& pool, const std::vector<G1Affine>& extra_points,
+                       const std::vector<Scalar>& extra_scalars) {
+  if (!crs.device) throw std::runtime_error("CRS without a device holder");
+  const curdle_dbases* bases = crs.device->Get(crs);
+  curdle_dacc* acc = nullptr;
+  int rc = curdle_dacc_begin(bases, reinterpret_cast<const uint64_t*>(inst.data()), inst.size(), &acc);
+  if (rc != CURDLE_OK) throw device_error("starting the device accumulator", rc);
+  uint64_t out[18];
+  rc = curdle_dacc_run(acc, checks.data(), checks.size(), reinterpret_cast<const uint64_t*>(pool.data()), pool.size(),
+                       reinterpret_cast<const uint64_t*>(extra_points.data()),
+                       reinterpret_cast<const uint64_t*>(extra_scalars.data()), extra_points.size(), out, nullptr);
+  if (rc != CURDLE_OK) throw device_error("verifying msm accumulator: computing msm", rc);
+  return Point::FromJac(out).IsInfinity();
+}
+
+void DeviceSink::Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs,
+                       const std::vector<LooseBase>& loose, common::Rand& rand, const char* what) {
+  rec_.Check(C, x, segs, loose, rand, what);
 }
 
 bool DeviceSink::Run(std::vector<Scalar>* slot_scalars) {
@@ -117,9 +156,9 @@ bool DeviceSink::Run(std::vector<Scalar>* slot_scalars) {
   if (slot_scalars) slot_scalars->assign(n_crs_ + n_inst_, Scalar::Zero());
   curdle_dacc* a = acc_;
   acc_ = nullptr;  // run() ends the accumulation whatever happens
-  int rc = curdle_dacc_run(a, checks_.data(), checks_.size(), reinterpret_cast<const uint64_t*>(pool_.data()), pool_.size(),
-                           reinterpret_cast<const uint64_t*>(extra_points_.data()),
-                           reinterpret_cast<const uint64_t*>(extra_scalars_.data()), extra_points_.size(), out,
+  int rc = curdle_dacc_run(a, rec_.checks.data(), rec_.checks.size(), reinterpret_cast<const uint64_t*>(rec_.pool.data()), rec_.pool.size(),
+                           reinterpret_cast<const uint64_t*>(rec_.extra_points.data()),
+                           reinterpret_cast<const uint64_t*>(rec_.extra_scalars.data()), rec_.extra_points.size(), out,
                            slot_scalars ? reinterpret_cast<uint64_t*>(slot_scalars->data()) : nullptr);
   if (rc != CURDLE_OK) throw device_error("verifying msm accumulator: computing msm", rc);  // msmaccumulator.go:60
   return Point::FromJac(out).IsInfinity();  // :63, A_c is the point at infinity here
@@ -136,9 +175,9 @@ bool DeviceSink::VerifyAndExport(std::vector<G1Affine>* bases, std::vector<Scala
   bases->push_back(crs_.Gt.Affine());
   bases->push_back(crs_.Gu.Affine());
   for (const auto* v : inst_) bases->insert(bases->end(), v->begin(), v->end());
-  bases->insert(bases->end(), extra_points_.begin(), extra_points_.end());
+  bases->insert(bases->end(), rec_.extra_points.begin(), rec_.extra_points.end());
   *scalars = slots;
-  scalars->insert(scalars->end(), extra_scalars_.begin(), extra_scalars_.end());
+  scalars->insert(scalars->end(), rec_.extra_scalars.begin(), rec_.extra_scalars.end());
   return ok;
 }
 

@@ -42,6 +42,35 @@ class DeviceCrs {
 bool DeviceAccumulatorEnabled();
 int SetDeviceAccumulator(int on);  // returns the previous setting
 
+// The checks of ONE verification as descriptions for the device accumulator: what DeviceSink
+// ships, without owning a device accumulation, so that several recordings can be concatenated
+// into one group (cross-proof batch verification: one resident CRS, the members' instances one
+// after the other, one MSM per group).
+class CheckRecorder : public CheckSink {
+ public:
+  void Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs, const std::vector<LooseBase>& loose,
+             common::Rand& rand, const char* what) override;
+  // Appends this recording to a group whose instance set already holds `inst_base` slots and
+  // whose pool holds group_pool->size() elements: offsets are rebased.
+  void AppendTo(size_t inst_base, std::vector<curdle_dacc_check>* group_checks, std::vector<Scalar>* group_pool,
+                std::vector<G1Affine>* group_extra_points, std::vector<Scalar>* group_extra_scalars) const;
+  std::vector<curdle_dacc_check> checks;
+  std::vector<Scalar> pool;
+  std::vector<G1Affine> extra_points;
+  std::vector<Scalar> extra_scalars;
+
+ private:
+  uint32_t Put(const Scalar& s);
+};
+
+// One MSM over a resident CRS, `inst` (the members' instance points, back to back) and the
+// loose pairs, with the slot scalars built on the device from `checks`: true iff the sum is the
+// point at infinity (every recorded check holds, up to the soundness error of the random
+// weights).  Throws alg::MsmError on a device failure.
+bool RunRecordedChecks(const CRS& crs, const std::vector<G1Affine>& inst, const std::vector<curdle_dacc_check>& checks,
+                       const std::vector<Scalar>& pool, const std::vector<G1Affine>& extra_points,
+                       const std::vector<Scalar>& extra_scalars);
+
 class DeviceSink : public CheckSink {
  public:
   DeviceSink(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
@@ -58,16 +87,11 @@ class DeviceSink : public CheckSink {
 
  private:
   bool Run(std::vector<Scalar>* slot_scalars);
-  uint32_t Put(const Scalar& s);
   curdle_dacc* acc_ = nullptr;
   size_t ell_, n_crs_, n_inst_;
-  std::vector<G1Affine> resident_;  // for VerifyAndExport only (filled lazily)
   const CRS& crs_;
   const std::vector<G1Affine>*inst_[4];
-  std::vector<curdle_dacc_check> checks_;
-  std::vector<Scalar> pool_;
-  std::vector<G1Affine> extra_points_;
-  std::vector<Scalar> extra_scalars_;
+  CheckRecorder rec_;
 };
 
 }  // namespace proto

@@ -296,7 +296,7 @@ size_t curdle_dbases_size(const curdle_dbases* b);
 #define CURDLE_VEC_FOLD 2     /* x_i = scale * prod_{j : bit j of i set} gammas[m-1-j]                */
 #define CURDLE_VEC_FOLD_POW 3 /* ... * q^(min(i, q_cap) + 1)                                          */
 #define CURDLE_DACC_MAX_SEGS 6
-#define CURDLE_DACC_MAX_EXTRA 4096
+#define CURDLE_DACC_MAX_EXTRA 16384
 #define CURDLE_SET_CRS 0
 #define CURDLE_SET_INST 1
 /* One AccumulateCheck: sum_i x_i v_i (== C, which the caller moves to the other side as extra

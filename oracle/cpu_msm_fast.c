@@ -35,7 +35,9 @@ typedef unsigned __int128 u128;
 
 static const u64 P[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
                          0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+#if !(defined(__BMI2__) && defined(__ADX__))
 static const u64 P_INV = 0x89f3fffcfffcfffdull; /* -p^-1 mod 2^64 */
+#endif
 static const u64 ONE[6] = {0x760900000002fffdull, 0xebf4000bc40c0002ull, 0x5f48985753c758baull,
                            0x77ce585370525745ull, 0x5c071a97a256ec6dull, 0x15f65ec3fa80e493ull};
 static const u64 R_MOD[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};

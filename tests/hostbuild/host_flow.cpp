@@ -39,10 +39,13 @@ struct Instance {
   std::vector<uint8_t> proof;
 };
 
-static Instance Make(size_t ell, uint64_t seed) {
+static Instance Make(size_t ell, uint64_t seed, const proto::CRS* crs = nullptr) {
   Instance in;
   common::Rand rand(seed);
-  in.crs = proto::GenerateCRS(ell, rand);
+  if (crs)
+    in.crs = *crs;  // another instance over the same CRS
+  else
+    in.crs = proto::GenerateCRS(ell, rand);
   common::Rand prand(seed + 42);
   prand.GeneratePermutation(ell, in.perm);
   rand.GetFr(in.k.v);
@@ -188,7 +191,43 @@ static int Flow(size_t ell) {
     CHECK(!VerifyBytes(bad, in.proof, 51));
     proto::SetDeviceAccumulator(1);
   }
-  printf("flow ell=%zu: completeness, round trip, soundness flips, accumulator table, mirror == device accumulator: ok\n", ell);
+  // cross-proof batch verification, on the device accumulator's description path and on the
+  // host mirror: exact per-proof bits with a bad instance, a truncated and a bit-flipped proof
+  {
+    Instance other = Make(ell, 21, &in.crs);
+    std::vector<uint8_t> truncated(in.proof.begin(), in.proof.end() - 5), flipped(in.proof);
+    flipped[flipped.size() - 9] ^= 0x20;
+    std::vector<proto::BatchItem> items;
+    uint64_t Mj[2][18];
+    in.M.Jac(Mj[0]);
+    other.M.Jac(Mj[1]);
+    auto item = [&](const std::vector<uint8_t>& pf, const Instance& inst, const uint64_t* M) {
+      return proto::BatchItem{pf.data(), pf.size(), inst.Rs.data(), inst.Ss.data(), inst.Ts.data(), inst.Us.data(), ell, M};
+    };
+    items.push_back(item(in.proof, in, Mj[0]));
+    items.push_back(item(other.proof, other, Mj[1]));
+    items.push_back(item(in.proof, other, Mj[1]));      // another proof's instance
+    items.push_back(item(truncated, in, Mj[0]));
+    items.push_back(item(flipped, in, Mj[0]));
+    items.push_back(item(other.proof, other, Mj[1]));
+    const std::vector<int> want = {1, 1, 0, 0, 0, 1};
+    for (int dev = 1; dev >= 0; dev--) {
+      proto::SetDeviceAccumulator(dev);
+      common::Rand br(5);
+      const std::vector<int> got = proto::VerifyBatch(in.crs, items, br, 2);
+      if (got != want) {
+        fprintf(stderr, "batch (device accumulator %d):", dev);
+        for (int v : got) fprintf(stderr, " %d", v);
+        fprintf(stderr, "\n");
+      }
+      CHECK(got == want);
+      common::Rand br2(6);
+      std::vector<proto::BatchItem> good = {items[0], items[1], items[5]};
+      CHECK(proto::VerifyBatch(in.crs, good, br2, 3) == (std::vector<int>{1, 1, 1}));
+    }
+    proto::SetDeviceAccumulator(1);
+  }
+  printf("flow ell=%zu: completeness, round trip, soundness flips, accumulator table, mirror == device accumulator, batch: ok\n", ell);
   return 0;
 }
 

@@ -32,7 +32,7 @@ def _run(exe, *args):
 
 def test_protocol_flow_under_asan_ubsan(harness):
     out = _run(harness, "flow", "12")
-    assert "mirror == device accumulator: ok" in out
+    assert "mirror == device accumulator, batch: ok" in out
 
 
 def test_parsers_survive_mutated_proofs_under_asan_ubsan(harness):
