@@ -288,7 +288,7 @@ def main():
         dom = max(solo, key=solo.get) if solo else None
         roofline = None
         if dom:
-            ach = BYTES_PER_PAIR * n / (solo[dom] * 1e-3) / 1e9
+            ach = BYTES_PER_PAIR * n_mine / (solo[dom] * 1e-3) / 1e9   # the pairs THIS rank's launch reads
             traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc) and world == 1 and args.logn == 20:
