@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--logn", type=int, default=20, help="log2 of the MSM size (default: the headline 2^20)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="MSMs in flight (curdle_msm_g1_device_submit/wait); 1 = strictly one after the other; "
-                         "default: 4 for a whole MSM per GPU, 5 for a window-range partial (measured best)")
+                         "default: 4 for a whole MSM per GPU, 6 for a window-range partial (measured best)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the verifies/s leg")
     ap.add_argument("--split", choices=["windows", "points"], default="windows",
@@ -170,7 +170,7 @@ def main():
     W = cm.num_windows(n, c)
     parts = world if world > 1 else max(1, args.emulate_world)
     my_part = rank if world > 1 else 0
-    in_flight = args.in_flight or (4 if parts == 1 else 5)
+    in_flight = args.in_flight or (4 if parts == 1 else 6)
     depth = max(1, min(in_flight, cm.MSM_SLOTS - 1))
     from curdlemsm.distributed import gather_partials, point_partition, window_partition
     wb, we, p_lo, p_hi = 0, W, 0, n

@@ -325,6 +325,13 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (ch > n_max) ch = n_max ? n_max : 1;
   p.chunk = (uint32_t)ch;
   p.gpu_combine = k * sets >= kGpuCombineMin ? 1u : 0u;
+  // One single-block scan launch instead of six: up to 8,192 slots it is also the faster one; up to
+  // 65,536 slots (a two-window partial of the multi-GPU split) it is slower in isolation (0.14 ms:
+  // 64 consecutive slots per thread) but a pipelined caller only pays for launches, not latency.
+  {
+    const uint64_t slots = (uint64_t)k * p.NB;
+    p.fuse_scan = slots <= 8192 || (!latency_mode && slots <= 65536) ? 1u : 0u;
+  }
   return CURDLE_OK;
 }
 

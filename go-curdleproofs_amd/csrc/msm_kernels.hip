@@ -244,53 +244,49 @@ __global__ void __launch_bounds__(kBlock) k_fix_foff(u32* __restrict__ foff, con
   }
 }
 
-// All of the above in ONE single-block launch for calls with at most 16,384 bucket slots
-// (small MSMs are launch-latency-bound: six dependent launches were ~30 us of a 0.4 ms call).
-static constexpr u32 kScanFusedMax = 16 * kScanThreads;
+// All of the above in ONE single-block launch for calls with at most 65,536 bucket slots
+// (small MSMs are launch-latency-bound: six dependent launches were ~30 us of a 0.4 ms call;
+// a two-window partial of the multi-GPU split has 65,536 slots).
+static constexpr u32 kScanFusedMax = 64 * kScanThreads;
 __global__ void __launch_bounds__(kScanThreads)
     k_scan_fused(const u32* __restrict__ counts, u32 nb, u32* __restrict__ starts, u32* __restrict__ cursor,
                  u32* __restrict__ fragcnt, u32* __restrict__ foff, u32* __restrict__ large, u32* __restrict__ nlarge, u32 L,
                  u32 max_small, u32 max_large) {
   __shared__ u32 sh[kScanThreads];
   const u32 tid = threadIdx.x;
-  const u32 per = (nb + kScanThreads - 1) / kScanThreads;  // <= 16
-  const u32 base = tid * per;
+  const u32 per = (nb + kScanThreads - 1) / kScanThreads;  // <= 64 consecutive slots per thread
+  const u32 lo = min(tid * per, nb), hi = min(lo + per, nb);
   if (tid == 0) *nlarge = 0;
-  u32 v[16], fc[16], sum = 0;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    v[k] = ((u32)k < per && base + k < nb) ? counts[base + k] : 0u;
-    sum += v[k];
-  }
+  // the slots are read twice (the second time from L2) rather than kept in registers
+  u32 sum = 0;
+  for (u32 i = lo; i < hi; i++) sum += counts[i];
   u32 total;
-  u32 run = block_exclusive_scan_1024(sum, sh, total);
-  u32 fsum = 0;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    fc[k] = 0;
-    if ((u32)k < per && base + k < nb) {
-      starts[base + k] = run;
-      cursor[base + k] = run;
-      fc[k] = v[k] ? ((run + v[k] - 1) / L - run / L + 1) : 0u;
-      fragcnt[base + k] = fc[k];
-      fsum += fc[k];
-      run += v[k];
-    }
+  const u32 first = block_exclusive_scan_1024(sum, sh, total);
+  u32 run = first, fsum = 0;
+  for (u32 i = lo; i < hi; i++) {
+    const u32 cnt = counts[i];
+    starts[i] = run;
+    cursor[i] = run;
+    const u32 fc = cnt ? ((run + cnt - 1) / L - run / L + 1) : 0u;
+    fragcnt[i] = fc;
+    fsum += fc;
+    run += cnt;
   }
   if (tid == 0) starts[nb] = total;
   __syncthreads();  // sh is reused; nlarge = 0 is visible to the block
   u32 ftotal;
   u32 frun = block_exclusive_scan_1024(fsum, sh, ftotal);
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    if ((u32)k < per && base + k < nb) {
-      foff[base + k] = frun;
-      if (fc[k] > max_small) {
-        u32 q = atomicAdd(nlarge, 1u);
-        if (q < max_large) large[q] = base + k;
-      }
-      frun += fc[k];
+  run = first;
+  for (u32 i = lo; i < hi; i++) {
+    const u32 cnt = counts[i];
+    const u32 fc = cnt ? ((run + cnt - 1) / L - run / L + 1) : 0u;
+    foff[i] = frun;
+    if (fc > max_small) {
+      u32 q = atomicAdd(nlarge, 1u);
+      if (q < max_large) large[q] = i;
     }
+    frun += fc;
+    run += cnt;
   }
   if (tid == 0) foff[nb] = ftotal;
 }
@@ -771,7 +767,7 @@ static hipError_t scan_u32(const u32* in, u32 len, u32* out, u32* blocksum, hipS
 
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nb = p.k * p.NB;
-  if (nb <= kScanFusedMax) {
+  if (p.fuse_scan && nb <= kScanFusedMax) {
     hipLaunchKernelGGL(k_scan_fused, dim3(1), dim3(kScanThreads), 0, stream, ws.counts, nb, ws.starts, ws.cursor,
                        ws.fragcnt, ws.foff, ws.large, ws.nlarge, p.L, p.max_small, p.max_large);
     return hipGetLastError();
