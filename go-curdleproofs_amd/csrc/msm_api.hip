@@ -142,6 +142,7 @@ struct Ctx {
   hipStream_t pre_stream2 = nullptr;
   int pre_streams = 2;
   Slot slots[kSlots];
+  unsigned epoch = 0;  // bumped by curdle_shutdown: resident base sets of a closed context are refused
   int profile = 0;  // 0 off, 1 every phase, 2 the dominant kernel only
   curdle_profile last = {};
 };
@@ -946,6 +947,7 @@ extern "C" int curdle_shutdown(void) {
   (void)hipStreamDestroy(C.util_stream);
   C.util_stream = nullptr;
   C.inited = false;
+  C.epoch++;  // device memory of curdle_dbases handles made under this context is gone with it
   return CURDLE_OK;
 }
 
@@ -1157,6 +1159,7 @@ extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k,
 struct curdle_dbases {
   void* d28 = nullptr;  // n internal-form points, kA28Bytes apart
   size_t n = 0;
+  unsigned epoch = 0;   // the context generation the memory belongs to
 };
 struct curdle_dacc {
   int slot = -1;
@@ -1175,6 +1178,7 @@ extern "C" int curdle_dbases_create(const uint64_t* points, size_t n, curdle_dba
   curdle_dbases* b = new (std::nothrow) curdle_dbases();
   if (!b) return fail(CURDLE_ENOMEM, "out of memory");
   b->n = n;
+  b->epoch = g_ctx.epoch;
   if (n) {
     void* tmp = nullptr;
     hipError_t e = hipMalloc(&b->d28, n * kA28Bytes);
@@ -1197,7 +1201,7 @@ extern "C" void curdle_dbases_free(curdle_dbases* b) {
   if (!b) return;
   if (b->d28) {
     std::lock_guard<std::mutex> g(g_ctx.mu);
-    if (g_ctx.inited) {  // after curdle_shutdown the context's memory is gone with it
+    if (g_ctx.inited && b->epoch == g_ctx.epoch) {  // after curdle_shutdown the context's memory is gone with it
       (void)hipSetDevice(g_ctx.device);
       (void)hipFree(b->d28);
     }
@@ -1206,6 +1210,12 @@ extern "C" void curdle_dbases_free(curdle_dbases* b) {
 }
 
 extern "C" size_t curdle_dbases_size(const curdle_dbases* b) { return b ? b->n : 0; }
+
+extern "C" int curdle_dbases_valid(const curdle_dbases* b) {
+  if (!b) return 0;
+  std::lock_guard<std::mutex> g(g_ctx.mu);
+  return g_ctx.inited && b->epoch == g_ctx.epoch ? 1 : 0;
+}
 
 namespace {
 int ensure_pinned(Slot& S, int which, size_t bytes) {
@@ -1226,6 +1236,10 @@ extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_
   int idx;
   int rc = acquire_slot(true, &idx);
   if (rc) return rc;
+  if (crs->epoch != g_ctx.epoch) {
+    release_slot(idx);
+    return fail(CURDLE_EINVAL, "resident bases belong to a context that was shut down; create them again");
+  }
   Slot& S = g_ctx.slots[idx];
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(g_ctx.device));

@@ -60,7 +60,7 @@ SYMBOLS = [
     "curdle_whisk_is_valid_tracker_proof", "curdle_whisk_generate_tracker_proof", "curdle_proof_reencode", "curdle_merlin_test_vector", "curdle_g1_decompress_batch", "curdle_g1_decompress_begin", "curdle_g1_decompress_finish", "curdle_g1_decompress_start", "curdle_g1_decompress_points",
     "curdle_g1_scalar_mul_batch",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error", "curdle_fr_inner_product",
-    "curdle_dbases_create", "curdle_dbases_free", "curdle_dbases_size",
+    "curdle_dbases_create", "curdle_dbases_free", "curdle_dbases_size", "curdle_dbases_valid",
     "curdle_dacc_begin", "curdle_dacc_run", "curdle_dacc_abort",
     "curdle_verify_set_device_acc", "curdle_verify_export_accumulator",
 ]

@@ -33,6 +33,10 @@ DeviceCrs::~DeviceCrs() { curdle_dbases_free(h_); }
 
 const curdle_dbases* DeviceCrs::Get(const CRS& crs) {
   std::lock_guard<std::mutex> g(mu_);
+  if (h_ && !curdle_dbases_valid(h_)) {  // the library was shut down and re-initialised since
+    curdle_dbases_free(h_);
+    h_ = nullptr;
+  }
   if (!h_) {
     std::vector<G1Affine> pts(crs.Gs);  // Gs | Hs | H | Gt | Gu  (CrsIndex)
     pts.insert(pts.end(), crs.Hs.begin(), crs.Hs.end());

@@ -290,6 +290,9 @@ typedef struct curdle_dbases curdle_dbases; /* a base set on the device, in the 
 int curdle_dbases_create(const uint64_t* points /* n x 12, gnark G1Affine */, size_t n, curdle_dbases** out);
 void curdle_dbases_free(curdle_dbases* b);
 size_t curdle_dbases_size(const curdle_dbases* b);
+/* 0 once curdle_shutdown has closed the context the set was made under (its device memory is
+ * gone: free the handle and create it again). */
+int curdle_dbases_valid(const curdle_dbases* b);
 
 #define CURDLE_VEC_EXPLICIT 0 /* x_i = tail[i]                                                        */
 #define CURDLE_VEC_CONST 1    /* x_i = scale                                                          */

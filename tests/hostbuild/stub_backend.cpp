@@ -174,6 +174,7 @@ extern "C" int curdle_dbases_create(const uint64_t* points, size_t n, curdle_dba
 }
 extern "C" void curdle_dbases_free(curdle_dbases* b) { delete b; }
 extern "C" size_t curdle_dbases_size(const curdle_dbases* b) { return b ? b->pts.size() : 0; }
+extern "C" int curdle_dbases_valid(const curdle_dbases* b) { return b ? 1 : 0; }
 extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_points, size_t n_inst, curdle_dacc** out) {
   curdle_dacc* a = new curdle_dacc();
   a->crs = crs;

@@ -112,3 +112,16 @@ def test_device_accumulator_abi_rejects_malformed_descriptions(gpu):
     assert run([2, 8, 2, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 8, 0]) == gpu.EINVAL       # 8 structured elements, 2^2 folds
     assert run([7, 8, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 8, 0]) == gpu.EINVAL       # unknown kind
     lib.curdle_dbases_free(bases)
+
+
+def test_resident_crs_survives_shutdown_and_reinit(gpu):
+    """curdle_shutdown frees every device buffer, the CRS's resident copy included: the next
+    verification notices (context epoch) and makes it resident again instead of reading freed
+    memory."""
+    crs, Rs, Ss, Ts, Us, M, perm, k, rs_m = setup(gpu, 16)
+    proof = gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(1))
+    assert gpu.verify(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(2)) is True
+    gpu.shutdown()
+    gpu.init(0)
+    assert gpu.verify(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(2)) is True
+    assert gpu.verify(crs, proof, Ss, Rs, Ts, Us, M, gpu.Rand(2)) is False
