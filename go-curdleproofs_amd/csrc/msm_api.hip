@@ -102,7 +102,9 @@ struct Slot {
 // call MSM entry points while the subgroup test runs, and eight such callers holding the
 // eight MSM slots would wait for each other forever.
 struct DSlot {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // decoding kernel, then the subgroup test, back to back
+  hipStream_t copy_stream = nullptr;  // hands the points back while the subgroup test runs
+  hipEvent_t decoded = nullptr;       // recorded between the two kernels
   Buf in, out, status;
   void* h_in = nullptr;  // pinned staging of the compressed records
   size_t h_in_cap = 0;
@@ -176,6 +178,7 @@ int init_locked(int device) {
   HIP_TRY(hipStreamCreateWithFlags(&g_ctx.util_stream, hipStreamNonBlocking));
   int prio_least = 0, prio_greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+  if (getenv("CURDLE_DEBUG_PRIO")) fprintf(stderr, "[curdle] stream priority range: least %d greatest %d\n", prio_least, prio_greatest);
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_stream, hipStreamNonBlocking, prio_least));
   for (auto& st : g_ctx.main_extra) HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_least));
   if (const char* ms = getenv("CURDLE_MAIN_STREAMS")) {
@@ -195,7 +198,19 @@ int init_locked(int device) {
     HIP_TRY(hipEventCreateWithFlags(&s.acc_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
   }
-  for (DSlot& d : g_ctx.dslots) HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+  for (DSlot& d : g_ctx.dslots) {
+    // The two decoding streams at the HIGHEST priority: their kernels are a few waves (one
+    // serial chain per point) that the caller's MSM must run beside, not behind -- measured on
+    // one verification from bytes (ell = 252, default 4 hardware queues): the accumulator's MSM
+    // takes 0.46 ms next to a high-priority subgroup test, 0.88 ms queued behind a low-priority
+    // one (profiles/r02_verify_from_bytes_queues.txt).  CURDLE_DECODE_PRIO=0 restores the
+    // lowest priority, =2 the default one.
+    const char* dp = getenv("CURDLE_DECODE_PRIO");
+    const int dprio = dp ? (atoi(dp) == 0 ? prio_least : atoi(dp) == 2 ? 0 : prio_greatest) : prio_greatest;
+    HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, dprio));
+    HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d.decoded, hipEventDisableTiming));
+  }
   g_ctx.device = device;
   g_ctx.inited = true;
   return CURDLE_OK;
@@ -754,6 +769,10 @@ extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* tick
     HIP_TRY(hipMemcpyAsync(D.in.p, D.h_in, n * 48, hipMemcpyHostToDevice, D.stream));
     HIP_TRY(launch_g1_decompress((const uint8_t*)D.in.p, (uint32_t)n, 0, (uint32_t*)D.out.p, (uint8_t*)D.status.p,
                                  D.stream));
+    // the subgroup test is queued right behind (no host round trip between the two kernels);
+    // curdle_g1_decompress_points reads the points on the other stream as soon as they exist
+    HIP_TRY(hipEventRecord(D.decoded, D.stream));
+    HIP_TRY(launch_g1_subgroup_check((const uint32_t*)D.out.p, (uint32_t)n, (uint8_t*)D.status.p, D.stream));
     return CURDLE_OK;
   };
   int rc = body();
@@ -789,14 +808,16 @@ extern "C" int curdle_g1_decompress_points(int ticket, uint64_t* out_affine, uin
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(g_ctx.device));
     if (n == 0) return CURDLE_OK;
-    HIP_TRY(hipMemcpyAsync(out_affine, D.out.p, n * 96, hipMemcpyDeviceToHost, D.stream));
-    HIP_TRY(hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.stream));
-    HIP_TRY(hipStreamSynchronize(D.stream));
-    HIP_TRY(launch_g1_subgroup_check((const uint32_t*)D.out.p, (uint32_t)n, (uint8_t*)D.status.p, D.stream));
+    // the statuses may already carry some of the subgroup test's verdicts (it only ever turns
+    // OK into NOT_IN_SUBGROUP): either view is a correct answer for the caller
+    HIP_TRY(hipStreamWaitEvent(D.copy_stream, D.decoded, 0));
+    HIP_TRY(hipMemcpyAsync(out_affine, D.out.p, n * 96, hipMemcpyDeviceToHost, D.copy_stream));
+    HIP_TRY(hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.copy_stream));
+    HIP_TRY(hipStreamSynchronize(D.copy_stream));
     return CURDLE_OK;
   };
   int rc = body();
-  if (rc) (void)hipStreamSynchronize(D.stream);  // the ticket stays valid: the caller still has to finish it
+  if (rc) (void)hipStreamSynchronize(D.copy_stream);  // the ticket stays valid: the caller still has to finish it
   return rc;
 }
 
@@ -830,6 +851,7 @@ extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
   hipError_t he = hipSetDevice(g_ctx.device);
   if (he == hipSuccess && n && status) he = hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.stream);
   if (he == hipSuccess) he = hipStreamSynchronize(D.stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(D.copy_stream);
   if (he != hipSuccess) rc = fail(CURDLE_EHIP, "decompress finish: %s", hipGetErrorString(he));
   {
     std::lock_guard<std::mutex> g(g_ctx.mu);
@@ -904,6 +926,11 @@ extern "C" int curdle_shutdown(void) {
     d.h_in_cap = 0;
     (void)hipStreamDestroy(d.stream);
     d.stream = nullptr;
+    (void)hipStreamSynchronize(d.copy_stream);
+    (void)hipStreamDestroy(d.copy_stream);
+    d.copy_stream = nullptr;
+    (void)hipEventDestroy(d.decoded);
+    d.decoded = nullptr;
   }
   for (Slot& S : C.slots) {
     (void)hipStreamSynchronize(S.stream);

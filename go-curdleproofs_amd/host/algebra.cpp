@@ -140,18 +140,26 @@ static bool y_is_larger(const Fp& y_mont) {
 }
 
 Point Point::operator+(const Point& o) const {
-  Point r = *this;
+  NeedValue();
+  o.NeedValue();
+  Point r;
+  r.p = p;
   AddImpl(r.p, o.p);
   return r;
 }
 
 G1Affine Point::Affine() const {
+  NeedValue();
   G1Affine a;
   ToAffineImpl(a, p);
   return a;
 }
 
-bool Point::operator==(const Point& o) const { return curdle_host_equal(&p, &o.p) != 0; }
+bool Point::operator==(const Point& o) const {
+  NeedValue();
+  o.NeedValue();
+  return curdle_host_equal(&p, &o.p) != 0;
+}
 
 Point Point::FromJac(const uint64_t jac[18]) {
   G1Jac j;
@@ -168,6 +176,7 @@ Point Point::Generator() {
 }
 
 Point Point::Mul(const Scalar& k) const {
+  NeedValue();
   u32 c[8];
   k.Canonical(c);
   Point r;
@@ -176,6 +185,10 @@ Point Point::Mul(const Scalar& k) const {
 }
 
 void Point::Compressed(uint8_t out[48]) const {
+  if (wire) {
+    memcpy(out, wire, 48);
+    return;
+  }
   G1Affine a;
   if (!ToAffineImpl(a, p)) {
     memset(out, 0, 48);

@@ -81,6 +81,17 @@ Scalar InnerProduct(const std::vector<Scalar>& a, const std::vector<Scalar>& b);
 
 struct Point {
   G1XYZZ p;
+  // Set only by the verifier's lazy proof reader (proto::Reader with `lazy`), for points whose
+  // decoding is still running on the GPU: `wire` is the 48-byte record the point comes from --
+  // what the transcript absorbs, so it needs no coordinates -- and `pending` >= 0 says the
+  // coordinates are NOT known yet (the record's index in the proto::PointDecoder).  A pending
+  // point can be hashed and listed as a base; arithmetic on it is a logic error.  Both die with
+  // the verification call: results of operators never carry them.
+  const uint8_t* wire = nullptr;
+  int32_t pending = -1;
+  void NeedValue() const {
+    if (pending >= 0) throw std::logic_error("arithmetic on a point that is still being decoded");
+  }
 
   static Point Infinity() {
     Point r;
@@ -96,18 +107,27 @@ struct Point {
   static Point Generator();
   Point operator+(const Point& o) const;
   Point Neg() const {
-    Point r = *this;
+    NeedValue();
+    Point r;
+    r.p = p;
     if (!g1_is_inf(r.p)) fp_neg(r.p.y, r.p.y);
     return r;
   }
   Point operator-(const Point& o) const { return *this + o.Neg(); }
   Point Mul(const Scalar& k) const;   // ScalarMultiplication with FrToBigInt(k)
-  bool IsInfinity() const { return g1_is_inf(p); }
+  bool IsInfinity() const {
+    NeedValue();
+    return g1_is_inf(p);
+  }
   bool operator==(const Point& o) const;   // G1Jac.Equal
   G1Affine Affine() const;
-  void Jac(uint64_t out[18]) const { g1_to_canonical_jac(out, p); }
+  void Jac(uint64_t out[18]) const {
+    NeedValue();
+    g1_to_canonical_jac(out, p);
+  }
   // gnark G1Affine.Bytes(): 48 bytes, big-endian x, flags in the top three bits
-  // (0x80 compressed, 0x40 infinity, 0x20 y is the lexicographically larger root).
+  // (0x80 compressed, 0x40 infinity, 0x20 y is the lexicographically larger root).  A point
+  // that carries its wire record hands that back (a valid record is its point's only encoding).
   void Compressed(uint8_t out[48]) const;
   // G1Affine.SetBytes: false on a malformed encoding or a point not on the curve;
   // the (slow, [r]P) subgroup check is optional.

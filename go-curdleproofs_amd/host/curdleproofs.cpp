@@ -93,6 +93,17 @@ int Log2Exact(size_t n, const char* what) {
 
 G1Affine AffineOf(const Point& p) { return p.Affine(); }
 
+// The value of a point the verifier must compute with before the GPU has decoded it: square root
+// on the host (~15 us), no subgroup test -- the GPU's verdict on the same record still gates the
+// result (VerifyWhileDecoding).
+Point Decoded(const Point& p) {
+  if (p.pending < 0) return p;
+  Point out;
+  if (!Point::FromCompressed(p.wire, &out, /*subgroup_check=*/false)) throw err("decoding proof: invalid point");
+  out.wire = p.wire;
+  return out;
+}
+
 const G1Affine kZeroPoint = [] {
   G1Affine z;
   f_zero(z.x);
@@ -166,7 +177,13 @@ void MirrorSink::Check(const Terms& C, const VecExpr& x, const std::vector<BaseS
         v[sg.vec_first + j] = inst_[slot / ell_]->at(slot % ell_);
       }
     }
-  for (const LooseBase& lb : loose) v.at(lb.index) = lb.point;
+  // the host mirror needs coordinates: pending points belong to VerifyWhileDecoding's DeviceSink
+  for (int32_t pd : C.pending)
+    if (pd >= 0) throw std::logic_error(std::string(what) + ": pending point handed to the host accumulator");
+  for (const LooseBase& lb : loose) {
+    if (lb.pending >= 0) throw std::logic_error(std::string(what) + ": pending point handed to the host accumulator");
+    v.at(lb.index) = lb.point;
+  }
   std::vector<Fr> xs(xv.size());
   for (size_t i = 0; i < xv.size(); i++) xs[i] = xv[i].v;
   msmaccumulator::Status st;
@@ -289,12 +306,22 @@ bool PointDecoder::Get(size_t index, Point* out) const {
   return true;
 }
 
+bool PointDecoder::GetAffine(size_t index, G1Affine* out) const {
+  if (index >= n_ || status_[index] > CURDLE_DECODE_INFINITY) return false;
+  *out = status_[index] == CURDLE_DECODE_INFINITY ? kZeroPoint : pts_[index];
+  return true;
+}
+
 Point Reader::GetPoint(const char* what) {
   if (left < 48) throw err(std::string("decoding ") + what + ": unexpected end of input");
   Point out;
   if (collect) {
-    collect->Add(p);
+    const size_t at = collect->Add(p);
     out = Point::Infinity();
+    if (lazy) {
+      out.wire = p;
+      out.pending = (int32_t)at;
+    }
   } else if (decoded) {
     if (!decoded->Get(decoded_pos++, &out)) throw err(std::string("decoding ") + what + ": invalid point");
   } else if (!Point::FromCompressed(p, &out, subgroup_check)) {
@@ -437,10 +464,10 @@ bool Verify(const Proof& proof, const Point& Gt, const Point& Gu, const Point& H
       sink->Check(c, VecExpr::Explicit(std::move(x)), segs, loose, *rand, what);
     };
     check(proof.A.T_1, T.T_1, {proof.Z_t}, {{kSetCrs, ix.Gt(), 1, 0}}, {}, "same scalar check A.T_1");
-    check(proof.A.T_2, T.T_2, {proof.Z_k, proof.Z_t}, {{kSetCrs, ix.H(), 1, 1}}, {{0, R.Affine()}},
+    check(proof.A.T_2, T.T_2, {proof.Z_k, proof.Z_t}, {{kSetCrs, ix.H(), 1, 1}}, {{0, R}},
           "same scalar check A.T_2");
     check(proof.B.T_1, U.T_1, {proof.Z_u}, {{kSetCrs, ix.Gu(), 1, 0}}, {}, "same scalar check B.T_1");
-    check(proof.B.T_2, U.T_2, {proof.Z_k, proof.Z_u}, {{kSetCrs, ix.H(), 1, 1}}, {{0, S.Affine()}},
+    check(proof.B.T_2, U.T_2, {proof.Z_k, proof.Z_u}, {{kSetCrs, ix.H(), 1, 1}}, {{0, S}},
           "same scalar check B.T_2");
     return true;
   }
@@ -753,7 +780,7 @@ bool Verify(const Proof& proof, const CRS& crs, const Point& B, const Scalar& re
   const Point gs = crs.GsumTable ? crs.GsumTable->Mul(betaInv) : Point::FromAffine(crs.Gsum).Mul(betaInv);
   const Point hs = crs.HsumTable ? crs.HsumTable->Mul(alpha) : Point::FromAffine(crs.Hsum).Mul(alpha);
   // normalised once: D is hashed into the transcript AND rides in the accumulator as a base
-  const Point D = Point::FromAffine((B - gs + hs).Affine());
+  const Point D = Point::FromAffine((Decoded(B) - gs + hs).Affine());
 
   const Scalar betaExpL = beta.Pow(ell);
   const Scalar z = result * betaExpL + proof.Rp * (betaExpL * beta) - Scalar::One();  // :253-260
@@ -1090,36 +1117,38 @@ void StartVerify(VerifyPrelude& pre, const std::vector<G1Affine>& Rs, const std:
   StartVerify(pre, ell, &b[0], &b[48 * ell], &b[96 * ell], &b[144 * ell], &b[192 * ell]);
 }
 
-bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
-                    const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
-                    CheckSink& sink, VerifyPrelude* started) {
-  // curdleproof.go:199-311
+// curdleproof.go:225-311 -- everything after the prelude.  Ts / Us are only needed when the
+// prelude did not keep their encodings (it always does); the instance as BASES is addressed by
+// index, so a caller that does not have the decoded instance yet passes null.
+static bool VerifyBody(const Proof& proof, const CRS& crs, const std::vector<G1Affine>* Ts, const std::vector<G1Affine>* Us,
+                       const Point& M, common::Rand& rand, CheckSink& sink, VerifyPrelude& started) {
   const size_t ell = crs.Gs.size();
-  if (Rs.size() != ell || Ss.size() != ell || Ts.size() != ell || Us.size() != ell)
-    throw err("instance vectors do not match the CRS");
-  if (Ts.empty() || g1_affine_is_inf(Ts[0])) throw err("randomizer is zero");  // :213-215
-  VerifyPrelude own;
-  if (!started) {
-    StartVerify(own, Rs, Ss, Ts, Us, M);
-    started = &own;
-  }
-  if (started->as.size() != ell) throw err("verification prelude does not match the CRS");
-  Transcript& tr = started->tr;
-  const std::vector<Scalar>& as = started->as;
+  if (started.as.size() != ell) throw err("verification prelude does not match the CRS");
+  Transcript& tr = started.tr;
+  const std::vector<Scalar>& as = started.as;
 
   if (!sameperm::Verify(proof.proofSamePermutation, crs, proof.A, M, as, tr, sink, rand)) return false;
   if (!samescalar::Verify(proof.proofSameScalar, crs.Gt, crs.Gu, crs.H, proof.R, proof.S, proof.T, proof.U, tr, &sink,
                           &rand, ell))
     return false;
 
-  const Point Aprime = Point::FromAffine((proof.A + proof.T.T_1 + proof.U.T_1).Affine());  // hashed and accumulated
+  const Point Aprime =
+      Point::FromAffine((Decoded(proof.A) + Decoded(proof.T.T_1) + Decoded(proof.U.T_1)).Affine());  // hashed and accumulated
   // T' = Ts | 0 | 0 | H | 0 and U' = Us | 0 | 0 | 0 | H for the transcript (curdleproof.go:271-285)
   const G1Affine Haff = AffineOf(crs.H);
-  std::vector<G1Affine> Tp(Ts), Up(Us);
+  std::vector<G1Affine> Tp, Up;
+  if (Ts && Us) {
+    Tp = *Ts;
+    Up = *Us;
+  } else {  // absorbed from the encodings below; only the length matters
+    if (started.Tb.size() != 48 * ell || started.Ub.size() != 48 * ell) throw err("verification prelude without the instance's encodings");
+    Tp.assign(ell, kZeroPoint);
+    Up.assign(ell, kZeroPoint);
+  }
   Tp.insert(Tp.end(), {kZeroPoint, kZeroPoint, Haff, kZeroPoint});
   Up.insert(Up.end(), {kZeroPoint, kZeroPoint, kZeroPoint, Haff});
   // ... and their encodings: the instance's, kept by the prelude, plus the four padding points
-  std::vector<uint8_t> Tpb(started->Tb), Upb(started->Ub);
+  std::vector<uint8_t> Tpb(started.Tb), Upb(started.Ub);
   {
     uint8_t zero[48], h[48];
     alg::CompressAffine(kZeroPoint, zero);
@@ -1143,6 +1172,67 @@ bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affi
   sink.Check(R, xa, {{kSetInst, in.R(0), (uint32_t)ell, 0}}, {}, rand, "msm accumulator check R, as, Rs");  // :306
   sink.Check(S, xa, {{kSetInst, in.S(0), (uint32_t)ell, 0}}, {}, rand, "msm accumulator check S, as, Ss");  // :309
   return true;
+}
+
+bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
+                    const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M, common::Rand& rand,
+                    CheckSink& sink, VerifyPrelude* started) {
+  // curdleproof.go:199-311
+  const size_t ell = crs.Gs.size();
+  if (Rs.size() != ell || Ss.size() != ell || Ts.size() != ell || Us.size() != ell)
+    throw err("instance vectors do not match the CRS");
+  if (Ts.empty() || g1_affine_is_inf(Ts[0])) throw err("randomizer is zero");  // :213-215
+  VerifyPrelude own;
+  if (!started) {
+    StartVerify(own, Rs, Ss, Ts, Us, M);
+    started = &own;
+  }
+  return VerifyBody(proof, crs, &Ts, &Us, M, rand, sink, *started);
+}
+
+bool CanVerifyWhileDecoding() { return !EagerChecks() && DeviceAccumulatorEnabled(); }
+
+bool VerifyWhileDecoding(VerifyPrelude& pre, const Proof& proof, const CRS& crs, const Point& M, PointDecoder& dec,
+                         const std::function<void(DecodedInstance&)>& after_decode, common::Rand& rand) {
+  if (!CanVerifyWhileDecoding()) throw std::logic_error("VerifyWhileDecoding needs the device accumulator and deferred checks");
+  const size_t ell = crs.Gs.size();
+  static const bool trace = [] {  // CURDLE_VERIFY_TRACE=1: where the time goes (stderr)
+    const char* e = getenv("CURDLE_VERIFY_TRACE");
+    return e && *e && *e != '0';
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  DeviceSink sink(crs);  // records; the accumulation itself starts once the instance is there
+  // the whole host part, from the wire bytes, while the GPU takes the square roots
+  bool body_ok = false;
+  std::string body_error;
+  try {
+    body_ok = VerifyBody(proof, crs, nullptr, nullptr, M, rand, sink, pre);
+  } catch (const alg::MsmError&) {
+    throw;
+  } catch (const std::runtime_error& e) {
+    body_error = e.what();
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  dec.Run(/*defer_subgroup=*/true);  // the points (the subgroup test may still be running)
+  const auto t2 = std::chrono::steady_clock::now();
+  DecodedInstance inst;
+  after_decode(inst);                // decoding errors first, in the caller's (the reference's) order
+  if (inst.Rs.size() != ell || inst.Ss.size() != ell || inst.Ts.size() != ell || inst.Us.size() != ell)
+    throw err("instance vectors do not match the CRS");
+  if (inst.Ts.empty() || g1_affine_is_inf(inst.Ts[0])) throw err("randomizer is zero");  // :213-215
+  if (!body_error.empty()) throw err(body_error);
+  if (!body_ok) return false;
+  sink.Resolve(dec);                 // the proof points, now that they are known, as the check points' bases
+  sink.Begin(inst.Rs, inst.Ss, inst.Ts, inst.Us);
+  const auto t3 = std::chrono::steady_clock::now();
+  const bool ok = sink.Verify();     // :313, the accumulator's one MSM
+  if (trace) {
+    const auto t4 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[verify while decoding] host transcript+algebra %.0f us, wait for the points %.0f us, instance+begin %.0f us, device run %.0f us\n",
+            us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
+  }
+  return ok;
 }
 
 bool VerifyInto(const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
@@ -1290,6 +1380,11 @@ Proof Proof::FromStarted(const uint8_t* data, size_t len, PointDecoder& dec) {
   dec.Run(/*defer_subgroup=*/true);
   Reader r(data, len, true);
   r.decoded = &dec;
+  return FromReader(r);
+}
+Proof Proof::ScanLazy(Reader& r) {
+  if (!r.collect) throw std::logic_error("ScanLazy needs a collecting reader");
+  r.lazy = true;
   return FromReader(r);
 }
 Proof Proof::FromReader(Reader& r) {

@@ -17,6 +17,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -65,6 +66,7 @@ class PointDecoder {
   void Start();
   bool Finish();                              // true: no record failed the (deferred) subgroup test
   bool Get(size_t index, Point* out) const;   // false: not a valid encoding / not on the curve / not in G1
+  bool GetAffine(size_t index, G1Affine* out) const;  // the same without the detour; infinity is (0, 0)
   size_t size() const { return n_; }
   static bool OnDevice();                     // false only under CURDLE_HOST_DECODE=1
   static constexpr size_t kMinDeviceBatch = 48;
@@ -84,7 +86,11 @@ struct Reader {
   bool subgroup_check;
   // two-pass decoding: with `collect` set GetPoint only registers the record and returns
   // infinity; with `decoded` set it hands out the records in the same order
+  // ... and with `lazy` on top of `collect` it returns the point as a pending one (alg::Point:
+  // wire record + decoder index, no coordinates), so that ONE pass yields a proof value the
+  // verifier can hash and list as bases while the GPU still decodes (VerifyWhileDecoding)
   PointDecoder* collect = nullptr;
+  bool lazy = false;
   const PointDecoder* decoded = nullptr;
   size_t decoded_pos = 0;
   Reader(const uint8_t* data, size_t len, bool subgroup = false) : p(data), left(len), subgroup_check(subgroup) {}
@@ -140,9 +146,11 @@ ShuffleCommit ShufflePermuteCommit(const std::vector<G1Affine>& crsGs, const std
 struct Terms {
   std::vector<Scalar> s;
   std::vector<G1Affine> p;
+  std::vector<int32_t> pending;  // per term: >= 0 -> p[j] is not known yet, PointDecoder record index
   void Add(const Scalar& k, const Point& pt) {
     s.push_back(k);
-    p.push_back(pt.Affine());
+    pending.push_back(pt.pending);
+    p.push_back(pt.pending >= 0 ? G1Affine{} : pt.Affine());
   }
   void Add(const std::vector<Scalar>& ks, const std::vector<Point>& pts) {
     for (size_t i = 0; i < pts.size(); i++) Add(ks[i], pts[i]);
@@ -222,6 +230,8 @@ struct BaseSeg {  // slots [first, first + len) of resident set `set` take x[vec
 struct LooseBase {  // a base outside the resident sets takes x[index]
   uint32_t index;
   G1Affine point;
+  int32_t pending = -1;  // >= 0: `point` is still being decoded (PointDecoder record index)
+  LooseBase(uint32_t i, const Point& pt) : index(i), point(pt.pending >= 0 ? G1Affine{} : pt.Affine()), pending(pt.pending) {}
 };
 
 class CheckSink {
@@ -356,6 +366,10 @@ struct Proof {
   // for the points and builds the value (the subgroup verdict still comes from dec.Finish()).
   static void ScanAndStart(const uint8_t* data, size_t len, PointDecoder& dec);
   static Proof FromStarted(const uint8_t* data, size_t len, PointDecoder& dec);
+  // One pass for VerifyWhileDecoding: registers the records with `dec` and returns the proof with
+  // every point pending (valid only while `data` and `dec` live).  The caller adds what else it
+  // wants decoded and calls dec.Start().
+  static Proof ScanLazy(Reader& r);
 };
 Proof Prove(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
             const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us, const Point& M,
@@ -396,6 +410,23 @@ bool VerifyWithSink(const Proof& proof, const CRS& crs, const std::vector<G1Affi
 bool VerifyStarted(VerifyPrelude& pre, const Proof& proof, const CRS& crs, const std::vector<G1Affine>& Rs,
                    const std::vector<G1Affine>& Ss, const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us,
                    const Point& M, common::Rand& rand);
+
+// curdleproof.Verify for a proof whose points the GPU is still decoding: `proof` and M come from
+// a lazy Reader over `dec` (Proof::ScanLazy), so the WHOLE transcript and challenge algebra run
+// from the wire bytes while the decoding kernel works; the four points the verifier does
+// arithmetic on (B, and A, T.T_1, U.T_1 for A') are decoded on the host meanwhile -- the GPU's
+// verdict on the same records still decides.  Then: wait for the points, `after_decode` (the
+// caller checks the records' statuses in the reference's order, throwing its decoding errors,
+// and fills the instance), the pending bases are filled in and the accumulator's one MSM runs.
+// Structural errors of the proof surface after the decoding errors, as in the reference (where
+// decoding comes first).  Needs the device accumulator and deferred checks
+// (CanVerifyWhileDecoding); the caller still owes dec.Finish() for the subgroup verdict.
+bool CanVerifyWhileDecoding();
+struct DecodedInstance {
+  std::vector<G1Affine> Rs, Ss, Ts, Us;
+};
+bool VerifyWhileDecoding(VerifyPrelude& pre, const Proof& proof, const CRS& crs, const Point& M, PointDecoder& dec,
+                         const std::function<void(DecodedInstance&)>& after_decode, common::Rand& rand);
 
 // Cross-proof batch verification over one CRS: one shared accumulator, one MSM (see the
 // definition).  Returns the per-proof accept bits.

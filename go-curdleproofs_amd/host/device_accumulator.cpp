@@ -49,14 +49,28 @@ const curdle_dbases* DeviceCrs::Get(const CRS& crs) {
   return h_;
 }
 
+DeviceSink::DeviceSink(const CRS& crs)
+    : ell_(crs.Gs.size()), n_crs_(CrsIndex{crs.Gs.size()}.size()), n_inst_(4 * crs.Gs.size()), crs_(crs),
+      inst_{nullptr, nullptr, nullptr, nullptr} {
+  if (!crs.device) throw std::runtime_error("CRS without a device holder");
+}
+
 DeviceSink::DeviceSink(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
                        const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us)
-    : ell_(crs.Gs.size()), n_crs_(CrsIndex{crs.Gs.size()}.size()), n_inst_(4 * crs.Gs.size()), crs_(crs),
-      inst_{&Rs, &Ss, &Ts, &Us} {
-  if (!crs.device) throw std::runtime_error("CRS without a device holder");
+    : DeviceSink(crs) {
+  Begin(Rs, Ss, Ts, Us);
+}
+
+void DeviceSink::Begin(const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss, const std::vector<G1Affine>& Ts,
+                       const std::vector<G1Affine>& Us) {
+  if (acc_ || consumed_) throw std::runtime_error("device accumulator already started");
   if (Rs.size() != ell_ || Ss.size() != ell_ || Ts.size() != ell_ || Us.size() != ell_)
     throw std::runtime_error("instance vectors do not match the CRS");
-  const curdle_dbases* bases = crs.device->Get(crs);
+  inst_[0] = &Rs;
+  inst_[1] = &Ss;
+  inst_[2] = &Ts;
+  inst_[3] = &Us;
+  const curdle_dbases* bases = crs_.device->Get(crs_);
   // Rs | Ss | Ts | Us (InstIndex), uploaded now: converted on the GPU while the host hashes
   std::vector<G1Affine> inst;
   inst.reserve(n_inst_);
@@ -103,15 +117,38 @@ void CheckRecorder::Check(const Terms& C, const VecExpr& x, const std::vector<Ba
   checks.push_back(ck);
   // bases outside the resident sets: the proof points of the same-scalar argument
   for (const LooseBase& lb : loose) {
-    if (g1_affine_is_inf(lb.point)) continue;
+    if (lb.pending >= 0)
+      pending_extras.emplace_back((uint32_t)extra_points.size(), (uint32_t)lb.pending);
+    else if (g1_affine_is_inf(lb.point))
+      continue;
     extra_points.push_back(lb.point);
     extra_scalars.push_back(alpha * x.At(lb.index));
   }
   // C moves to the base side: - alpha c_j P_j  (MsmAccumulator::AccumulateCheckDeferred)
   for (size_t j = 0; j < C.p.size(); j++) {
-    if (g1_affine_is_inf(C.p[j])) continue;
+    if (C.pending[j] >= 0)
+      pending_extras.emplace_back((uint32_t)extra_points.size(), (uint32_t)C.pending[j]);
+    else if (g1_affine_is_inf(C.p[j]))
+      continue;
     extra_points.push_back(C.p[j]);
     extra_scalars.push_back(-(alpha * C.s[j]));
+  }
+}
+
+void CheckRecorder::Resolve(const PointDecoder& dec) {
+  std::vector<uint32_t> drop;
+  for (const auto& pe : pending_extras) {
+    G1Affine a;
+    if (!dec.GetAffine(pe.second, &a)) throw std::runtime_error("decoding proof: invalid point");
+    if (g1_affine_is_inf(a))
+      drop.push_back(pe.first);
+    else
+      extra_points[pe.first] = a;
+  }
+  pending_extras.clear();
+  for (size_t k = drop.size(); k-- > 0;) {  // ascending indices: erase from the back
+    extra_points.erase(extra_points.begin() + drop[k]);
+    extra_scalars.erase(extra_scalars.begin() + drop[k]);
   }
 }
 
@@ -155,7 +192,9 @@ void DeviceSink::Check(const Terms& C, const VecExpr& x, const std::vector<BaseS
 }
 
 bool DeviceSink::Run(std::vector<Scalar>* slot_scalars) {
-  if (!acc_) throw std::runtime_error("device accumulator already consumed");
+  if (!acc_) throw std::runtime_error(consumed_ ? "device accumulator already consumed" : "device accumulator not started");
+  if (!rec_.pending_extras.empty()) throw std::logic_error("device accumulator run with undecoded points");
+  consumed_ = true;
   uint64_t out[18];
   if (slot_scalars) slot_scalars->assign(n_crs_ + n_inst_, Scalar::Zero());
   curdle_dacc* a = acc_;

@@ -58,6 +58,12 @@ class CheckRecorder : public CheckSink {
   std::vector<Scalar> pool;
   std::vector<G1Affine> extra_points;
   std::vector<Scalar> extra_scalars;
+  // Loose pairs whose point was still being decoded when the check was recorded
+  // (VerifyWhileDecoding): (index into extra_points, PointDecoder record).  Resolve() fills them
+  // in -- a pair whose point turns out to be infinity is dropped, like every other -- and throws
+  // the decoding error if a record is not a valid point.
+  std::vector<std::pair<uint32_t, uint32_t>> pending_extras;
+  void Resolve(const PointDecoder& dec);
 
  private:
   uint32_t Put(const Scalar& s);
@@ -75,6 +81,12 @@ class DeviceSink : public CheckSink {
  public:
   DeviceSink(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,
              const std::vector<G1Affine>& Ts, const std::vector<G1Affine>& Us);
+  // Recording only: for a verification whose instance is still being decoded.  Begin() uploads
+  // it (the vectors must outlive the sink's Verify) and must come before Verify().
+  explicit DeviceSink(const CRS& crs);
+  void Begin(const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss, const std::vector<G1Affine>& Ts,
+             const std::vector<G1Affine>& Us);
+  void Resolve(const PointDecoder& dec) { rec_.Resolve(dec); }
   ~DeviceSink() override;
   void Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs, const std::vector<LooseBase>& loose,
              common::Rand& rand, const char* what) override;
@@ -91,6 +103,7 @@ class DeviceSink : public CheckSink {
   size_t ell_, n_crs_, n_inst_;
   const CRS& crs_;
   const std::vector<G1Affine>*inst_[4];
+  bool consumed_ = false;
   CheckRecorder rec_;
 };
 

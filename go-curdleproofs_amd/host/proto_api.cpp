@@ -119,13 +119,36 @@ extern "C" int curdle_verify(const curdle_crs* crs, const uint8_t* proof, size_t
     // The subgroup half of that runs on the GPU while the host verifies; its verdict is
     // collected before anything is reported.
     proto::PointDecoder dec(/*subgroup_check=*/true);
-    proto::Proof::ScanAndStart(proof, proof_len, dec);  // the GPU takes the square roots ...
-    const std::vector<G1Affine> R = Affines(Rs, ell), S = Affines(Ss, ell), T = Affines(Ts, ell), U = Affines(Us, ell);
     const Point Mp = Point::FromJac(M);
-    proto::VerifyPrelude pre;
-    proto::StartVerify(pre, R, S, T, U, Mp);            // ... while the host absorbs the instance and draws `as`
-    proto::Proof p = proto::Proof::FromStarted(proof, proof_len, dec);
-    bool accept = proto::VerifyStarted(pre, p, crs->crs, R, S, T, U, Mp, rand->r);
+    bool accept;
+    if (proto::CanVerifyWhileDecoding()) {
+      // one pass over the wire format: the records go to the GPU, the proof comes back with its
+      // points pending, and the WHOLE host part (transcript, challenge algebra) runs from the
+      // bytes while the decoding kernel takes the square roots
+      proto::Reader scan(proof, proof_len, true);
+      scan.collect = &dec;
+      const proto::Proof p = proto::Proof::ScanLazy(scan);
+      dec.Start();
+      proto::DecodedInstance given{Affines(Rs, ell), Affines(Ss, ell), Affines(Ts, ell), Affines(Us, ell)};
+      proto::VerifyPrelude pre;
+      proto::StartVerify(pre, given.Rs, given.Ss, given.Ts, given.Us, Mp);
+      accept = proto::VerifyWhileDecoding(
+          pre, p, crs->crs, Mp, dec,
+          [&](proto::DecodedInstance& inst) {
+            G1Affine a;
+            for (size_t i = 0; i < dec.size(); i++)
+              if (!dec.GetAffine(i, &a)) throw std::runtime_error("decoding proof: invalid point");
+            inst = std::move(given);
+          },
+          rand->r);
+    } else {
+      proto::Proof::ScanAndStart(proof, proof_len, dec);  // the GPU takes the square roots ...
+      const std::vector<G1Affine> R = Affines(Rs, ell), S = Affines(Ss, ell), T = Affines(Ts, ell), U = Affines(Us, ell);
+      proto::VerifyPrelude pre;
+      proto::StartVerify(pre, R, S, T, U, Mp);            // ... while the host absorbs the instance and draws `as`
+      proto::Proof p = proto::Proof::FromStarted(proof, proof_len, dec);
+      accept = proto::VerifyStarted(pre, p, crs->crs, R, S, T, U, Mp, rand->r);
+    }
     if (!dec.Finish()) throw std::runtime_error("decoding proof: invalid point (not in the prime-order subgroup)");
     *ok = accept ? 1 : 0;
     return CURDLE_OK;

@@ -71,13 +71,18 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
   // the first error reported is the one the reference would report.
   const size_t n = preST.size();
   proto::PointDecoder dec(/*subgroup_check=*/true);
+  const bool lazy = proto::CanVerifyWhileDecoding();
+  Point M;
+  proto::Proof p;
   try {
     // WhiskShuffleProof.FromReader: M, then the curdleproof; the fixed-size array's zero
-    // padding after the proof is never read
+    // padding after the proof is never read.  In the lazy form this one pass also yields the
+    // proof, its points pending.
     proto::Reader scan(proof, WHISK_SHUFFLE_PROOF_SIZE, true);
     scan.collect = &dec;
-    scan.GetPoint("M");
-    proto::Proof::FromReader(scan);
+    scan.lazy = lazy;
+    M = scan.GetPoint("M");
+    p = proto::Proof::FromReader(scan);
   } catch (const std::runtime_error& e) {
     throw err(std::string("decoding proof: ") + e.what());
   }
@@ -89,9 +94,9 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
     dec.Add(postST[i].krG);
   }
   dec.Start();  // the GPU takes the 4 n + ~100 square roots ...
-  // ... while the host runs the first steps of Verify from the RAW encodings: the transcript
-  // absorbs a point as its 48-byte compressed form, which for a valid record is the record
-  // itself (an invalid one fails the call below whatever was hashed).  curdleproof.go:217-224.
+  // ... while the host runs Verify from the RAW encodings: the transcript absorbs a point as
+  // its 48-byte compressed form, which for a valid record is the record itself (an invalid one
+  // fails the call below whatever was hashed).  curdleproof.go:217-224.
   proto::VerifyPrelude pre;
   {
     std::vector<uint8_t> b(4 * n * G1POINT_SIZE);
@@ -103,39 +108,62 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
     }
     proto::StartVerify(pre, n, &b[0], &b[48 * n], &b[96 * n], &b[144 * n], proof);  // M is the proof's first record
   }
-  dec.Run(/*defer_subgroup=*/true);  // the points; the subgroup test keeps running on the GPU, collected below
-
-  Point M;
-  proto::Proof p;
-  try {
-    proto::Reader r(proof, WHISK_SHUFFLE_PROOF_SIZE, true);
-    r.decoded = &dec;
-    M = r.GetPoint("M");
-    p = proto::Proof::FromReader(r);
-  } catch (const std::runtime_error& e) {
-    throw err(std::string("decoding proof: ") + e.what());
-  }
-  std::vector<G1Affine> Rs(n), Ss(n), Ts(n), Us(n);
-  for (size_t i = 0; i < n; i++) {  // :35-44
-    Point pt;
-    const size_t at = first_tracker + 4 * i;
-    if (!dec.Get(at, &pt)) throw err("getting pre shuffle points: failed to set rG");
-    Rs[i] = pt.Affine();
-    if (!dec.Get(at + 1, &pt)) throw err("getting pre shuffle points: failed to set krG");
-    Ss[i] = pt.Affine();
-    if (!dec.Get(at + 2, &pt)) throw err("getting post shuffle points: failed to set rG");
-    Ts[i] = pt.Affine();
-    if (!dec.Get(at + 3, &pt)) throw err("getting post shuffle points: failed to set krG");
-    Us[i] = pt.Affine();
-  }
+  // the trackers' points out of the decoder, in the reference's order and with its errors (:35-44)
+  auto instance = [&](std::vector<G1Affine>& Rs, std::vector<G1Affine>& Ss, std::vector<G1Affine>& Ts,
+                      std::vector<G1Affine>& Us) {
+    Rs.resize(n);
+    Ss.resize(n);
+    Ts.resize(n);
+    Us.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      const size_t at = first_tracker + 4 * i;
+      if (!dec.GetAffine(at, &Rs[i])) throw err("getting pre shuffle points: failed to set rG");
+      if (!dec.GetAffine(at + 1, &Ss[i])) throw err("getting pre shuffle points: failed to set krG");
+      if (!dec.GetAffine(at + 2, &Ts[i])) throw err("getting post shuffle points: failed to set rG");
+      if (!dec.GetAffine(at + 3, &Us[i])) throw err("getting post shuffle points: failed to set krG");
+    }
+  };
   bool accept = false;
   std::string verify_error;
-  try {
-    accept = proto::VerifyStarted(pre, p, crs, Rs, Ss, Ts, Us, M, rand);  // :46-58
-  } catch (const alg::MsmError&) {
-    throw;
-  } catch (const std::runtime_error& e) {
-    verify_error = e.what();
+  if (lazy) {
+    // the whole of Verify's host part overlaps the decoding; only the accumulator's MSM waits for it
+    bool decoded = false;
+    try {
+      accept = proto::VerifyWhileDecoding(
+          pre, p, crs, M, dec,
+          [&](proto::DecodedInstance& inst) {
+            G1Affine a;
+            for (size_t i = 0; i < first_tracker; i++)
+              if (!dec.GetAffine(i, &a)) throw err("decoding proof: invalid point");
+            instance(inst.Rs, inst.Ss, inst.Ts, inst.Us);
+            decoded = true;
+          },
+          rand);  // :46-58
+    } catch (const alg::MsmError&) {
+      throw;
+    } catch (const std::runtime_error& e) {
+      if (!decoded) throw;  // a decoding error: reported as it is
+      verify_error = e.what();
+    }
+  } else {
+    dec.Run(/*defer_subgroup=*/true);  // the points; the subgroup test keeps running on the GPU, collected below
+    try {
+      proto::Reader r(proof, WHISK_SHUFFLE_PROOF_SIZE, true);
+      r.decoded = &dec;
+      M = r.GetPoint("M");
+      p = proto::Proof::FromReader(r);
+    } catch (const std::runtime_error& e) {
+      throw err(std::string("decoding proof: ") + e.what());
+    }
+    std::vector<G1Affine> Rs, Ss, Ts, Us;
+    instance(Rs, Ss, Ts, Us);
+    try {
+      accept = proto::VerifyStarted(pre, p, crs, Rs, Ss, Ts, Us, M, rand);  // :46-58
+    } catch (const alg::MsmError&) {
+      throw;
+    } catch (const std::runtime_error& e) {
+      verify_error = e.what();
+    }
   }
   // the decoding verdict comes first, as in the reference (SetBytes / Decode fail before Verify runs)
   if (!dec.Finish()) {

@@ -6,6 +6,7 @@
 // (.github/workflows/buildlintcheck.yml:21).  Modes:
 //   host_flow flow <ell>          Prove -> serialise -> Verify (deferred and eager), soundness
 //                                 flips of curdleproof_test.go:48-182, encode/decode round trip
+//   host_flow whisk 0             Whisk shuffle proof: generate, verify (both routes), tampered trackers
 //   host_flow fuzz <ell> <iters>  attacker-controlled bytes into every parser: bit flips,
 //                                 truncations, random slice prefixes, random blobs
 //   host_flow time <ell> <reps>   host share of Verify (everything but the final MSM), for gprof
@@ -65,6 +66,33 @@ static bool VerifyBytes(const Instance& in, const std::vector<uint8_t>& bytes, u
   proto::Proof p = proto::Proof::FromBytes(bytes.data(), bytes.size(), true);
   common::Rand vr(seed);
   return proto::Verify(p, in.crs, in.Rs, in.Ss, in.Ts, in.Us, in.M, vr);
+}
+
+// curdle_verify's default route (proto_api.cpp): one lazy pass over the bytes, the whole host part
+// run while the points are "still being decoded", pending bases filled in at the end
+static bool VerifyLazyBytes(const Instance& in, const std::vector<uint8_t>& bytes, uint64_t seed) {
+  proto::PointDecoder dec(true);
+  proto::Reader scan(bytes.data(), bytes.size(), true);
+  scan.collect = &dec;
+  const proto::Proof p = proto::Proof::ScanLazy(scan);
+  dec.Start();
+  proto::VerifyPrelude pre;
+  proto::StartVerify(pre, in.Rs, in.Ss, in.Ts, in.Us, in.M);
+  common::Rand vr(seed);
+  const bool accept = proto::VerifyWhileDecoding(
+      pre, p, in.crs, in.M, dec,
+      [&](proto::DecodedInstance& inst) {
+        G1Affine a;
+        for (size_t i = 0; i < dec.size(); i++)
+          if (!dec.GetAffine(i, &a)) throw std::runtime_error("decoding proof: invalid point");
+        inst.Rs = in.Rs;
+        inst.Ss = in.Ss;
+        inst.Ts = in.Ts;
+        inst.Us = in.Us;
+      },
+      vr);
+  if (!dec.Finish()) throw std::runtime_error("decoding proof: invalid point (not in the prime-order subgroup)");
+  return accept;
 }
 
 #define CHECK(cond)                                                          \
@@ -190,6 +218,21 @@ static int Flow(size_t ell) {
     CHECK(VerifyBytes(in, in.proof, 50));
     CHECK(!VerifyBytes(bad, in.proof, 51));
     proto::SetDeviceAccumulator(1);
+    // ... and so does the verification that runs while the proof is still being decoded
+    CHECK(proto::CanVerifyWhileDecoding());
+    CHECK(VerifyLazyBytes(in, in.proof, 50));
+    CHECK(!VerifyLazyBytes(bad, in.proof, 51));
+    {
+      Instance zero = in;  // curdleproof.go:213-215
+      zero.Ts[0] = G1Affine{};
+      bool threw = false;
+      try {
+        VerifyLazyBytes(zero, in.proof, 52);
+      } catch (const std::runtime_error& e) {
+        threw = std::string(e.what()).find("randomizer is zero") != std::string::npos;
+      }
+      CHECK(threw);
+    }
   }
   // cross-proof batch verification, on the device accumulator's description path and on the
   // host mirror: exact per-proof bits with a bad instance, a truncated and a bit-flipped proof
@@ -231,6 +274,52 @@ static int Flow(size_t ell) {
   return 0;
 }
 
+// the Whisk byte API end to end (whisk.go:20, :63) over Whisk's own CRS size: the route that
+// verifies while the points are being decoded (device accumulator) and the two-pass one
+static int WhiskFlow() {
+  const size_t ell = whisk::ELL;
+  common::Rand cr(3);
+  Instance in;
+  in.crs = proto::GenerateCRS(ell, cr);
+    common::Rand wr(77);
+    std::vector<G1Affine> rg, krg;
+    wr.GetG1Affines(ell, rg);
+    wr.GetG1Affines(ell, krg);
+    std::vector<whisk::WhiskTracker> pre(ell);
+    for (size_t i = 0; i < ell; i++) pre[i] = whisk::NewWhiskTracker(rg[i], krg[i]);
+    std::vector<uint8_t> wproof(whisk::WHISK_SHUFFLE_PROOF_SIZE);
+    std::vector<whisk::WhiskTracker> post;
+    bool generated = true;
+    try {
+      post = whisk::GenerateWhiskShuffleProof(in.crs, pre, wr, wproof.data());
+    } catch (const std::runtime_error&) {
+      generated = false;  // the fixed-size proof array only fits Whisk's own ell
+    }
+    if (generated) {
+      for (int dev = 1; dev >= 0; dev--) {
+        proto::SetDeviceAccumulator(dev);
+        common::Rand v1(78), v2(79), v3(80);
+        CHECK(whisk::IsValidWhiskShuffleProof(in.crs, pre, post, wproof.data(), v1));
+        std::vector<whisk::WhiskTracker> swapped(post);
+        std::swap(swapped[0], swapped[1]);
+        CHECK(!whisk::IsValidWhiskShuffleProof(in.crs, pre, swapped, wproof.data(), v2));
+        std::vector<whisk::WhiskTracker> broken(post);
+        memset(broken[2].krG, 0xff, 48);  // not an encoding
+        bool threw = false;
+        try {
+          whisk::IsValidWhiskShuffleProof(in.crs, pre, broken, wproof.data(), v3);
+        } catch (const std::runtime_error& e) {
+          threw = std::string(e.what()).find("getting post shuffle points") != std::string::npos;
+        }
+        CHECK(threw);
+      }
+      proto::SetDeviceAccumulator(1);
+    }
+  CHECK(generated);
+  printf("whisk flow: shuffle proof accepted, swapped trackers rejected, broken tracker reported, both routes: ok\n");
+  return 0;
+}
+
 static uint64_t g_rng = 0x9e3779b97f4a7c15ull;
 static uint64_t Rng() {
   g_rng ^= g_rng << 13;
@@ -243,14 +332,22 @@ static int Fuzz(size_t ell, int iters) {
   Instance in = Make(ell, 9);
   long accepted = 0, rejected = 0, errors = 0;
   auto attempt = [&](const std::vector<uint8_t>& bytes) {
+    int eager = 2, lazy = 2;  // 1 accept, 0 reject, 2 error
     try {
-      if (VerifyBytes(in, bytes, 77))
-        accepted++;
-      else
-        rejected++;
+      eager = VerifyBytes(in, bytes, 77) ? 1 : 0;
     } catch (const std::runtime_error&) {
-      errors++;
     }
+    try {  // the verification that overlaps the decoding must classify every input the same way
+      lazy = VerifyLazyBytes(in, bytes, 77) ? 1 : 0;
+    } catch (const std::runtime_error&) {
+    }
+    CHECK(eager == lazy);
+    if (eager == 1)
+      accepted++;
+    else if (eager == 0)
+      rejected++;
+    else
+      errors++;
   };
   for (int it = 0; it < iters; it++) {
     std::vector<uint8_t> b = in.proof;
@@ -347,6 +444,7 @@ int main(int argc, char** argv) {
   const size_t ell = (size_t)atoi(argv[2]);
   try {
     if (mode == "flow") return Flow(ell);
+    if (mode == "whisk") return WhiskFlow();
     if (mode == "fuzz") return Fuzz(ell, argc > 3 ? atoi(argv[3]) : 200);
     if (mode == "time") return Time(ell, argc > 3 ? atoi(argv[3]) : 20);
     if (mode == "timedev") return TimeDevicePath(ell, argc > 3 ? atoi(argv[3]) : 20);

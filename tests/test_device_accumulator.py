@@ -79,6 +79,40 @@ def test_verify_decides_the_same_on_either_accumulator(gpu):
         gpu.verify_set_device_acc(True)
 
 
+def test_verifying_while_decoding_classifies_mutated_proofs_like_the_two_pass_route(gpu):
+    """curdle_verify's default route runs the whole transcript from the wire bytes while the GPU
+    decodes (pending points filled in as bases afterwards); with the device accumulator off it
+    takes the two-pass route over the host mirror.  Same accept / reject / error class for the
+    honest proof and for byte flips in every part of it: point records (invalid encodings, points
+    off the curve, other valid points), slice prefixes and scalars."""
+    crs, Rs, Ss, Ts, Us, M, perm, k, rs_m = setup(gpu, 64)
+    proof = gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(1))
+    rng = np.random.default_rng(11)
+    cases = [bytes(proof)]
+    for at in rng.choice(len(proof), size=48, replace=False):
+        bad = bytearray(proof)
+        bad[int(at)] ^= 1 << int(rng.integers(8))
+        cases.append(bytes(bad))
+    cases.append(bytes(proof[:-7]))
+
+    def outcome(pf):
+        try:
+            return "accept" if gpu.verify(crs, pf, Rs, Ss, Ts, Us, M, gpu.Rand(3)) else "reject"
+        except gpu.CurdleError:
+            return "error"
+
+    try:
+        gpu.verify_set_device_acc(True)
+        lazy = [outcome(c) for c in cases]
+        gpu.verify_set_device_acc(False)
+        two_pass = [outcome(c) for c in cases]
+    finally:
+        gpu.verify_set_device_acc(True)
+    assert lazy == two_pass
+    assert lazy[0] == "accept" and "accept" not in lazy[1:]
+    assert "error" in lazy and "reject" in lazy  # both kinds of failure were exercised
+
+
 def test_device_accumulator_abi_rejects_malformed_descriptions(gpu):
     """curdle_dacc_run validates every offset of the caller's descriptions before a kernel
     reads through them."""

@@ -35,6 +35,11 @@ def test_protocol_flow_under_asan_ubsan(harness):
     assert "mirror == device accumulator, batch: ok" in out
 
 
+def test_whisk_shuffle_flow_under_asan_ubsan(harness):
+    out = _run(harness, "whisk", "0")
+    assert "both routes: ok" in out
+
+
 def test_parsers_survive_mutated_proofs_under_asan_ubsan(harness):
-    out = _run(harness, "fuzz", "12", "300")
+    out = _run(harness, "fuzz", "12", "200")
     assert "0 accepted" in out
