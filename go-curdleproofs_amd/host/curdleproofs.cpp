@@ -1303,18 +1303,32 @@ bool VerifyStarted(VerifyPrelude& pre, const Proof& proof, const CRS& crs, const
 // joining a group.
 std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items, common::Rand& rand, int nthreads) {
   const size_t k = items.size();
-  // one batched GPU decode for every point of every proof: pass 1 walks each proof's wire
-  // format and registers its records (a proof that does not parse is rejected here)
+  // pass 1 (DecodeAhead's producers, chunk by chunk, ahead of the workers) walks each proof's
+  // wire format and registers its records -- a proof that does not parse is rejected here --,
+  // one GPU decoding per chunk; pass 2 (workers) builds the values
   struct BytesSource {
     const std::vector<BatchItem>& items;
-    PointDecoder dec{/*subgroup_check=*/true};
     std::vector<size_t> first_point;
     std::vector<char> parses;
+    std::unique_ptr<DecodeAhead> ahead;
     explicit BytesSource(const std::vector<BatchItem>& it) : items(it), first_point(it.size(), 0), parses(it.size(), 0) {}
-    bool Usable(size_t i) const { return parses[i] != 0; }
-    Proof DecodeProof(size_t i) const {
+    void Scan(size_t i, PointDecoder& dec) {
+      first_point[i] = dec.size();
+      try {
+        Reader scan(items[i].proof, items[i].proof_len, true);
+        scan.collect = &dec;
+        Proof::FromReader(scan);
+        parses[i] = 1;
+      } catch (const std::runtime_error&) {
+      }
+    }
+    bool Usable(size_t i) {
+      ahead->Wait(i);
+      return parses[i] != 0;
+    }
+    Proof DecodeProof(size_t i) {
       Reader r(items[i].proof, items[i].proof_len, true);
-      r.decoded = &dec;
+      r.decoded = &ahead->Wait(i);
       r.decoded_pos = first_point[i];
       return Proof::FromReader(r);
     }
@@ -1328,18 +1342,14 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
       M = Point::FromJac(it.M);
     }
   } src(items);
-  for (size_t i = 0; i < k; i++) {
-    src.first_point[i] = src.dec.size();
-    try {
-      Reader scan(items[i].proof, items[i].proof_len, true);
-      scan.collect = &src.dec;
-      Proof::FromReader(scan);
-      src.parses[i] = 1;
-    } catch (const std::runtime_error&) {
-    }
+  src.ahead = std::make_unique<DecodeAhead>(k, DecodeAheadChunk(k), DecodeAheadProducers(),
+                                            [&src](size_t i, PointDecoder& dec) { src.Scan(i, dec); });
+  try {
+    return VerifyBatchCore(crs, k, src, rand, BatchWorkers(nthreads));
+  } catch (...) {
+    src.ahead->Abandon();
+    throw;
   }
-  src.dec.Run();
-  return VerifyBatchCore(crs, k, src, rand, nthreads);
 }
 
 std::vector<uint8_t> Proof::Serialize() const {  // :358-387

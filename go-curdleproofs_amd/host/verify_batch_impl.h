@@ -6,7 +6,14 @@
 #pragma once
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -18,6 +25,114 @@
 
 namespace curdle {
 namespace proto {
+
+// The batch's point decoding, in chunks, AHEAD of the verifying workers: producer threads walk
+// the wire format of the proofs of chunk c (`scan(i, dec)` registers proof i's records with the
+// chunk's decoder; a proof that does not parse throws and is simply not usable) and run the
+// chunk's ONE GPU decoding, while the workers are busy with the chunks before it.  One decoding
+// over the whole batch first -- what this replaces -- left the GPU idle during the serial scan
+// and every host core idle during the decoding (k = 1,024 Whisk proofs: 17 + 32 ms of 100).
+// Workers call Wait(i) before they touch proof i; proofs are handed out in index order, so
+// chunks are consumed in the order they are produced.
+inline bool BatchTrace() {  // CURDLE_VERIFY_TRACE=1: the batch's chunk / group timeline (stderr)
+  static const bool on = [] {
+    const char* e = getenv("CURDLE_VERIFY_TRACE");
+    return e && *e && *e != '0';
+  }();
+  return on;
+}
+
+class DecodeAhead {
+ public:
+  using ScanFn = std::function<void(size_t i, PointDecoder& dec)>;
+  DecodeAhead(size_t k, size_t chunk, int producers, ScanFn scan)
+      : k_(k), chunk_(chunk < 1 ? 1 : chunk), scan_(std::move(scan)) {
+    const size_t nchunks = (k_ + chunk_ - 1) / chunk_;
+    decs_.resize(nchunks);
+    ready_.assign(nchunks, 0);
+    if (producers < 1) producers = 1;
+    if ((size_t)producers > nchunks) producers = (int)nchunks;
+    for (int t = 0; t < producers; t++) threads_.emplace_back([this] { Produce(); });
+  }
+  ~DecodeAhead() {
+    stop_.store(true);
+    for (auto& t : threads_) t.join();
+  }
+  DecodeAhead(const DecodeAhead&) = delete;
+  DecodeAhead& operator=(const DecodeAhead&) = delete;
+  // The decoder holding proof i's records, once its chunk is decoded.  Rethrows a producer's
+  // failure (a device error: the whole batch fails, as before).
+  const PointDecoder& Wait(size_t i) {
+    const size_t c = i / chunk_;
+    std::unique_lock<std::mutex> g(mu_);
+    cv_.wait(g, [&] { return ready_[c] != 0 || error_ != nullptr; });
+    if (!ready_[c]) std::rethrow_exception(error_);
+    return *decs_[c];
+  }
+  void Abandon() { stop_.store(true); }  // the workers gave up: producers stop after their current chunk
+
+ private:
+  void Produce() {
+    try {
+      for (size_t c = next_.fetch_add(1); c < decs_.size() && !stop_.load(); c = next_.fetch_add(1)) {
+        auto dec = std::make_unique<PointDecoder>(/*subgroup_check=*/true);
+        const size_t end = (c + 1) * chunk_ < k_ ? (c + 1) * chunk_ : k_;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t i = c * chunk_; i < end; i++) scan_(i, *dec);
+        const auto t1 = std::chrono::steady_clock::now();
+        dec->Run();
+        if (BatchTrace()) {
+          const auto t2 = std::chrono::steady_clock::now();
+          auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+          fprintf(stderr, "[batch] chunk %zu (%zu points): at %.2f ms, scan %.2f ms, decode %.2f ms\n", c, dec->size(), ms(start_, t0),
+                  ms(t0, t1), ms(t1, t2));
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        decs_[c] = std::move(dec);
+        ready_[c] = 1;
+        cv_.notify_all();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> g(mu_);
+      if (!error_) error_ = std::current_exception();
+      cv_.notify_all();
+    }
+  }
+  size_t k_, chunk_;
+  ScanFn scan_;
+  std::chrono::steady_clock::time_point start_ = std::chrono::steady_clock::now();
+  std::vector<std::unique_ptr<PointDecoder>> decs_;
+  std::vector<char> ready_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::exception_ptr error_;
+  std::atomic<size_t> next_{0};
+  std::atomic<bool> stop_{false};
+  std::vector<std::thread> threads_;
+};
+
+// Chunk size and producer count for a batch of k proofs.  64 proofs per chunk (a quarter of
+// the batch below 256 proofs, never under 16): a decoding kernel is a ~1.1 ms dependent chain
+// however few points it has, so small chunks cost producer time, but its waves sit on their
+// SIMDs at a fraction of the issue rate for that long, so LARGE chunks starve the groups' MSMs
+// of SIMD slots -- measured at k = 1,024 (profiles/r02_batch_chunk_sweep.txt): ell = 252
+// verify_batch 58-66 ms at 64 proofs per chunk, 140-180 ms at 128, 68-82 ms undivided; Whisk
+// 63 ms at 64, 97-111 ms undivided.  Two producers (a third takes a core from the workers).
+inline size_t DecodeAheadChunk(size_t k) {
+  if (const char* e = getenv("CURDLE_BATCH_CHUNK")) return atoi(e) < 1 ? 1 : (size_t)atoi(e);  // tests, tuning
+  const size_t c = k / 4;
+  return c < 16 ? 16 : c > 64 ? 64 : c;
+}
+inline int DecodeAheadProducers() {
+  if (const char* e = getenv("CURDLE_BATCH_PRODUCERS")) return atoi(e) < 1 ? 1 : atoi(e);
+  return 2;
+}
+// The caller's thread budget covers the producers: `nthreads` threads in all while they run.
+inline int BatchWorkers(int nthreads) {
+  if (getenv("CURDLE_BATCH_EXTRA_PRODUCERS")) return nthreads;  // A/B: producers on top of the budget
+  const int w = nthreads - DecodeAheadProducers();
+  return nthreads >= 4 ? (w < 2 ? 2 : w) : nthreads;
+}
 
 template <class Source>
 std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::Rand& rand, int nthreads) {
@@ -46,7 +161,14 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
   // per group -- no host-side vectors, no 96-byte-key map.  Eager
   // mode and CURDLE_DEVICE_ACC=0 keep the host mirror.
   const bool on_device = !EagerChecksEnabled() && DeviceAccumulatorEnabled() && crs.device != nullptr;
+  // Workers start together and take equal time per proof, so with one threshold they would all
+  // settle their groups at the same moment -- 16 MSMs queueing for the GPU, then none for a
+  // while.  Each worker's FIRST group is cut at its own fraction of the threshold.
+  std::atomic<int> worker_ids(0);
   auto device_worker = [&]() {
+    const int wid = worker_ids.fetch_add(1);
+    size_t threshold = flush * (size_t)(wid + 1) / (size_t)nthreads;
+    if (threshold < 4) threshold = flush < 4 ? flush : 4;
     std::vector<G1Affine> inst;
     std::vector<curdle_dacc_check> checks;
     std::vector<Scalar> pool, extra_scalars;
@@ -54,7 +176,11 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
     std::vector<size_t> members;
     auto settle = [&]() {
       if (members.empty()) return;
+      const auto ts0 = std::chrono::steady_clock::now();
       const bool all = RunRecordedChecks(crs, inst, checks, pool, extra_points, extra_scalars);
+      if (BatchTrace())
+        fprintf(stderr, "[batch] group of %zu proofs (%zu instance points, %zu loose): %.2f ms\n", members.size(), inst.size(),
+                extra_points.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
       for (size_t i : members) {
         if (all) {
           oks[i] = 1;
@@ -104,7 +230,10 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
         inst.insert(inst.end(), Ts.begin(), Ts.end());
         inst.insert(inst.end(), Us.begin(), Us.end());
         members.push_back(i);
-        if (members.size() >= flush || extra_points.size() + 512 > CURDLE_DACC_MAX_EXTRA) settle();
+        if (members.size() >= threshold || extra_points.size() + 512 > CURDLE_DACC_MAX_EXTRA) {
+          settle();
+          threshold = flush;
+        }
       }
       settle();
     } catch (const alg::MsmError& e) {

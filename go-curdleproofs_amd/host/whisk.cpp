@@ -1,6 +1,9 @@
 // whisk package restatement -- see whisk.h.  Reference: /root/reference/whisk/whisk.go, types.go.
 #include "whisk.h"
 
+#include <chrono>
+#include <memory>
+
 #include "verify_batch_impl.h"
 
 #include <string.h>
@@ -185,60 +188,82 @@ bool IsValidWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTrac
 std::vector<int> IsValidWhiskShuffleProofBatch(const proto::CRS& crs, const std::vector<ShuffleBatchItem>& items,
                                                common::Rand& rand, int nthreads) {
   const size_t k = items.size();
+  // Pass 1 (producers, chunk by chunk, ahead of the workers): walk each proof's wire format,
+  // register its records and the trackers' with the chunk's decoder, one GPU decoding per chunk.
+  // Pass 2 (workers): read the decoded points back in the same order.
   struct Source {
     const std::vector<ShuffleBatchItem>& items;
-    proto::PointDecoder dec{/*subgroup_check=*/true};
     std::vector<size_t> first_point, first_tracker;
     std::vector<char> parses;
+    std::unique_ptr<proto::DecodeAhead> ahead;
     explicit Source(const std::vector<ShuffleBatchItem>& it)
         : items(it), first_point(it.size(), 0), first_tracker(it.size(), 0), parses(it.size(), 0) {}
-    bool Usable(size_t i) const { return parses[i] != 0; }
-    proto::Proof DecodeProof(size_t i) const {
+    void Scan(size_t i, proto::PointDecoder& dec) {
+      first_point[i] = dec.size();
+      try {
+        proto::Reader scan(items[i].proof, WHISK_SHUFFLE_PROOF_SIZE, true);
+        scan.collect = &dec;
+        scan.GetPoint("M");
+        proto::Proof::FromReader(scan);
+        parses[i] = 1;
+      } catch (const std::runtime_error&) {
+      }
+      first_tracker[i] = dec.size();
+      for (size_t t = 0; t < items[i].n; t++) {
+        dec.Add(items[i].preST[t].rG);
+        dec.Add(items[i].preST[t].krG);
+        dec.Add(items[i].postST[t].rG);
+        dec.Add(items[i].postST[t].krG);
+      }
+    }
+    bool Usable(size_t i) {
+      ahead->Wait(i);
+      return parses[i] != 0;
+    }
+    proto::Proof DecodeProof(size_t i) {
       proto::Reader r(items[i].proof, WHISK_SHUFFLE_PROOF_SIZE, true);
-      r.decoded = &dec;
+      r.decoded = &ahead->Wait(i);
       r.decoded_pos = first_point[i];
       r.GetPoint("M");
       return proto::Proof::FromReader(r);
     }
     void Instance(size_t i, std::vector<G1Affine>& Rs, std::vector<G1Affine>& Ss, std::vector<G1Affine>& Ts,
-                  std::vector<G1Affine>& Us, Point& M) const {
+                  std::vector<G1Affine>& Us, Point& M) {
+      const proto::PointDecoder& dec = ahead->Wait(i);
       const size_t n = items[i].n;
       Rs.resize(n);
       Ss.resize(n);
       Ts.resize(n);
       Us.resize(n);
       if (!dec.Get(first_point[i], &M)) throw err("decoding proof: invalid point");
-      Point pt;
       for (size_t t = 0; t < n; t++) {
         const size_t at = first_tracker[i] + 4 * t;
         std::vector<G1Affine>* dst[4] = {&Rs, &Ss, &Ts, &Us};
-        for (int c = 0; c < 4; c++) {
-          if (!dec.Get(at + c, &pt)) throw err("getting shuffle points: invalid tracker point");
-          (*dst[c])[t] = pt.Affine();
-        }
+        for (int c = 0; c < 4; c++)
+          if (!dec.GetAffine(at + c, &(*dst[c])[t])) throw err("getting shuffle points: invalid tracker point");
       }
     }
   } src(items);
-  for (size_t i = 0; i < k; i++) {
-    src.first_point[i] = src.dec.size();
-    try {
-      proto::Reader scan(items[i].proof, WHISK_SHUFFLE_PROOF_SIZE, true);
-      scan.collect = &src.dec;
-      scan.GetPoint("M");
-      proto::Proof::FromReader(scan);
-      src.parses[i] = 1;
-    } catch (const std::runtime_error&) {
-    }
-    src.first_tracker[i] = src.dec.size();
-    for (size_t t = 0; t < items[i].n; t++) {
-      src.dec.Add(items[i].preST[t].rG);
-      src.dec.Add(items[i].preST[t].krG);
-      src.dec.Add(items[i].postST[t].rG);
-      src.dec.Add(items[i].postST[t].krG);
-    }
+  static const bool trace = [] {  // CURDLE_VERIFY_TRACE=1: the batch's wall time (stderr)
+    const char* e = getenv("CURDLE_VERIFY_TRACE");
+    return e && *e && *e != '0';
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  src.ahead = std::make_unique<proto::DecodeAhead>(k, proto::DecodeAheadChunk(k), proto::DecodeAheadProducers(),
+                                                   [&src](size_t i, proto::PointDecoder& dec) { src.Scan(i, dec); });
+  std::vector<int> oks;
+  try {
+    oks = proto::VerifyBatchCore(crs, k, src, rand, proto::BatchWorkers(nthreads));
+  } catch (...) {
+    src.ahead->Abandon();
+    throw;
   }
-  src.dec.Run();
-  return proto::VerifyBatchCore(crs, k, src, rand, nthreads);
+  if (trace) {
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[whisk batch] k=%zu, chunks of %zu, %d threads: %.2f ms\n", k, proto::DecodeAheadChunk(k), nthreads,
+            std::chrono::duration<double, std::milli>(t1 - t0).count());
+  }
+  return oks;
 }
 
 std::vector<WhiskTracker> GenerateWhiskShuffleProof(const proto::CRS& crs, const std::vector<WhiskTracker>& preTrackers,

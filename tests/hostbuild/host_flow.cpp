@@ -235,8 +235,10 @@ static int Flow(size_t ell) {
     }
   }
   // cross-proof batch verification, on the device accumulator's description path and on the
-  // host mirror: exact per-proof bits with a bad instance, a truncated and a bit-flipped proof
+  // host mirror: exact per-proof bits with a bad instance, a truncated and a bit-flipped proof;
+  // decoded two proofs per chunk, ahead of the workers
   {
+    setenv("CURDLE_BATCH_CHUNK", "2", 1);
     Instance other = Make(ell, 21, &in.crs);
     std::vector<uint8_t> truncated(in.proof.begin(), in.proof.end() - 5), flipped(in.proof);
     flipped[flipped.size() - 9] ^= 0x20;
@@ -268,6 +270,7 @@ static int Flow(size_t ell) {
       std::vector<proto::BatchItem> good = {items[0], items[1], items[5]};
       CHECK(proto::VerifyBatch(in.crs, good, br2, 3) == (std::vector<int>{1, 1, 1}));
     }
+    unsetenv("CURDLE_BATCH_CHUNK");
     proto::SetDeviceAccumulator(1);
   }
   printf("flow ell=%zu: completeness, round trip, soundness flips, accumulator table, mirror == device accumulator, batch: ok\n", ell);
@@ -314,6 +317,23 @@ static int WhiskFlow() {
         CHECK(threw);
       }
       proto::SetDeviceAccumulator(1);
+      // the batch form, decoded chunk by chunk ahead of the workers (one proof per chunk here)
+      setenv("CURDLE_BATCH_CHUNK", "1", 1);
+      std::vector<whisk::WhiskTracker> swapped(post);
+      std::swap(swapped[0], swapped[1]);
+      std::vector<uint8_t> garbled(wproof);
+      garbled[100] ^= 0x10;
+      std::vector<whisk::ShuffleBatchItem> items = {
+          {pre.data(), post.data(), ell, wproof.data()},    {pre.data(), swapped.data(), ell, wproof.data()},
+          {pre.data(), post.data(), ell, garbled.data()},   {pre.data(), post.data(), ell, wproof.data()},
+          {pre.data(), post.data(), ell, wproof.data()}};
+      for (int dev = 1; dev >= 0; dev--) {
+        proto::SetDeviceAccumulator(dev);
+        common::Rand br(81);
+        CHECK(whisk::IsValidWhiskShuffleProofBatch(in.crs, items, br, 3) == (std::vector<int>{1, 0, 0, 1, 1}));
+      }
+      proto::SetDeviceAccumulator(1);
+      unsetenv("CURDLE_BATCH_CHUNK");
     }
   CHECK(generated);
   printf("whisk flow: shuffle proof accepted, swapped trackers rejected, broken tracker reported, both routes: ok\n");

@@ -43,14 +43,18 @@ for nthreads in (4, 8, 16):
     res[nthreads] = nthreads * per / (time.perf_counter() - t0)
 # many shuffle proofs at once (BASELINE config 5: 1024 Whisk proofs): one decode kernel for all
 # 594 * k points, worker threads, one MSM per 32 proofs
-batch = {}
+batch, batch_runs = {}, {}
 if not os.environ.get("CURDLE_HOST_DECODE"):
     for kb in (64, 256, 1024):
         args = ([pre] * kb, [post] * kb, [proof] * kb)
         assert all(cm.whisk_is_valid_shuffle_proof_batch(crs, *args, cm.Rand(3), nthreads=16))
-        t0 = time.perf_counter()
-        assert all(cm.whisk_is_valid_shuffle_proof_batch(crs, *args, cm.Rand(4), nthreads=16))
-        batch[f"k={kb},threads=16"] = kb / (time.perf_counter() - t0)
+        ts = []
+        for rep in range(3):  # best of three
+            t0 = time.perf_counter()
+            assert all(cm.whisk_is_valid_shuffle_proof_batch(crs, *args, cm.Rand(4 + rep), nthreads=16))
+            ts.append(time.perf_counter() - t0)
+        batch[f"k={kb},threads=16"] = kb / min(ts)
+        batch_runs[f"k={kb},threads=16"] = [round(t * 1e3, 2) for t in ts]
 # tracker opening proof
 import bls12381_ref as oracle
 k = 12345
@@ -67,6 +71,6 @@ for i in range(50):
 t_tval = (time.perf_counter() - t0) / 50
 out = {"decode": "host" if os.environ.get("CURDLE_HOST_DECODE") else "gpu",
        "generate_shuffle_proof_ms": t_gen * 1e3, "is_valid_shuffle_proof_ms": t_valid * 1e3,
-       "is_valid_shuffle_proof_per_s": 1 / t_valid, "is_valid_shuffle_proof_per_s_threads": res, "is_valid_shuffle_proof_batch_per_s": batch,
+       "is_valid_shuffle_proof_per_s": 1 / t_valid, "is_valid_shuffle_proof_per_s_threads": res, "is_valid_shuffle_proof_batch_per_s": batch, "batch_runs_ms": batch_runs,
        "generate_tracker_proof_ms": t_tgen * 1e3, "is_valid_tracker_proof_ms": t_tval * 1e3}
 print(json.dumps(out))
