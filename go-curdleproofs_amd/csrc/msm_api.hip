@@ -132,6 +132,7 @@ struct Ctx {
   // chip while the previous one drains its last blocks, instead of waiting behind it in
   // one in-order queue (measured at N = 2^20: 3.44 -> 3.30 ms per MSM with 4 in flight).
   hipStream_t main_extra[3] = {nullptr, nullptr, nullptr};
+  int prio_least = 0, prio_greatest = 0;  // stream priority range of the device
   int main_streams = 2;
   std::atomic<unsigned> submit_count{0};  // submits come from any thread
   // Recoding + bucket sort of every MSM, in order; light, memory/LDS-bound phases that
@@ -205,11 +206,15 @@ int init_locked(int device) {
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   if (getenv("CURDLE_DEBUG_PRIO")) fprintf(stderr, "[curdle] stream priority range: least %d greatest %d\n", prio_least, prio_greatest);
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_stream, hipStreamNonBlocking, prio_least));
-  for (auto& st : g_ctx.main_extra) HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_least));
   if (const char* ms = getenv("CURDLE_MAIN_STREAMS")) {
     g_ctx.main_streams = atoi(ms);
     if (g_ctx.main_streams < 1 || g_ctx.main_streams > 4) g_ctx.main_streams = 1;
   }
+  // Only the streams that will be used: with more streams than hardware queues
+  // (GPU_MAX_HW_QUEUES: 4 by default, 16 under bench.py) streams share queues, and which ones
+  // do depends on the creation order -- a stream nobody launches on must not cost a queue.
+  for (int i = 0; i + 1 < g_ctx.main_streams; i++)
+    HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_extra[i], hipStreamNonBlocking, prio_least));
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.pre_stream, hipStreamNonBlocking, prio_least));
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.pre_stream2, hipStreamNonBlocking, prio_least));
   if (const char* ps = getenv("CURDLE_PRE_STREAMS")) g_ctx.pre_streams = atoi(ps) == 1 ? 1 : 2;
@@ -223,19 +228,8 @@ int init_locked(int device) {
     HIP_TRY(hipEventCreateWithFlags(&s.acc_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
   }
-  for (DSlot& d : g_ctx.dslots) {
-    // The two decoding streams at the HIGHEST priority: their kernels are a few waves (one
-    // serial chain per point) that the caller's MSM must run beside, not behind -- measured on
-    // one verification from bytes (ell = 252, default 4 hardware queues): the accumulator's MSM
-    // takes 0.46 ms next to a high-priority subgroup test, 0.88 ms queued behind a low-priority
-    // one (profiles/r02_verify_from_bytes_queues.txt).  CURDLE_DECODE_PRIO=0 restores the
-    // lowest priority, =2 the default one.
-    const char* dp = getenv("CURDLE_DECODE_PRIO");
-    const int dprio = dp ? (atoi(dp) == 0 ? prio_least : atoi(dp) == 2 ? 0 : prio_greatest) : prio_greatest;
-    HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, dprio));
-    HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&d.decoded, hipEventDisableTiming));
-  }
+  g_ctx.prio_greatest = prio_greatest;
+  g_ctx.prio_least = prio_least;
   g_ctx.device = device;
   g_ctx.inited = true;
   return CURDLE_OK;
@@ -312,14 +306,16 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // and is better served by the smaller total work of 16-bucket segments (3.27 -> 3.13 ms
   // per MSM at N = 2^20); a synchronous caller waits for the chain (4.3 vs 5.0 ms).
   p.seg = nbk >= (1u << 19) ? (latency_mode ? 8 : 16) : (nbk >= (1u << 14) ? 4 : 2);
-  // Four lanes per point (quad28.h) in the latency-bound kernels when the caller waits for
-  // this very call (synchronous entry points): the segments are lengthened until the
-  // four-fold lane count is at most one round of the chip at two waves per SIMD (131,072
-  // lanes), because a quad's addition is 4 product steps against 14 and the chain
-  // (2.5 seg + log2(buckets) point operations) is what the caller waits for.  Pipelined
-  // (submit / wait) calls hide their tails behind other MSMs' accumulation and keep one lane
-  // per operation (a quad spends ~30 % more issue slots per addition), unless the call is
-  // small enough (a window-range partial, a small MSM) to leave most of the chip idle anyway.
+  // Four lanes per point (quad28.h) in the latency-bound kernels.  When the caller waits for
+  // this very call (synchronous entry points) the segments are lengthened until the four-fold
+  // lane count is at most one round of the chip at two waves per SIMD (131,072 lanes),
+  // because a quad's addition is 4 product steps against 14 and the chain (2.5 seg +
+  // log2(buckets) point operations) is what the caller waits for.  Pipelined (submit / wait)
+  // calls hide their tails behind other MSMs' accumulation; they too take quads, with 32-bucket
+  // segments (half a round of lanes: room beside the accumulation's waves), when that fits --
+  // N = 2^20, four in flight: 3.09 -> 2.92-3.04 ms per MSM against one lane per operation with
+  // 16-bucket segments, whose kernel also spills 76 registers; 64 buckets per segment 2.97,
+  // 128: 3.13 -- and one lane per operation only beyond 2^20 bucket slots (large batches).
   p.quad = 0;
   if (latency_mode) {
     uint32_t seg = p.seg;
@@ -329,6 +325,9 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
       p.quad = 1;
     }
   } else if (nbk / p.seg * 4 <= 65536) {
+    p.quad = 1;
+  } else if (nbk / 32 * 4 <= 131072) {
+    p.seg = 32;
     p.quad = 1;
   }
   if (const char* env = getenv("CURDLE_REDUCE_SEG")) p.seg = (uint32_t)atoi(env);
@@ -633,7 +632,8 @@ void drain_slot(Slot& S) {
   (void)hipStreamSynchronize(g_ctx.pre_stream);
   (void)hipStreamSynchronize(g_ctx.pre_stream2);
   (void)hipStreamSynchronize(g_ctx.main_stream);
-  for (auto& st : g_ctx.main_extra) (void)hipStreamSynchronize(st);
+  for (auto& st : g_ctx.main_extra)
+    if (st) (void)hipStreamSynchronize(st);
   (void)hipStreamSynchronize(S.stream);
 }
 
@@ -758,6 +758,25 @@ extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status);
 // on the context's stream; finish waits for it and returns the final status bytes.  The caller
 // can hash its transcript between start and points, and verify between points and finish.
 // begin = start + points.
+namespace {
+// A decode context's streams, made on its first use (see init_locked: unused streams must not
+// take hardware queues).  The decoding stream at the HIGHEST priority: its kernels are a few
+// waves (one serial chain per point) that the caller's MSM must run beside, not behind --
+// measured on one verification from bytes (ell = 252, default 4 hardware queues): the
+// accumulator's MSM takes 0.46 ms next to a high-priority subgroup test, 0.88 ms queued behind
+// a low-priority one (profiles/r02_verify_from_bytes_queues.txt).  CURDLE_DECODE_PRIO=0
+// restores the lowest priority, =2 the default one.
+int ensure_dslot_streams(DSlot& d) {
+  if (d.stream) return CURDLE_OK;
+  const char* dp = getenv("CURDLE_DECODE_PRIO");
+  const int dprio = dp ? (atoi(dp) == 0 ? g_ctx.prio_least : atoi(dp) == 2 ? 0 : g_ctx.prio_greatest) : g_ctx.prio_greatest;
+  HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, dprio));
+  HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&d.decoded, hipEventDisableTiming));
+  return CURDLE_OK;
+}
+}  // namespace
+
 extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* ticket) {
   if (!ticket || (n && !in)) return fail(CURDLE_EINVAL, "null argument");
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 points", n);
@@ -787,8 +806,9 @@ extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* tick
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(g_ctx.device));
     D.n = (uint32_t)n;
-    if (n == 0) return CURDLE_OK;
     int r;
+    if ((r = ensure_dslot_streams(D))) return r;
+    if (n == 0) return CURDLE_OK;
     if ((r = ensure(D.in, n * 48))) return r;
     if ((r = ensure(D.out, n * 96))) return r;
     if ((r = ensure(D.status, n))) return r;
@@ -812,7 +832,7 @@ extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* tick
   };
   int rc = body();
   if (rc) {
-    (void)hipStreamSynchronize(D.stream);
+    if (D.stream) (void)hipStreamSynchronize(D.stream);
     {
       std::lock_guard<std::mutex> g(g_ctx.mu);
       D.busy = false;
@@ -950,7 +970,7 @@ extern "C" int curdle_shutdown(void) {
     if (d.busy) return fail(CURDLE_EBUSY, "a point decoding is still in flight");
   (void)hipSetDevice(C.device);
   for (DSlot& d : C.dslots) {
-    (void)hipStreamSynchronize(d.stream);
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
     for (Buf* b : {&d.in, &d.out, &d.status}) {
       if (b->p) (void)hipFree(b->p);
       b->p = nullptr;
@@ -959,12 +979,14 @@ extern "C" int curdle_shutdown(void) {
     if (d.h_in) (void)hipHostFree(d.h_in);
     d.h_in = nullptr;
     d.h_in_cap = 0;
-    (void)hipStreamDestroy(d.stream);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
     d.stream = nullptr;
-    (void)hipStreamSynchronize(d.copy_stream);
-    (void)hipStreamDestroy(d.copy_stream);
+    if (d.copy_stream) {
+      (void)hipStreamSynchronize(d.copy_stream);
+      (void)hipStreamDestroy(d.copy_stream);
+    }
     d.copy_stream = nullptr;
-    (void)hipEventDestroy(d.decoded);
+    if (d.decoded) (void)hipEventDestroy(d.decoded);
     d.decoded = nullptr;
   }
   for (Slot& S : C.slots) {
@@ -996,6 +1018,7 @@ extern "C" int curdle_shutdown(void) {
   (void)hipStreamDestroy(C.main_stream);
   C.main_stream = nullptr;
   for (auto& st : C.main_extra) {
+    if (!st) continue;
     (void)hipStreamSynchronize(st);
     (void)hipStreamDestroy(st);
     st = nullptr;
