@@ -302,40 +302,30 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   const uint64_t nbk = (uint64_t)k * sets * p.NB;  // bucket slots the reduce kernels walk
   // Buckets per running-sum segment: long segments amortise the per-segment scalar
   // multiple, short ones keep the serial chain short when there are few buckets.
-  // A pipelined caller (submit / wait) hides the chain behind the next MSM's accumulation
-  // and is better served by the smaller total work of 16-bucket segments (3.27 -> 3.13 ms
-  // per MSM at N = 2^20); a synchronous caller waits for the chain (4.3 vs 5.0 ms).
+  // This is the starting point; the quad rule below lengthens it for large calls.
   p.seg = nbk >= (1u << 19) ? (latency_mode ? 8 : 16) : (nbk >= (1u << 14) ? 4 : 2);
-  // Four lanes per point (quad28.h) in the latency-bound kernels.  When the caller waits for
-  // this very call (synchronous entry points) the segments are lengthened until the four-fold
-  // lane count is at most one round of the chip at two waves per SIMD (131,072 lanes),
-  // because a quad's addition is 4 product steps against 14 and the chain (2.5 seg +
-  // log2(buckets) point operations) is what the caller waits for.  Pipelined (submit / wait)
-  // calls hide their tails behind other MSMs' accumulation; they too take quads, with 32-bucket
-  // segments (half a round of lanes: room beside the accumulation's waves), when that fits --
-  // N = 2^20, four in flight: 3.09 -> 2.92-3.04 ms per MSM against one lane per operation with
-  // 16-bucket segments, whose kernel also spills 76 registers; 64 buckets per segment 2.97,
-  // 128: 3.13 -- and one lane per operation only beyond 2^20 bucket slots (large batches).
-  p.quad = 0;
+  // The latency-bound kernels work on quads (four lanes per point, quad28.h).  When the caller
+  // waits for this very call (synchronous entry points) the segments are lengthened, up to 32
+  // buckets, until the four-fold lane count is at most one round of the chip at two waves per
+  // SIMD (131,072 lanes): a quad's addition is 4 product steps against 14, and the chain (2.5
+  // seg + log2(buckets) point operations) is what the caller waits for; a call too large for
+  // one round even so (big batches) takes 16-bucket segments over several rounds (1,024 x 628
+  // pairs: 7.67 ms against 7.69 / 7.70 with 32 / 64).  Pipelined (submit / wait) calls hide
+  // their tails behind other MSMs' accumulation and take 32-bucket segments from 2^19 bucket
+  // slots on (half a round of lanes: room beside the accumulation's waves; N = 2^20, four in
+  // flight: 3.04 ms per MSM, 2.97 with 64, 3.13 with 128).
   if (latency_mode) {
     uint32_t seg = p.seg;
     while (nbk / seg * 4 > 131072 && seg < 32) seg *= 2;
-    if (nbk / seg * 4 <= 131072) {
-      p.seg = seg;
-      p.quad = 1;
-    }
-  } else if (nbk / p.seg * 4 <= 65536) {
-    p.quad = 1;
-  } else if (nbk / 32 * 4 <= 131072) {
+    p.seg = nbk / seg * 4 <= 131072 ? seg : 16;
+  } else if (nbk / p.seg * 4 > 65536 && nbk >= (1u << 19)) {
     p.seg = 32;
-    p.quad = 1;
   }
   if (const char* env = getenv("CURDLE_REDUCE_SEG")) p.seg = (uint32_t)atoi(env);
   if (p.seg < 1) p.seg = 1;
   while (p.seg > min_nbkt || (p.seg & (p.seg - 1))) p.seg >>= 1;
   p.NS = p.NB / p.seg;
-  if (const char* env = getenv("CURDLE_QUAD")) p.quad = atoi(env) ? 1u : 0u;
-  const uint32_t gmax = p.quad ? 64u : 256u;
+  const uint32_t gmax = 64u;  // quads per block
   p.G = min_nbkt / p.seg < gmax ? min_nbkt / p.seg : gmax;
   // Sorted positions per accumulate lane: about two full-chip rounds of lanes
   // (256 CUs x 4 SIMDs x 2 waves x 64 lanes) for large inputs, never below 8.

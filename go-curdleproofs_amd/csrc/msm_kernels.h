@@ -39,7 +39,6 @@ struct MsmPlan {
   uint32_t max_large;  // capacity of the large-bucket queue
   uint32_t chunk;      // pairs per sort block
   uint32_t gpu_combine;  // 1: window sums combined on the GPU (large batches), 0: on the host
-  uint32_t quad;         // 1: latency-bound kernels use four lanes per point operation
   uint32_t fuse_scan;    // 1: the bucket-slot scans run as one single-block launch
   uint8_t bits[kMaxWindows];    // width of window w
   uint16_t shift[kMaxWindows];  // bit offset of window w

@@ -451,61 +451,13 @@ __global__ void __launch_bounds__(kBlock, 2)
   }
 }
 
-// One lane per segment of `seg` consecutive buckets; the lanes run flat over the
-// segments of all windows of all MSMs of the call (q = j * NS + base[w]/seg + t):
-//   sum_{u < seg} (lo + u + 1) * bucket[lo + u]
-// as the classic running sum over the segment plus lo * (segment total); a
-// bucket's value is the sum of its fragments, folded into the running sum here.
-// Aligned groups of G lanes (G = min(256, smallest segment count of a window), a
-// power of two, so a group never straddles two windows) are then tree-summed in
-// LDS and one partial per group is written.
-// WAVES = waves per SIMD the register budget is sized for: 1 (512 VGPRs, no spills)
-// when the launch has at most one wave per SIMD anyway, 2 for large batches.
-template <int WAVES>
-__global__ void __launch_bounds__(kBlock, WAVES)
-    k_bucket_reduce(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
-                    X28* __restrict__ partials, MsmPlan p) {
-  __shared__ X28 sh[4];
-  const u32 tid = threadIdx.x;
-  const u32 q = blockIdx.x * kBlock + tid;
-  X28 acc, b;
-  d28::set_inf(acc);
-  if (q < p.kr * p.NS) {
-    const u32 jr = q / p.NS;            // result index = set * k + j
-    const u32 r = q - jr * p.NS;
-    const u32 set = jr / p.k, j = jr - set * p.k;
-    frags += (size_t)set * p.frag_stride;
-    int w = p.win_begin;
-    while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
-    const u32 lo = (r - p.base[w] / p.seg) * p.seg;
-    const u32 g0 = j * p.NB + p.base[w] + lo;
-    X28 run;
-    d28::set_inf(run);
-    for (int u = (int)p.seg - 1; u >= 0; u--) {
-      u32 m = fragcnt[g0 + u];
-      if (m > p.max_small) m = 1;  // pre-merged by k_merge_large into its first slot
-      const X28* f = frags + foff[g0 + u];
-      for (u32 k = 0; k < m; k++) {
-        d28::load(b, &f[k]);
-        d28::add(run, b);
-      }
-      d28::add(acc, run);
-    }
-    if (lo != 0) {
-      d28::mul_small(b, run, lo);
-      d28::add(acc, b);
-    }
-  }
-  if (p.G > 1) group_sum(acc, p.G, sh);
-  if ((tid & (p.G - 1)) == 0 && q < p.kr * p.NS) d28::store(&partials[q / p.G], acc);
-}
-
 // ---------------------------------------------------------------------------
-// Quad variants of the latency-bound kernels (quad28.h): four adjacent lanes own ONE
-// point between them (X | Y | ZZ | ZZZ), so a 256-thread block carries 64 logical
-// lanes ("quads") and a point addition is 4 product steps instead of 14.  Used when the
-// launch has few enough logical lanes that the four-fold lane count still fits the chip
-// in one round.
+// The latency-bound kernels (quad28.h): four adjacent lanes own ONE point between them
+// (X | Y | ZZ | ZZZ), so a 256-thread block carries 64 logical lanes ("quads") and a point
+// addition is 4 product steps instead of 14.  (A one-lane-per-segment build of the bucket
+// reduction existed until round 2: 256 VGPRs with 76 spilled, and slower wherever it was
+// measured against quads with the right segment length -- N = 2^20 pipelined 3.09 vs 3.04
+// ms, 1,024 x 628-pair batch 8.09 vs 7.67 ms, profiles/r02_quad_everywhere.txt.)
 // ---------------------------------------------------------------------------
 // Sum over aligned groups of G quads (G a power of two <= 64); valid in the first quad of
 // each group.  wave_partials: LDS, [4 waves][4 coordinates].
@@ -606,42 +558,12 @@ __device__ __forceinline__ void write_window_sum(const X28& acc, G1XYZZ* winsums
 }
 
 // Window sums from the group partials.  A window owns nseg / G consecutive
-// partials.  Wide windows (many partials): one 64-lane block per (window, MSM)
+// partials.  Wide windows (many partials): one 64-quad block per (window, MSM)
 // with an LDS tree.  A call whose windows all have <= 4 partials (batches of small
 // MSMs): one lane per window, so tens of thousands of windows fill the chip.
 // With the host combine (single MSMs, small batches) the window sums are written in
 // gnark form (canonical XYZZ coordinates); a large batch keeps them in internal form
 // for k_combine.
-__global__ void __launch_bounds__(64, 1)
-    k_window_sum_wide(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28,
-                      MsmPlan p) {
-  __shared__ X28 sh[64];
-  const u32 lw = blockIdx.x, j = blockIdx.y;
-  const u32 w = p.win_begin + lw;
-  const u32 tid = threadIdx.x;
-  const u32 np = p.nbkt[w] / p.seg / p.G;
-  const X28* pw = partials + ((size_t)j * p.NS + p.base[w] / p.seg) / p.G;
-  X28 acc, b;
-  d28::set_inf(acc);
-  for (u32 k = tid; k < np; k += 64) {
-    d28::load(b, &pw[k]);
-    d28::add(acc, b);
-  }
-  u32 width = 1;
-  while (width < np && width < 64) width <<= 1;
-  sh[tid] = acc;
-  __syncthreads();
-  for (u32 off = width / 2; off > 0; off >>= 1) {
-    if (tid < off) {
-      b = sh[tid + off];
-      d28::add(acc, b);
-      sh[tid] = acc;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) write_window_sum(acc, winsums, winsums28, p, j, lw);
-}
-
 // The quad's own coordinate of a window sum: gnark form for the host combine, internal form
 // for k_combine.
 __device__ __forceinline__ void write_window_sum_quad(const F28& c, G1XYZZ* winsums, X28* winsums28, const MsmPlan& p,
@@ -811,18 +733,11 @@ hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream
   const u32 nw = p.win_end - p.win_begin;
   const u32 nb = p.k * p.NB;
   const u32 nlanes = cdiv((u64)nw * p.n, p.L);
-  static const int waves = [] {
-    const char* e = getenv("CURDLE_ACC_WAVES");
-    return e ? atoi(e) : 2;
-  }();
-  if (waves == 3)
-    hipLaunchKernelGGL(k_accumulate<3>, dim3(cdiv(nlanes, kBlock), p.sets), dim3(kBlock), 0, stream,
-                       reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
-                       reinterpret_cast<X28*>(ws.frags), nb, p.L, p.n, p.frag_stride);
-  else
-    hipLaunchKernelGGL(k_accumulate<2>, dim3(cdiv(nlanes, kBlock), p.sets), dim3(kBlock), 0, stream,
-                       reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
-                       reinterpret_cast<X28*>(ws.frags), nb, p.L, p.n, p.frag_stride);
+  // two waves per SIMD (203 VGPRs, no spills): a three-wave build (168 VGPRs) spilled 26
+  // registers and was slower
+  hipLaunchKernelGGL(k_accumulate<2>, dim3(cdiv(nlanes, kBlock), p.sets), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
+                     reinterpret_cast<X28*>(ws.frags), nb, p.L, p.n, p.frag_stride);
   return hipGetLastError();
 }
 
@@ -833,26 +748,17 @@ hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStrea
 }
 
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  // The 256-register build (2 waves per SIMD) even when the launch has one wave per SIMD:
-  // it leaves room for an accumulate wave of the next MSM on the same SIMD.
-  const u64 lanes = (u64)p.kr * p.NS;
-  if (p.quad)
-    hipLaunchKernelGGL(k_bucket_reduce_quad, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream,
-                       reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
-  else
-    hipLaunchKernelGGL(k_bucket_reduce<2>, dim3(cdiv(lanes, kBlock)), dim3(kBlock), 0, stream,
-                       reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
+  const u64 lanes = (u64)p.kr * p.NS;  // quads
+  hipLaunchKernelGGL(k_bucket_reduce_quad, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
   return hipGetLastError();
 }
 
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nw = p.win_end - p.win_begin;
-  if (p.max_nbkt / p.seg / p.G > 4 && p.quad)
+  if (p.max_nbkt / p.seg / p.G > 4)
     hipLaunchKernelGGL(k_window_sum_wide_quad, dim3(nw, p.kr), dim3(kBlock), 0, stream,
                        reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
-  else if (p.max_nbkt / p.seg / p.G > 4)
-    hipLaunchKernelGGL(k_window_sum_wide, dim3(nw, p.kr), dim3(64), 0, stream, reinterpret_cast<const X28*>(ws.partials),
-                       ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
   else
     hipLaunchKernelGGL(k_window_sum_flat, dim3(cdiv((u64)p.kr * nw, kBlock)), dim3(kBlock), 0, stream,
                        reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);

@@ -104,18 +104,18 @@ def test_segment_lengths(gpu, golden):
         os.environ.pop("CURDLE_SEG_LEN", None)
 
 
-def test_quad_and_single_lane_reduce_paths(gpu, golden, oracle, coracle):
-    """The latency-bound kernels exist in two builds (one lane or four cooperating lanes
-    per point operation, fp28.h); both must give the same bits, including on inputs that
-    reach the doubling / infinity branches inside the reduction."""
+def test_reduce_segment_lengths(gpu, golden, oracle, coracle):
+    """The bucket reduction walks segments of 1..32 buckets per quad (the plan picks the length
+    from the call's size); every length must give the same bits, including on inputs that reach
+    the doubling / infinity branches inside the reduction."""
     k, q = oracle.Rand(15).get_frs(2)
     n = 3000
     pts = coracle.points_walk(k, q, n)
     sc = rand_scalars(np.random.default_rng(15), n, oracle)
     exp = coracle.msm_pippenger(pts, sc, threads=8)
     try:
-        for quad in ("0", "1"):
-            os.environ["CURDLE_QUAD"] = quad
+        for quad in ("1", "4", "32"):
+            os.environ["CURDLE_REDUCE_SEG"] = quad
             for name in ("rand0_n16", "rand0_n257", "rand0_n1024", "edge_duplicate_bases", "edge_opposite_points",
                          "edge_cancels_to_infinity", "edge_all_equal_scalars", "edge_small_scalars",
                          "edge_window_boundaries", "edge_all_infinity"):
@@ -126,7 +126,7 @@ def test_quad_and_single_lane_reduce_paths(gpu, golden, oracle, coracle):
                 assert (gpu.msm_g1(pts, sc) == exp).all(), (quad, c)
             os.environ.pop("CURDLE_WINDOW_BITS", None)
     finally:
-        os.environ.pop("CURDLE_QUAD", None)
+        os.environ.pop("CURDLE_REDUCE_SEG", None)
         os.environ.pop("CURDLE_WINDOW_BITS", None)
 
 
@@ -199,12 +199,12 @@ def test_randomised_differential_small_cases(gpu, oracle, coracle):
             sc = np.array([oracle.fr_to_mont_limbs(v) for v in sc_int], dtype=np.uint64)
             os.environ["CURDLE_WINDOW_BITS"] = str(int(rng.integers(4, 17)))
             os.environ["CURDLE_SEG_LEN"] = str(int(rng.integers(8, 40)))
-            os.environ["CURDLE_QUAD"] = str(case % 2)
+            os.environ["CURDLE_REDUCE_SEG"] = str(1 << (case % 6))
             got = gpu.msm_g1(pts, sc)
             exp = coracle.msm_naive(pts, sc)
             assert (got == exp).all(), (case, n, os.environ["CURDLE_WINDOW_BITS"], os.environ["CURDLE_SEG_LEN"])
     finally:
-        for v in ("CURDLE_WINDOW_BITS", "CURDLE_SEG_LEN", "CURDLE_QUAD"):
+        for v in ("CURDLE_WINDOW_BITS", "CURDLE_SEG_LEN", "CURDLE_REDUCE_SEG"):
             os.environ.pop(v, None)
 
 
