@@ -204,7 +204,6 @@ int init_locked(int device) {
   HIP_TRY(hipStreamCreateWithFlags(&g_ctx.util_stream, hipStreamNonBlocking));
   int prio_least = 0, prio_greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-  if (getenv("CURDLE_DEBUG_PRIO")) fprintf(stderr, "[curdle] stream priority range: least %d greatest %d\n", prio_least, prio_greatest);
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_stream, hipStreamNonBlocking, prio_least));
   if (const char* ms = getenv("CURDLE_MAIN_STREAMS")) {
     g_ctx.main_streams = atoi(ms);
