@@ -496,26 +496,38 @@ def verify_proof(crs: CRS, proof: Proof, Rs, Ss, Ts, Us, M, rand: Rand) -> bool:
     return bool(ok.value)
 
 
+class PreparedVerifyBatch:
+    """The arguments of curdle_verify_batch marshalled once (pointer tables over contiguous
+    arrays), so that run() is the C call and nothing else -- what a benchmark should time, and
+    what a caller verifying the same batch layout repeatedly wants."""
+
+    def __init__(self, proofs, Rs, Ss, Ts, Us, Ms):
+        k = self.k = len(proofs)
+        self._keep = []
+
+        def ptr_array(arrs, width):
+            a = [_as_u64(x, width) for x in arrs]
+            self._keep.append(a)
+            return (C.c_void_p * k)(*[x.ctypes.data for x in a])
+
+        self._pbufs = [np.frombuffer(p, dtype=np.uint8).copy() for p in proofs]
+        self._pp = (C.c_void_p * k)(*[b.ctypes.data for b in self._pbufs])
+        self._lens = (C.c_size_t * k)(*[len(b) for b in self._pbufs])
+        self._ms = np.ascontiguousarray(np.stack([_as_u64(m) for m in Ms]) if k else np.zeros((0, 18), dtype=np.uint64))
+        self._inst = [ptr_array(v, 12) for v in (Rs, Ss, Ts, Us)]
+
+    def run(self, crs: CRS, rand: Rand, nthreads: int = 8):
+        oks = (C.c_int * self.k)()
+        _check(_verify_batch(crs._h, self.k, self._pp, self._lens, *self._inst, crs.ell, _ptr(self._ms), rand._h,
+                             int(nthreads), oks))
+        return [bool(v) for v in oks]
+
+
 def verify_batch(crs: CRS, proofs, Rs, Ss, Ts, Us, Ms, rand: Rand, nthreads: int = 8):
     """Cross-proof batch verification: k proofs over one CRS, one shared accumulator, one MSM.
     proofs: list of bytes; Rs/Ss/Ts/Us: lists of (ell, 12) arrays; Ms: list of 18-limb points.
     Returns the list of accept bits (exact: a failing batch is settled proof by proof)."""
-    k = len(proofs)
-    keep = []
-
-    def ptr_array(arrs, width):
-        a = [_as_u64(x, width) for x in arrs]
-        keep.append(a)
-        return (C.c_void_p * k)(*[x.ctypes.data for x in a])
-
-    pbufs = [np.frombuffer(p, dtype=np.uint8).copy() for p in proofs]
-    pp = (C.c_void_p * k)(*[b.ctypes.data for b in pbufs])
-    lens = (C.c_size_t * k)(*[len(b) for b in pbufs])
-    ms = np.ascontiguousarray(np.stack([_as_u64(m) for m in Ms]) if k else np.zeros((0, 18), dtype=np.uint64))
-    oks = (C.c_int * k)()
-    _check(_verify_batch(crs._h, k, pp, lens, ptr_array(Rs, 12), ptr_array(Ss, 12), ptr_array(Ts, 12),
-                         ptr_array(Us, 12), crs.ell, _ptr(ms), rand._h, int(nthreads), oks))
-    return [bool(v) for v in oks]
+    return PreparedVerifyBatch(proofs, Rs, Ss, Ts, Us, Ms).run(crs, rand, nthreads)
 
 
 # ---- whisk package (whisk/whisk.go, whisk/types.go): trackers are 96-byte strings rG || krG ----
@@ -539,20 +551,32 @@ def whisk_is_valid_shuffle_proof(crs: CRS, pre_trackers, post_trackers, proof: b
     return bool(ok.value)
 
 
+class PreparedWhiskBatch:
+    """The arguments of curdle_whisk_is_valid_shuffle_proof_batch marshalled once; run() is the
+    C call and nothing else (see PreparedVerifyBatch)."""
+
+    def __init__(self, pre_sets, post_sets, proofs):
+        k = self.k = len(proofs)
+        n = self.n = len(pre_sets[0]) if k else 0
+        self._pre = [_bytes_arr(b"".join(s)) for s in pre_sets]
+        self._post = [_bytes_arr(b"".join(s)) for s in post_sets]
+        self._pb = [_bytes_arr(p) for p in proofs]
+        if any(len(a) != 96 * n for a in self._pre + self._post) or any(len(p) != WHISK_SHUFFLE_PROOF_SIZE for p in self._pb):
+            raise ValueError("every tracker set needs the same length; proofs are %d bytes" % WHISK_SHUFFLE_PROOF_SIZE)
+        arr = lambda bufs: (C.c_void_p * k)(*[b.ctypes.data for b in bufs])
+        self._ptrs = (arr(self._pre), arr(self._post), arr(self._pb))
+
+    def run(self, crs: CRS, rand: Rand, nthreads: int = 16):
+        oks = (C.c_int * self.k)()
+        _check(_whisk_valid_shuffle_batch(crs._h, self.k, self._ptrs[0], self._ptrs[1], self.n, self._ptrs[2], rand._h,
+                                          int(nthreads), oks))
+        return [bool(v) for v in oks]
+
+
 def whisk_is_valid_shuffle_proof_batch(crs: CRS, pre_sets, post_sets, proofs, rand: Rand, nthreads: int = 16):
     """k shuffle proofs at once: pre_sets / post_sets are lists of tracker lists (all the same
     length), proofs a list of 4,576-byte strings.  Returns the list of accept bits."""
-    k = len(proofs)
-    n = len(pre_sets[0]) if k else 0
-    pre = [_bytes_arr(b"".join(s)) for s in pre_sets]
-    post = [_bytes_arr(b"".join(s)) for s in post_sets]
-    pb = [_bytes_arr(p) for p in proofs]
-    if any(len(a) != 96 * n for a in pre + post) or any(len(p) != WHISK_SHUFFLE_PROOF_SIZE for p in pb):
-        raise ValueError("every tracker set needs the same length; proofs are %d bytes" % WHISK_SHUFFLE_PROOF_SIZE)
-    arr = lambda bufs: (C.c_void_p * k)(*[b.ctypes.data for b in bufs])
-    oks = (C.c_int * k)()
-    _check(_whisk_valid_shuffle_batch(crs._h, k, arr(pre), arr(post), n, arr(pb), rand._h, int(nthreads), oks))
-    return [bool(v) for v in oks]
+    return PreparedWhiskBatch(pre_sets, post_sets, proofs).run(crs, rand, nthreads)
 
 
 def whisk_generate_shuffle_proof(crs: CRS, pre_trackers, rand: Rand):

