@@ -260,42 +260,67 @@ __global__ void __launch_bounds__(kBlock, 2)
   status[i] = CURDLE_DECODE_OK;
 }
 
-// The subgroup test alone, on points decoded earlier (gnark affine, still in device memory):
-// lets a caller start working with the decoded points while this runs, and learn at the end
-// whether any of them has to be rejected.  Only entries with status OK are tested; a failure
-// overwrites the entry's status.
+// The subgroup test WITHOUT the square root, so that it can run beside the decoding kernel
+// instead of behind it (the two ~0.5 ms chains per point were the whole latency of a small
+// decoding).  For a record's x let w = x^3 + 4.  If w = s^2 is a non-zero square, the map
+//     psi(X, Y) = (w X, w s Y)            (u = s in the usual (u^2 X, u^3 Y))
+// is an isomorphism, over Fp, from E: Y^2 = X^3 + 4 onto E': Y^2 = X^3 + 4 w^3; it sends the
+// decoded point (x, s) to P' = (w x, w^2), whose coordinates need no square root, and it
+// commutes with phi(X, Y) = (beta X, Y).  The group law of a curve with a = 0 never uses b,
+// so the SAME doubling / addition code decides [z^2] phi(P') + P' == inf on E', which holds iff
+// [z^2] phi(P) + P == inf on E -- for (x, s) and equally for its negative (x, -s), whichever
+// root the sign flag asks for.  If w is not a square the record is not on the curve: the
+// decoding kernel says so and this kernel's verdict for it is never read.  (w = 0 cannot
+// happen for x < p: the curve has odd order, so no point has y = 0.)
+// Writes sub[i] = 1 (in the subgroup, or not a candidate: malformed / infinity records) or 0.
 template <bool QUAD>
 __global__ void __launch_bounds__(kBlock, 2)
-    k_g1_subgroup_check(const u32* __restrict__ points, u32 n, uint8_t* __restrict__ status) {
+    k_g1_subgroup_from_x(const uint8_t* __restrict__ in, u32 n, uint8_t* __restrict__ sub) {
   __shared__ u32 sh_x[d28::N][kBlock];
   __shared__ u32 sh_y[d28::N][kBlock];
   const u32 tid = threadIdx.x;
   const u32 lane = blockIdx.x * kBlock + tid;
   const u32 i = QUAD ? lane >> 2 : lane;
-  if (i >= n) return;
-  if (status[i] != CURDLE_DECODE_OK) return;  // uniform over a quad
-  u32 w[24];
-  d28::load_words<24>(w, reinterpret_cast<const uint4*>(points) + (size_t)i * 6);
-  F28 x, y;
-  d28::from_gnark(x, w);
-  d28::from_gnark(y, w + 12);
+  const bool writer = !QUAD || (tid & 3u) == 0;
+  if (i >= n) return;  // whole quads leave together
+  u32 xw[12];
+  const u32* b32 = reinterpret_cast<const u32*>(in + (size_t)i * 48);
+#pragma unroll
+  for (int k = 0; k < 12; k++) xw[k] = __builtin_bswap32(b32[11 - k]);
+  const u32 flags = xw[11] >> 29;
+  xw[11] &= 0x1fffffffu;
+  // not a candidate (the decoding kernel reports these): uniform over a quad
+  if (!(flags & 4u) || (flags & 2u) || cmp12([&](int k) { return xw[k]; }, [](int k) { return kP32(k); }) >= 0) {
+    if (writer) sub[i] = 1;
+    return;
+  }
+  F28 x, t, c, w, xp, yp;
+  d28::unpack(t, xw);
+#pragma unroll
+  for (int k = 0; k < d28::N; k++) c.l[k] = kCanonToInt(k);
+  d28::mul(x, t, c);
+  d28::sqr(t, x);
+  d28::mul(t, t, x);
+#pragma unroll
+  for (int k = 0; k < d28::N; k++) c.l[k] = kFour(k);
+  d28::add(w, t, c);    // w = x^3 + 4 < 4p
+  d28::mul(xp, w, x);   // P' = (w x, w^2)
+  d28::sqr(yp, w);
 #pragma unroll
   for (int k = 0; k < d28::N; k++) {
-    sh_x[k][tid] = x.l[k];
-    sh_y[k][tid] = y.l[k];
+    sh_x[k][tid] = xp.l[k];
+    sh_y[k][tid] = yp.l[k];
   }
-  const bool ok = in_subgroup<QUAD>(x, y, sh_x, sh_y, tid);
-  if (!ok && (!QUAD || (tid & 3u) == 0)) status[i] = CURDLE_DECODE_NOT_IN_SUBGROUP;
+  const bool ok = in_subgroup<QUAD>(xp, yp, sh_x, sh_y, tid);
+  if (writer) sub[i] = ok ? 1 : 0;
 }
 
-hipError_t launch_g1_subgroup_check(const uint32_t* points, uint32_t n, uint8_t* status, hipStream_t stream) {
+hipError_t launch_g1_subgroup_from_bytes(const uint8_t* in, uint32_t n, uint8_t* sub, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   if ((uint64_t)n * 4 <= 131072)
-    hipLaunchKernelGGL(k_g1_subgroup_check<true>, dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, points, n,
-                       status);
+    hipLaunchKernelGGL(k_g1_subgroup_from_x<true>, dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n, sub);
   else
-    hipLaunchKernelGGL(k_g1_subgroup_check<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, points, n,
-                       status);
+    hipLaunchKernelGGL(k_g1_subgroup_from_x<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n, sub);
   return hipGetLastError();
 }
 

@@ -103,10 +103,13 @@ struct Slot {
 // call MSM entry points while the subgroup test runs, and eight such callers holding the
 // eight MSM slots would wait for each other forever.
 struct DSlot {
-  hipStream_t stream = nullptr;       // decoding kernel, then the subgroup test, back to back
+  hipStream_t stream = nullptr;       // upload, decoding kernel (square roots)
+  hipStream_t sub_stream = nullptr;   // the subgroup test, from the records, beside the decoding kernel
   hipStream_t copy_stream = nullptr;  // hands the points back while the subgroup test runs
-  hipEvent_t decoded = nullptr;       // recorded between the two kernels
-  Buf in, out, status;
+  hipEvent_t uploaded = nullptr;      // the records are in device memory
+  hipEvent_t decoded = nullptr;       // the decoding kernel is done
+  Buf in, out, status, sub;
+  std::vector<uint8_t> h_sub;         // finish(): the subgroup verdicts on the host
   void* h_in = nullptr;  // pinned staging of the compressed records
   size_t h_in_cap = 0;
   bool busy = false;
@@ -702,6 +705,23 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
   if (n && (!in || !out_affine || !status)) return fail(CURDLE_EINVAL, "null argument");
   if (n == 0) return CURDLE_OK;
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 points", n);
+  // A batch small enough to be one latency-bound chain per point (four lanes per point still fit
+  // one round of the chip) takes the two-kernel form of the three-step entry points: the square
+  // roots and, beside them, the subgroup test on the twisted model -- two ~0.5 ms chains that
+  // overlap (98 points: 1.10 -> 0.63 ms) where the fused kernel below runs them one after the
+  // other.  With both decode contexts taken it falls through to the fused kernel.
+  if (subgroup_check && n <= 32768) {
+    int ticket = -1;
+    int rc2 = curdle_g1_decompress_begin(in, n, out_affine, status, &ticket);
+    if (rc2 == CURDLE_OK) {
+      rc2 = curdle_g1_decompress_finish(ticket, status);
+      if (rc2 == CURDLE_OK)  // this entry point hands back zeros for every record that is not a usable point
+        for (size_t i = 0; i < n; i++)
+          if (status[i] == CURDLE_DECODE_NOT_IN_SUBGROUP) memset(out_affine + 12 * i, 0, 96);
+      return rc2;
+    }
+    if (rc2 != CURDLE_EBUSY) return rc2;
+  }
   int idx;
   int rc = acquire_slot(true, &idx);
   if (rc) return rc;
@@ -760,7 +780,9 @@ int ensure_dslot_streams(DSlot& d) {
   const char* dp = getenv("CURDLE_DECODE_PRIO");
   const int dprio = dp ? (atoi(dp) == 0 ? g_ctx.prio_least : atoi(dp) == 2 ? 0 : g_ctx.prio_greatest) : g_ctx.prio_greatest;
   HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, dprio));
+  HIP_TRY(hipStreamCreateWithPriority(&d.sub_stream, hipStreamNonBlocking, dprio));
   HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&d.uploaded, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&d.decoded, hipEventDisableTiming));
   return CURDLE_OK;
 }
@@ -801,6 +823,7 @@ extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* tick
     if ((r = ensure(D.in, n * 48))) return r;
     if ((r = ensure(D.out, n * 96))) return r;
     if ((r = ensure(D.status, n))) return r;
+    if ((r = ensure(D.sub, n))) return r;
     // pinned staging: the copy must not block the caller, who wants to hash meanwhile
     if (D.h_in_cap < n * 48) {
       if (D.h_in) HIP_TRY(hipHostFree(D.h_in));
@@ -811,17 +834,21 @@ extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* tick
     }
     memcpy(D.h_in, in, n * 48);
     HIP_TRY(hipMemcpyAsync(D.in.p, D.h_in, n * 48, hipMemcpyHostToDevice, D.stream));
+    HIP_TRY(hipEventRecord(D.uploaded, D.stream));
     HIP_TRY(launch_g1_decompress((const uint8_t*)D.in.p, (uint32_t)n, 0, (uint32_t*)D.out.p, (uint8_t*)D.status.p,
                                  D.stream));
-    // the subgroup test is queued right behind (no host round trip between the two kernels);
-    // curdle_g1_decompress_points reads the points on the other stream as soon as they exist
     HIP_TRY(hipEventRecord(D.decoded, D.stream));
-    HIP_TRY(launch_g1_subgroup_check((const uint32_t*)D.out.p, (uint32_t)n, (uint8_t*)D.status.p, D.stream));
+    // The subgroup test does not wait for the square roots: it works on a twisted model of the
+    // curve that needs only x (decode_kernels.hip), on its own stream, beside the decoding
+    // kernel -- the two ~0.5 ms chains per point overlap instead of adding up.
+    HIP_TRY(hipStreamWaitEvent(D.sub_stream, D.uploaded, 0));
+    HIP_TRY(launch_g1_subgroup_from_bytes((const uint8_t*)D.in.p, (uint32_t)n, (uint8_t*)D.sub.p, D.sub_stream));
     return CURDLE_OK;
   };
   int rc = body();
   if (rc) {
     if (D.stream) (void)hipStreamSynchronize(D.stream);
+    if (D.sub_stream) (void)hipStreamSynchronize(D.sub_stream);
     {
       std::lock_guard<std::mutex> g(g_ctx.mu);
       D.busy = false;
@@ -852,8 +879,7 @@ extern "C" int curdle_g1_decompress_points(int ticket, uint64_t* out_affine, uin
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(g_ctx.device));
     if (n == 0) return CURDLE_OK;
-    // the statuses may already carry some of the subgroup test's verdicts (it only ever turns
-    // OK into NOT_IN_SUBGROUP): either view is a correct answer for the caller
+    // encoding / curve verdicts only: the subgroup test's arrive with curdle_g1_decompress_finish
     HIP_TRY(hipStreamWaitEvent(D.copy_stream, D.decoded, 0));
     HIP_TRY(hipMemcpyAsync(out_affine, D.out.p, n * 96, hipMemcpyDeviceToHost, D.copy_stream));
     HIP_TRY(hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.copy_stream));
@@ -893,10 +919,18 @@ extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
   const size_t n = D.n;
   int rc = CURDLE_OK;
   hipError_t he = hipSetDevice(g_ctx.device);
-  if (he == hipSuccess && n && status) he = hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.stream);
+  if (he == hipSuccess && n && status) {
+    D.h_sub.resize(n);
+    he = hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(D.h_sub.data(), D.sub.p, n, hipMemcpyDeviceToHost, D.sub_stream);
+  }
   if (he == hipSuccess) he = hipStreamSynchronize(D.stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(D.sub_stream);
   if (he == hipSuccess) he = hipStreamSynchronize(D.copy_stream);
   if (he != hipSuccess) rc = fail(CURDLE_EHIP, "decompress finish: %s", hipGetErrorString(he));
+  if (rc == CURDLE_OK && n && status)  // a decoded point outside the subgroup: the one verdict the points came without
+    for (size_t i = 0; i < n; i++)
+      if (status[i] == CURDLE_DECODE_OK && !D.h_sub[i]) status[i] = CURDLE_DECODE_NOT_IN_SUBGROUP;
   {
     std::lock_guard<std::mutex> g(g_ctx.mu);
     D.busy = false;
@@ -960,7 +994,14 @@ extern "C" int curdle_shutdown(void) {
   (void)hipSetDevice(C.device);
   for (DSlot& d : C.dslots) {
     if (d.stream) (void)hipStreamSynchronize(d.stream);
-    for (Buf* b : {&d.in, &d.out, &d.status}) {
+    if (d.sub_stream) {
+      (void)hipStreamSynchronize(d.sub_stream);
+      (void)hipStreamDestroy(d.sub_stream);
+    }
+    d.sub_stream = nullptr;
+    if (d.uploaded) (void)hipEventDestroy(d.uploaded);
+    d.uploaded = nullptr;
+    for (Buf* b : {&d.in, &d.out, &d.status, &d.sub}) {
       if (b->p) (void)hipFree(b->p);
       b->p = nullptr;
       b->cap = 0;

@@ -98,7 +98,10 @@ hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_o
 hipError_t launch_g1_decompress(const uint8_t* in, uint32_t n, int subgroup_check, uint32_t* out, uint8_t* status,
                                 hipStream_t stream);
 
-hipError_t launch_g1_subgroup_check(const uint32_t* points, uint32_t n, uint8_t* status, hipStream_t stream);
+// The subgroup test straight from the n compressed records, without their square roots (so it
+// can run beside launch_g1_decompress(..., subgroup_check = 0, ...)): sub[i] = 0 iff record i,
+// if it decodes to a point at all, is not in the prime-order subgroup.
+hipError_t launch_g1_subgroup_from_bytes(const uint8_t* in, uint32_t n, uint8_t* sub, hipStream_t stream);
 
 // group_kernels.hip: out[i] = addends[i] + scalars[i or 0] * points[i] as gnark-format XYZZ
 // (ZZ = 0 for infinity); points / addends gnark affine (addends may be null), scalars

@@ -208,6 +208,15 @@ def test_batched_point_decoding_on_the_gpu(gpu, oracle):
         else:
             assert st == st0
     assert list(gpu.g1_decompress_finish(ticket, len(want_st))) == want_st
+    # ... and on a batch too large for four lanes per point (the one-lane build of both
+    # kernels): the same records repeated, statuses and points periodic with them
+    reps = 33000 // len(recs) + 1
+    big_pt, big_st, ticket = gpu.g1_decompress_begin(blob * reps)
+    big_final = gpu.g1_decompress_finish(ticket, reps * len(recs))
+    k = len(recs)
+    assert (big_final.reshape(reps, k) == np.array(want_st, dtype=np.uint8)).all()
+    assert (big_st.reshape(reps, k) == st2).all()
+    assert (big_pt.reshape(reps, k, 12) == pts2).all()
 
 
 def test_same_scalar_argument_is_enforced(gpu, check_mode):
