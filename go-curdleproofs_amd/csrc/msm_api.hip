@@ -61,6 +61,10 @@ extern "C" int curdle_set_last_error(int code, const char* msg) { return fail(co
 namespace {
 
 static constexpr int kSlots = 8;
+static const size_t kTwoKernelMax = [] {  // one-shot decodings up to this size take the two-kernel form
+  const char* e = getenv("CURDLE_TWO_KERNEL_MAX");
+  return e ? (size_t)atoll(e) : (size_t)32768;
+}();
 static constexpr int kMaxDeferred = 2;          // two-step point decodings in flight (see curdle_g1_decompress_begin)
 static constexpr size_t kGpuCombineMin = 32;  // batches at least this large combine their window sums on the GPU
 
@@ -710,7 +714,7 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
   // roots and, beside them, the subgroup test on the twisted model -- two ~0.5 ms chains that
   // overlap (98 points: 1.10 -> 0.63 ms) where the fused kernel below runs them one after the
   // other.  With both decode contexts taken it falls through to the fused kernel.
-  if (subgroup_check && n <= 32768) {
+  if (subgroup_check && n <= kTwoKernelMax) {
     int ticket = -1;
     int rc2 = curdle_g1_decompress_begin(in, n, out_affine, status, &ticket);
     if (rc2 == CURDLE_OK) {
