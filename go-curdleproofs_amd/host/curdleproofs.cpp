@@ -214,6 +214,36 @@ void Writer::PutPoints(const std::vector<Point>& v) {
   buf.insert(buf.end(), len, len + 4);
   for (const auto& p : v) PutPoint(p);
 }
+namespace {
+// The decoders' three arrays come from (and go back to) a small process-wide pool: a batch
+// verification makes and drops one decoder per chunk -- 87 MB of records, points and statuses for
+// 1,024 Whisk proofs -- and handing that to the allocator each time cost ~11 ms per batch in page
+// faults and munmap (of 55).  At most kPoolBytes are kept.
+struct DecoderBuffers {
+  std::vector<uint8_t> blob, status;
+  std::vector<G1Affine> pts;
+  size_t bytes() const { return blob.capacity() + status.capacity() + pts.capacity() * sizeof(G1Affine); }
+};
+constexpr size_t kPoolBytes = (size_t)256 << 20;
+std::mutex g_pool_mu;
+std::vector<DecoderBuffers> g_pool;
+size_t g_pool_bytes = 0;
+}  // namespace
+
+PointDecoder::PointDecoder(bool subgroup_check) : subgroup_(subgroup_check) {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  if (g_pool.empty()) return;
+  DecoderBuffers b = std::move(g_pool.back());
+  g_pool.pop_back();
+  g_pool_bytes -= b.bytes();
+  blob_ = std::move(b.blob);
+  status_ = std::move(b.status);
+  pts_ = std::move(b.pts);
+  blob_.clear();
+  status_.clear();
+  pts_.clear();
+}
+
 size_t PointDecoder::Add(const uint8_t rec[48]) {
   blob_.insert(blob_.end(), rec, rec + 48);
   return n_++;
@@ -299,6 +329,17 @@ bool PointDecoder::Finish() {
 }
 PointDecoder::~PointDecoder() {
   if (ticket_ >= 0) (void)curdle_g1_decompress_finish(ticket_, nullptr);  // never leak the workspace slot
+  DecoderBuffers b;
+  b.blob = std::move(blob_);
+  b.status = std::move(status_);
+  b.pts = std::move(pts_);
+  const size_t sz = b.bytes();
+  if (sz < ((size_t)64 << 10)) return;  // one proof's worth: not worth a lock
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  if (g_pool_bytes + sz <= kPoolBytes) {
+    g_pool_bytes += sz;
+    g_pool.push_back(std::move(b));
+  }
 }
 bool PointDecoder::Get(size_t index, Point* out) const {
   if (index >= n_ || status_[index] > CURDLE_DECODE_INFINITY) return false;

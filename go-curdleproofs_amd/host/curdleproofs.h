@@ -50,7 +50,7 @@ struct Writer {
 // the host decoder for A/B measurements.
 class PointDecoder {
  public:
-  explicit PointDecoder(bool subgroup_check) : subgroup_(subgroup_check) {}
+  explicit PointDecoder(bool subgroup_check);
   ~PointDecoder();
   PointDecoder(const PointDecoder&) = delete;
   PointDecoder& operator=(const PointDecoder&) = delete;
