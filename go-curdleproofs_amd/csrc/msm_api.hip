@@ -1284,6 +1284,11 @@ struct curdle_dacc {
   int slot = -1;
   const curdle_dbases* crs = nullptr;
   size_t n_inst = 0;
+  // after curdle_dacc_submit
+  bool submitted = false;
+  size_t n_total = 0;                  // resident + loose bases of the MSM
+  uint64_t* export_scalars = nullptr;  // caller's buffer for the slot scalars (tests), filled by wait
+  size_t export_off = 0;               // where they wait in the slot's pinned staging
 };
 
 extern "C" int curdle_dbases_create(const uint64_t* points, size_t n, curdle_dbases** out) {
@@ -1396,15 +1401,16 @@ extern "C" void curdle_dacc_abort(curdle_dacc* acc) {
   delete acc;
 }
 
-extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
-                               size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars,
-                               size_t n_extra, uint64_t out_jac[18], uint64_t* export_scalars) {
+extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
+                                  size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars,
+                                  size_t n_extra, uint64_t* export_scalars) {
   if (!acc) return fail(CURDLE_EINVAL, "null accumulator");
+  if (acc->submitted) return fail(CURDLE_EINVAL, "accumulation already submitted");
   const int idx = acc->slot;
   Slot& S = g_ctx.slots[idx];
   const size_t n_crs = acc->crs->n, n_inst = acc->n_inst, n_res = n_crs + n_inst, n = n_res + n_extra;
   auto body = [&]() -> int {
-    if (!out_jac || (n_checks && !checks) || (pool_len && !pool) || (n_extra && (!extra_points || !extra_scalars)))
+    if ((n_checks && !checks) || (pool_len && !pool) || (n_extra && (!extra_points || !extra_scalars)))
       return fail(CURDLE_EINVAL, "null argument");
     if (n_extra > CURDLE_DACC_MAX_EXTRA) return fail(CURDLE_EINVAL, "%zu loose bases exceed CURDLE_DACC_MAX_EXTRA", n_extra);
     // the descriptions come from the caller: every offset is checked before a kernel reads through it
@@ -1426,8 +1432,10 @@ extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks
       }
     }
     HIP_TRY(hipSetDevice(g_ctx.device));
+    acc->export_scalars = export_scalars;
+    acc->n_total = n;
     if (n == 0) {
-      set_out_infinity(out_jac);
+      acc->submitted = true;
       return CURDLE_OK;
     }
     // one pinned block: checks | pool | extra points | extra scalars
@@ -1459,8 +1467,51 @@ extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks
     if ((r = enqueue_slot(S, nullptr, S.scalars.p, off, 1, 0, 0, -1, st, st, st, /*latency_mode=*/true,
                           /*points28_ready=*/true)))
       return r;
+    acc->export_off = bytes;
+    acc->submitted = true;
+    return CURDLE_OK;
+  };
+  int rc = body();
+  if (rc) {  // a failed submission ends the accumulation, like a failed run
+    (void)hipStreamSynchronize(S.stream);
+    release_slot(idx);
+    delete acc;
+  }
+  return rc;
+}
+
+extern "C" int curdle_dacc_poll(curdle_dacc* acc, int* done) {
+  if (!acc || !done) return fail(CURDLE_EINVAL, "null argument");
+  if (!acc->submitted) return fail(CURDLE_EINVAL, "accumulation not submitted");
+  *done = 1;
+  if (acc->n_total == 0) return CURDLE_OK;
+  Slot& S = g_ctx.slots[acc->slot];
+  (void)hipSetDevice(g_ctx.device);
+  const hipError_t e = hipStreamQuery(S.run_stream);
+  if (e == hipErrorNotReady) {
+    *done = 0;
+    return CURDLE_OK;
+  }
+  if (e != hipSuccess) return fail(CURDLE_EHIP, "dacc poll: %s", hipGetErrorString(e));
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_dacc_wait(curdle_dacc* acc, uint64_t out_jac[18]) {
+  if (!acc) return fail(CURDLE_EINVAL, "null accumulator");
+  if (!acc->submitted) return fail(CURDLE_EINVAL, "accumulation not submitted");
+  const int idx = acc->slot;
+  Slot& S = g_ctx.slots[idx];
+  auto body = [&]() -> int {
+    if (!out_jac) return fail(CURDLE_EINVAL, "null argument");
+    if (acc->n_total == 0) {
+      set_out_infinity(out_jac);
+      return CURDLE_OK;
+    }
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    int r;
     if ((r = finish_slot(S, out_jac))) return r;
-    if (export_scalars && n_res) memcpy(export_scalars, h + bytes, n_res * 32);
+    const size_t n_res = acc->crs->n + acc->n_inst;
+    if (acc->export_scalars && n_res) memcpy(acc->export_scalars, (char*)S.h_stage[1] + acc->export_off, n_res * 32);
     return CURDLE_OK;
   };
   int rc = body();
@@ -1468,6 +1519,19 @@ extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks
   release_slot(idx);
   delete acc;
   return rc;
+}
+
+extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
+                               size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars,
+                               size_t n_extra, uint64_t out_jac[18], uint64_t* export_scalars) {
+  if (!acc) return fail(CURDLE_EINVAL, "null accumulator");
+  if (!out_jac) {
+    curdle_dacc_abort(acc);
+    return fail(CURDLE_EINVAL, "null argument");
+  }
+  int rc = curdle_dacc_submit(acc, checks, n_checks, pool, pool_len, extra_points, extra_scalars, n_extra, export_scalars);
+  if (rc) return rc;  // the submission already ended the accumulation
+  return curdle_dacc_wait(acc, out_jac);
 }
 
 // ---------------------------------------------------------------------------

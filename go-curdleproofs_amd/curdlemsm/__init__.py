@@ -61,7 +61,7 @@ SYMBOLS = [
     "curdle_g1_scalar_mul_batch",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error", "curdle_fr_inner_product",
     "curdle_dbases_create", "curdle_dbases_free", "curdle_dbases_size", "curdle_dbases_valid",
-    "curdle_dacc_begin", "curdle_dacc_run", "curdle_dacc_abort",
+    "curdle_dacc_begin", "curdle_dacc_run", "curdle_dacc_submit", "curdle_dacc_poll", "curdle_dacc_wait", "curdle_dacc_abort",
     "curdle_verify_set_device_acc", "curdle_verify_export_accumulator",
 ]
 

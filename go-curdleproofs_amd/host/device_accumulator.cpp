@@ -186,6 +186,44 @@ bool RunRecordedChecks(const CRS& crs, const std::vector<G1Affine>& inst, const 
   return Point::FromJac(out).IsInfinity();
 }
 
+RecordedChecksRun::~RecordedChecksRun() {
+  if (acc_) curdle_dacc_abort(acc_);
+}
+
+void RecordedChecksRun::Start(const CRS& crs, const std::vector<G1Affine>& inst, const std::vector<curdle_dacc_check>& checks,
+                              const std::vector<Scalar>& pool, const std::vector<G1Affine>& extra_points,
+                              const std::vector<Scalar>& extra_scalars) {
+  if (acc_) throw std::logic_error("a recorded-checks run is already in flight");
+  if (!crs.device) throw std::runtime_error("CRS without a device holder");
+  const curdle_dbases* bases = crs.device->Get(crs);
+  curdle_dacc* acc = nullptr;
+  int rc = curdle_dacc_begin(bases, reinterpret_cast<const uint64_t*>(inst.data()), inst.size(), &acc);
+  if (rc != CURDLE_OK) throw device_error("starting the device accumulator", rc);
+  rc = curdle_dacc_submit(acc, checks.data(), checks.size(), reinterpret_cast<const uint64_t*>(pool.data()), pool.size(),
+                          reinterpret_cast<const uint64_t*>(extra_points.data()),
+                          reinterpret_cast<const uint64_t*>(extra_scalars.data()), extra_points.size(), nullptr);
+  if (rc != CURDLE_OK) throw device_error("verifying msm accumulator: computing msm", rc);  // the submission ended it
+  acc_ = acc;
+}
+
+bool RecordedChecksRun::Done() {
+  if (!acc_) return true;
+  int done = 0;
+  const int rc = curdle_dacc_poll(acc_, &done);
+  if (rc != CURDLE_OK) throw device_error("verifying msm accumulator: computing msm", rc);
+  return done != 0;
+}
+
+bool RecordedChecksRun::Finish() {
+  if (!acc_) throw std::logic_error("no recorded-checks run in flight");
+  curdle_dacc* a = acc_;
+  acc_ = nullptr;  // wait() ends the accumulation whatever happens
+  uint64_t out[18];
+  const int rc = curdle_dacc_wait(a, out);
+  if (rc != CURDLE_OK) throw device_error("verifying msm accumulator: computing msm", rc);
+  return Point::FromJac(out).IsInfinity();
+}
+
 void DeviceSink::Check(const Terms& C, const VecExpr& x, const std::vector<BaseSeg>& segs,
                        const std::vector<LooseBase>& loose, common::Rand& rand, const char* what) {
   rec_.Check(C, x, segs, loose, rand, what);

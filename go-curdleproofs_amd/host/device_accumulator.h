@@ -77,6 +77,26 @@ bool RunRecordedChecks(const CRS& crs, const std::vector<G1Affine>& inst, const 
                        const std::vector<Scalar>& pool, const std::vector<G1Affine>& extra_points,
                        const std::vector<Scalar>& extra_scalars);
 
+// The same in two steps: Start queues the group's MSM and returns; Done() polls; Finish() waits
+// and gives the verdict.  The group holds one of the library's eight workspace slots from Start
+// to Finish, so a caller polls between its other work and finishes as soon as Done() says so.
+class RecordedChecksRun {
+ public:
+  RecordedChecksRun() = default;
+  ~RecordedChecksRun();
+  RecordedChecksRun(const RecordedChecksRun&) = delete;
+  RecordedChecksRun& operator=(const RecordedChecksRun&) = delete;
+  void Start(const CRS& crs, const std::vector<G1Affine>& inst, const std::vector<curdle_dacc_check>& checks,
+             const std::vector<Scalar>& pool, const std::vector<G1Affine>& extra_points,
+             const std::vector<Scalar>& extra_scalars);  // every argument is copied before it returns
+  bool Active() const { return acc_ != nullptr; }
+  bool Done();
+  bool Finish();
+
+ private:
+  curdle_dacc* acc_ = nullptr;
+};
+
 class DeviceSink : public CheckSink {
  public:
   DeviceSink(const CRS& crs, const std::vector<G1Affine>& Rs, const std::vector<G1Affine>& Ss,

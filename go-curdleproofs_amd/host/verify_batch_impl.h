@@ -174,14 +174,20 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
     std::vector<Scalar> pool, extra_scalars;
     std::vector<G1Affine> extra_points;
     std::vector<size_t> members;
-    auto settle = [&]() {
-      if (members.empty()) return;
-      const auto ts0 = std::chrono::steady_clock::now();
-      const bool all = RunRecordedChecks(crs, inst, checks, pool, extra_points, extra_scalars);
+    // A group's MSM runs while this worker verifies the proofs of its NEXT group: settle() only
+    // queues it (RecordedChecksRun::Start copies every argument), collect() takes the verdict --
+    // polled after every proof, because the group holds a workspace slot until then -- and only a
+    // group that failed is gone through member by member.
+    RecordedChecksRun run;
+    std::vector<size_t> in_flight;  // the members of the group `run` is computing
+    std::chrono::steady_clock::time_point run_t0;
+    auto collect = [&]() {
+      if (!run.Active()) return;
+      const bool all = run.Finish();
       if (BatchTrace())
-        fprintf(stderr, "[batch] group of %zu proofs (%zu instance points, %zu loose): %.2f ms\n", members.size(), inst.size(),
-                extra_points.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
-      for (size_t i : members) {
+        fprintf(stderr, "[batch] group of %zu proofs: verdict %.2f ms after its submission\n", in_flight.size(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - run_t0).count());
+      for (size_t i : in_flight) {
         if (all) {
           oks[i] = 1;
           continue;
@@ -199,6 +205,14 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
           oks[i] = 0;
         }
       }
+      in_flight.clear();
+    };
+    auto settle = [&]() {
+      if (members.empty()) return;
+      collect();  // at most one group in flight per worker
+      run_t0 = std::chrono::steady_clock::now();
+      run.Start(crs, inst, checks, pool, extra_points, extra_scalars);
+      in_flight.swap(members);
       inst.clear();
       checks.clear();
       pool.clear();
@@ -233,9 +247,12 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
         if (members.size() >= threshold || extra_points.size() + 512 > CURDLE_DACC_MAX_EXTRA) {
           settle();
           threshold = flush;
+        } else if (run.Active() && run.Done()) {
+          collect();
         }
       }
       settle();
+      collect();
     } catch (const alg::MsmError& e) {
       std::lock_guard<std::mutex> g(err_mu);
       if (!failed.exchange(true)) {

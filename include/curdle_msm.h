@@ -328,7 +328,18 @@ int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_points, siz
 int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
                     size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars, size_t n_extra,
                     uint64_t out_jac[CURDLE_G1_JAC_U64], uint64_t* export_scalars);
-void curdle_dacc_abort(curdle_dacc* acc); /* ends an accumulation without running it */
+/* The same in two steps, for a caller with work to do while the MSM runs (batch verification:
+ * a worker submits its group of proofs and goes on verifying the next ones): submit copies
+ * every argument and queues the kernels, poll says without blocking whether they are done
+ * (the accumulation holds one of the eight workspace slots until it is waited for: collect it
+ * soon after), wait hands out the result and ends the accumulation.  A failed submit ends it
+ * too.  export_scalars, if given to submit, must stay valid until wait. */
+int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
+                       size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars, size_t n_extra,
+                       uint64_t* export_scalars);
+int curdle_dacc_poll(curdle_dacc* acc, int* done);
+int curdle_dacc_wait(curdle_dacc* acc, uint64_t out_jac[CURDLE_G1_JAC_U64]);
+void curdle_dacc_abort(curdle_dacc* acc); /* ends an accumulation without its result (submitted or not) */
 
 /* curdleproof.Verify keeps its accumulator on the device by default (the section above);
  * 0 moves it back to the host mirror of msmaccumulator (same accept bit).  Returns the

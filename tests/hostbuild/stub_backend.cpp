@@ -164,6 +164,8 @@ struct curdle_dbases {
 struct curdle_dacc {
   const curdle_dbases* crs;
   std::vector<G1Affine> inst;
+  bool submitted = false;
+  uint64_t result[18] = {0};
 };
 extern "C" int curdle_dbases_create(const uint64_t* points, size_t n, curdle_dbases** out) {
   curdle_dbases* b = new curdle_dbases();
@@ -184,9 +186,12 @@ extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_
   return CURDLE_OK;
 }
 extern "C" void curdle_dacc_abort(curdle_dacc* acc) { delete acc; }
-extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
-                               size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars,
-                               size_t n_extra, uint64_t out_jac[18], uint64_t* export_scalars) {
+// submit computes at once (there is nothing to overlap with on the host backend); poll is always
+// done; wait hands the stored result out
+extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
+                                  size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars,
+                                  size_t n_extra, uint64_t* export_scalars) {
+  uint64_t* out_jac = acc->result;
   const size_t n_crs = acc->crs->pts.size(), n_inst = acc->inst.size(), n_res = n_crs + n_inst;
   auto P = [&](uint32_t off) {
     alg::Scalar s;
@@ -235,7 +240,27 @@ extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks
     }
     msm_naive(reinterpret_cast<const uint64_t*>(pts.data()), sc.data(), pts.size(), out_jac);
     if (export_scalars && n_res) memcpy(export_scalars, slots.data(), n_res * 32);
+    acc->submitted = true;
+  } else {
+    delete acc;  // a failed submission ends the accumulation
   }
-  delete acc;
   return rc;
+}
+extern "C" int curdle_dacc_poll(curdle_dacc* acc, int* done) {
+  if (!acc || !done || !acc->submitted) return curdle_set_last_error(CURDLE_EINVAL, "accumulation not submitted");
+  *done = 1;
+  return CURDLE_OK;
+}
+extern "C" int curdle_dacc_wait(curdle_dacc* acc, uint64_t out_jac[18]) {
+  if (!acc || !out_jac || !acc->submitted) return curdle_set_last_error(CURDLE_EINVAL, "accumulation not submitted");
+  memcpy(out_jac, acc->result, sizeof(acc->result));
+  delete acc;
+  return CURDLE_OK;
+}
+extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
+                               size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars,
+                               size_t n_extra, uint64_t out_jac[18], uint64_t* export_scalars) {
+  int rc = curdle_dacc_submit(acc, checks, n_checks, pool, pool_len, extra_points, extra_scalars, n_extra, export_scalars);
+  if (rc) return rc;
+  return curdle_dacc_wait(acc, out_jac);
 }
