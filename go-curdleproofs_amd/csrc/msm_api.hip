@@ -113,9 +113,10 @@ struct DSlot {
   hipEvent_t uploaded = nullptr;      // the records are in device memory
   hipEvent_t decoded = nullptr;       // the decoding kernel is done
   Buf in, out, status, sub;
-  std::vector<uint8_t> h_sub;         // finish(): the subgroup verdicts on the host
   void* h_in = nullptr;  // pinned staging of the compressed records
   size_t h_in_cap = 0;
+  void* h_out = nullptr;  // pinned staging of what comes back: n x 96 B of points, 2 x n status bytes
+  size_t h_out_cap = 0;
   bool busy = false;
   bool claimed = false;
   uint32_t gen = 0;
@@ -773,21 +774,37 @@ extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status);
 // begin = start + points.
 namespace {
 // A decode context's streams, made on its first use (see init_locked: unused streams must not
-// take hardware queues).  The decoding stream at the HIGHEST priority: its kernels are a few
-// waves (one serial chain per point) that the caller's MSM must run beside, not behind --
-// measured on one verification from bytes (ell = 252, default 4 hardware queues): the
-// accumulator's MSM takes 0.46 ms next to a high-priority subgroup test, 0.88 ms queued behind
-// a low-priority one (profiles/r02_verify_from_bytes_queues.txt).  CURDLE_DECODE_PRIO=0
-// restores the lowest priority, =2 the default one.
+// take hardware queues), at the same (lowest) priority as every other stream of the library.
+// While the subgroup test still ran BEHIND the square roots, for 0.65 ms beside the caller's MSM,
+// the highest priority kept that MSM from queueing behind it (0.46 against 0.88 ms,
+// profiles/r02_verify_from_bytes_queues.txt); since the two chains overlap the test is over when
+// the MSM starts, priorities no longer change one verification's latency (1.14-1.17 ms at ell =
+// 252 in all six combinations of 4 / 16 hardware queues and the three priorities), and with
+// eight threads verifying at once the lowest one measured best.  CURDLE_DECODE_PRIO=1 selects
+// the highest, =2 the default one.
 int ensure_dslot_streams(DSlot& d) {
   if (d.stream) return CURDLE_OK;
+  // every decode context at once, under the lock: creating a stream (its hardware queue) takes
+  // tens of milliseconds, and a second context first used under load would put that into some
+  // caller's verification (seen as 354 instead of 1,300 Whisk verifications/s from four threads)
+  std::lock_guard<std::mutex> g(g_ctx.mu);
   const char* dp = getenv("CURDLE_DECODE_PRIO");
-  const int dprio = dp ? (atoi(dp) == 0 ? g_ctx.prio_least : atoi(dp) == 2 ? 0 : g_ctx.prio_greatest) : g_ctx.prio_greatest;
-  HIP_TRY(hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, dprio));
-  HIP_TRY(hipStreamCreateWithPriority(&d.sub_stream, hipStreamNonBlocking, dprio));
-  HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&d.uploaded, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&d.decoded, hipEventDisableTiming));
+  const int dprio = dp ? (atoi(dp) == 1 ? g_ctx.prio_greatest : atoi(dp) == 2 ? 0 : g_ctx.prio_least) : g_ctx.prio_least;
+  for (DSlot& x : g_ctx.dslots) {
+    if (x.stream) continue;
+    hipStream_t a = nullptr, b = nullptr, c = nullptr;
+    hipEvent_t e1 = nullptr, e2 = nullptr;
+    HIP_TRY(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, dprio));
+    HIP_TRY(hipStreamCreateWithPriority(&b, hipStreamNonBlocking, dprio));
+    HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    x.sub_stream = b;
+    x.copy_stream = c;
+    x.uploaded = e1;
+    x.decoded = e2;
+    x.stream = a;  // last: the unlocked fast path above tests it
+  }
   return CURDLE_OK;
 }
 }  // namespace
@@ -835,6 +852,13 @@ extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* tick
       D.h_in_cap = 0;
       HIP_TRY(hipHostMalloc(&D.h_in, grow_size(n * 48), hipHostMallocDefault));
       D.h_in_cap = grow_size(n * 48);
+    }
+    if (D.h_out_cap < n * 98) {
+      if (D.h_out) HIP_TRY(hipHostFree(D.h_out));
+      D.h_out = nullptr;
+      D.h_out_cap = 0;
+      HIP_TRY(hipHostMalloc(&D.h_out, grow_size(n * 98), hipHostMallocDefault));
+      D.h_out_cap = grow_size(n * 98);
     }
     memcpy(D.h_in, in, n * 48);
     HIP_TRY(hipMemcpyAsync(D.in.p, D.h_in, n * 48, hipMemcpyHostToDevice, D.stream));
@@ -884,10 +908,15 @@ extern "C" int curdle_g1_decompress_points(int ticket, uint64_t* out_affine, uin
     HIP_TRY(hipSetDevice(g_ctx.device));
     if (n == 0) return CURDLE_OK;
     // encoding / curve verdicts only: the subgroup test's arrive with curdle_g1_decompress_finish
+    // through pinned staging: a copy into the caller's pageable memory goes through the runtime's
+    // shared bounce buffers, which concurrent verifications then queue for
+    uint8_t* h = static_cast<uint8_t*>(D.h_out);
     HIP_TRY(hipStreamWaitEvent(D.copy_stream, D.decoded, 0));
-    HIP_TRY(hipMemcpyAsync(out_affine, D.out.p, n * 96, hipMemcpyDeviceToHost, D.copy_stream));
-    HIP_TRY(hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.copy_stream));
+    HIP_TRY(hipMemcpyAsync(h, D.out.p, n * 96, hipMemcpyDeviceToHost, D.copy_stream));
+    HIP_TRY(hipMemcpyAsync(h + n * 96, D.status.p, n, hipMemcpyDeviceToHost, D.copy_stream));
     HIP_TRY(hipStreamSynchronize(D.copy_stream));
+    memcpy(out_affine, h, n * 96);
+    memcpy(status, h + n * 96, n);
     return CURDLE_OK;
   };
   int rc = body();
@@ -923,18 +952,18 @@ extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
   const size_t n = D.n;
   int rc = CURDLE_OK;
   hipError_t he = hipSetDevice(g_ctx.device);
+  uint8_t* h = static_cast<uint8_t*>(D.h_out);  // [0, n): statuses, [n, 2n): subgroup verdicts (the points' block is free again)
+  if (he == hipSuccess) he = hipStreamSynchronize(D.copy_stream);
   if (he == hipSuccess && n && status) {
-    D.h_sub.resize(n);
-    he = hipMemcpyAsync(status, D.status.p, n, hipMemcpyDeviceToHost, D.stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(D.h_sub.data(), D.sub.p, n, hipMemcpyDeviceToHost, D.sub_stream);
+    he = hipMemcpyAsync(h, D.status.p, n, hipMemcpyDeviceToHost, D.stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(h + n, D.sub.p, n, hipMemcpyDeviceToHost, D.sub_stream);
   }
   if (he == hipSuccess) he = hipStreamSynchronize(D.stream);
   if (he == hipSuccess) he = hipStreamSynchronize(D.sub_stream);
-  if (he == hipSuccess) he = hipStreamSynchronize(D.copy_stream);
   if (he != hipSuccess) rc = fail(CURDLE_EHIP, "decompress finish: %s", hipGetErrorString(he));
   if (rc == CURDLE_OK && n && status)  // a decoded point outside the subgroup: the one verdict the points came without
     for (size_t i = 0; i < n; i++)
-      if (status[i] == CURDLE_DECODE_OK && !D.h_sub[i]) status[i] = CURDLE_DECODE_NOT_IN_SUBGROUP;
+      status[i] = (h[i] == CURDLE_DECODE_OK && !h[n + i]) ? (uint8_t)CURDLE_DECODE_NOT_IN_SUBGROUP : h[i];
   {
     std::lock_guard<std::mutex> g(g_ctx.mu);
     D.busy = false;
@@ -1013,6 +1042,9 @@ extern "C" int curdle_shutdown(void) {
     if (d.h_in) (void)hipHostFree(d.h_in);
     d.h_in = nullptr;
     d.h_in_cap = 0;
+    if (d.h_out) (void)hipHostFree(d.h_out);
+    d.h_out = nullptr;
+    d.h_out_cap = 0;
     if (d.stream) (void)hipStreamDestroy(d.stream);
     d.stream = nullptr;
     if (d.copy_stream) {
