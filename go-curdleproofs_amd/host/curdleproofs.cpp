@@ -1383,7 +1383,7 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
       M = Point::FromJac(it.M);
     }
   } src(items);
-  src.ahead = std::make_unique<DecodeAhead>(k, DecodeAheadChunk(k), DecodeAheadProducers(),
+  src.ahead = std::make_unique<DecodeAhead>(k, DecodeAheadChunk(k, k ? items[0].proof_len / 48 : 0), DecodeAheadProducers(),
                                             [&src](size_t i, PointDecoder& dec) { src.Scan(i, dec); });
   try {
     return VerifyBatchCore(crs, k, src, rand, BatchWorkers(nthreads));

@@ -118,10 +118,15 @@ class DecodeAhead {
 // of SIMD slots -- measured at k = 1,024 (profiles/r02_batch_chunk_sweep.txt): ell = 252
 // verify_batch 58-66 ms at 64 proofs per chunk, 140-180 ms at 128, 68-82 ms undivided; Whisk
 // 63 ms at 64, 97-111 ms undivided.  Two producers (a third takes a core from the workers).
-inline size_t DecodeAheadChunk(size_t k) {
+inline size_t DecodeAheadChunk(size_t k, size_t points_per_proof = 0) {
   if (const char* e = getenv("CURDLE_BATCH_CHUNK")) return atoi(e) < 1 ? 1 : (size_t)atoi(e);  // tests, tuning
-  const size_t c = k / 4;
-  return c < 16 ? 16 : c > 64 ? 64 : c;
+  size_t c = k / 4;
+  c = c < 16 ? 16 : c > 64 ? 64 : c;
+  // ... and at most 32,768 points: up to there a decoding is the pair of concurrent four-lane
+  // kernels (0.7 ms) instead of the fused one-lane kernel (2.2 ms for the 37,440 points of 64
+  // Whisk proofs) -- 1,024 Whisk proofs: 39-41 ms at 64 proofs per chunk, 33 ms at 56
+  if (points_per_proof && c * points_per_proof > 32768) c = 32768 / points_per_proof;
+  return c < 16 ? 16 : c;
 }
 inline int DecodeAheadProducers() {
   if (const char* e = getenv("CURDLE_BATCH_PRODUCERS")) return atoi(e) < 1 ? 1 : atoi(e);

@@ -249,7 +249,9 @@ std::vector<int> IsValidWhiskShuffleProofBatch(const proto::CRS& crs, const std:
     return e && *e && *e != '0';
   }();
   const auto t0 = std::chrono::steady_clock::now();
-  src.ahead = std::make_unique<proto::DecodeAhead>(k, proto::DecodeAheadChunk(k), proto::DecodeAheadProducers(),
+  const size_t points_per_proof = k ? WHISK_SHUFFLE_PROOF_SIZE / 48 + 4 * items[0].n : 0;  // an upper bound
+  const size_t chunk = proto::DecodeAheadChunk(k, points_per_proof);
+  src.ahead = std::make_unique<proto::DecodeAhead>(k, chunk, proto::DecodeAheadProducers(),
                                                    [&src](size_t i, proto::PointDecoder& dec) { src.Scan(i, dec); });
   std::vector<int> oks;
   try {
@@ -260,7 +262,7 @@ std::vector<int> IsValidWhiskShuffleProofBatch(const proto::CRS& crs, const std:
   }
   if (trace) {
     const auto t1 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[whisk batch] k=%zu, chunks of %zu, %d threads: %.2f ms\n", k, proto::DecodeAheadChunk(k), nthreads,
+    fprintf(stderr, "[whisk batch] k=%zu, chunks of %zu, %d threads: %.2f ms\n", k, chunk, nthreads,
             std::chrono::duration<double, std::milli>(t1 - t0).count());
   }
   return oks;
