@@ -21,9 +21,10 @@ for _ in range(3):
     assert cm.whisk_is_valid_shuffle_proof(crs, pre, post, proof, cm.Rand(1))
 out = []
 for T in (1, 2, 3, 4, 8, 16):
+    rands = [[cm.Rand(1000 + 50 * t + i) for i in range(per)] for t in range(T)]  # made outside the timed region
     def worker(tid):
         for i in range(per):
-            assert cm.whisk_is_valid_shuffle_proof(crs, pre, post, proof, cm.Rand(1000 + 50 * tid + i))
+            assert cm.whisk_is_valid_shuffle_proof(crs, pre, post, proof, rands[tid][i])
     # a first round untimed: workspace slots and their buffers are made on first use, and T
     # threads reach slots no smaller thread count touched
     warm = [threading.Thread(target=lambda tid=t: [cm.whisk_is_valid_shuffle_proof(crs, pre, post, proof, cm.Rand(7 + tid)) for _ in range(4)])
