@@ -145,6 +145,42 @@ def test_device_accumulator_abi_rejects_malformed_descriptions(gpu):
     assert run([1, 4, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 8, 0]) == gpu.EINVAL       # segment past the vector
     assert run([2, 8, 2, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 8, 0]) == gpu.EINVAL       # 8 structured elements, 2^2 folds
     assert run([7, 8, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 8, 0]) == gpu.EINVAL       # unknown kind
+
+    # the two-step form: submit, poll until done, wait -- the same sum; misuse is refused
+    lib.curdle_dacc_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]
+    lib.curdle_dacc_poll.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.curdle_dacc_wait.argtypes = [C.c_void_p, C.c_void_p]
+    lib.curdle_dacc_abort.argtypes = [C.c_void_p]
+    want = out.copy()
+    assert run(good) == 0 and (out == want).all() and want.any()
+    chk = np.zeros(35, dtype=np.uint32)
+    chk[:len(good)] = good
+    acc = C.c_void_p()
+    done = C.c_int(0)
+    assert lib.curdle_dacc_begin(bases, pts.ctypes.data, 4, C.byref(acc)) == 0
+    assert lib.curdle_dacc_poll(acc, C.byref(done)) == gpu.EINVAL                  # nothing submitted yet
+    assert lib.curdle_dacc_wait(acc, out.ctypes.data) == gpu.EINVAL
+    assert lib.curdle_dacc_submit(acc, chk.ctypes.data, 1, pool.ctypes.data, 4, None, None, 0, None) == 0
+    assert lib.curdle_dacc_submit(acc, chk.ctypes.data, 1, pool.ctypes.data, 4, None, None, 0, None) == gpu.EINVAL  # twice
+    for _ in range(100000):
+        assert lib.curdle_dacc_poll(acc, C.byref(done)) == 0
+        if done.value:
+            break
+    assert done.value == 1
+    two_step = np.zeros(18, dtype=np.uint64)
+    assert lib.curdle_dacc_wait(acc, two_step.ctypes.data) == 0
+    assert (two_step == want).all()
+    # a submitted accumulation can be dropped; a malformed submission ends it by itself
+    assert lib.curdle_dacc_begin(bases, pts.ctypes.data, 4, C.byref(acc)) == 0
+    assert lib.curdle_dacc_submit(acc, chk.ctypes.data, 1, pool.ctypes.data, 4, None, None, 0, None) == 0
+    lib.curdle_dacc_abort(acc)
+    bad = chk.copy()
+    bad[4] = 9
+    assert lib.curdle_dacc_begin(bases, pts.ctypes.data, 4, C.byref(acc)) == 0
+    assert lib.curdle_dacc_submit(acc, bad.ctypes.data, 1, pool.ctypes.data, 4, None, None, 0, None) == gpu.EINVAL
+    for _ in range(12):  # ... and no workspace slot leaked on any of those paths (there are eight)
+        assert run(good) == 0
     lib.curdle_dbases_free(bases)
 
 
