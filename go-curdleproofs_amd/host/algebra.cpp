@@ -1,6 +1,8 @@
 // Fr / G1 value types, wire encodings and the MSM funnel -- see algebra.h.
 #include "algebra.h"
 
+#include <stdlib.h>
+
 #include "host_ops.h"
 
 #include <stdexcept>
@@ -225,6 +227,25 @@ void CompressAffine(const G1Affine& a, uint8_t out[48]) {
   }
   out[0] |= 0x80;
   if (y_is_larger(a.y)) out[0] |= 0x20;
+}
+
+void CompressAffineAvx512(const G1Affine* pts, size_t n, uint8_t* out);  // compress_avx512.cpp
+
+void CompressAffineBatch(const G1Affine* pts, size_t n, uint8_t* out) {
+  static const bool ifma = [] {
+    const char* e = getenv("CURDLE_NO_IFMA");  // A/B measurements
+    if (e && *e && *e != '0') return false;
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512ifma") && __builtin_cpu_supports("avx512vl") &&
+           __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq");
+  }();
+  if (!ifma || n < 8) {
+    for (size_t i = 0; i < n; i++) CompressAffine(pts[i], out + 48 * i);
+    return;
+  }
+  CompressAffineAvx512(pts, n, out);
+  for (size_t i = 0; i < n; i++)  // the vector routine knows no point at infinity
+    if (g1_affine_is_inf(pts[i])) CompressAffine(pts[i], out + 48 * i);
 }
 
 FixedBase::FixedBase(const G1Affine& p) : table_(32 * 255) { curdle_host_fixed_base_table(table_.data(), &p); }

@@ -139,6 +139,10 @@ std::vector<G1Affine> BatchToAffine(const std::vector<Point>& pts);   // BatchJa
 // gnark G1Affine.Bytes() of an affine point without the round trip through Point: two
 // Montgomery reductions (x to canonical bytes, y for the sign bit).
 void CompressAffine(const G1Affine& a, uint8_t out[48]);
+// n points -> 48 n bytes.  Eight at a time with AVX-512 IFMA where the CPU has it (the verifier
+// hashes 4 ell instance points per verification), the scalar routine otherwise and for the tail
+// of fewer than eight.
+void CompressAffineBatch(const G1Affine* pts, size_t n, uint8_t* out);
 
 // k * P for a base that never changes (CRS points): 8-bit windows precomputed once, then at
 // most 32 mixed additions per multiplication instead of ~255 doublings + 64 additions.

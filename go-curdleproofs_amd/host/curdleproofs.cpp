@@ -1152,8 +1152,7 @@ void StartVerify(VerifyPrelude& pre, const std::vector<G1Affine>& Rs, const std:
   if (Ss.size() != ell || Ts.size() != ell || Us.size() != ell) throw err("instance vectors differ in length");
   std::vector<uint8_t> b(48 * (4 * ell + 1));
   const std::vector<G1Affine>* v[4] = {&Rs, &Ss, &Ts, &Us};
-  for (int k = 0; k < 4; k++)
-    for (size_t i = 0; i < ell; i++) alg::CompressAffine((*v[k])[i], &b[48 * (k * ell + i)]);
+  for (int k = 0; k < 4; k++) alg::CompressAffineBatch(v[k]->data(), ell, &b[48 * k * ell]);
   M.Compressed(&b[48 * 4 * ell]);
   StartVerify(pre, ell, &b[0], &b[48 * ell], &b[96 * ell], &b[144 * ell], &b[192 * ell]);
 }

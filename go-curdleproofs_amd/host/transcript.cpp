@@ -123,11 +123,9 @@ void Transcript::AppendPoints(const std::string& label, const std::vector<alg::P
   for (const auto& p : points) AppendPoint(label, p);  // :25-30 (normalise, then one message per point)
 }
 void Transcript::AppendPointsAffine(const std::string& label, const std::vector<G1Affine>& points) {
-  for (const auto& a : points) {
-    uint8_t b[48];
-    alg::CompressAffine(a, b);
-    inner_.AppendMessage(label, b, 48);
-  }
+  std::vector<uint8_t> b(48 * points.size());
+  alg::CompressAffineBatch(points.data(), points.size(), b.data());
+  AppendCompressed(label, b.data(), points.size());
 }
 void Transcript::AppendCompressed(const std::string& label, const uint8_t* records, size_t count) {
   for (size_t i = 0; i < count; i++) inner_.AppendMessage(label, records + 48 * i, 48);

@@ -7,6 +7,7 @@
 //   host_flow flow <ell>          Prove -> serialise -> Verify (deferred and eager), soundness
 //                                 flips of curdleproof_test.go:48-182, encode/decode round trip
 //   host_flow whisk 0             Whisk shuffle proof: generate, verify (both routes), tampered trackers
+//   host_flow compress 0          the vectorised point compressor against the scalar one
 //   host_flow fuzz <ell> <iters>  attacker-controlled bytes into every parser: bit flips,
 //                                 truncations, random slice prefixes, random blobs
 //   host_flow time <ell> <reps>   host share of Verify (everything but the final MSM), for gprof
@@ -102,6 +103,48 @@ static bool VerifyLazyBytes(const Instance& in, const std::vector<uint8_t>& byte
       exit(1);                                                               \
     }                                                                        \
   } while (0)
+
+// alg::CompressAffineBatch (AVX-512 IFMA, eight points per step, where the CPU has it) against
+// the scalar CompressAffine: random points, every tail length, infinity, coordinates at the
+// edges of the field
+static int CompressCheck() {
+  common::Rand r(99);
+  std::vector<G1Affine> pts;
+  r.GetG1Affines(67, pts);
+  pts[3] = G1Affine{};   // infinity
+  pts[40] = G1Affine{};
+  // (x, y) pairs that are not curve points but exercise the reductions: Montgomery images of 0, 1, p - 1, (p - 1) / 2, (p + 1) / 2
+  {
+    alg::Point g = alg::Point::Generator();
+    G1Affine ga = g.Affine();
+    G1Affine t = ga;
+    memset(&t.x, 0xff, sizeof(t.x));
+    t.x.l[11] = 0x0a0111eau;  // a large value below p in Montgomery form
+    pts[7] = t;
+    t = ga;
+    memset(&t.y, 0, sizeof(t.y));
+    t.y.l[0] = 1;
+    pts[8] = t;
+  }
+  for (size_t n = 0; n <= pts.size(); n++) {
+    std::vector<uint8_t> a(48 * n + 1, 0xAB), b(48 * n + 1, 0xAB);
+    alg::CompressAffineBatch(pts.data(), n, a.data());
+    for (size_t i = 0; i < n; i++) alg::CompressAffine(pts[i], &b[48 * i]);
+    CHECK(a == b);
+  }
+  // y and p - y: exactly one of them is "larger"
+  for (size_t i = 0; i < 16; i++) {
+    if (g1_affine_is_inf(pts[i])) continue;
+    alg::Point neg = alg::Point::FromAffine(pts[i]).Neg();
+    G1Affine both[8];
+    for (int k = 0; k < 8; k++) both[k] = (k & 1) ? neg.Affine() : pts[i];
+    uint8_t out[8 * 48];
+    alg::CompressAffineBatch(both, 8, out);
+    CHECK(((out[0] ^ out[48]) & 0x20) == 0x20);
+  }
+  printf("compress: batch == scalar for every length up to %zu\n", pts.size());
+  return 0;
+}
 
 static int Flow(size_t ell) {
   Instance in = Make(ell, 7);
@@ -465,6 +508,7 @@ int main(int argc, char** argv) {
   try {
     if (mode == "flow") return Flow(ell);
     if (mode == "whisk") return WhiskFlow();
+    if (mode == "compress") return CompressCheck();
     if (mode == "fuzz") return Fuzz(ell, argc > 3 ? atoi(argv[3]) : 200);
     if (mode == "time") return Time(ell, argc > 3 ? atoi(argv[3]) : 20);
     if (mode == "timedev") return TimeDevicePath(ell, argc > 3 ? atoi(argv[3]) : 20);

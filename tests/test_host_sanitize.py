@@ -35,6 +35,11 @@ def test_protocol_flow_under_asan_ubsan(harness):
     assert "mirror == device accumulator, batch: ok" in out
 
 
+def test_vectorised_point_compression_matches_scalar(harness):
+    out = _run(harness, "compress", "0")
+    assert "batch == scalar" in out
+
+
 def test_whisk_shuffle_flow_under_asan_ubsan(harness):
     out = _run(harness, "whisk", "0")
     assert "both routes: ok" in out
