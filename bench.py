@@ -333,8 +333,8 @@ def main():
             "roofline": roofline,
         }
         # the verification leg BEFORE the CPU baseline: sixteen saturated host threads right in
-        # front of a latency measurement run into the box's CPU quota (observed: 870 instead of
-        # 980 verifies/s)
+        # front of a latency measurement run into the box's CPU quota (observed: 12 % fewer
+        # verifies/s)
         if world == 1 and not args.no_verify and args.logn == 20:
             out["verify"] = verify_leg(cm, 200, 20)
         if world == 1 and not args.no_cpu_baseline:
