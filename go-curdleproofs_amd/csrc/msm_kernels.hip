@@ -543,19 +543,6 @@ __global__ void __launch_bounds__(kBlock, 2)
   if (((tid >> 2) & (p.G - 1)) == 0 && live) q28::store(&partials[q / p.G], acc);
 }
 
-__device__ __forceinline__ void write_window_sum(const X28& acc, G1XYZZ* winsums, X28* winsums28, const MsmPlan& p,
-                                                 u32 j, u32 lw) {
-  const u32 nw = p.win_end - p.win_begin;
-  if (!p.gpu_combine) {
-    G1XYZZ o;
-    d28::to_gnark(o, acc);
-    u32* dst = reinterpret_cast<u32*>(&winsums[(size_t)j * nw + lw]);
-    const u32* src = reinterpret_cast<const u32*>(&o);
-    for (int q = 0; q < 48; q++) dst[q] = src[q];
-  } else {
-    d28::store(&winsums28[(size_t)j * nw + lw], acc);
-  }
-}
 
 // Window sums from the group partials.  A window owns nseg / G consecutive
 // partials.  Wide windows (many partials): one 64-quad block per (window, MSM)
@@ -603,20 +590,21 @@ __global__ void __launch_bounds__(kBlock, 2)
 __global__ void __launch_bounds__(kBlock, 2)
     k_window_sum_flat(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28,
                       MsmPlan p) {
+  // one quad per window (an addition is 4 product steps against a single lane's 14)
   const u32 nw = p.win_end - p.win_begin;
-  const u32 gw = blockIdx.x * kBlock + threadIdx.x;
-  if (gw >= p.kr * nw) return;
+  const u32 gw = (blockIdx.x * kBlock + threadIdx.x) >> 2;
+  if (gw >= p.kr * nw) return;  // whole quads leave together
   const u32 j = gw / nw, lw = gw - j * nw;
   const u32 w = p.win_begin + lw;
   const u32 np = p.nbkt[w] / p.seg / p.G;
   const X28* pw = partials + ((size_t)j * p.NS + p.base[w] / p.seg) / p.G;
-  X28 acc, b;
-  d28::load(acc, &pw[0]);
+  F28 acc, b;
+  q28::load(acc, &pw[0]);
   for (u32 k = 1; k < np; k++) {
-    d28::load(b, &pw[k]);
-    d28::add(acc, b);
+    q28::load(b, &pw[k]);
+    q28::add(acc, b);
   }
-  write_window_sum(acc, winsums, winsums28, p, j, lw);
+  write_window_sum_quad(acc, winsums, winsums28, p, j, lw);
 }
 
 // Batched calls: one quad per MSM runs the Horner pass over its window sums (what the host
@@ -760,7 +748,7 @@ hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream
     hipLaunchKernelGGL(k_window_sum_wide_quad, dim3(nw, p.kr), dim3(kBlock), 0, stream,
                        reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
   else
-    hipLaunchKernelGGL(k_window_sum_flat, dim3(cdiv((u64)p.kr * nw, kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(k_window_sum_flat, dim3(cdiv((u64)p.kr * nw, kBlock / 4)), dim3(kBlock), 0, stream,
                        reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
   return hipGetLastError();
 }
