@@ -344,7 +344,8 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // small MSMs are latency-bound on the lane's chain of L mixed additions: halve it while the
   // launch stays far below one round of the chip (every lane emits at least one fragment,
   // which the bucket reduce has to add, so not below 4)
-  const uint64_t Lmin = entries <= 8 * 65536 ? 4 : 8;
+  uint64_t Lmin = entries <= 8 * 65536 ? 4 : 8;
+  if (const char* env = getenv("CURDLE_SEG_LEN_MIN")) Lmin = (uint64_t)atoi(env) < 1 ? 1 : (uint64_t)atoi(env);
   if (L < Lmin) L = Lmin;
   if (L > 128) L = 128;
   // beyond ~2^25 pairs even 128 positions per lane leave more than 4M lanes and cut a bucket
