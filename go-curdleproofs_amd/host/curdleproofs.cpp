@@ -365,6 +365,7 @@ Point Reader::GetPoint(const char* what) {
     }
   } else if (decoded) {
     if (!decoded->Get(decoded_pos++, &out)) throw err(std::string("decoding ") + what + ": invalid point");
+    if (keep_wire) out.wire = p;
   } else if (!Point::FromCompressed(p, &out, subgroup_check)) {
     throw err(std::string("decoding ") + what + ": invalid point");
   }
@@ -1370,8 +1371,10 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
       Reader r(items[i].proof, items[i].proof_len, true);
       r.decoded = &ahead->Wait(i);
       r.decoded_pos = first_point[i];
+      r.keep_wire = true;  // the proof value lives inside this call, like the caller's bytes
       return Proof::FromReader(r);
     }
+    bool Prelude(size_t, VerifyPrelude&) const { return false; }  // the instance arrives decoded
     void Instance(size_t i, std::vector<G1Affine>& Rs, std::vector<G1Affine>& Ss, std::vector<G1Affine>& Ts,
                   std::vector<G1Affine>& Us, Point& M) const {
       const BatchItem& it = items[i];

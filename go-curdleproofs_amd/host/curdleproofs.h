@@ -93,6 +93,10 @@ struct Reader {
   bool lazy = false;
   const PointDecoder* decoded = nullptr;
   size_t decoded_pos = 0;
+  // with `decoded`: the points also keep a pointer to their wire record, which the transcript
+  // then absorbs as it is instead of compressing the point again.  Only for callers whose proof
+  // value does not outlive the bytes (the batch verifiers).
+  bool keep_wire = false;
   Reader(const uint8_t* data, size_t len, bool subgroup = false) : p(data), left(len), subgroup_check(subgroup) {}
   Point GetPoint(const char* what);
   Scalar GetScalar(const char* what);

@@ -236,7 +236,9 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
           common::Rand r(seeds[i]);
           Point M;
           src.Instance(i, Rs, Ss, Ts, Us, M);
-          pre = VerifyWithSink(p, crs, Rs, Ss, Ts, Us, M, r, rec);
+          VerifyPrelude from_bytes;  // a source that has the instance's encodings starts the transcript from them
+          const bool have = src.Prelude(i, from_bytes);
+          pre = VerifyWithSink(p, crs, Rs, Ss, Ts, Us, M, r, rec, have ? &from_bytes : nullptr);
         } catch (const alg::MsmError&) {
           throw;
         } catch (const std::runtime_error&) {

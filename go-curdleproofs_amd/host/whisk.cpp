@@ -224,8 +224,22 @@ std::vector<int> IsValidWhiskShuffleProofBatch(const proto::CRS& crs, const std:
       proto::Reader r(items[i].proof, WHISK_SHUFFLE_PROOF_SIZE, true);
       r.decoded = &ahead->Wait(i);
       r.decoded_pos = first_point[i];
+      r.keep_wire = true;  // the proof value lives inside this call, like the caller's bytes
       r.GetPoint("M");
       return proto::Proof::FromReader(r);
+    }
+    // curdleproof.go:217-224 from the trackers' own bytes (a valid record is its point's encoding)
+    bool Prelude(size_t i, proto::VerifyPrelude& pre) const {
+      const size_t n = items[i].n;
+      std::vector<uint8_t> b(4 * n * G1POINT_SIZE);
+      for (size_t t = 0; t < n; t++) {
+        memcpy(&b[48 * t], items[i].preST[t].rG, 48);
+        memcpy(&b[48 * (n + t)], items[i].preST[t].krG, 48);
+        memcpy(&b[48 * (2 * n + t)], items[i].postST[t].rG, 48);
+        memcpy(&b[48 * (3 * n + t)], items[i].postST[t].krG, 48);
+      }
+      proto::StartVerify(pre, n, &b[0], &b[48 * n], &b[96 * n], &b[144 * n], items[i].proof);  // M is the proof's first record
+      return true;
     }
     void Instance(size_t i, std::vector<G1Affine>& Rs, std::vector<G1Affine>& Ss, std::vector<G1Affine>& Ts,
                   std::vector<G1Affine>& Us, Point& M) {
