@@ -430,7 +430,26 @@ __device__ __forceinline__ void dbl(X28& p) {
 
 // acc += (x2, y2), affine with x2 < 2p, y2 < 4p + (a negated y is 4p - y), limbs
 // < 2^30, not infinity.  madd-2008-s with the exceptional cases.
+// INLINE: the eight products of the main path inlined instead of called.  The out-of-line
+// products cost 28 register moves per call to put the operands where the callee wants them --
+// 624 v_mov per mixed addition, 7 % of its issue slots -- so the ONE addition site of
+// k_accumulate inlines them (2.50 -> 2.27-2.35 ms at N = 2^20, 342 -> 360 M pairs/s; the ~45 KB
+// loop body still fits the instruction cache, which round 1 had assumed it would not); every
+// other kernel has several addition sites and keeps the calls.
+template <bool INLINE = false>
 __device__ __forceinline__ void madd(X28& acc, const F28& x2, const F28& y2) {
+  auto pmul = [](F28& r, const F28& a, const F28& b) {
+    if constexpr (INLINE)
+      mul_inl(r, a, b);
+    else
+      mul(r, a, b);
+  };
+  auto psqr = [](F28& r, const F28& a) {
+    if constexpr (INLINE)
+      sqr_inl(r, a);
+    else
+      sqr(r, a);
+  };
   if (is_inf(acc)) {
     acc.x = x2;
     acc.y = y2;
@@ -440,11 +459,11 @@ __device__ __forceinline__ void madd(X28& acc, const F28& x2, const F28& y2) {
     return;
   }
   F28 pp, r, t, q, ppp, p;
-  mul(p, x2, acc.zz);
+  pmul(p, x2, acc.zz);
   sub_raw<16>(p, p, acc.x);  // P = U2 - X1 < 18p
-  mul(r, y2, acc.zzz);
+  pmul(r, y2, acc.zzz);
   sub_raw<16>(r, r, acc.y);  // R = S2 - Y1 < 18p
-  sqr(pp, p);                // PP < 2p
+  psqr(pp, p);    // PP < 2p
   if (is_zero_lt2p(pp)) {    // P == 0 mod p: same x
     sqr(t, r);
     if (is_zero_lt2p(t)) {
@@ -456,11 +475,11 @@ __device__ __forceinline__ void madd(X28& acc, const F28& x2, const F28& y2) {
     }
     return;
   }
-  mul(ppp, p, pp);           // PPP
-  mul(q, acc.x, pp);         // Q
-  mul(acc.zz, acc.zz, pp);
-  mul(acc.zzz, acc.zzz, ppp);
-  sqr(t, r);
+  pmul(ppp, p, pp);  // PPP
+  pmul(q, acc.x, pp);  // Q
+  pmul(acc.zz, acc.zz, pp);
+  pmul(acc.zzz, acc.zzz, ppp);
+  psqr(t, r);
   x3_fused(t, t, ppp, q);    // X3 = R^2 - PPP - 2Q < 10p
   sub_raw<16>(q, q, t);      // Q - X3 < 18p
   F28 ny, z;

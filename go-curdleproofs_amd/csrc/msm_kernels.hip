@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(kBlock, WAVES)
       d28::set_zero(z);
       d28::sub_raw<4>(pt.y, z, pt.y);  // 4p - y
     }
-    d28::madd(acc, pt.x, pt.y);
+    d28::madd<true>(acc, pt.x, pt.y);
   }
   d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
 }
