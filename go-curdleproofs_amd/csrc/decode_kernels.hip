@@ -145,10 +145,12 @@ __device__ __forceinline__ bool in_subgroup(F28& x, F28& y, u32 (*sh_x)[kBlock],
 // point operations of the subgroup test (quad28.h: 3 and 4 product steps per doubling /
 // addition instead of 9 and 14), which shortens the per-point chain from ~1,900 to ~1,050 products:
 // the launch is latency-bound until tens of thousands of points, so small batches use it.
-template <bool QUAD>
+// SUB: with the subgroup test behind the square root (one-shot decodings too large for the
+// two-kernel form); without it the kernel is the square-root half of that form and carries none
+// of the point arithmetic's registers.
+template <bool QUAD, bool SUB>
 __global__ void __launch_bounds__(kBlock, 2)
-    k_g1_decompress(const uint8_t* __restrict__ in, u32 n, int subgroup_check, u32* __restrict__ out,
-                    uint8_t* __restrict__ status) {
+    k_g1_decompress(const uint8_t* __restrict__ in, u32 n, u32* __restrict__ out, uint8_t* __restrict__ status) {
   // x and y wait in LDS (limb-major: conflict-free) while the subgroup test runs: with the
   // two 56-register points of the scalar multiplication live there is no room for them.
   __shared__ u32 sh_x[d28::N][kBlock];
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(kBlock, 2)
     sh_y[k][tid] = y.l[k];
   }
 
-  if (subgroup_check) {
+  if constexpr (SUB) {
     if (!in_subgroup<QUAD>(x, y, sh_x, sh_y, tid)) return fail(CURDLE_DECODE_NOT_IN_SUBGROUP);
   }
 #pragma unroll
@@ -330,11 +332,14 @@ hipError_t launch_g1_decompress(const uint8_t* in, uint32_t n, int subgroup_chec
   if (n == 0) return hipSuccess;
   // four lanes per point while even that is at most one round of the chip (2 waves per SIMD)
   if (subgroup_check && (uint64_t)n * 4 <= 131072)
-    hipLaunchKernelGGL(k_g1_decompress<true>, dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n,
-                       subgroup_check, out, status);
+    hipLaunchKernelGGL((k_g1_decompress<true, true>), dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n, out,
+                       status);
+  else if (subgroup_check)
+    hipLaunchKernelGGL((k_g1_decompress<false, true>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n, out,
+                       status);
   else
-    hipLaunchKernelGGL(k_g1_decompress<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n,
-                       subgroup_check, out, status);
+    hipLaunchKernelGGL((k_g1_decompress<false, false>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n, out,
+                       status);
   return hipGetLastError();
 }
 
