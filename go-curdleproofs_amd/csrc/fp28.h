@@ -186,8 +186,11 @@ __device__ __forceinline__ void mul2_inl(F28& r, const F28& a, const F28& b, con
   for (int i = 0; i < N; i++) r.l[i] = t[i];
 }
 
-// Out-of-line entry points (one copy per code object, operands in VGPRs): a mixed
-// addition holds ten products and would overflow the instruction cache inlined.
+// Out-of-line entry points (one copy per code object, operands in VGPRs) for kernels with many
+// product sites (the one-lane decoding / subgroup kernels, the exceptional branches): ~4 KB of
+// code per inlined product adds up there.  A call costs 28 register moves to marshal its
+// operands, so the kernels with one or few sites -- k_accumulate's mixed addition, the quad
+// formulas, the square-root chain -- inline the products instead (mul_inl / sqr_inl).
 typedef u32 u32x14 __attribute__((ext_vector_type(14)));
 __device__ __noinline__ inline u32x14 mul_call(u32x14 a, u32x14 b) {
   F28 x, y, r;
