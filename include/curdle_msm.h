@@ -370,11 +370,13 @@ int curdle_g1_decompress(const uint8_t in[48], int subgroup_check, uint64_t out_
  * grandproductargument.go:94-103 and common/util.go:55-63. */
 int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t* scalars, size_t n_scalars,
                                const uint64_t* addends, size_t n, uint64_t* out_affine);
-/* Batched decoding of gnark's compressed G1 encoding ON THE GPU (one lane per point: square
- * root, curve check, sign selection, and with subgroup_check != 0 the endomorphism subgroup
- * test gnark's Decoder / SetBytes apply): n x 48 bytes in, n x 12 limbs of gnark affine
- * points out (directly usable as MSM bases), one status byte per point.  Invalid points
- * do not fail the call: they get a non-zero status and (0, 0).  Replaces the per-point
+/* Batched decoding of gnark's compressed G1 encoding ON THE GPU (square root, curve check,
+ * sign selection, and with subgroup_check != 0 the endomorphism subgroup test gnark's Decoder /
+ * SetBytes apply -- run BESIDE the square roots, from the records' x alone, on a twisted model
+ * of the curve, for batches of up to 32,768 points; behind them in one kernel for larger
+ * ones): n x 48 bytes in, n x 12 limbs of gnark affine points out (directly usable as MSM
+ * bases), one status byte per point.  Invalid points do not fail the call: they get a
+ * non-zero status and (0, 0).  Replaces the per-point
  * G1Affine.SetBytes loops of whisk/types.go:85-95 (4 * ell tracker points per shuffle) and
  * of Proof.FromReader (curdleproof.go:320-356). */
 #define CURDLE_DECODE_OK 0
@@ -383,16 +385,17 @@ int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t* scalars, 
 #define CURDLE_DECODE_NOT_ON_CURVE 3
 #define CURDLE_DECODE_NOT_IN_SUBGROUP 4
 int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgroup_check, uint64_t* out_affine, uint8_t* status);
-/* The same in two steps, so the caller's host work overlaps the subgroup test (the longer half
- * of the kernel): begin decodes -- square root, curve check, sign -- and returns the points
- * with a preliminary status (0, 1, 2 or 3), leaving the subgroup test running on the GPU;
- * finish waits for it and writes the final status bytes (now possibly 4).  Every begin must
- * be matched by a finish.  At most two may be in flight: a third begin returns CURDLE_EBUSY (with
- * several verifications in flight the GPU is busy anyway; use the one-shot form then). */
+/* The same in two steps, so the caller can work with the points while the subgroup test (the
+ * longer of the two chains, on its own stream) is still running: begin decodes -- square root,
+ * curve check, sign -- and returns the points with a preliminary status (0, 1, 2 or 3; here
+ * points outside the subgroup are still handed out); finish waits for the subgroup test and
+ * writes the final status bytes (now possibly 4).  Every begin must be matched by a finish.
+ * At most four may be in flight: a fifth begin returns CURDLE_EBUSY (use the one-shot form
+ * then). */
 int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t* out_affine, uint8_t* status, int* ticket);
-/* begin, split once more: start only launches the decoding and returns (the caller hashes its
- * transcript from the raw bytes meanwhile); points waits for the square-root half, hands back
- * the points and leaves the subgroup test running; finish as above.  begin = start + points. */
+/* begin, split once more: start only launches the two kernels and returns (the caller hashes its
+ * transcript from the raw bytes meanwhile); points waits for the square roots and hands back the
+ * points; finish as above.  begin = start + points. */
 int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* ticket);
 int curdle_g1_decompress_points(int ticket, uint64_t* out_affine, uint8_t* status);
 int curdle_g1_decompress_finish(int ticket, uint8_t* status);
