@@ -179,6 +179,7 @@ def test_batched_point_decoding_on_the_gpu(gpu, oracle):
         on_curve_not_g1 += 1
     blob = b"".join(recs)
     got_pt, got_st = gpu.g1_decompress_batch(blob, True)
+    got_pt_first = got_pt.copy()
     assert list(got_st) == want_st
     for g, w, st in zip(got_pt, want_pt, want_st):
         if st == gpu.DECODE_OK:
@@ -217,6 +218,10 @@ def test_batched_point_decoding_on_the_gpu(gpu, oracle):
     assert (big_final.reshape(reps, k) == np.array(want_st, dtype=np.uint8)).all()
     assert (big_st.reshape(reps, k) == st2).all()
     assert (big_pt.reshape(reps, k, 12) == pts2).all()
+    # the one-shot form at that size is the fused kernel (square root, then the subgroup test)
+    one_pt, one_st = gpu.g1_decompress_batch(blob * reps, True)
+    assert (one_st.reshape(reps, k) == np.array(want_st, dtype=np.uint8)).all()
+    assert (one_pt.reshape(reps, k, 12) == got_pt_first).all()
 
 
 def test_same_scalar_argument_is_enforced(gpu, check_mode):
