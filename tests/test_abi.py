@@ -105,6 +105,17 @@ def test_digit_recoding_covers_every_scalar(cm, oracle):
                     assert abs(d) <= 1 << (widths[w] - 1), (c, w)   # 2^(b-1) slots
 
 
+def test_host_compression_of_the_generator(cm, oracle):
+    """curdle_g1_compress (host code: what the transcript hashes) on the one published value of
+    the encoding, and its negative."""
+    from test_oracle import G1_GENERATOR_COMPRESSED, G1_INFINITY_COMPRESSED
+    g = np.array(oracle.jac_to_mont_limbs(oracle.G1), dtype=np.uint64)
+    assert cm.g1_compress(g) == G1_GENERATOR_COMPRESSED
+    assert cm.g1_compress(np.array(oracle.jac_to_mont_limbs(oracle.INF), dtype=np.uint64)) == G1_INFINITY_COMPRESSED
+    n = np.array(oracle.jac_to_mont_limbs(oracle.neg(oracle.G1)), dtype=np.uint64)
+    assert cm.g1_compress(n) == bytes([0xB7]) + G1_GENERATOR_COMPRESSED[1:]
+
+
 def test_g1_sum_host(cm, oracle):
     pts = oracle.Rand(9).get_g1_affines(5)
     jac = np.array([oracle.jac_to_mont_limbs(p) for p in pts] + [oracle.jac_to_mont_limbs(oracle.INF)], dtype=np.uint64)

@@ -14,6 +14,23 @@ def test_curve_parameters_and_montgomery_constants(oracle):
     oracle.self_check()
 
 
+# The compressed encoding of the BLS12-381 G1 generator, as published with the curve (ZCash
+# serialisation, the format gnark-crypto's G1Affine.Bytes / SetBytes use for this curve): the
+# one externally fixed value of the wire format -- 0x80 = compressed, 0x40 = infinity, 0x20 = the
+# lexicographically larger y, then x big-endian.
+G1_GENERATOR_COMPRESSED = bytes.fromhex(
+    "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac58"
+    "6c55e83ff97a1aeffb3af00adb22c6bb")
+G1_INFINITY_COMPRESSED = bytes([0xC0]) + bytes(47)
+
+
+def test_compressed_encoding_of_the_generator(oracle):
+    assert oracle.compress(oracle.G1) == G1_GENERATOR_COMPRESSED
+    assert oracle.compress(oracle.INF) == G1_INFINITY_COMPRESSED
+    neg = oracle.compress(oracle.neg(oracle.G1))
+    assert neg[0] == 0xB7 and neg[1:] == G1_GENERATOR_COMPRESSED[1:]  # same x, the larger root
+
+
 def test_rand_known_answers(oracle):
     # SURVEY.md 8(c) "Derived known-answers for common.Rand"
     assert oracle.Rand(0).get_fr() == 0x119141DCE89807096095D9729B0DA80481A492498E235346EFC58AA73335A351

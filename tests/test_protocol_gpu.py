@@ -137,6 +137,18 @@ def test_batch_verification_shares_one_accumulator(gpu, check_mode):
     assert gpu.verify_batch(crs, *bad, gpu.Rand(9), nthreads=2) == [True, True, False, True, False]
 
 
+def test_gpu_decodes_the_published_generator_encoding(gpu, oracle):
+    from test_oracle import G1_GENERATOR_COMPRESSED, G1_INFINITY_COMPRESSED
+    recs = [G1_GENERATOR_COMPRESSED, bytes([0xB7]) + G1_GENERATOR_COMPRESSED[1:], G1_INFINITY_COMPRESSED] * 20
+    pts, st = gpu.g1_decompress_batch(b"".join(recs), True)
+    want = [oracle.G1, oracle.neg(oracle.G1), None] * 20
+    for g, w, code in zip(pts, want, st):
+        if w is None:
+            assert code == gpu.DECODE_INFINITY and not g.any()
+        else:
+            assert code == gpu.DECODE_OK and oracle.affine_from_mont_limbs([int(v) for v in g]) == w
+
+
 def test_batched_point_decoding_on_the_gpu(gpu, oracle):
     """curdle_g1_decompress_batch: every status class, against the oracle's compress / curve /
     subgroup definitions and the host decoder."""
