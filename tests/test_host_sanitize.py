@@ -30,6 +30,24 @@ def _run(exe, *args):
     return p.stdout
 
 
+@pytest.fixture(scope="module")
+def tsan_harness():
+    subprocess.run(["make", "-C", HB, "tsan"], check=True, capture_output=True, timeout=600)
+    return os.path.join(HB, "host_flow_tsan")
+
+
+def test_batch_threads_under_tsan(tsan_harness):
+    """The counterpart of the reference CI's `go test -race`: batch verification's producer and
+    worker threads (decode-ahead, queued group MSMs, the decoder buffer pool) under
+    ThreadSanitizer, over the test-only backend."""
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    for args in (("flow", "12"), ("whisk", "0")):
+        p = subprocess.run([tsan_harness, *args], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "ThreadSanitizer" not in p.stderr, p.stderr
+        assert "ok" in p.stdout
+
+
 def test_protocol_flow_under_asan_ubsan(harness):
     out = _run(harness, "flow", "12")
     assert "mirror == device accumulator, batch: ok" in out
