@@ -320,7 +320,7 @@ def main():
                         "note": "achieved = 128 B x n / the kernel's own duration (HIP events, nothing else in flight); "
                                 "integer-VALU bound (381-bit Montgomery arithmetic), see DESIGN.md"}
         out = {
-            "metric": "BLS12-381 G1 MSM scalar-point pairs/sec at N=2^20",
+            "metric": f"BLS12-381 G1 MSM scalar-point pairs/sec at N=2^{args.logn}",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",

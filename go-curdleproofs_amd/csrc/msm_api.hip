@@ -320,15 +320,23 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // seg + log2(buckets) point operations) is what the caller waits for; a call too large for
   // one round even so (big batches) takes 16-bucket segments over several rounds (1,024 x 628
   // pairs: 7.67 ms against 7.69 / 7.70 with 32 / 64).  Pipelined (submit / wait) calls hide
-  // their tails behind other MSMs' accumulation and take 32-bucket segments from 2^19 bucket
-  // slots on (half a round of lanes: room beside the accumulation's waves; N = 2^20, four in
-  // flight: 3.04 ms per MSM, 2.97 with 64, 3.13 with 128).
+  // their tails behind other MSMs' accumulation, whose waves leave room for ONE more wave of
+  // quads per SIMD at best: their segments are lengthened, up to 64 buckets, until the quads are
+  // a quarter of a round (32,768 lanes).  Measured per MSM with 4-6 in flight
+  // (profiles/r02_multi_gpu_emulation.jsonl): all 16 windows of N = 2^20 2.89 -> 2.84 ms
+  // against half a round; the 8 / 4 / 2 windows of a rank of the multi-GPU split -- which the
+  // rule before this one left at 4-bucket segments, two rounds of quads for 8 windows --
+  // 1.83 -> 1.52, 0.98 -> 0.88 and 0.61 -> 0.59 ms.
   if (latency_mode) {
     uint32_t seg = p.seg;
     while (nbk / seg * 4 > 131072 && seg < 32) seg *= 2;
     p.seg = nbk / seg * 4 <= 131072 ? seg : 16;
-  } else if (nbk / p.seg * 4 > 65536 && nbk >= (1u << 19)) {
-    p.seg = 32;
+  } else {
+    uint64_t lanes = 32768;
+    if (const char* env = getenv("CURDLE_PIPE_LANES")) lanes = (uint64_t)atoll(env);
+    uint32_t seg = p.seg;
+    while (nbk / seg * 4 > lanes && seg < 64) seg *= 2;
+    p.seg = seg;
   }
   if (const char* env = getenv("CURDLE_REDUCE_SEG")) p.seg = (uint32_t)atoi(env);
   if (p.seg < 1) p.seg = 1;
@@ -340,6 +348,13 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // (256 CUs x 4 SIMDs x 2 waves x 64 lanes) for large inputs, never below 8.
   const uint64_t entries = (uint64_t)(win_end - win_begin) * n_total;
   uint64_t L = (entries + 2 * 131072 - 1) / (2 * 131072);
+  // ... but ONE round up to 32 positions per lane: every lane ends with a fragment the bucket
+  // reduce has to add, and with 2^21..2^22 entries (a window range of the multi-GPU split) half
+  // as many lanes take 0.03-0.05 ms off its chain at no cost to the accumulation
+  if (!getenv("CURDLE_TWO_ROUNDS")) {
+    const uint64_t one = (entries + 131072 - 1) / 131072;
+    if (one <= 32 && one > L) L = one;
+  }
   if (const char* env = getenv("CURDLE_SEG_LEN")) L = (uint64_t)atoi(env);
   // small MSMs are latency-bound on the lane's chain of L mixed additions: halve it while the
   // launch stays far below one round of the chip (every lane emits at least one fragment,
@@ -370,7 +385,9 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // 64 consecutive slots per thread) but a pipelined caller only pays for launches, not latency.
   {
     const uint64_t slots = (uint64_t)k * p.NB;
-    p.fuse_scan = slots <= 8192 || (!latency_mode && slots <= 65536) ? 1u : 0u;
+    uint64_t pipelined_max = 65536;
+    if (const char* env = getenv("CURDLE_FUSE_SCAN_MAX")) pipelined_max = (uint64_t)atoll(env);
+    p.fuse_scan = slots <= 8192 || (!latency_mode && slots <= pipelined_max) ? 1u : 0u;
   }
   return CURDLE_OK;
 }
