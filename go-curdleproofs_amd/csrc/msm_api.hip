@@ -309,16 +309,19 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   const uint64_t nbk = (uint64_t)k * sets * p.NB;  // bucket slots the reduce kernels walk
   // Buckets per running-sum segment: long segments amortise the per-segment scalar
   // multiple, short ones keep the serial chain short when there are few buckets.
-  // This is the starting point; the quad rule below lengthens it for large calls.
-  // Below 2^14 bucket slots (the verifier's 1,370-pair MSM: 4,096) one bucket per quad: the chain
-  // is then fragments + multiple + tree, 0.158 ms against 0.199 with two buckets (n = 1,268).
-  p.seg = nbk >= (1u << 19) ? (latency_mode ? 8 : 16) : (nbk >= (1u << 14) ? 4 : 1);
+  // This is the starting point of the pipelined rule below.
+  p.seg = nbk >= (1u << 19) ? 16 : (nbk >= (1u << 14) ? 4 : 1);
   // The latency-bound kernels work on quads (four lanes per point, quad28.h).  When the caller
-  // waits for this very call (synchronous entry points) the segments are lengthened, up to 32
-  // buckets, until the four-fold lane count is at most one round of the chip at two waves per
-  // SIMD (131,072 lanes): a quad's addition is 4 product steps against 14, and the chain (2.5
-  // seg + log2(buckets) point operations) is what the caller waits for; a call too large for
-  // one round even so (big batches) takes 16-bucket segments over several rounds (1,024 x 628
+  // waits for this very call (synchronous entry points) a segment is ONE bucket (the verifier's
+  // 1,370-pair MSM, 4,096 slots: fragments + multiple + tree, 0.158 ms against 0.199 with two)
+  // and is lengthened, up to 32 buckets, until the four-fold lane count is at most HALF a round
+  // of the chip at two waves per SIMD (65,536 lanes): a quad's addition is 4 product steps
+  // against 14, the chain (2.5 seg + log2(buckets) point operations) is what the caller waits
+  // for, and beyond one wave per SIMD the waves share the multiplier.  Measured against the rule
+  // before it (4 buckets from 2^14 slots, a whole round of lanes;
+  // profiles/r02_sync_reduce_segments.txt): 8,192 pairs 0.566 -> 0.511 ms, 32,768 pairs 0.762 ->
+  // 0.722, 65,536 pairs 0.836 -> 0.778, 2^18 pairs 1.59 -> 1.56, 2^20 pairs 3.63 -> 3.58.  A call
+  // too large for half a round even so (big batches) takes 16-bucket segments over several rounds (1,024 x 628
   // pairs: 7.67 ms against 7.69 / 7.70 with 32 / 64).  Pipelined (submit / wait) calls hide
   // their tails behind other MSMs' accumulation, whose waves leave room for ONE more wave of
   // quads per SIMD at best: their segments are lengthened, up to 64 buckets, until the quads are
@@ -328,9 +331,11 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // rule before this one left at 4-bucket segments, two rounds of quads for 8 windows --
   // 1.83 -> 1.52, 0.98 -> 0.88 and 0.61 -> 0.59 ms.
   if (latency_mode) {
-    uint32_t seg = p.seg;
-    while (nbk / seg * 4 > 131072 && seg < 32) seg *= 2;
-    p.seg = nbk / seg * 4 <= 131072 ? seg : 16;
+    uint64_t lanes = 65536;
+    if (const char* env = getenv("CURDLE_SYNC_LANES")) lanes = (uint64_t)atoll(env);
+    uint32_t seg = 1;
+    while (nbk / seg * 4 > lanes && seg < 32) seg *= 2;
+    p.seg = nbk / seg * 4 <= lanes ? seg : 16;
   } else {
     uint64_t lanes = 32768;
     if (const char* env = getenv("CURDLE_PIPE_LANES")) lanes = (uint64_t)atoll(env);

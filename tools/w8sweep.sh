@@ -1,8 +1,7 @@
 mkdir -p gpurun_out/w8
-out=gpurun_out/w8/emul2.jsonl
+out=gpurun_out/w8/segsweep3.txt
 : > $out
-python bench.py --logn 24 --emulate-world 8 --steps 30 --warmup 4 2>> gpurun_out/w8/sweep.err >> $out || exit 1
-python bench.py --logn 24 --emulate-world 8 --split points --steps 30 --warmup 4 2>> gpurun_out/w8/sweep.err >> $out || exit 1
-python bench.py --logn 24 --steps 12 --warmup 2 --no-cpu-baseline --no-verify 2>> gpurun_out/w8/sweep.err >> $out || exit 1
-python bench.py --logn 22 --emulate-world 8 --split points --steps 60 --warmup 6 2>> gpurun_out/w8/sweep.err >> $out || exit 1
-python bench.py --logn 20 --emulate-world 8 --split points --steps 60 --warmup 6 2>> gpurun_out/w8/sweep.err >> $out || exit 1
+python tools/sweep.py >> $out 2>> gpurun_out/w8/sweep.err || exit 1
+python tools/sweep.py 4096,8192,16384,32768,131072,524288 >> $out 2>> gpurun_out/w8/sweep.err || exit 1
+python tools/bench_configs.py > gpurun_out/w8/configs.json 2>> gpurun_out/w8/sweep.err || exit 1
+python tools/bench_verify.py > gpurun_out/w8/verify.txt 2>> gpurun_out/w8/sweep.err || exit 1
