@@ -389,6 +389,12 @@ def test_async_submit_wait_and_concurrent_callers(gpu, oracle, coracle):
     t1 = gpu.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), sizes[0], window_bits=12, win_begin=0, win_end=W // 2)
     t2 = gpu.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), sizes[0], window_bits=12, win_begin=W // 2, win_end=W)
     assert (gpu.g1_sum(np.stack([gpu.msm_wait(t1), gpu.msm_wait(t2)])) == exp[0]).all()
+    # ... and with the library's own width: a range counts the windows num_windows(n, 0) reports
+    W0 = gpu.num_windows(sizes[2], 0)
+    t1 = gpu.msm_g1_device_submit(d_p[2].data_ptr(), d_s[2].data_ptr(), sizes[2], win_begin=0, win_end=W0 // 3)
+    t2 = gpu.msm_g1_device_submit(d_p[2].data_ptr(), d_s[2].data_ptr(), sizes[2], win_begin=W0 // 3, win_end=W0)
+    assert (gpu.g1_sum(np.stack([gpu.msm_wait(t1), gpu.msm_wait(t2)])) == exp[2]).all()
+    assert (gpu.msm_wait(gpu.msm_g1_device_submit(d_p[2].data_ptr(), d_s[2].data_ptr(), sizes[2])) == exp[2]).all()
     # threads
     errs = []
 

@@ -1,7 +1,4 @@
 mkdir -p gpurun_out/w8
-out=gpurun_out/w8/segsweep3.txt
-: > $out
-python tools/sweep.py >> $out 2>> gpurun_out/w8/sweep.err || exit 1
-python tools/sweep.py 4096,8192,16384,32768,131072,524288 >> $out 2>> gpurun_out/w8/sweep.err || exit 1
-python tools/bench_configs.py > gpurun_out/w8/configs.json 2>> gpurun_out/w8/sweep.err || exit 1
-python tools/bench_verify.py > gpurun_out/w8/verify.txt 2>> gpurun_out/w8/sweep.err || exit 1
+python tools/bench_verify.py 252 > gpurun_out/w8/verify.txt 2>> gpurun_out/w8/sweep.err || exit 1
+python tools/bench_whisk.py > gpurun_out/w8/whisk.txt 2>> gpurun_out/w8/sweep.err || exit 1
+python bench.py --emulate-world 8 --split points --steps 60 --warmup 6 2>> gpurun_out/w8/sweep.err | cut -c1-200 > gpurun_out/w8/pts.txt || exit 1
