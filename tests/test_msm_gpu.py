@@ -240,6 +240,37 @@ def test_full_size_known_discrete_log(gpu, oracle, coracle, logn):
         assert (gpu.msm_g1(d_pts.cpu().numpy().view(np.uint64), sc) == got).all()
 
 
+def test_sizes_at_the_steps_of_the_plan_tables(gpu, oracle, coracle):
+    """The window width, the reduce segments and the positions per accumulate lane are stepwise
+    rules of n (make_plan, choose_window_bits): both sides of every step, synchronous and
+    pipelined, against the closed form -- prefixes of one walk, so one set of inputs serves."""
+    import torch
+    sizes = [299, 300, 4096, 4097, 10000, 10001, 65536, 80000, 80001, 131072, 300000]
+    nmax = max(sizes)
+    k, q = oracle.Rand(1).get_frs(2)
+    d_pts = torch.empty((nmax, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, nmax, d_pts.data_ptr())
+    sc = rand_scalars(np.random.default_rng(77), nmax, oracle)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    s = canonical_ints(sc, oracle)
+    widths = set()
+    s0 = s1 = 0
+    done = 0
+    for n in sizes:
+        for i in range(done, n):
+            s0 += s[i]
+            s1 += i * s[i]
+        done = n
+        aff = coracle.scalar_mul_gen((k * s0 + q * s1) % oracle.R)
+        exp = np.array(oracle.jac_to_mont_limbs(oracle.affine_from_mont_limbs([int(v) for v in aff])), dtype=np.uint64)
+        widths.add(gpu.window_bits(n))
+        assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == exp).all(), n
+        tickets = [gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n) for _ in range(3)]
+        for t in tickets:
+            assert (gpu.msm_wait(t) == exp).all(), n
+    assert len(widths) >= 5      # the table's steps were really crossed
+
+
 def test_linearity_at_full_size(gpu, oracle):
     """MSM(P, a) + MSM(P, b) == MSM(P, a + b) at N = 2^18 (size-independent property)."""
     import torch
