@@ -735,6 +735,87 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
   return rc;
 }
 
+// One large MSM from HOST buffers (what a cgo caller hands over): the pairs go to the GPU in
+// point-range chunks, each an MSM of its own on the submit / wait pipeline, so that chunk i + 1
+// crosses PCIe while chunk i is being accumulated -- a copy from pageable memory occupies the
+// calling thread, not the GPU -- and the partial sums are added on the host.  At N = 2^20 the
+// copy (128 MiB) costs more than the arithmetic.
+constexpr size_t kHostChunkMin = (size_t)1 << 19;  // below this a call is one chunk
+int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out) {
+  // measured (tools/bench_host_buffers.py, pageable memory, ~29 GB/s at best): N = 2^20 6.4 ms in
+  // one copy, 5.8 in two chunks, 6.5 in four (32 MiB copies run below that rate); N = 2^22 23.1 ms
+  // in one copy, 18.3-18.5 in two to eight chunks -- the copy itself is what is left
+  size_t nchunks = n >= ((size_t)1 << 21) ? 4 : 2;
+  if (const char* e = getenv("CURDLE_HOST_CHUNKS")) nchunks = atoi(e) < 1 ? 1 : (size_t)atoi(e);
+  const size_t per = (n + nchunks - 1) / nchunks;
+  std::vector<int> pending;  // slots with a chunk in flight, oldest first
+  G1XYZZ total;
+  g1_set_inf(total);
+  auto collect_oldest = [&]() -> int {
+    const int idx = pending.front();
+    pending.erase(pending.begin());
+    uint64_t part[18];
+    int rc = finish_slot(g_ctx.slots[idx], part);
+    if (rc) drain_slot(g_ctx.slots[idx]);
+    release_slot(idx);
+    if (rc) return rc;
+    G1Jac j;
+    memcpy(&j, part, sizeof(j));
+    G1XYZZ t;
+    g1_from_jac(t, j);
+    g1_add(total, t);
+    return CURDLE_OK;
+  };
+  auto body = [&]() -> int {
+    for (size_t lo = 0; lo < n; lo += per) {
+      const size_t m = n - lo < per ? n - lo : per;
+      // never wait for a slot while holding one: another chunked caller may be doing the same
+      int idx = -1;
+      int rc = acquire_slot(false, &idx);
+      while (rc == CURDLE_EBUSY) {
+        if (pending.empty()) {
+          rc = acquire_slot(true, &idx);
+          break;
+        }
+        if ((rc = collect_oldest())) return rc;
+        rc = acquire_slot(false, &idx);
+      }
+      if (rc) return rc;
+      Slot& S = g_ctx.slots[idx];
+      pending.push_back(idx);
+      HIP_TRY(hipSetDevice(g_ctx.device));
+      int r;
+      if ((r = ensure(S.points, m * 96))) return r;
+      if ((r = ensure(S.scalars, m * 32))) return r;
+      const unsigned seq = g_ctx.submit_count.fetch_add(1, std::memory_order_relaxed);
+      const unsigned turn = seq % (unsigned)g_ctx.main_streams;
+      hipStream_t main = turn == 0 ? g_ctx.main_stream : g_ctx.main_extra[turn - 1];
+      // the copies on the chunk's own stream, the pipeline behind them
+      HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars + 4 * lo, m * 32, hipMemcpyHostToDevice, S.stream));
+      HIP_TRY(hipMemcpyAsync(S.points.p, points + 12 * lo, m * 96, hipMemcpyHostToDevice, S.stream));
+      HIP_TRY(hipEventRecord(S.pre_done, S.stream));
+      HIP_TRY(hipStreamWaitEvent(g_ctx.pre_stream, S.pre_done, 0));
+      const uint32_t off[2] = {0, (uint32_t)m};
+      if ((r = enqueue_slot(S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, g_ctx.pre_stream, main, S.stream,
+                            /*latency_mode=*/false)))
+        return r;
+      if (pending.size() > 2 && (r = collect_oldest())) return r;
+    }
+    while (!pending.empty()) {
+      int r = collect_oldest();
+      if (r) return r;
+    }
+    g1_to_canonical_jac(out, total);
+    return CURDLE_OK;
+  };
+  int rc = body();
+  for (int idx : pending) {  // only after a failure
+    drain_slot(g_ctx.slots[idx]);
+    release_slot(idx);
+  }
+  return rc;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1174,6 +1255,7 @@ extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, si
   }
   if (!points || !scalars) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
+  if (n >= kHostChunkMin && !getenv("CURDLE_HOST_ONE_COPY")) return run_host_chunked(points, scalars, n, out_jac);
   const uint32_t off[2] = {0, (uint32_t)n};
   return run_host(points, scalars, off, 1, out_jac);
 }
