@@ -130,6 +130,7 @@ struct Ctx {
   bool inited = false;
   int device = 0;
   hipStream_t util_stream = nullptr;  // synthetic inputs, self-test
+  hipStream_t h2d_stream = nullptr;   // the chunk copies of large host-buffer MSMs, one behind the other
   // Sort + accumulate of every MSM run in order on this normal-priority stream; each
   // slot's latency-bound tail (merge / bucket reduce / window sum / D2H) runs on the
   // slot's own high-priority stream, so it fills the chip's idle issue slots beside the
@@ -210,6 +211,7 @@ int init_locked(int device) {
   if (device < 0 || device >= ndev) return fail(CURDLE_EINVAL, "device %d out of range (%d visible)", device, ndev);
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&g_ctx.util_stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.h2d_stream, hipStreamNonBlocking));
   int prio_least = 0, prio_greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_stream, hipStreamNonBlocking, prio_least));
@@ -661,6 +663,7 @@ int finish_slot(Slot& S, uint64_t* out) {
 }
 
 void drain_slot(Slot& S) {
+  (void)hipStreamSynchronize(g_ctx.h2d_stream);
   (void)hipStreamSynchronize(g_ctx.pre_stream);
   (void)hipStreamSynchronize(g_ctx.pre_stream2);
   (void)hipStreamSynchronize(g_ctx.main_stream);
@@ -790,10 +793,13 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       const unsigned seq = g_ctx.submit_count.fetch_add(1, std::memory_order_relaxed);
       const unsigned turn = seq % (unsigned)g_ctx.main_streams;
       hipStream_t main = turn == 0 ? g_ctx.main_stream : g_ctx.main_extra[turn - 1];
-      // the copies on the chunk's own stream, the pipeline behind them
-      HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars + 4 * lo, m * 32, hipMemcpyHostToDevice, S.stream));
-      HIP_TRY(hipMemcpyAsync(S.points.p, points + 12 * lo, m * 96, hipMemcpyHostToDevice, S.stream));
-      HIP_TRY(hipEventRecord(S.pre_done, S.stream));
+      // every chunk's copy on ONE stream, so that the first chunk arrives at the full PCIe rate
+      // instead of sharing it with the ones behind it (from page-locked memory all the copies are
+      // queued at once; measured, such memory buys nothing else here: the link gives ~29 GB/s to
+      // pageable and page-locked sources alike), the pipeline behind its own chunk's copy
+      HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars + 4 * lo, m * 32, hipMemcpyHostToDevice, g_ctx.h2d_stream));
+      HIP_TRY(hipMemcpyAsync(S.points.p, points + 12 * lo, m * 96, hipMemcpyHostToDevice, g_ctx.h2d_stream));
+      HIP_TRY(hipEventRecord(S.pre_done, g_ctx.h2d_stream));
       HIP_TRY(hipStreamWaitEvent(g_ctx.pre_stream, S.pre_done, 0));
       const uint32_t off[2] = {0, (uint32_t)m};
       if ((r = enqueue_slot(S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, g_ctx.pre_stream, main, S.stream,
@@ -1213,6 +1219,8 @@ extern "C" int curdle_shutdown(void) {
   C.pre_stream2 = nullptr;
   (void)hipStreamDestroy(C.util_stream);
   C.util_stream = nullptr;
+  (void)hipStreamDestroy(C.h2d_stream);
+  C.h2d_stream = nullptr;
   C.inited = false;
   C.epoch++;  // device memory of curdle_dbases handles made under this context is gone with it
   return CURDLE_OK;
