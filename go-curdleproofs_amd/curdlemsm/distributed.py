@@ -36,19 +36,41 @@ def point_partition(n: int, world_size: int, rank: int) -> Tuple[int, int]:
     return window_partition(n, world_size, rank)
 
 
+class PartialExchange:
+    """The all_gather of one uint64[18] Jacobian point per rank, in two halves: start() queues
+    it and returns at once, finish() hands back uint64[world, 18].  A pipelined caller starts
+    the exchange of step i and finishes it while step i + 1 is on the GPU -- the RCCL kernel has
+    to find a free wave slot beside a bucket accumulation that fills the chip, which can take as
+    long as a whole 8-way rank step; started and finished in one go it would put that wait into
+    every step.  One [world, 18] result tensor and one copy back (not one per rank)."""
+
+    def __init__(self, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.group, self.device = group, device
+        self.world = dist.get_world_size(group)
+        self._torch, self._dist = torch, dist
+
+    def start(self, partial: np.ndarray):
+        torch, dist = self._torch, self._dist
+        # torch has no uint64 collectives on every backend; int64 carries the same bits
+        t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64).copy())
+        if self.device is not None:
+            t = t.pin_memory().to(self.device, non_blocking=True)
+        out = torch.empty((self.world, t.numel()), dtype=t.dtype, device=t.device)
+        work = dist.all_gather(list(out.unbind(0)), t, group=self.group, async_op=True)
+        return work, out, t        # t kept alive until the collective has run
+
+    def finish(self, handle) -> np.ndarray:
+        work, out, _ = handle
+        work.wait()
+        return out.cpu().numpy().view(np.uint64)
+
+
 def gather_partials(partial: np.ndarray, group=None, device=None) -> np.ndarray:
     """all_gather of one uint64[18] Jacobian point per rank -> uint64[world, 18]."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    # torch has no uint64 collectives on every backend; int64 carries the same bits
-    t = torch.from_numpy(partial.view(np.int64).copy())
-    if device is not None:
-        t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t, group=group)
-    return np.stack([o.cpu().numpy().view(np.uint64) for o in out])
+    ex = PartialExchange(group=group, device=device)
+    return ex.finish(ex.start(partial))
 
 
 def choose_split(n: int, world_size: int) -> str:

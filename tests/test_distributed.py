@@ -70,6 +70,15 @@ def _worker(rank, world, port, n, result_dir):
         bits = verify_replicas(11, verify_shard)
         ok = ok and (bits == truth).all() and seen == [int(i) for i in replica_shard(11, world, rank)]
         ok = ok and len(verify_replicas(0, lambda idx: np.zeros(0, dtype=np.uint8))) == 0
+        # the pipelined form of the exchange (bench.py): three all_gathers in flight, finished in
+        # order, each handing every rank's partial of ITS step to every rank
+        from curdlemsm.distributed import PartialExchange
+        ex = PartialExchange()
+        mine = [np.full(18, 1000 * step + rank, dtype=np.uint64) for step in range(3)]
+        handles = [ex.start(m) for m in mine]
+        for step, h in enumerate(handles):
+            got = ex.finish(h)
+            ok = ok and got.shape == (world, 18) and all((got[r] == 1000 * step + r).all() for r in range(world))
         np.save(os.path.join(result_dir, f"rank{rank}.npy"), np.array([int(ok)]))
     finally:
         dist.destroy_process_group()
