@@ -105,7 +105,7 @@ def test_segment_lengths(gpu, golden):
 
 
 def test_reduce_segment_lengths(gpu, golden, oracle, coracle):
-    """The bucket reduction walks segments of 1..32 buckets per quad (the plan picks the length
+    """The bucket reduction walks segments of 1..64 buckets per quad (the plan picks the length
     from the call's size); every length must give the same bits, including on inputs that reach
     the doubling / infinity branches inside the reduction."""
     k, q = oracle.Rand(15).get_frs(2)
@@ -114,7 +114,7 @@ def test_reduce_segment_lengths(gpu, golden, oracle, coracle):
     sc = rand_scalars(np.random.default_rng(15), n, oracle)
     exp = coracle.msm_pippenger(pts, sc, threads=8)
     try:
-        for quad in ("1", "4", "32"):
+        for quad in ("1", "4", "32", "64"):
             os.environ["CURDLE_REDUCE_SEG"] = quad
             for name in ("rand0_n16", "rand0_n257", "rand0_n1024", "edge_duplicate_bases", "edge_opposite_points",
                          "edge_cancels_to_infinity", "edge_all_equal_scalars", "edge_small_scalars",
