@@ -148,6 +148,12 @@ static int CompressCheck() {
 
 static int Flow(size_t ell) {
   Instance in = Make(ell, 7);
+  {  // the prover that never folds its bases (default) against the reference's order of operations
+    setenv("CURDLE_PROVER_FOLD_BASES", "1", 1);
+    Instance ref = Make(ell, 7);
+    unsetenv("CURDLE_PROVER_FOLD_BASES");
+    CHECK(ref.proof == in.proof);
+  }
   for (int eager = 0; eager < 2; eager++) {
     proto::SetEagerChecks(eager);
     CHECK(VerifyBytes(in, in.proof, 43));  // TestCompleteness, curdleproof_test.go:14-46

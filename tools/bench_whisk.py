@@ -21,9 +21,11 @@ crs = cm.CRS(cm.WHISK_ELL, rand)
 # trackers (rG, krG): any two subgroup points do for timing; take them from Rand
 pts = rand.get_g1_affines(2 * cm.WHISK_ELL)
 pre = [compress(pts[2 * i]) + compress(pts[2 * i + 1]) for i in range(cm.WHISK_ELL)]
-t0 = time.perf_counter()
-post, proof = cm.whisk_generate_shuffle_proof(crs, pre, rand)
-t_gen = time.perf_counter() - t0
+t_gen = 1e9
+for _ in range(3):      # best of three: the first call also sizes the workspaces
+    t0 = time.perf_counter()
+    post, proof = cm.whisk_generate_shuffle_proof(crs, pre, rand)
+    t_gen = min(t_gen, time.perf_counter() - t0)
 assert cm.whisk_is_valid_shuffle_proof(crs, pre, post, proof, cm.Rand(1))
 reps = 20
 t0 = time.perf_counter()
