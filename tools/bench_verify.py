@@ -20,9 +20,11 @@ for n in ([int(a) + 4 for a in sys.argv[1:]] or (64, 128, 256, 512)):  # optiona
     k = rand.get_fr()
     Rs, Ss = rand.get_g1_affines(ell), rand.get_g1_affines(ell)
     Ts, Us, M, rs_m = cm.shuffle_permute_commit(crs, Rs, Ss, perm, k, rand)
-    t0 = time.perf_counter()
-    proof = cm.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, cm.Rand(42))
-    t_prove = time.perf_counter() - t0
+    t_prove = 1e9
+    for _ in range(3):      # best of three: the first call at a new size also sizes the workspaces
+        t0 = time.perf_counter()
+        proof = cm.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, cm.Rand(42))
+        t_prove = min(t_prove, time.perf_counter() - t0)
     assert cm.verify(crs, proof, Rs, Ss, Ts, Us, M, cm.Rand(43))
     reps = 10
     t0 = time.perf_counter()
