@@ -576,16 +576,23 @@ static void GenerateBlinders(common::Rand& rand, const std::vector<Scalar>& cs, 
 
 Proof Prove(std::vector<G1Affine> Gs, std::vector<G1Affine> Gs_prime, const Point& Hcrs, const Point& C,
             const Point& D, const Scalar& z, std::vector<Scalar> cs, std::vector<Scalar> ds, Transcript& tr,
-            common::Rand& rand) {
+            common::Rand& rand, const std::vector<Scalar>* Gs_prime_scale) {
   // innerproductargument.go:42-188
   if (cs.size() != ds.size()) throw err("cs and ds are not the same length");
   if (cs.empty() || (cs.size() & (cs.size() - 1))) throw err("cs and ds are not a power of two");
+  if (Gs_prime_scale && (Gs_prime_scale->size() != cs.size() || ProverFoldsBases()))
+    throw std::logic_error("ipa prover: scaled second bases need one scale per base and the unfolded form");
 
   std::vector<Scalar> rs_c, rs_d;
   GenerateBlinders(rand, cs, ds, &rs_c, &rs_d);
   Proof proof;
   {
-    std::vector<Point> b = alg::MultiExpBatch({&Gs, &Gs_prime}, {&rs_c, &rs_d});  // :66, :70
+    std::vector<Scalar> rs_d_scaled;
+    if (Gs_prime_scale) {
+      rs_d_scaled.resize(rs_d.size());
+      for (size_t i = 0; i < rs_d.size(); i++) rs_d_scaled[i] = rs_d[i] * (*Gs_prime_scale)[i];
+    }
+    std::vector<Point> b = alg::MultiExpBatch({&Gs, &Gs_prime}, {&rs_c, Gs_prime_scale ? &rs_d_scaled : &rs_d});  // :66, :70
     proof.B_c = b[0];
     proof.B_d = b[1];
   }
@@ -619,7 +626,10 @@ Proof Prove(std::vector<G1Affine> Gs, std::vector<G1Affine> Gs_prime, const Poin
   std::vector<Scalar> coefG, coefGp;
   if (!fold_bases) {
     coefG.assign(N, Scalar::One());
-    coefGp.assign(N, Scalar::One());
+    if (Gs_prime_scale)
+      coefGp = *Gs_prime_scale;
+    else
+      coefGp.assign(N, Scalar::One());
   }
   const G1Affine H_affine = H.Affine();
   while (n > 1) {  // :101-173
@@ -816,17 +826,23 @@ Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, co
   const Scalar beta = tr.GetAndAppendChallenge(kBeta);
   if (beta.IsZero()) throw err("beta is zero");
 
-  // step 3: rescaled bases G'_i = beta^-(i+1) G_i, H'_i = beta^-(ell+1) H_i (:94-103)
+  // step 3: rescaled bases G'_i = beta^-(i+1) G_i, H'_i = beta^-(ell+1) H_i (:94-103) -- ell + 4
+  // scalar multiplications in the reference.  They are only ever MSM bases (D, the self-check,
+  // the inner product argument), so the scale goes into those MSMs' scalars instead and the
+  // points are never computed (CURDLE_PROVER_FOLD_BASES=1: computed, in one GPU batch).
   const Scalar betaInv = beta.Inverse();
-  std::vector<G1Affine> Gs_prime(ell), Hs_prime(Hs.size());
+  const bool scale_bases = ProverFoldsBases();
+  std::vector<Scalar> ks(ell + Hs.size());
   {
-    std::vector<Scalar> ks(ell + Hs.size());
     Scalar bi = betaInv;
     for (size_t i = 0; i < ell; i++) {
       ks[i] = bi;
       bi = bi * betaInv;
     }
     for (size_t i = 0; i < Hs.size(); i++) ks[ell + i] = bi;
+  }
+  std::vector<G1Affine> Gs_prime = Gs, Hs_prime = Hs;
+  if (scale_bases) {
     const std::vector<G1Affine> scaled = alg::ScalarMulBatch(Concat(Gs, Hs), ks);  // ell + 4 in one batch
     std::copy(scaled.begin(), scaled.begin() + ell, Gs_prime.begin());
     std::copy(scaled.begin() + ell, scaled.end(), Hs_prime.begin());
@@ -845,7 +861,12 @@ Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, co
   for (size_t i = 0; i < nb; i++) r_ds[i] = betaExpLPlus1 * r_b_plus_alpha[i];
   Point D;
   {
-    std::vector<Point> dd = alg::MultiExpBatch({&Gs_prime, &Hs_prime}, {&betaPowers, &alphaBeta});  // :132, :135
+    std::vector<Scalar> bp_s = betaPowers, ab_s = alphaBeta;
+    if (!scale_bases) {
+      for (size_t i = 0; i < ell; i++) bp_s[i] = bp_s[i] * ks[i];
+      for (size_t i = 0; i < nb; i++) ab_s[i] = ab_s[i] * ks[ell + i];
+    }
+    std::vector<Point> dd = alg::MultiExpBatch({&Gs_prime, &Hs_prime}, {&bp_s, &ab_s});  // :132, :135
     D = B - dd[0] + dd[1];
   }
 
@@ -855,11 +876,14 @@ Proof Prove(const std::vector<G1Affine>& Gs, const std::vector<G1Affine>& Hs, co
   const std::vector<Scalar> cs_full = Concat(cs, r_cs), ds_full = Concat(ds, r_ds);
   if (alg::InnerProduct(cs_full, ds_full) != z) throw err("IPA(C, D) != z");
   {
-    std::vector<Point> chk = alg::MultiExpBatch({&G_full, &Gp_full}, {&cs_full, &ds_full});  // :165, :172 self-checks
+    std::vector<Scalar> ds_s = ds_full;
+    if (!scale_bases)
+      for (size_t i = 0; i < ds_s.size(); i++) ds_s[i] = ds_s[i] * ks[i];
+    std::vector<Point> chk = alg::MultiExpBatch({&G_full, &Gp_full}, {&cs_full, &ds_s});  // :165, :172 self-checks
     if (!(chk[0] == proof.C)) throw err("msm(G, c) != C");
     if (!(chk[1] == D)) throw err("msm(G', d) != D");
   }
-  proof.IPAProof = ipa::Prove(G_full, Gp_full, H, proof.C, D, z, cs_full, ds_full, tr, rand);
+  proof.IPAProof = ipa::Prove(G_full, Gp_full, H, proof.C, D, z, cs_full, ds_full, tr, rand, scale_bases ? nullptr : &ks);
   return proof;
 }
 

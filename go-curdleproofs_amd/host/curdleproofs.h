@@ -291,10 +291,13 @@ struct Proof {
   void Serialize(Writer& w) const;
   void FromReader(Reader& r);
 };
-// Gs / Gs_prime / cs / ds are taken by value: the prover folds them in place.
+// Gs / Gs_prime / cs / ds are taken by value: the prover folds them in place.  With
+// `Gs_prime_scale` the second base vector is scale[i] * Gs_prime[i] without anybody having
+// computed those points: the prover only ever uses them as MSM bases and multiplies the scale
+// into its scalars (the grand product argument's rescaled bases, grandproductargument.go:94-103).
 Proof Prove(std::vector<G1Affine> Gs, std::vector<G1Affine> Gs_prime, const Point& H, const Point& C, const Point& D,
             const Scalar& z, std::vector<Scalar> cs, std::vector<Scalar> ds, transcript::Transcript& tr,
-            common::Rand& rand);
+            common::Rand& rand, const std::vector<Scalar>* Gs_prime_scale = nullptr);
 // Bases Gs | Hs (n = ell + 4, the CRS's, by index) and H; us_i = u_q^(min(i, ell) + 1).
 bool Verify(const Proof& proof, size_t ell, const Point& H, const Point& C, const Point& D, const Scalar& z,
             const Scalar& u_q, transcript::Transcript& tr, CheckSink& sink, common::Rand& rand);
