@@ -129,6 +129,13 @@ def test_shuffle_proof(gpu, oracle):
     with pytest.raises(gpu.CurdleError) as e:
         gpu.whisk_is_valid_shuffle_proof(crs, pre, post, rogue + proof[48:], gpu.Rand(1))
     assert "decoding proof" in e.value.msg
+    # the prover decodes its 2n tracker points in one GPU batch too: the same errors as getPoints
+    for bad_tracker, what in ((b"\x01" * 96, "rG"), (pre[3][:48] + rogue, "krG")):
+        bad = list(pre)
+        bad[3] = bad_tracker
+        with pytest.raises(gpu.CurdleError) as e:
+            gpu.whisk_generate_shuffle_proof(crs, bad, gpu.Rand(2))
+        assert "getting points" in e.value.msg and what in e.value.msg
 
 
 @pytest.mark.gpu
