@@ -61,6 +61,9 @@ CURDLE_D28_TABLE(kOne, 0x347fcb8u, 0xd800000u, 0x002b119u, 0x0cde6d2u, 0xc7212e0
 // 2^400 mod p: mul by it maps gnark form (x*2^384) to internal form (x*2^392)
 CURDLE_D28_TABLE(kToInt, 0x80e6299u, 0x3500034u, 0xeb12856u, 0xdeb2699u, 0xc988670u, 0x4ef6697u, 0x70983e8u, 0xa4e6fe9u,
                  0x3e8a053u, 0xecf271eu, 0xc20d323u, 0x6eb6385u, 0x47f1286u, 0x00156dau)
+// beta * 2^392 mod p, beta the cube root of unity with (beta x, y) = [lambda](x, y), lambda = z^2 - 1
+CURDLE_D28_TABLE(kBeta, 0x2421b59u, 0xbee4867u, 0x1d31002u, 0x4760184u, 0x4cc5086u, 0xc76dc00u, 0xaae891bu, 0xac70ad2u,
+                 0xfe377c4u, 0xe4686b8u, 0x5ed1568u, 0x8f5a180u, 0x02b5c1fu, 0x000d1a4u)
 // 2^384 mod p: mul by it maps internal form back to gnark form
 CURDLE_D28_TABLE(kToExt, 0x002fffdu, 0x0900000u, 0xc000276u, 0x000bc40u, 0x8baebf4u, 0x5753c75u, 0x55f4898u, 0x7052574u,
                  0x7ce5853u, 0x56ec6d7u, 0x71a97a2u, 0xe4935c0u, 0xec3fa80u, 0x0015f65u)

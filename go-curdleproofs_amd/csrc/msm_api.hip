@@ -252,6 +252,9 @@ int choose_window_bits(size_t n, bool many = false) {
     int c = atoi(env);
     if (c >= 4 && c <= 16) return c;
   }
+  // the tables below are in TERMS of the GLV split, two per pair: that is what a window's
+  // buckets hold (they were measured before the split existed, when a term was a pair)
+  n *= 2;
   int lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
   int c = lg - 2;
@@ -268,19 +271,22 @@ int choose_window_bits(size_t n, bool many = false) {
   // 180,000: 2.2 ms -- buckets of hundreds of entries go through merge_large), so the steps sit
   // well before them.  A large batch of small MSMs is throughput-bound instead (wider windows
   // double its bucket-reduce work) and keeps lg - 2.
-  if (!many && n >= 300) c = n <= 4096 ? 8 : n <= 10000 ? 10 : n <= 80000 ? 11 : n <= 900000 ? 14 : 16;
-  if (n >= 300 && c < 8 && !many) c = 8;
+  if (!many && n >= 600) c = n <= 4096 ? 8 : n <= 10000 ? 10 : n <= 80000 ? 11 : n <= 900000 ? 14 : 16;
+  if (n >= 600 && c < 8 && !many) c = 8;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
   return c;
 }
 
-// Window widths for a maximum width c: W = ceil(255 / c) windows, the 255 scalar
-// bits spread as evenly as possible (the wider windows lowest), the top window
-// unsigned.  For c = 16 that is 15 windows of 16 bits and a 15-bit top window.
+// Window widths for a maximum width c.  The kernels never see a 255-bit scalar: k_digits splits
+// every scalar into two 127-bit halves (GLV, msm_kernels.hip: k P = k1 P + k2 phi(P)), so an MSM
+// of n pairs is 2 n terms over W = ceil(127 / c) windows, the 127 bits spread as evenly as
+// possible (the wider windows lowest), the top window unsigned.  For c = 16 that is 7 windows
+// of 16 bits and a 15-bit top window.
+constexpr int kScalarBits = 127;
 int window_widths(int c, uint8_t bits[kMaxWindows]) {
-  const int W = (255 + c - 1) / c;
-  const int base = 255 / W, extra = 255 % W;
+  const int W = (kScalarBits + c - 1) / c;
+  const int base = kScalarBits / W, extra = kScalarBits % W;
   for (int w = 0; w < W; w++) bits[w] = (uint8_t)(base + (w < extra ? 1 : 0));
   return W;
 }
@@ -292,6 +298,9 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (c == 0) c = choose_window_bits(n_max, k * sets >= kGpuCombineMin);
   if (c < 4 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", c);
   memset(&p, 0, sizeof(p));
+  // from here on the counts are the split's terms: two per pair (k1 P and k2 phi(P), adjacent)
+  n_total *= 2;
+  n_max *= 2;
   p.n = (uint32_t)n_total;
   p.k = (uint32_t)k;
   p.sets = (uint32_t)sets;
@@ -379,6 +388,13 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   uint64_t Lmin = entries <= 8 * 65536 ? 4 : 8;
   if (const char* env = getenv("CURDLE_SEG_LEN_MIN")) Lmin = (uint64_t)atoi(env) < 1 ? 1 : (uint64_t)atoi(env);
   if (L < Lmin) L = Lmin;
+  // ... and long enough that an evenly loaded bucket of the narrowest window is cut into about
+  // eight fragments at most: beyond max_small (16) a bucket takes the merge_large detour, which
+  // is there for skewed scalars, not for uniform ones (16,384 pairs: 0.81 -> 0.5 ms)
+  if (!getenv("CURDLE_SEG_LEN") && min_nbkt) {
+    const uint64_t load = (n_max + min_nbkt - 1) / min_nbkt;
+    if (L < (load + 7) / 8) L = (load + 7) / 8;
+  }
   if (L > 128) L = 128;
   // beyond ~2^25 pairs even 128 positions per lane leave more than 4M lanes and cut a bucket
   // into more than max_small fragments (they would all take the merge_large detour): grow L
@@ -489,15 +505,17 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
                  bool latency_mode = true, bool points28_ready = false, size_t sets = 1) {
   // sets > 1 (curdle_msm_g1_multi): d_points holds `sets` base sets of h_off[k] points each, all
   // multiplied by the SAME scalars: recoded and sorted once, accumulated per set
-  const size_t n = h_off[k];
+  const size_t n_pairs = h_off[k];
   size_t n_max = 0;
   for (size_t j = 0; j < k; j++) {
     if (h_off[j + 1] < h_off[j]) return fail(CURDLE_EINVAL, "offsets not monotone at %zu", j);
     if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
   }
   MsmPlan& p = S.plan;
-  int rc = make_plan(p, n, k, n_max, c, win_begin, win_end, latency_mode, sets);
+  int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets);
   if (rc) return rc;
+  // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
+  const size_t n = 2 * n_pairs;
   const size_t kr = k * sets;
   S.run_stream = tail;
   S.profiled = false;
@@ -554,13 +572,13 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
   // the offsets are staged in pinned memory (tail of h_buf) so the copy is truly asynchronous
   uint32_t* h_off_pinned = (uint32_t*)((char*)S.h_buf + host_need - (k + 1) * 4);
   if (k > 1) {  // a single MSM's kernels take [0, n) from the plan
-    memcpy(h_off_pinned, h_off, (k + 1) * 4);
+    for (size_t j = 0; j <= k; j++) h_off_pinned[j] = 2 * h_off[j];  // in terms, like everything the kernels index
     HIP_TRY(hipMemcpyAsync(S.offsets.p, h_off_pinned, (k + 1) * 4, hipMemcpyHostToDevice, pre));
   }
   // counts are cleared by k_digits, the large-bucket counter by the scan
   Prof prof(S, pre, g_ctx.profile);
   if (!points28_ready) {  // the device accumulator fills S.points28 itself (resident bases: no conversion here)
-    HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n), ws.points28, pre));
+    HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre));
     prof.mark("convert_points");
   }
   HIP_TRY(launch_digits(p, ws, d_scalars, pre));
@@ -1462,7 +1480,7 @@ extern "C" int curdle_dbases_create(const uint64_t* points, size_t n, curdle_dba
   b->epoch = g_ctx.epoch;
   if (n) {
     void* tmp = nullptr;
-    hipError_t e = hipMalloc(&b->d28, n * kA28Bytes);
+    hipError_t e = hipMalloc(&b->d28, 2 * n * kA28Bytes);  // P and phi(P) per base (launch_convert_points_raw)
     if (e == hipSuccess) e = hipMalloc(&tmp, n * 96);
     if (e == hipSuccess) e = hipMemcpyAsync(tmp, points, n * 96, hipMemcpyHostToDevice, g_ctx.util_stream);
     if (e == hipSuccess) e = launch_convert_points_raw(tmp, (uint32_t)n, b->d28, g_ctx.util_stream);
@@ -1518,16 +1536,16 @@ extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_
     const size_t cap = crs->n + n_inst + CURDLE_DACC_MAX_EXTRA;
     int r;
     // sized for the whole accumulation now: the MSM pipeline's own ensure() must not move them later
-    if ((r = ensure(S.points28, cap * kA28Bytes))) return r;
+    if ((r = ensure(S.points28, 2 * cap * kA28Bytes))) return r;  // two records per base: P, phi(P)
     if ((r = ensure(S.scalars, cap * 32))) return r;
     if ((r = ensure(S.points, (n_inst + CURDLE_DACC_MAX_EXTRA) * 96))) return r;
     if ((r = ensure_pinned(S, 0, n_inst * 96))) return r;
     if (crs->n)
-      HIP_TRY(hipMemcpyAsync(S.points28.p, crs->d28, crs->n * kA28Bytes, hipMemcpyDeviceToDevice, S.stream));
+      HIP_TRY(hipMemcpyAsync(S.points28.p, crs->d28, 2 * crs->n * kA28Bytes, hipMemcpyDeviceToDevice, S.stream));
     if (n_inst) {
       memcpy(S.h_stage[0], inst_points, n_inst * 96);  // pinned: the copy below is truly asynchronous
       HIP_TRY(hipMemcpyAsync(S.points.p, S.h_stage[0], n_inst * 96, hipMemcpyHostToDevice, S.stream));
-      HIP_TRY(launch_convert_points_raw(S.points.p, (uint32_t)n_inst, (char*)S.points28.p + crs->n * kA28Bytes, S.stream));
+      HIP_TRY(launch_convert_points_raw(S.points.p, (uint32_t)n_inst, (char*)S.points28.p + 2 * crs->n * kA28Bytes, S.stream));
     }
     return CURDLE_OK;
   };
@@ -1614,7 +1632,7 @@ extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* che
     HIP_TRY(hipMemcpyAsync(S.job.p, h, bytes, hipMemcpyHostToDevice, st));
     char* dj = (char*)S.job.p;
     if (n_extra) {
-      HIP_TRY(launch_convert_points_raw(dj + o_xp, (uint32_t)n_extra, (char*)S.points28.p + n_res * kA28Bytes, st));
+      HIP_TRY(launch_convert_points_raw(dj + o_xp, (uint32_t)n_extra, (char*)S.points28.p + 2 * n_res * kA28Bytes, st));
       HIP_TRY(hipMemcpyAsync((char*)S.scalars.p + n_res * 32, dj + o_xs, n_extra * 32, hipMemcpyDeviceToDevice, st));
     }
     HIP_TRY(launch_dacc_scalars(dj, (uint32_t)n_checks, dj + o_pool, (uint32_t)n_crs, (uint32_t)n_inst, S.scalars.p, st));

@@ -72,7 +72,6 @@ struct MsmWorkspace {
 };
 
 // Every launcher enqueues on `stream` and returns the launch status.
-hipError_t launch_convert_points(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, hipStream_t stream);
 // n gnark affine points -> internal form at d_out28 (kA28Bytes apart), outside a plan: the device accumulator
 // converts its resident base sets once and per-verification points as they arrive.
 hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_out28, hipStream_t stream);
