@@ -252,26 +252,22 @@ int choose_window_bits(size_t n, bool many = false) {
     int c = atoi(env);
     if (c >= 4 && c <= 16) return c;
   }
-  // the tables below are in TERMS of the GLV split, two per pair: that is what a window's
-  // buckets hold (they were measured before the split existed, when a term was a pair)
+  // in TERMS of the GLV split, two per pair: that is what a window's buckets hold
   n *= 2;
   int lg = 0;
   while (((size_t)1 << (lg + 1)) <= n) lg++;
   int c = lg - 2;
-  // The widths that divide 255 bits unevenly (c = 11: 24 windows of 10-11 bits, c = 14: 19 of
-  // 13-14) have the fewest bucket slots per window count, and below 2^20 pairs the bucket
-  // reduction's chain weighs more than the additions a wider window saves.  Measured with
-  // tools/sweep.py n,c (profiles/r02_window_bits_sweep.txt; lg - 2, the rule before, in
-  // brackets): 8-bit windows up to 4,096 pairs -- 32 windows of 128 buckets, one bucket per quad,
-  // 64 results one tree; narrower windows only lengthen the host's Horner pass --, then 10 up to
-  // 10,000 (8,192 pairs: 0.488 ms [0.505]), 11 up to 80,000 (32,768: 0.646 [0.712]), 14 up to
-  // 900,000 (131,072: 0.947 [1.223]; 400,000: 1.80 [2.04]), 16 beyond.  Pipelined calls agree
-  // (ms per MSM, 4 in flight: 2^16 pairs 0.43 [0.49], 2^17 0.62 [0.84], 2^18 0.99 [1.11], 2^19
-  // 1.60 [1.67]).  Each width has a cliff below it (c = 8 at 8,192 pairs: 1.09 ms, c = 11 at
-  // 180,000: 2.2 ms -- buckets of hundreds of entries go through merge_large), so the steps sit
-  // well before them.  A large batch of small MSMs is throughput-bound instead (wider windows
-  // double its bucket-reduce work) and keeps lg - 2.
-  if (!many && n >= 600) c = n <= 4096 ? 8 : n <= 10000 ? 10 : n <= 80000 ? 11 : n <= 900000 ? 14 : 16;
+  // Below 2^20 pairs the bucket reduction's chain weighs more than the additions a wider window
+  // saves, and widths that cut the 127 bits unevenly have fewer bucket slots per window.
+  // Measured with tools/sweep.py n,c (profiles/r02_window_bits_sweep.txt, last section: with the
+  // split; pairs -> ms): 8 up to 1,500 pairs (1,268: 0.390; 10: 0.393), 10 up to 6,000 (2,000:
+  // 0.400 against 0.505 at 8), 11 up to 80,000 (40,000: 0.636; 14: 0.661), 14 up to 200,000
+  // (131,072: 0.936; 11: 1.047), 15 up to 450,000 (262,144: 1.336; 14: 1.453; 16: 1.368), 16
+  // beyond (524,288: 2.258; 15: 2.278).  Each width has a cliff below it (buckets of hundreds of
+  // terms go through merge_large), so the steps sit well before them.  A large batch of small
+  // MSMs is throughput-bound instead (wider windows double its bucket-reduce work) and keeps
+  // lg - 2.
+  if (!many && n >= 600) c = n <= 3000 ? 8 : n <= 12000 ? 10 : n <= 160000 ? 11 : n <= 400000 ? 14 : n <= 900000 ? 15 : 16;
   if (n >= 600 && c < 8 && !many) c = 8;
   if (c < 4) c = 4;
   if (c > 16) c = 16;

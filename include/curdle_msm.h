@@ -107,10 +107,12 @@ int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, si
                                  int window_bits, int win_begin, int win_end,
                                  uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
 int curdle_msm_window_bits(size_t n);              /* the library's choice of c for n   */
-int curdle_msm_num_windows(size_t n, int window_bits); /* W = ceil(255 / c) for that choice */
-/* Widths of the W windows for (n, window_bits), lowest window first (sum = 255):
- * the scalar bits are spread as evenly as possible; all windows but the top one
- * are recoded into signed digits, the top one is unsigned.  Returns W. */
+int curdle_msm_num_windows(size_t n, int window_bits); /* W = ceil(127 / c) for that choice */
+/* Widths of the W windows for (n, window_bits), lowest window first (sum = 127: the
+ * library splits every scalar into two 127-bit halves, k P = k1 P + k2 phi(P), and a
+ * window covers the same bits of both): the bits are spread as evenly as possible; all
+ * windows but the top one are recoded into signed digits, the top one is unsigned.
+ * Returns W. */
 int curdle_msm_window_widths(size_t n, int window_bits, int widths[64]);
 
 /* out = sum of k Jacobian points (host memory, any representatives).

@@ -53,15 +53,30 @@ def test_length_mismatch_is_an_error(cm):
     assert e.value.code == cm.EINVAL
 
 
+GLV_LAMBDA = 0xac45a4010001a40200000000ffffffff      # z^2 - 1, z = 0xd201000000010000: lambda^2 + lambda + 1 = r
+
+
+def glv_split(k, R):
+    """Host restatement of the kernels' split (msm_kernels.hip glv_split): k = s * (k1 + k2 *
+    lambda) mod r with s = -1 for k > (r - 1) / 2, k2 = round(k' / lambda) >= 0 and k1 in
+    [-lambda / 2, lambda / 2).  Returns the two signed halves."""
+    s = -1 if k > (R - 1) // 2 else 1
+    kp = R - k if s < 0 else k
+    k2 = (kp + (GLV_LAMBDA >> 1)) // GLV_LAMBDA
+    k1 = kp - k2 * GLV_LAMBDA
+    return s * k1, s * k2
+
+
 def test_window_plan(cm):
-    assert cm.num_windows(1 << 20, 16) == 16
-    assert cm.window_widths(1 << 20, 16) == [16] * 15 + [15]
-    assert cm.window_widths(10, 15) == [15] * 17
-    assert cm.window_widths(10, 14) == [14] * 8 + [13] * 11
+    # the windows cover ONE half of the split: 127 bits
+    assert cm.num_windows(1 << 20, 16) == 8
+    assert cm.window_widths(1 << 20, 16) == [16] * 7 + [15]
+    assert cm.window_widths(10, 15) == [15] + [14] * 8
+    assert cm.window_widths(10, 14) == [13] * 7 + [12] * 3
     for c in range(4, 17):
         w = cm.window_widths(10, c)
-        assert len(w) == cm.num_windows(10, c) == -(-255 // c)
-        assert sum(w) == 255 and max(w) <= c and max(w) - min(w) <= 1
+        assert len(w) == cm.num_windows(10, c) == -(-127 // c)
+        assert sum(w) == 127 and max(w) <= c and max(w) - min(w) <= 1
         assert w[-1] == min(w) and w[-1] <= 15          # top window: narrowest, unsigned, fits the LDS histogram
     for n in (1, 7, 308, 1268, 1 << 16, 1 << 20):
         assert 4 <= cm.window_bits(n) <= 16
@@ -71,9 +86,11 @@ def test_window_plan(cm):
 
 
 def recode(s, widths):
-    """Host restatement of the kernels' recoding (msm_kernels.hip for_each_digit):
-    signed digits below the top window, unsigned top window.  Returns [(digit, shift)]."""
-    out, carry, v, shift = [], 0, s, 0
+    """Host restatement of the kernels' recoding of ONE half of the split (msm_kernels.hip
+    for_each_digit): sign taken out, signed digits below the top window, unsigned top window.
+    Returns [(digit, shift)]."""
+    sign = -1 if s < 0 else 1
+    out, carry, v, shift = [], 0, abs(s), 0
     for w, c in enumerate(widths):
         raw = (v & ((1 << c) - 1)) + carry
         v >>= c
@@ -81,28 +98,36 @@ def recode(s, widths):
         d = raw
         if w != len(widths) - 1 and raw > (1 << (c - 1)):
             d, carry = raw - (1 << c), 1
-        out.append((d, shift))
+        out.append((sign * d, shift))
         shift += c
     assert carry == 0 and v == 0
     return out
 
 
 def test_digit_recoding_covers_every_scalar(cm, oracle):
-    """For every window plan the digits of r-1 (the largest scalar) and of awkward
-    values reconstruct the scalar, stay inside the bucket range of their window and
-    leave no carry behind."""
-    vals = [oracle.R - 1, oracle.R - 2, (1 << 254) + (1 << 253), (1 << 255) % oracle.R, 0x8000800080008000, 1, 0,
-            (1 << 254) - 1, int("5" * 63, 16) % oracle.R]
+    """For every window plan the split and the digits of r-1 (the largest scalar), of the
+    scalars around (r - 1) / 2 and the multiples of lambda, and of awkward values reconstruct the
+    scalar, stay inside the bucket range of their window and leave no carry behind."""
+    R, lam = oracle.R, GLV_LAMBDA
+    assert (lam * lam + lam + 1) % R == 0
+    vals = [R - 1, R - 2, (1 << 254) + (1 << 253), (1 << 255) % R, 0x8000800080008000, 1, 0,
+            (1 << 254) - 1, int("5" * 63, 16) % R, (R - 1) // 2, (R - 1) // 2 + 1, lam, lam - 1, lam + 1,
+            lam >> 1, (lam >> 1) + 1, (lam // 2) * lam, (lam // 2) * lam + (lam >> 1) - 1]
+    rng = np.random.default_rng(5)
+    vals += [int.from_bytes(rng.bytes(32), "big") % R for _ in range(200)]
     for c in range(4, 17):
         widths = cm.window_widths(10, c)
         for s in vals:
-            digs = recode(s, widths)
-            assert sum(d << sh for d, sh in digs) == s, (c, hex(s))
-            for w, (d, _) in enumerate(digs):
-                if w == len(widths) - 1:
-                    assert 0 <= d <= (1 << widths[w]), (c, w)       # 2^b slots, index d-1
-                else:
-                    assert abs(d) <= 1 << (widths[w] - 1), (c, w)   # 2^(b-1) slots
+            k1, k2 = glv_split(s, R)
+            assert (k1 + k2 * lam - s) % R == 0 and abs(k1) < 1 << 127 and abs(k2) < 1 << 127, hex(s)
+            for half in (k1, k2):
+                digs = recode(half, widths)
+                assert sum(d << sh for d, sh in digs) == half, (c, hex(s))
+                for w, (d, _) in enumerate(digs):
+                    if w == len(widths) - 1:
+                        assert abs(d) <= (1 << widths[w]), (c, w)       # 2^b slots, index |d| - 1
+                    else:
+                        assert abs(d) <= 1 << (widths[w] - 1), (c, w)   # 2^(b-1) slots
 
 
 def test_host_compression_of_the_generator(cm, oracle):

@@ -23,12 +23,15 @@ def _free_port():
 
 
 def partial_scalars(scalars, widths, begin, end, R):
-    """Value of digits [begin, end) of the library's recoding (what a rank covers)."""
-    from test_abi import recode
+    """Value of digits [begin, end) of the library's recoding (what a rank covers): both halves
+    of the scalar's split, the second one times lambda."""
+    from test_abi import GLV_LAMBDA, glv_split, recode
     out = []
     for s in scalars:
-        digs = recode(s, widths)
-        out.append(sum(d << sh for d, sh in digs[begin:end]) % R)
+        k1, k2 = glv_split(s, R)
+        v1 = sum(d << sh for d, sh in recode(k1, widths)[begin:end])
+        v2 = sum(d << sh for d, sh in recode(k2, widths)[begin:end])
+        out.append((v1 + v2 * GLV_LAMBDA) % R)
     return out
 
 

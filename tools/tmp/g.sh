@@ -1,7 +1,6 @@
-mkdir -p gpurun_out/g
-python tools/sweep.py 8,128,308,628,1268,2548,4096,8192,16384,32768,65536,131072,262144,524288,1048576 > gpurun_out/g/sweep.txt 2>/dev/null; cut -c1-75 gpurun_out/g/sweep.txt
-python tools/bench_verify.py 252 2>/dev/null | head -1 | cut -c1-300
-python tools/bench_configs.py 2>/dev/null | python -c "
+for cfg in CURDLE_REDUCE_SEG=1 CURDLE_REDUCE_SEG=2 "CURDLE_REDUCE_SEG=2 CURDLE_SEG_LEN=32" "CURDLE_REDUCE_SEG=1 CURDLE_SEG_LEN=32" CURDLE_REDUCE_SEG=8; do
+echo "$cfg: $(env $cfg python bench.py --emulate-world 8 --steps 150 --warmup 10 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print({k: round(v['ms'], 3) for k, v in d.items() if 'ms' in v})"
+print(round(d['ms_per_step_rank0'],4), round(d['single_call_ms'],3), {k: v for k, v in d['kernel_ms_alone'].items() if k in ('accumulate','bucket_reduce','window_sum')})")"
+done
