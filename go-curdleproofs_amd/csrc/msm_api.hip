@@ -370,12 +370,13 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // (256 CUs x 4 SIMDs x 2 waves x 64 lanes) for large inputs, never below 8.
   const uint64_t entries = (uint64_t)(win_end - win_begin) * n_total;
   uint64_t L = (entries + 2 * 131072 - 1) / (2 * 131072);
-  // ... but ONE round up to 32 positions per lane: every lane ends with a fragment the bucket
+  // ... but ONE round up to 128 positions per lane: every lane ends with a fragment the bucket
   // reduce has to add, and with 2^21..2^22 entries (a window range of the multi-GPU split) half
-  // as many lanes take 0.03-0.05 ms off its chain at no cost to the accumulation
+  // as many lanes take 0.03-0.05 ms off its chain at no cost to the accumulation; at 2^24
+  // entries (N = 2^20) it is 1 % of the pipelined step (2.71 -> 2.68 ms)
   if (!getenv("CURDLE_TWO_ROUNDS")) {
     const uint64_t one = (entries + 131072 - 1) / 131072;
-    if (one <= 32 && one > L) L = one;
+    if (one <= 128 && one > L) L = one;
   }
   if (const char* env = getenv("CURDLE_SEG_LEN")) L = (uint64_t)atoi(env);
   // small MSMs are latency-bound on the lane's chain of L mixed additions: halve it while the

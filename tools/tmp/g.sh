@@ -1,6 +1,11 @@
-for cfg in CURDLE_REDUCE_SEG=1 CURDLE_REDUCE_SEG=2 "CURDLE_REDUCE_SEG=2 CURDLE_SEG_LEN=32" "CURDLE_REDUCE_SEG=1 CURDLE_SEG_LEN=32" CURDLE_REDUCE_SEG=8; do
-echo "$cfg: $(env $cfg python bench.py --emulate-world 8 --steps 150 --warmup 10 2>/dev/null | python -c "
+for w in 1 2 4; do
+if [ $w = 1 ]; then python bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-verify 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print(round(d['ms_per_step_rank0'],4), round(d['single_call_ms'],3), {k: v for k, v in d['kernel_ms_alone'].items() if k in ('accumulate','bucket_reduce','window_sum')})")"
+print('world 1', round(d['ms_per_step'],4), d['config']['single_call_ms'])"
+else python bench.py --emulate-world $w --steps 100 --warmup 10 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('world', d['emulated_world'], round(d['ms_per_step_rank0'],4), round(d['single_call_ms'],3))"; fi
 done
+python tools/sweep.py 262144,524288,1048576 2>/dev/null | cut -c1-62
