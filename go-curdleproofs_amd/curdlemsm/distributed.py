@@ -76,10 +76,11 @@ def gather_partials(partial: np.ndarray, group=None, device=None) -> np.ndarray:
 def choose_split(n: int, world_size: int) -> str:
     """Which partition pays at which size (per-rank step times measured on one MI355X with
     bench.py --emulate-world, profiles/r02_multi_gpu_emulation.jsonl): with
-    a window range every rank still converts and recodes all n pairs, with a point range it
-    runs its own, narrower Pippenger (more windows per pair); the window range is ahead up to
-    N = 2^22, the point range from 2^23 on (8 ranks, N = 2^24: 5.8 ms against 6.9 ms per step)."""
-    return "points" if n >= (1 << 23) and world_size > 1 else "windows"
+    a window range every rank still converts and recodes all n pairs (two records per point since
+    the GLV split), with a point range it runs its own, narrower Pippenger (more windows per
+    pair); the window range is ahead up to N = 2^21 (8 ranks: 0.56 against 0.67 ms at 2^20, 0.94
+    against 0.95 at 2^21), the point range from 2^22 on (1.53 against 1.86 ms; N = 2^24: 5.2 ms)."""
+    return "points" if n >= (1 << 22) and world_size > 1 else "windows"
 
 
 def msm_g1_distributed(d_points: int, d_scalars: int, n: int, group=None, device=None, stream: int = 0,
