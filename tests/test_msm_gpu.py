@@ -240,12 +240,35 @@ def test_full_size_known_discrete_log(gpu, oracle, coracle, logn):
     assert (gpu.msm_g1(d_pts.cpu().numpy().view(np.uint64), sc) == got).all()
 
 
+def test_scalars_at_the_boundaries_of_the_split(gpu, oracle, coracle):
+    """k_digits splits every scalar as k = +-(k1 + k2 lambda) with a Barrett division
+    (msm_kernels.hip glv_split): the scalars where its branches flip -- around (r - 1) / 2,
+    multiples of lambda and lambda / 2 either side (remainder 0, rounding boundary, the
+    quotient's correction steps), 0, 1, r - 1, powers of two -- each on its own point and all
+    together, against the C oracle."""
+    from test_abi import GLV_LAMBDA as lam
+    R = oracle.R
+    half = (R - 1) // 2
+    vals = [0, 1, 2, R - 1, R - 2, half, half + 1, half - 1, lam, lam - 1, lam + 1, lam >> 1, (lam >> 1) + 1, (lam >> 1) - 1,
+            R - lam, R - lam - 1, R - lam + 1, half - (half % lam), half - (half % lam) + (lam >> 1),
+            half - (half % lam) + (lam >> 1) + 1, half - (half % lam) - 1]
+    vals += [(j * lam + d) % R for j in (2, 3, lam >> 1, (lam >> 1) - 1, lam - 1) for d in (-1, 0, 1, lam >> 1, (lam >> 1) + 1)]
+    vals += [1 << b for b in (31, 32, 63, 64, 126, 127, 128, 191, 192, 253, 254)]
+    vals = [v % R for v in vals]
+    k, q = oracle.Rand(21).get_frs(2)
+    pts = coracle.points_walk(k, q, len(vals))
+    sc = np.array([oracle.fr_to_mont_limbs(v) for v in vals], dtype=np.uint64)
+    assert (gpu.msm_g1(pts, sc) == coracle.msm_naive(pts, sc)).all()
+    for i in range(len(vals)):          # one at a time: a wrong half cannot cancel against another
+        assert (gpu.msm_g1(pts[i:i + 1], sc[i:i + 1]) == coracle.msm_naive(pts[i:i + 1], sc[i:i + 1])).all(), hex(vals[i])
+
+
 def test_sizes_at_the_steps_of_the_plan_tables(gpu, oracle, coracle):
     """The window width, the reduce segments and the positions per accumulate lane are stepwise
     rules of n (make_plan, choose_window_bits): both sides of every step, synchronous and
     pipelined, against the closed form -- prefixes of one walk, so one set of inputs serves."""
     import torch
-    sizes = [299, 300, 4096, 4097, 10000, 10001, 65536, 80000, 80001, 131072, 300000]
+    sizes = [299, 300, 1500, 1501, 6000, 6001, 65536, 80000, 80001, 200001, 450001]
     nmax = max(sizes)
     k, q = oracle.Rand(1).get_frs(2)
     d_pts = torch.empty((nmax, 12), dtype=torch.int64, device="cuda:0")
@@ -268,7 +291,7 @@ def test_sizes_at_the_steps_of_the_plan_tables(gpu, oracle, coracle):
         tickets = [gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n) for _ in range(3)]
         for t in tickets:
             assert (gpu.msm_wait(t) == exp).all(), n
-    assert len(widths) >= 5      # the table's steps were really crossed
+    assert len(widths) >= 6      # the table's steps were really crossed
 
 
 def test_linearity_at_full_size(gpu, oracle):
