@@ -66,7 +66,15 @@ static const size_t kTwoKernelMax = [] {  // one-shot decodings up to this size 
   return e ? (size_t)atoll(e) : (size_t)32768;
 }();
 static constexpr int kMaxDeferred = 4;          // two-step point decodings in flight (see curdle_g1_decompress_begin); with 2, eight threads verifying from bytes ran at 1,500-2,200 /s, with 4 at 2,400-2,500
-static constexpr size_t kGpuCombineMin = 32;  // batches at least this large combine their window sums on the GPU
+// Batches at least this large combine their window sums on the GPU (k_combine: one quad per
+// MSM, 127 doublings, ~0.5 ms however many) instead of one Horner pass per MSM on the host
+// (0.05 ms each for small MSMs).  Measured after the GLV split, k x 128 / 628 pairs: k = 8 0.67
+// (host) against 0.81 ms, k = 12 0.89 against 0.76, k = 16 1.09 against 0.77, k = 24 1.51
+// against 0.77.
+static const size_t kGpuCombineMin = [] {
+  const char* e = getenv("CURDLE_GPU_COMBINE_MIN");
+  return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)12;
+}();
 
 struct Buf {
   void* p = nullptr;
