@@ -240,6 +240,26 @@ def test_full_size_known_discrete_log(gpu, oracle, coracle, logn):
     assert (gpu.msm_g1(d_pts.cpu().numpy().view(np.uint64), sc) == got).all()
 
 
+def test_host_buffers_in_uneven_chunks(gpu, oracle, coracle):
+    """curdle_msm_g1 sends a large call to the GPU in point-range chunks (run_host_chunked): an odd
+    size cut into 3 and into 5 chunks, the last one short, against the device-resident call."""
+    import torch
+    n = (1 << 19) + 5
+    k, q = oracle.Rand(1).get_frs(2)
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    sc = rand_scalars(np.random.default_rng(19), n, oracle)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    exp = gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
+    pts = d_pts.cpu().numpy().view(np.uint64)
+    try:
+        for chunks in ("3", "5"):
+            os.environ["CURDLE_HOST_CHUNKS"] = chunks
+            assert (gpu.msm_g1(pts, sc) == exp).all(), chunks
+    finally:
+        os.environ.pop("CURDLE_HOST_CHUNKS", None)
+
+
 def test_scalars_at_the_boundaries_of_the_split(gpu, oracle, coracle):
     """k_digits splits every scalar as k = +-(k1 + k2 lambda) with a Barrett division
     (msm_kernels.hip glv_split): the scalars where its branches flip -- around (r - 1) / 2,
