@@ -74,144 +74,7 @@ __device__ __forceinline__ void for_each_digit(u32 s0, u32 s1, u32 s2, u32 s3, c
 // GLV: phi(x, y) = (beta x, y) is multiplication by lambda = z^2 - 1 (lambda^2 + lambda + 1 =
 // r), so k P = k1 P + k2 phi(P) with half-length k1, k2: the MSM runs over 2n points with half
 // the windows -- the same bucket additions, half the buckets and half the Horner pass.  The
-// split: k' = min(k, r - k) (sign s), k2 = round(k' / lambda), k1 = k' - k2 lambda in
-// [-lambda/2, lambda/2); both magnitudes are below 1.35 * 2^126, so 127 bits suffice and the top
-// window's digit plus carry stays below 2^(width of the top window).  k2 by Barrett division
-// (HAC 14.42: mu = floor(2^256 / lambda), at most two corrections; checked against big-integer
-// division on 300,000 random and the boundary scalars).  Out: |k1|, k2 as four words each and
-// the signs of the two terms.
-__device__ __forceinline__ void glv_split(const Fr& k, u32 a[4], u32 b[4], u32& neg_a, u32& neg_b) {
-  constexpr u32 R_[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
-  constexpr u32 HALF[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};
-  constexpr u32 LAM[5] = {0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u, 0u};
-  constexpr u32 LH[5] = {0x7fffffffu, 0x00000000u, 0x8000d201u, 0x5622d200u, 0u};  // lambda >> 1
-  constexpr u32 MU[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};
-  // s = k > (r - 1) / 2;  m = (s ? r - k : k) + (lambda >> 1)
-  bool gt = false, decided = false;
-#pragma unroll
-  for (int i = 7; i >= 0; i--) {
-    if (!decided && k.l[i] != HALF[i]) {
-      gt = k.l[i] > HALF[i];
-      decided = true;
-    }
-  }
-  u32 m[9];
-  {
-    u64 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const u64 d = (u64)R_[i] - k.l[i] - borrow;
-      m[i] = gt ? (u32)d : k.l[i];
-      borrow = (d >> 32) & 1u;
-    }
-    u64 carry = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      carry += (u64)m[i] + (i < 4 ? LH[i] : 0u);
-      m[i] = (u32)carry;
-      carry >>= 32;
-    }
-    m[8] = 0;
-  }
-  // q1 = m >> 127 (< 2^128);  q3 = (q1 * mu) >> 129
-  u32 q1[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) q1[j] = (m[j + 3] >> 31) | (m[j + 4] << 1);
-  u32 q2[10];
-  {
-    u64 acc = 0, hi = 0;  // column sums of up to four 64-bit products: carry the overflow separately
-#pragma unroll
-    for (int col = 0; col < 9; col++) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int j = col - i;
-        if (j >= 0 && j < 5) {
-          const u64 pr = (u64)q1[i] * MU[j];
-          acc += pr;
-          hi += acc < pr ? 1u : 0u;
-        }
-      }
-      q2[col] = (u32)acc;
-      acc = (acc >> 32) | (hi << 32);
-      hi = 0;
-    }
-    q2[9] = (u32)acc;
-  }
-  u32 q3[5];
-#pragma unroll
-  for (int j = 0; j < 5; j++) q3[j] = (q2[j + 4] >> 1) | ((j + 5 < 10 ? q2[j + 5] : 0u) << 31);
-  // rem = m - q3 * lambda  (mod 2^160: the true remainder is below 3 lambda)
-  u32 rem[5];
-  {
-    u32 t[5];
-    u64 acc = 0, hi = 0;
-#pragma unroll
-    for (int col = 0; col < 5; col++) {
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        const int j = col - i;
-        if (j >= 0 && j < 4) {
-          const u64 pr = (u64)q3[i] * LAM[j];
-          acc += pr;
-          hi += acc < pr ? 1u : 0u;
-        }
-      }
-      t[col] = (u32)acc;
-      acc = (acc >> 32) | (hi << 32);
-      hi = 0;
-    }
-    u64 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const u64 d = (u64)m[i] - t[i] - borrow;
-      rem[i] = (u32)d;
-      borrow = (d >> 32) & 1u;
-    }
-  }
-  // at most two corrections: while rem >= lambda { rem -= lambda; q3 += 1 }
-#pragma unroll
-  for (int it = 0; it < 2; it++) {
-    u32 d[5];
-    u64 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const u64 x = (u64)rem[i] - LAM[i] - borrow;
-      d[i] = (u32)x;
-      borrow = (x >> 32) & 1u;
-    }
-    if (!borrow) {  // rem >= lambda
-#pragma unroll
-      for (int i = 0; i < 5; i++) rem[i] = d[i];
-      u64 carry = 1;
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        carry += q3[i];
-        q3[i] = (u32)carry;
-        carry >>= 32;
-      }
-    }
-  }
-  // k2 = q3;  k1 = rem - (lambda >> 1), as sign and magnitude
-  u32 d[4], e[4];
-  u64 b1 = 0, b2 = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const u64 x = (u64)rem[i] - LH[i] - b1;
-    d[i] = (u32)x;
-    b1 = (x >> 32) & 1u;
-    const u64 y = (u64)LH[i] - rem[i] - b2;
-    e[i] = (u32)y;
-    b2 = (y >> 32) & 1u;
-  }
-  const bool k1_neg = b1 != 0;  // rem < lambda >> 1  (rem < lambda < 2^128: limb 4 is zero)
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    a[i] = k1_neg ? e[i] : d[i];
-    b[i] = q3[i];
-  }
-  neg_b = gt ? 0x80000000u : 0u;
-  neg_a = neg_b ^ (k1_neg ? 0x80000000u : 0u);
-}
+// split itself is glv_split (bls12_381.h, shared with the host's scalar multiplication).
 
 __device__ __forceinline__ Fr load_scalar_canonical(const uint4* scalars, u32 i) {
   uint4 lo = scalars[2 * (size_t)i], hi = scalars[2 * (size_t)i + 1];

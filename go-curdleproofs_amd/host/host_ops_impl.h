@@ -5,8 +5,9 @@
 //
 //  * window combine: out = canonical Jacobian of sum_lw 2^(shift of window lw) * winsums[lw],
 //    the last step of the MSM (the Horner pass over the window sums the GPU produced):
-//    ~255 doublings with a strictly serial dependency, which a CPU core does in ~0.1 ms
-//    and a GPU lane would take milliseconds over;
+//    ~127 doublings (the kernels split every scalar into two 127-bit halves) with a strictly
+//    serial dependency, which a CPU core does in ~0.03 ms and a GPU lane would take a
+//    millisecond over;
 //  * the single-point operations of the protocol layers (one 255-bit scalar multiplication
 //    per AccumulateCheck / commitment opening / fold step, point addition, normalisation,
 //    the square root of point decompression).
@@ -34,7 +35,7 @@ extern "C" void CURDLE_FN(curdle_window_combine)(const void* winsums_xyzz, int n
 // r = k * p, k = 8 canonical little-endian 32-bit limbs
 extern "C" void CURDLE_FN(curdle_host_scalar_mul)(void* r_xyzz, const void* p_xyzz, const uint32_t* k) {
   using namespace curdle;
-  g1_scalar_mul(*static_cast<G1XYZZ*>(r_xyzz), *static_cast<const G1XYZZ*>(p_xyzz), k, 8);
+  g1_scalar_mul_glv(*static_cast<G1XYZZ*>(r_xyzz), *static_cast<const G1XYZZ*>(p_xyzz), k);
 }
 
 // acc += b

@@ -130,6 +130,39 @@ def test_digit_recoding_covers_every_scalar(cm, oracle):
                         assert abs(d) <= 1 << (widths[w] - 1), (c, w)   # 2^(b-1) slots
 
 
+def test_host_scalar_multiplication_through_the_split(cm, oracle):
+    """curdle_host_scalar_mul (host code: every single scalar multiplication of the protocol
+    layers) runs on the same GLV split as the kernels: the scalars where the split's branches
+    flip, and random ones, on the generator and on a second point, against the oracle."""
+    import ctypes as C
+    lib = C.CDLL(cm.LIB_PATH)
+    f = lib.curdle_host_scalar_mul
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = None
+    R, lam = oracle.R, GLV_LAMBDA
+    half = (R - 1) // 2
+    vals = [0, 1, 2, R - 1, half, half + 1, lam, lam - 1, lam + 1, lam >> 1, (lam >> 1) + 1, R - lam, (lam >> 1) * lam,
+            (lam >> 1) * lam + (lam >> 1), (lam >> 1) * lam + (lam >> 1) - 1, 3 * lam - 1, 1 << 127, 1 << 128, 1 << 254]
+    rng = np.random.default_rng(11)
+    vals += [int.from_bytes(rng.bytes(32), "big") % R for _ in range(40)]
+    one = oracle.fp_to_mont_limbs(1)
+    for base in (oracle.G1, oracle.scalar_mul(0xC0FFEE, oracle.G1)):
+        aff = oracle.affine_to_mont_limbs(base)
+        p = np.array(list(aff) + list(one) + list(one), dtype=np.uint64)      # X | Y | ZZ | ZZZ, Montgomery
+        for k in vals:
+            kk = np.array([(k >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=np.uint32)
+            out = np.zeros(24, dtype=np.uint64)
+            f(out.ctypes.data, p.ctypes.data, kk.ctypes.data)
+            X, Y, ZZ, ZZZ = (oracle.fp_from_mont_limbs([int(v) for v in out[6 * i: 6 * i + 6]]) for i in range(4))
+            exp = oracle.scalar_mul(k, base)
+            if exp is None:
+                assert ZZ == 0, hex(k)
+            else:
+                assert ZZ != 0, hex(k)
+                got = (X * pow(ZZ, -1, oracle.P) % oracle.P, Y * pow(ZZZ, -1, oracle.P) % oracle.P)   # x = X / ZZ, y = Y / ZZZ
+                assert got == exp, hex(k)
+
+
 def test_host_compression_of_the_generator(cm, oracle):
     """curdle_g1_compress (host code: what the transcript hashes) on the one published value of
     the encoding, and its negative."""
