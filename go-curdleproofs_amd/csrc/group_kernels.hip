@@ -25,22 +25,6 @@ using d28::X28;
 
 static constexpr int kBlock = 256;
 
-// The scalar of element i as an integer, bit 254 in the top bit of k.l[7] (r < 2^255).
-__device__ __forceinline__ void load_scalar_bits(Fr& k, const uint4* __restrict__ scalars, size_t si) {
-  uint4 lo = scalars[2 * si], hi = scalars[2 * si + 1];
-  Fr m;
-  m.l[0] = lo.x; m.l[1] = lo.y; m.l[2] = lo.z; m.l[3] = lo.w;
-  m.l[4] = hi.x; m.l[5] = hi.y; m.l[6] = hi.z; m.l[7] = hi.w;
-  f_from_mont<FrParams>(k, m);
-#pragma unroll
-  for (int j = 7; j > 0; j--) k.l[j] = (k.l[j] << 1) | (k.l[j - 1] >> 31);
-  k.l[0] <<= 1;
-}
-__device__ __forceinline__ void next_bit(Fr& k) {
-#pragma unroll
-  for (int j = 7; j > 0; j--) k.l[j] = (k.l[j] << 1) | (k.l[j - 1] >> 31);
-  k.l[0] <<= 1;
-}
 // gnark affine point -> internal affine; false for (0, 0) = infinity
 __device__ __forceinline__ bool load_affine(F28& x, F28& y, const uint4* __restrict__ points, size_t i) {
   u32 w[24];
@@ -129,16 +113,48 @@ __global__ void __launch_bounds__(kBlock, 2)
                        const uint4* __restrict__ addends, u32 n, G1XYZZ* __restrict__ out) {
   const u32 i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  // the same split; here the two halves' additions stay two mixed additions (their sum is not
+  // affine): 127 doublings and up to 254 mixed additions instead of 255 and 255
   Fr k;
-  load_scalar_bits(k, scalars, shared_scalar ? 0 : i);
+  {
+    const size_t si = shared_scalar ? 0 : i;
+    uint4 lo = scalars[2 * si], hi = scalars[2 * si + 1];
+    Fr m;
+    m.l[0] = lo.x; m.l[1] = lo.y; m.l[2] = lo.z; m.l[3] = lo.w;
+    m.l[4] = hi.x; m.l[5] = hi.y; m.l[6] = hi.z; m.l[7] = hi.w;
+    f_from_mont<FrParams>(k, m);
+  }
+  u32 a[4], b[4], neg_a, neg_b;
+  glv_split(k, a, b, neg_a, neg_b);
   F28 x, y;
   X28 acc;
   d28::set_inf(acc);
   if (load_affine(x, y, points, i)) {
-    for (int bit = 254; bit >= 0; bit--) {
+    F28 yn, z, beta, bx;
+    d28::set_zero(z);
+    d28::sub<4>(yn, z, y);  // 4p - y
+#pragma unroll
+    for (int j = 0; j < d28::N; j++) beta.l[j] = d28::kBeta(j);
+    d28::mul(bx, x, beta);
+    const F28 ya = neg_a ? yn : y, yb = neg_b ? yn : y;
+#pragma unroll
+    for (int j = 3; j > 0; j--) {
+      a[j] = (a[j] << 1) | (a[j - 1] >> 31);
+      b[j] = (b[j] << 1) | (b[j - 1] >> 31);
+    }
+    a[0] <<= 1;
+    b[0] <<= 1;
+    for (int bit = 126; bit >= 0; bit--) {
       d28::dbl(acc);
-      if (k.l[7] >> 31) d28::madd(acc, x, y);
-      next_bit(k);
+      if (a[3] >> 31) d28::madd(acc, x, ya);
+      if (b[3] >> 31) d28::madd(acc, bx, yb);
+#pragma unroll
+      for (int j = 3; j > 0; j--) {
+        a[j] = (a[j] << 1) | (a[j - 1] >> 31);
+        b[j] = (b[j] << 1) | (b[j - 1] >> 31);
+      }
+      a[0] <<= 1;
+      b[0] <<= 1;
     }
   }
   if (addends && load_affine(x, y, addends, i)) d28::madd(acc, x, y);

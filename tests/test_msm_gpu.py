@@ -594,11 +594,12 @@ def test_batched_scalar_multiplication(gpu, oracle):
     big = 32769
     pts = gpu.Rand(4).get_g1_affines(64)
     pts = np.concatenate([pts] * (big // 64 + 1))[:big]
-    k = np.array(oracle.fr_to_mont_limbs(0x1234567), dtype=np.uint64)
-    out = gpu.g1_scalar_mul_batch(pts, k)
-    ones = np.array([oracle.fr_to_mont_limbs(1)] * big, dtype=np.uint64)
-    lhs = gpu.msm_g1(out, ones)                                  # sum_i k P_i
-    rhs = gpu.msm_g1(pts, np.array([oracle.fr_to_mont_limbs(0x1234567)] * big, dtype=np.uint64))
-    assert (lhs == rhs).all()
-    assert oracle.affine_from_mont_limbs([int(v) for v in out[big - 1]]) == oracle.scalar_mul(
-        0x1234567, oracle.affine_from_mont_limbs([int(v) for v in pts[big - 1]]))
+    for K in (0x1234567, oracle.R * 2 // 3 + 0x1234567, oracle.R // 3 - 5):   # one half only; both halves, negative; both, positive
+        k = np.array(oracle.fr_to_mont_limbs(K), dtype=np.uint64)
+        out = gpu.g1_scalar_mul_batch(pts, k)
+        ones = np.array([oracle.fr_to_mont_limbs(1)] * big, dtype=np.uint64)
+        lhs = gpu.msm_g1(out, ones)                                  # sum_i k P_i
+        rhs = gpu.msm_g1(pts, np.array([oracle.fr_to_mont_limbs(K)] * big, dtype=np.uint64))
+        assert (lhs == rhs).all(), hex(K)
+        assert oracle.affine_from_mont_limbs([int(v) for v in out[big - 1]]) == oracle.scalar_mul(
+            K, oracle.affine_from_mont_limbs([int(v) for v in pts[big - 1]])), hex(K)
