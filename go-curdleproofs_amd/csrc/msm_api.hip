@@ -13,7 +13,10 @@
 #include <atomic>
 #include <condition_variable>
 #include <chrono>
+#include <deque>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/curdle_msm.h"
@@ -52,11 +55,14 @@ extern "C" int curdle_set_last_error(int code, const char* msg) { return fail(co
   } while (0)
 
 // ---------------------------------------------------------------------------
-// Context: one device per process; kSlots independent workspaces, each with its
-// own HIP stream, so several MSMs can be in flight (curdle_msm_g1_device_submit /
-// curdle_msm_wait): the latency-bound tail of one MSM (bucket reduce at one wave
-// per SIMD, D2H, host combine) overlaps the throughput-bound accumulation of the
-// next.  Workspaces only grow; nothing is allocated in steady state.
+// Contexts: one per configured device (curdle_init: one; curdle_init_devices: up to
+// CURDLE_MAX_DEVICES, one process driving several GPUs).  A context has kSlots independent
+// workspaces, each with its own HIP stream, so several MSMs can be in flight
+// (curdle_msm_g1_device_submit / curdle_msm_wait): the latency-bound tail of one MSM (bucket
+// reduce at one wave per SIMD, D2H, host combine) overlaps the throughput-bound accumulation
+// of the next.  Workspaces only grow; nothing is allocated in steady state.  Every entry
+// point works on the CALLING THREAD's current context (curdle_set_device, default 0), like
+// hipSetDevice; tickets and handles remember the context they were made on.
 // ---------------------------------------------------------------------------
 namespace {
 
@@ -131,12 +137,16 @@ struct DSlot {
   uint32_t n = 0;
 };
 
+struct DevWorker;
 struct Ctx {
   std::mutex mu;
   std::condition_variable cv;
   DSlot dslots[kMaxDeferred];
+  std::atomic<bool> dstreams_ready{false};  // the decode contexts' streams exist (published with release / acquire)
   bool inited = false;
-  int device = 0;
+  int device = 0;   // HIP device id
+  int ordinal = 0;  // index of this context (what curdle_set_device takes, what tickets carry)
+  DevWorker* worker = nullptr;  // the host thread of this device for multi-device calls (made by curdle_init_devices)
   hipStream_t util_stream = nullptr;  // synthetic inputs, self-test
   hipStream_t h2d_stream = nullptr;   // the chunk copies of large host-buffer MSMs, one behind the other
   // Sort + accumulate of every MSM run in order on this normal-priority stream; each
@@ -168,7 +178,59 @@ struct Ctx {
   curdle_profile last = {};
 };
 
-Ctx g_ctx;
+static constexpr int kMaxDevices = CURDLE_MAX_DEVICES;
+Ctx g_ctxs[kMaxDevices];
+std::atomic<int> g_ndev{1};  // configured contexts: [0, g_ndev)
+std::mutex g_cfg_mu;         // configuration (curdle_init_devices / curdle_shutdown)
+thread_local int tl_dev = 0;
+// the calling thread's context; a thread whose selection no longer exists (curdle_shutdown since) is on 0
+inline Ctx& cur() { return g_ctxs[tl_dev < g_ndev.load(std::memory_order_acquire) ? tl_dev : 0]; }
+const bool g_ordinals_set = [] {
+  for (int i = 0; i < kMaxDevices; i++) g_ctxs[i].ordinal = i;
+  return true;
+}();
+
+// The host thread of one context: calls that span devices (curdle_msm_g1 over host buffers,
+// curdle_msm_g1_replicated) hand each device's share to that device's thread, which lives on the
+// context (tl_dev) for good -- SURVEY.md section 7 step 6: one host thread per device.
+struct DevWorker {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  bool stop = false;
+  std::thread th;
+  explicit DevWorker(int ordinal) {
+    th = std::thread([this, ordinal] {
+      tl_dev = ordinal;
+      for (;;) {
+        std::function<void()> job;
+        {
+          std::unique_lock<std::mutex> g(mu);
+          cv.wait(g, [&] { return stop || !q.empty(); });
+          if (q.empty()) return;  // stop, and nothing left to run
+          job = std::move(q.front());
+          q.pop_front();
+        }
+        job();
+      }
+    });
+  }
+  void post(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      q.push_back(std::move(f));
+    }
+    cv.notify_one();
+  }
+  ~DevWorker() {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      stop = true;
+    }
+    cv.notify_one();
+    th.join();
+  }
+};
 
 // Capacity for a request of `bytes`: the next power of two up to 256 MiB (at least 64 KiB), an
 // eighth of slack above.  hipFree waits for the whole device, so a buffer that creeps up with
@@ -207,9 +269,9 @@ int ensure_pinned(Slot& S, int which, size_t bytes) {
   return CURDLE_OK;
 }
 
-int init_locked(int device) {
-  if (g_ctx.inited) {
-    if (device != g_ctx.device) return fail(CURDLE_EINVAL, "already initialised on device %d", g_ctx.device);
+int init_locked(Ctx& cx, int device) {
+  if (cx.inited) {
+    if (device != cx.device) return fail(CURDLE_EINVAL, "already initialised on device %d", cx.device);
     return CURDLE_OK;
   }
   int ndev = 0;
@@ -218,41 +280,41 @@ int init_locked(int device) {
     return fail(CURDLE_ENODEV, "no HIP device visible (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
   if (device < 0 || device >= ndev) return fail(CURDLE_EINVAL, "device %d out of range (%d visible)", device, ndev);
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.util_stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.h2d_stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&cx.util_stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&cx.h2d_stream, hipStreamNonBlocking));
   int prio_least = 0, prio_greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-  HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_stream, hipStreamNonBlocking, prio_least));
+  HIP_TRY(hipStreamCreateWithPriority(&cx.main_stream, hipStreamNonBlocking, prio_least));
   if (const char* ms = getenv("CURDLE_MAIN_STREAMS")) {
-    g_ctx.main_streams = atoi(ms);
-    if (g_ctx.main_streams < 1 || g_ctx.main_streams > 4) g_ctx.main_streams = 1;
+    cx.main_streams = atoi(ms);
+    if (cx.main_streams < 1 || cx.main_streams > 4) cx.main_streams = 1;
   }
   // Only the streams that will be used: with more streams than hardware queues
   // (GPU_MAX_HW_QUEUES: 4 by default, 16 under bench.py) streams share queues, and which ones
   // do depends on the creation order -- a stream nobody launches on must not cost a queue.
-  for (int i = 0; i + 1 < g_ctx.main_streams; i++)
-    HIP_TRY(hipStreamCreateWithPriority(&g_ctx.main_extra[i], hipStreamNonBlocking, prio_least));
-  HIP_TRY(hipStreamCreateWithPriority(&g_ctx.pre_stream, hipStreamNonBlocking, prio_least));
-  HIP_TRY(hipStreamCreateWithPriority(&g_ctx.pre_stream2, hipStreamNonBlocking, prio_least));
-  if (const char* ps = getenv("CURDLE_PRE_STREAMS")) g_ctx.pre_streams = atoi(ps) == 1 ? 1 : 2;
+  for (int i = 0; i + 1 < cx.main_streams; i++)
+    HIP_TRY(hipStreamCreateWithPriority(&cx.main_extra[i], hipStreamNonBlocking, prio_least));
+  HIP_TRY(hipStreamCreateWithPriority(&cx.pre_stream, hipStreamNonBlocking, prio_least));
+  HIP_TRY(hipStreamCreateWithPriority(&cx.pre_stream2, hipStreamNonBlocking, prio_least));
+  if (const char* ps = getenv("CURDLE_PRE_STREAMS")) cx.pre_streams = atoi(ps) == 1 ? 1 : 2;
   // Tail streams at normal priority by default: on ROCm 7.2 all high-priority streams of a
   // process appear to share one hardware queue, which serialises the tails of consecutive
   // MSMs (measured: 0.93 vs 0.84 ms per 2-window partial).  CURDLE_TAIL_PRIO=1 restores it.
   const char* tp = getenv("CURDLE_TAIL_PRIO");
   const int tail_prio = (tp && atoi(tp) == 1) ? prio_greatest : prio_least;
-  for (Slot& s : g_ctx.slots) {
+  for (Slot& s : cx.slots) {
     HIP_TRY(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, tail_prio));
     HIP_TRY(hipEventCreateWithFlags(&s.acc_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
   }
-  g_ctx.prio_greatest = prio_greatest;
-  g_ctx.prio_least = prio_least;
-  g_ctx.device = device;
-  g_ctx.inited = true;
+  cx.prio_greatest = prio_greatest;
+  cx.prio_least = prio_least;
+  cx.device = device;
+  cx.inited = true;
   return CURDLE_OK;
 }
 
-int init_default_locked() { return init_locked(g_ctx.inited ? g_ctx.device : 0); }
+int init_default_locked(Ctx& cx) { return init_locked(cx, cx.device); }
 
 int choose_window_bits(size_t n, bool many = false) {
   const char* env = getenv("CURDLE_WINDOW_BITS");
@@ -297,9 +359,10 @@ int window_widths(int c, uint8_t bits[kMaxWindows]) {
 
 // Plan for k MSMs of n_total pairs in all, the largest having n_max pairs.
 int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end,
-              bool latency_mode, size_t sets = 1) {
+              bool latency_mode, size_t sets = 1, bool many = false) {
   if (n_total > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n_total);
-  if (c == 0) c = choose_window_bits(n_max, k * sets >= kGpuCombineMin);
+  many = many || k * sets >= kGpuCombineMin;  // a pass of a larger batch keeps the batch's rules
+  if (c == 0) c = choose_window_bits(n_max, many);
   if (c < 4 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", c);
   memset(&p, 0, sizeof(p));
   // from here on the counts are the split's terms: two per pair (k1 P and k2 phi(P), adjacent)
@@ -417,7 +480,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (const char* env = getenv("CURDLE_SORT_CHUNK")) ch = (uint64_t)atoll(env);
   if (ch > n_max) ch = n_max ? n_max : 1;
   p.chunk = (uint32_t)ch;
-  p.gpu_combine = k * sets >= kGpuCombineMin ? 1u : 0u;
+  p.gpu_combine = many ? 1u : 0u;
   // One single-block scan launch instead of six: up to 8,192 slots it is also the faster one; up to
   // 65,536 slots (a two-window partial of the multi-GPU split) it is slower in isolation (0.14 ms:
   // 64 consecutive slots per thread) but a pipelined caller only pays for launches, not latency.
@@ -439,39 +502,49 @@ void set_out_infinity(uint64_t out[18]) {
 // --- slot management -----------------------------------------------------------
 // A slot belongs to the caller from acquire to release; the context mutex only
 // guards the busy flags, so several threads can run MSMs concurrently.
-int acquire_slot(bool block, int* idx) {
-  std::unique_lock<std::mutex> g(g_ctx.mu);
-  int rc = init_default_locked();
+int acquire_slot(Ctx& cx, bool block, int* idx) {
+  std::unique_lock<std::mutex> g(cx.mu);
+  int rc = init_default_locked(cx);
   if (rc) return rc;
   for (;;) {
     for (int i = 0; i < kSlots; i++) {
-      if (!g_ctx.slots[i].busy) {
-        g_ctx.slots[i].busy = true;
-        g_ctx.slots[i].claimed = false;
-        g_ctx.slots[i].gen++;
+      if (!cx.slots[i].busy) {
+        cx.slots[i].busy = true;
+        cx.slots[i].claimed = false;
+        cx.slots[i].gen++;
         *idx = i;
         return CURDLE_OK;
       }
     }
     if (!block) return fail(CURDLE_EBUSY, "all %d MSM slots are in flight; call curdle_msm_wait first", kSlots);
-    g_ctx.cv.wait(g);
+    cx.cv.wait(g);
   }
 }
 
-void release_slot(int idx) {
+void release_slot(Ctx& cx, int idx) {
   {
-    std::lock_guard<std::mutex> g(g_ctx.mu);
-    g_ctx.slots[idx].busy = false;
+    std::lock_guard<std::mutex> g(cx.mu);
+    cx.slots[idx].busy = false;
   }
-  g_ctx.cv.notify_one();
+  cx.cv.notify_one();
 }
 
-// A ticket names a slot AND the acquisition it was handed out for (slot index in the low
-// byte, the slot's generation above it), so a ticket that was already waited for, or one
-// kept across a later submit, is refused instead of touching another caller's workspace.
-inline int make_ticket(int idx, uint32_t gen) { return (int)(((gen & 0x7fffffu) << 8) | (uint32_t)idx); }
-inline int ticket_index(int ticket) { return ticket & 0xff; }
+// A ticket names a context, a slot AND the acquisition it was handed out for (slot index in
+// the low three bits, the context's ordinal in the five above them, the slot's generation
+// above the low byte), so a ticket that was already waited for, or one kept across a later
+// submit, is refused instead of touching another caller's workspace, and a wait may come from
+// any thread whatever its current device.
+inline int make_ticket(const Ctx& cx, int idx, uint32_t gen) {
+  return (int)(((gen & 0x7fffffu) << 8) | ((uint32_t)cx.ordinal << 3) | (uint32_t)idx);
+}
+inline int ticket_index(int ticket) { return ticket & 0x7; }
+inline int ticket_dev(int ticket) { return (ticket >> 3) & 0x1f; }
 inline uint32_t ticket_gen(int ticket) { return ((uint32_t)ticket >> 8) & 0x7fffffu; }
+// the context a ticket was made on; nullptr for a ticket that names none
+inline Ctx* ticket_ctx(int ticket) {
+  if (ticket < 0 || ticket_dev(ticket) >= g_ndev.load(std::memory_order_acquire)) return nullptr;
+  return &g_ctxs[ticket_dev(ticket)];
+}
 
 // HIP-event bracketing of the phases of one call.  mode 1: an event after every phase (ten
 // timed events per MSM, on three streams).  mode 2: only the dominant kernel (accumulate) is
@@ -505,9 +578,9 @@ struct Prof {
 // Enqueue every GPU phase of k MSMs on the slot's stream (no host synchronisation).
 // d_points / d_scalars are device pointers holding the pairs of all MSMs back to back
 // and must stay valid until the matching finish_slot(); h_off has k + 1 entries.
-int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
+int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                  int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail,
-                 bool latency_mode = true, bool points28_ready = false, size_t sets = 1) {
+                 bool latency_mode = true, bool points28_ready = false, size_t sets = 1, bool many = false) {
   // sets > 1 (curdle_msm_g1_multi): d_points holds `sets` base sets of h_off[k] points each, all
   // multiplied by the SAME scalars: recoded and sorted once, accumulated per set
   const size_t n_pairs = h_off[k];
@@ -517,7 +590,7 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
     if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
   }
   MsmPlan& p = S.plan;
-  int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets);
+  int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets, many);
   if (rc) return rc;
   // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
   const size_t n = 2 * n_pairs;
@@ -527,7 +600,8 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
   const uint32_t nw = p.win_end - p.win_begin;
   if (n == 0 || nw == 0) return CURDLE_OK;  // finish_slot writes infinities
   const size_t nb = k * (size_t)p.NB;
-  if (nb > (size_t)1024 * 4096) return fail(CURDLE_EINVAL, "%zu bucket slots exceed the scan capacity", nb);
+  if (nb > (size_t)1024 * 4096)  // run_passes cuts larger batches; a caller that gets here skipped it
+    return fail(CURDLE_EINVAL, "%zu bucket slots exceed the scan capacity of one pass", nb);
   const size_t nlanes = ((size_t)nw * n + p.L - 1) / p.L;
   if ((rc = ensure(S.offsets, (k + 1) * 4))) return rc;
   if ((rc = ensure(S.counts, nb * 4))) return rc;
@@ -581,7 +655,7 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
     HIP_TRY(hipMemcpyAsync(S.offsets.p, h_off_pinned, (k + 1) * 4, hipMemcpyHostToDevice, pre));
   }
   // counts are cleared by k_digits, the large-bucket counter by the scan
-  Prof prof(S, pre, g_ctx.profile);
+  Prof prof(S, pre, cx.profile);
   if (!points28_ready) {  // the device accumulator fills S.points28 itself (resident bases: no conversion here)
     HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre));
     prof.mark("convert_points");
@@ -627,7 +701,7 @@ int enqueue_slot(Slot& S, const void* d_points, const void* d_scalars, const uin
 
 // Wait for the slot's GPU work and produce the k results (host combine unless the
 // batch combined on the GPU).
-int finish_slot(Slot& S, uint64_t* out) {
+int finish_slot(Ctx& cx, Slot& S, uint64_t* out) {
   const MsmPlan& p = S.plan;
   const size_t k = p.kr;  // results
   const uint32_t nw = p.win_end - p.win_begin;
@@ -637,8 +711,8 @@ int finish_slot(Slot& S, uint64_t* out) {
   }
   HIP_TRY(hipStreamSynchronize(S.run_stream));
   if (S.profiled) {
-    std::lock_guard<std::mutex> g(g_ctx.mu);
-    curdle_profile& L = g_ctx.last;
+    std::lock_guard<std::mutex> g(cx.mu);
+    curdle_profile& L = cx.last;
     L.n_kernels = S.prof_n;
     for (int i = 0; i < S.prof_n; i++) {
       L.name[i] = S.prof_name[i];
@@ -647,7 +721,7 @@ int finish_slot(Slot& S, uint64_t* out) {
     L.window_bits = p.c;
     L.num_windows = p.W;
     L.entries = L.fragments = 0;
-    if (g_ctx.profile == 1) {  // two 4-byte reads after the call has drained: diagnostics only
+    if (cx.profile == 1) {  // two 4-byte reads after the call has drained: diagnostics only
       const size_t nb = (size_t)p.k * p.NB;
       uint32_t v[2] = {0, 0};
       (void)hipMemcpy(&v[0], (const char*)S.starts.p + nb * 4, 4, hipMemcpyDeviceToHost);
@@ -685,12 +759,12 @@ int finish_slot(Slot& S, uint64_t* out) {
   return CURDLE_OK;
 }
 
-void drain_slot(Slot& S) {
-  (void)hipStreamSynchronize(g_ctx.h2d_stream);
-  (void)hipStreamSynchronize(g_ctx.pre_stream);
-  (void)hipStreamSynchronize(g_ctx.pre_stream2);
-  (void)hipStreamSynchronize(g_ctx.main_stream);
-  for (auto& st : g_ctx.main_extra)
+void drain_slot(Ctx& cx, Slot& S) {
+  (void)hipStreamSynchronize(cx.h2d_stream);
+  (void)hipStreamSynchronize(cx.pre_stream);
+  (void)hipStreamSynchronize(cx.pre_stream2);
+  (void)hipStreamSynchronize(cx.main_stream);
+  for (auto& st : cx.main_extra)
     if (st) (void)hipStreamSynchronize(st);
   (void)hipStreamSynchronize(S.stream);
 }
@@ -703,61 +777,102 @@ void drain_slot(Slot& S) {
 struct SyncStreams {
   hipStream_t pre, main, tail;
 };
-SyncStreams sync_streams(Slot& S) {
+SyncStreams sync_streams(Ctx& cx, Slot& S) {
   static const bool three = [] {
     const char* e = getenv("CURDLE_SYNC_STREAMS");
     return e && atoi(e) == 3;
   }();
-  if (three) return {g_ctx.pre_stream, g_ctx.main_stream, S.stream};
+  if (three) return {cx.pre_stream, cx.main_stream, S.stream};
   return {S.stream, S.stream, S.stream};
+}
+
+// The scans of the bucket slots hold 1,024 blocks of 4,096 slots: a batch with more slots than
+// that (1,024 MSMs of 2,548 pairs; 2,100 of 628) runs in passes of as many whole MSMs as fit,
+// one after the other on the caller's slot -- every pass is milliseconds of GPU work, so the
+// gap between two passes is noise, and the workspaces stay bounded.
+constexpr size_t kMaxSlotsPerPass = (size_t)1024 * 4096;
+
+// enqueue + finish of k MSMs on slot S, in passes if the batch is too large for one.
+int run_passes(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
+               int win_begin, int win_end, hipStream_t pre, hipStream_t main, hipStream_t tail, uint64_t* out) {
+  if (k > 1) {
+    size_t n_max = 0;
+    for (size_t j = 0; j < k; j++) {
+      if (h_off[j + 1] < h_off[j]) return fail(CURDLE_EINVAL, "offsets not monotone at %zu", j);
+      if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
+    }
+    MsmPlan probe;
+    int rc = make_plan(probe, h_off[k] - h_off[0], k, n_max, c, win_begin, win_end, true);
+    if (rc) return rc;
+    size_t per_pass = probe.NB ? kMaxSlotsPerPass / probe.NB : k;
+    if (const char* e = getenv("CURDLE_MAX_MSMS_PER_PASS")) per_pass = atoll(e) > 0 ? (size_t)atoll(e) : per_pass;
+    if (k > per_pass) {
+      std::vector<uint32_t> off;
+      for (size_t j0 = 0; j0 < k; j0 += per_pass) {
+        const size_t kg = k - j0 < per_pass ? k - j0 : per_pass;
+        off.resize(kg + 1);
+        for (size_t j = 0; j <= kg; j++) off[j] = h_off[j0 + j] - h_off[j0];
+        // the whole batch's window width for every pass (a pass's own n_max must not change it)
+        rc = enqueue_slot(cx, S, (const char*)d_points + (size_t)h_off[j0] * 96, (const char*)d_scalars + (size_t)h_off[j0] * 32,
+                          off.data(), kg, probe.c, win_begin, win_end, pre, main, tail, true, false, 1,
+                          /*many=*/true);
+        if (!rc) rc = finish_slot(cx, S, out + 18 * j0);
+        if (rc) return rc;
+      }
+      return CURDLE_OK;
+    }
+  }
+  int rc = enqueue_slot(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, pre, main, tail);
+  if (!rc) rc = finish_slot(cx, S, out);
+  return rc;
 }
 
 // Synchronous run of k MSMs with inputs on the device.
 int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c, int win_begin,
                int win_end, uint64_t* out, void* user_stream) {
+  Ctx& cx = cur();
   int idx;
-  int rc = acquire_slot(true, &idx);
+  int rc = acquire_slot(cx, true, &idx);
   if (rc) return rc;
-  Slot& S = g_ctx.slots[idx];
-  hipError_t he = hipSetDevice(g_ctx.device);
+  Slot& S = cx.slots[idx];
+  hipError_t he = hipSetDevice(cx.device);
   if (he != hipSuccess) {
-    release_slot(idx);
+    release_slot(cx, idx);
     return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
   }
   if (user_stream) {
-    rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, (hipStream_t)user_stream,
-                      (hipStream_t)user_stream, (hipStream_t)user_stream);
+    rc = run_passes(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, (hipStream_t)user_stream,
+                    (hipStream_t)user_stream, (hipStream_t)user_stream, out);
   } else {
-    const SyncStreams st = sync_streams(S);
-    rc = enqueue_slot(S, d_points, d_scalars, h_off, k, c, win_begin, win_end, st.pre, st.main, st.tail);
+    const SyncStreams st = sync_streams(cx, S);
+    rc = run_passes(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, st.pre, st.main, st.tail, out);
   }
-  if (!rc) rc = finish_slot(S, out);
-  else drain_slot(S);
-  release_slot(idx);
+  if (rc) drain_slot(cx, S);
+  release_slot(cx, idx);
   return rc;
 }
 
 // Synchronous run with inputs in host memory: staged through the slot's own buffers.
 int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_off, size_t k, uint64_t* out) {
+  Ctx& cx = cur();
   int idx;
-  int rc = acquire_slot(true, &idx);
+  int rc = acquire_slot(cx, true, &idx);
   if (rc) return rc;
-  Slot& S = g_ctx.slots[idx];
+  Slot& S = cx.slots[idx];
   const size_t n = h_off[k];
   auto body = [&]() -> int {
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    HIP_TRY(hipSetDevice(cx.device));
     int r;
     if ((r = ensure(S.points, n * 96))) return r;
     if ((r = ensure(S.scalars, n * 32))) return r;
-    const SyncStreams st = sync_streams(S);
+    const SyncStreams st = sync_streams(cx, S);
     HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, st.pre));
     HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st.pre));
-    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, st.pre, st.main, st.tail))) return r;
-    return finish_slot(S, out);
+    return run_passes(cx, S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, st.pre, st.main, st.tail, out);
   };
   rc = body();
-  if (rc) drain_slot(S);
-  release_slot(idx);
+  if (rc) drain_slot(cx, S);
+  release_slot(cx, idx);
   return rc;
 }
 
@@ -768,6 +883,7 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
 // copy (128 MiB) costs more than the arithmetic.
 constexpr size_t kHostChunkMin = (size_t)1 << 19;  // below this a call is one chunk
 int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out) {
+  Ctx& cx = cur();
   // measured (tools/bench_host_buffers.py, pageable memory, ~29 GB/s at best): N = 2^20 6.4 ms in
   // one copy, 5.8 in two chunks, 6.5 in four (32 MiB copies run below that rate); N = 2^22 23.1 ms
   // in one copy, 18.3-18.5 in two to eight chunks -- the copy itself is what is left
@@ -781,9 +897,9 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
     const int idx = pending.front();
     pending.erase(pending.begin());
     uint64_t part[18];
-    int rc = finish_slot(g_ctx.slots[idx], part);
-    if (rc) drain_slot(g_ctx.slots[idx]);
-    release_slot(idx);
+    int rc = finish_slot(cx, cx.slots[idx], part);
+    if (rc) drain_slot(cx, cx.slots[idx]);
+    release_slot(cx, idx);
     if (rc) return rc;
     G1Jac j;
     memcpy(&j, part, sizeof(j));
@@ -797,38 +913,47 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       const size_t m = n - lo < per ? n - lo : per;
       // never wait for a slot while holding one: another chunked caller may be doing the same
       int idx = -1;
-      int rc = acquire_slot(false, &idx);
+      int rc = acquire_slot(cx, false, &idx);
       while (rc == CURDLE_EBUSY) {
         if (pending.empty()) {
-          rc = acquire_slot(true, &idx);
+          rc = acquire_slot(cx, true, &idx);
           break;
         }
         if ((rc = collect_oldest())) return rc;
-        rc = acquire_slot(false, &idx);
+        rc = acquire_slot(cx, false, &idx);
       }
       if (rc) return rc;
-      Slot& S = g_ctx.slots[idx];
+      Slot& S = cx.slots[idx];
       pending.push_back(idx);
-      HIP_TRY(hipSetDevice(g_ctx.device));
+      HIP_TRY(hipSetDevice(cx.device));
       int r;
       if ((r = ensure(S.points, m * 96))) return r;
       if ((r = ensure(S.scalars, m * 32))) return r;
-      const unsigned seq = g_ctx.submit_count.fetch_add(1, std::memory_order_relaxed);
-      const unsigned turn = seq % (unsigned)g_ctx.main_streams;
-      hipStream_t main = turn == 0 ? g_ctx.main_stream : g_ctx.main_extra[turn - 1];
+      const unsigned seq = cx.submit_count.fetch_add(1, std::memory_order_relaxed);
+      const unsigned turn = seq % (unsigned)cx.main_streams;
+      hipStream_t main = turn == 0 ? cx.main_stream : cx.main_extra[turn - 1];
       // every chunk's copy on ONE stream, so that the first chunk arrives at the full PCIe rate
       // instead of sharing it with the ones behind it (from page-locked memory all the copies are
       // queued at once; measured, such memory buys nothing else here: the link gives ~29 GB/s to
       // pageable and page-locked sources alike), the pipeline behind its own chunk's copy
-      HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars + 4 * lo, m * 32, hipMemcpyHostToDevice, g_ctx.h2d_stream));
-      HIP_TRY(hipMemcpyAsync(S.points.p, points + 12 * lo, m * 96, hipMemcpyHostToDevice, g_ctx.h2d_stream));
-      HIP_TRY(hipEventRecord(S.pre_done, g_ctx.h2d_stream));
-      HIP_TRY(hipStreamWaitEvent(g_ctx.pre_stream, S.pre_done, 0));
+      HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars + 4 * lo, m * 32, hipMemcpyHostToDevice, cx.h2d_stream));
+      HIP_TRY(hipMemcpyAsync(S.points.p, points + 12 * lo, m * 96, hipMemcpyHostToDevice, cx.h2d_stream));
+      HIP_TRY(hipEventRecord(S.pre_done, cx.h2d_stream));
+      HIP_TRY(hipStreamWaitEvent(cx.pre_stream, S.pre_done, 0));
       const uint32_t off[2] = {0, (uint32_t)m};
-      if ((r = enqueue_slot(S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, g_ctx.pre_stream, main, S.stream,
+      if ((r = enqueue_slot(cx, S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, cx.pre_stream, main, S.stream,
                             /*latency_mode=*/false)))
         return r;
-      if (pending.size() > 2 && (r = collect_oldest())) return r;
+      // at most three chunks in flight, two while other callers hold slots: two or three
+      // concurrent large calls would otherwise take all eight slots between them and queue
+      // every other caller behind their copies
+      size_t busy_slots = 0;
+      {
+        std::lock_guard<std::mutex> g(cx.mu);
+        for (const Slot& x : cx.slots) busy_slots += x.busy ? 1 : 0;
+      }
+      const size_t cap = busy_slots > pending.size() ? 1 : 2;
+      if (pending.size() > cap && (r = collect_oldest())) return r;
     }
     while (!pending.empty()) {
       int r = collect_oldest();
@@ -839,8 +964,8 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
   };
   int rc = body();
   for (int idx : pending) {  // only after a failure
-    drain_slot(g_ctx.slots[idx]);
-    release_slot(idx);
+    drain_slot(cx, cx.slots[idx]);
+    release_slot(cx, idx);
   }
   return rc;
 }
@@ -852,6 +977,7 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
 // ---------------------------------------------------------------------------
 extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgroup_check, uint64_t* out_affine,
                                           uint8_t* status) {
+  Ctx& cx = cur();
   if (n && (!in || !out_affine || !status)) return fail(CURDLE_EINVAL, "null argument");
   if (n == 0) return CURDLE_OK;
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 points", n);
@@ -873,11 +999,11 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
     if (rc2 != CURDLE_EBUSY) return rc2;
   }
   int idx;
-  int rc = acquire_slot(true, &idx);
+  int rc = acquire_slot(cx, true, &idx);
   if (rc) return rc;
-  Slot& S = g_ctx.slots[idx];
+  Slot& S = cx.slots[idx];
   auto body = [&]() -> int {
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    HIP_TRY(hipSetDevice(cx.device));
     int r;
     // the slot's generic buffers: compressed input, decoded output, status bytes
     if ((r = ensure(S.scalars, n * 48))) return r;
@@ -903,7 +1029,7 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
   };
   rc = body();
   if (rc) (void)hipStreamSynchronize(S.stream);  // nothing queued may outlive the slot's hold
-  release_slot(idx);
+  release_slot(cx, idx);
   return rc;
 }
 
@@ -927,15 +1053,18 @@ namespace {
 // 252 in all six combinations of 4 / 16 hardware queues and the three priorities), and with
 // eight threads verifying at once the lowest one measured best.  CURDLE_DECODE_PRIO=1 selects
 // the highest, =2 the default one.
-int ensure_dslot_streams(DSlot& d) {
-  if (d.stream) return CURDLE_OK;
+int ensure_dslot_streams(Ctx& cx) {
+  // the flag is set (release) after every stream and event of every decode context was stored, and
+  // read (acquire) before any of them is used: no thread sees a half-made context
+  if (cx.dstreams_ready.load(std::memory_order_acquire)) return CURDLE_OK;
   // every decode context at once, under the lock: creating a stream (its hardware queue) takes
   // tens of milliseconds, and a second context first used under load would put that into some
   // caller's verification (seen as 354 instead of 1,300 Whisk verifications/s from four threads)
-  std::lock_guard<std::mutex> g(g_ctx.mu);
+  std::lock_guard<std::mutex> g(cx.mu);
+  if (cx.dstreams_ready.load(std::memory_order_relaxed)) return CURDLE_OK;
   const char* dp = getenv("CURDLE_DECODE_PRIO");
-  const int dprio = dp ? (atoi(dp) == 1 ? g_ctx.prio_greatest : atoi(dp) == 2 ? 0 : g_ctx.prio_least) : g_ctx.prio_least;
-  for (DSlot& x : g_ctx.dslots) {
+  const int dprio = dp ? (atoi(dp) == 1 ? cx.prio_greatest : atoi(dp) == 2 ? 0 : cx.prio_least) : cx.prio_least;
+  for (DSlot& x : cx.dslots) {
     if (x.stream) continue;
     hipStream_t a = nullptr, b = nullptr, c = nullptr;
     hipEvent_t e1 = nullptr, e2 = nullptr;
@@ -948,19 +1077,21 @@ int ensure_dslot_streams(DSlot& d) {
     x.copy_stream = c;
     x.uploaded = e1;
     x.decoded = e2;
-    x.stream = a;  // last: the unlocked fast path above tests it
+    x.stream = a;
   }
+  cx.dstreams_ready.store(true, std::memory_order_release);
   return CURDLE_OK;
 }
 }  // namespace
 
 extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* ticket) {
+  Ctx& cx = cur();
   if (!ticket || (n && !in)) return fail(CURDLE_EINVAL, "null argument");
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 points", n);
   int idx = -1;
   {
-    std::unique_lock<std::mutex> g(g_ctx.mu);
-    int rc = init_default_locked();
+    std::unique_lock<std::mutex> g(cx.mu);
+    int rc = init_default_locked(cx);
     if (rc) return rc;
     // Deferring the subgroup test only pays for a caller that would otherwise wait for it;
     // with several verifications in flight the GPU is busy anyway and every extra stream
@@ -968,23 +1099,23 @@ extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* tick
     // one-shot form.
     int busy = 0;
     for (int i = 0; i < kMaxDeferred; i++) {
-      if (g_ctx.dslots[i].busy)
+      if (cx.dslots[i].busy)
         busy++;
       else if (idx < 0)
         idx = i;
     }
     if (idx < 0 || busy >= kMaxDeferred)
       return fail(CURDLE_EBUSY, "%d deferred point decodings in flight; use curdle_g1_decompress_batch", busy);
-    g_ctx.dslots[idx].busy = true;
-    g_ctx.dslots[idx].claimed = false;
-    g_ctx.dslots[idx].gen++;
+    cx.dslots[idx].busy = true;
+    cx.dslots[idx].claimed = false;
+    cx.dslots[idx].gen++;
   }
-  DSlot& D = g_ctx.dslots[idx];
+  DSlot& D = cx.dslots[idx];
   auto body = [&]() -> int {
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    HIP_TRY(hipSetDevice(cx.device));
     D.n = (uint32_t)n;
     int r;
-    if ((r = ensure_dslot_streams(D))) return r;
+    if ((r = ensure_dslot_streams(cx))) return r;
     if (n == 0) return CURDLE_OK;
     if ((r = ensure(D.in, n * 48))) return r;
     if ((r = ensure(D.out, n * 96))) return r;
@@ -1023,21 +1154,23 @@ extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* tick
     if (D.stream) (void)hipStreamSynchronize(D.stream);
     if (D.sub_stream) (void)hipStreamSynchronize(D.sub_stream);
     {
-      std::lock_guard<std::mutex> g(g_ctx.mu);
+      std::lock_guard<std::mutex> g(cx.mu);
       D.busy = false;
     }
     return rc;
   }
-  *ticket = make_ticket(idx, D.gen);
+  *ticket = make_ticket(cx, idx, D.gen);
   return CURDLE_OK;
 }
 
 namespace {
 // the decode context behind a ticket that is in flight and not being finished; nullptr otherwise
 DSlot* dslot_of(int ticket) {
-  if (ticket < 0 || ticket_index(ticket) >= kMaxDeferred) return nullptr;
-  DSlot& D = g_ctx.dslots[ticket_index(ticket)];
-  std::lock_guard<std::mutex> g(g_ctx.mu);
+  Ctx* cp = ticket_ctx(ticket);
+  if (!cp || ticket_index(ticket) >= kMaxDeferred) return nullptr;
+  Ctx& cx = *cp;
+  DSlot& D = cx.dslots[ticket_index(ticket)];
+  std::lock_guard<std::mutex> g(cx.mu);
   if (!D.busy || D.claimed || (D.gen & 0x7fffffu) != ticket_gen(ticket)) return nullptr;
   return &D;
 }
@@ -1046,11 +1179,12 @@ DSlot* dslot_of(int ticket) {
 extern "C" int curdle_g1_decompress_points(int ticket, uint64_t* out_affine, uint8_t* status) {
   DSlot* Dp = dslot_of(ticket);
   if (!Dp) return fail(CURDLE_EINVAL, "ticket %d is not in flight (stale or already finished)", ticket);
+  Ctx& cx = *ticket_ctx(ticket);
   DSlot& D = *Dp;
   const size_t n = D.n;
   if (n && (!out_affine || !status)) return fail(CURDLE_EINVAL, "null argument");
   auto body = [&]() -> int {
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    HIP_TRY(hipSetDevice(cx.device));
     if (n == 0) return CURDLE_OK;
     // encoding / curve verdicts only: the subgroup test's arrive with curdle_g1_decompress_finish
     // through pinned staging: a copy into the caller's pageable memory goes through the runtime's
@@ -1086,17 +1220,19 @@ extern "C" int curdle_g1_decompress_begin(const uint8_t* in, size_t n, uint64_t*
 }
 
 extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
-  if (ticket < 0 || ticket_index(ticket) >= kMaxDeferred) return fail(CURDLE_EINVAL, "bad ticket");
-  DSlot& D = g_ctx.dslots[ticket_index(ticket)];
+  Ctx* cp = ticket_ctx(ticket);
+  if (!cp || ticket_index(ticket) >= kMaxDeferred) return fail(CURDLE_EINVAL, "bad ticket");
+  Ctx& cx = *cp;
+  DSlot& D = cx.dslots[ticket_index(ticket)];
   {
-    std::lock_guard<std::mutex> g(g_ctx.mu);
+    std::lock_guard<std::mutex> g(cx.mu);
     if (!D.busy || D.claimed || (D.gen & 0x7fffffu) != ticket_gen(ticket))
       return fail(CURDLE_EINVAL, "ticket %d is not in flight (stale or already finished)", ticket);
     D.claimed = true;
   }
   const size_t n = D.n;
   int rc = CURDLE_OK;
-  hipError_t he = hipSetDevice(g_ctx.device);
+  hipError_t he = hipSetDevice(cx.device);
   uint8_t* h = static_cast<uint8_t*>(D.h_out);  // [0, n): statuses, [n, 2n): subgroup verdicts (the points' block is free again)
   if (he == hipSuccess) he = hipStreamSynchronize(D.copy_stream);
   if (he == hipSuccess && n && status) {
@@ -1110,7 +1246,7 @@ extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
     for (size_t i = 0; i < n; i++)
       status[i] = (h[i] == CURDLE_DECODE_OK && !h[n + i]) ? (uint8_t)CURDLE_DECODE_NOT_IN_SUBGROUP : h[i];
   {
-    std::lock_guard<std::mutex> g(g_ctx.mu);
+    std::lock_guard<std::mutex> g(cx.mu);
     D.busy = false;
   }
   return rc;
@@ -1121,16 +1257,17 @@ extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
 // ---------------------------------------------------------------------------
 extern "C" int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t* scalars, size_t n_scalars,
                                           const uint64_t* addends, size_t n, uint64_t* out_affine) {
+  Ctx& cx = cur();
   if (n && (!points || !scalars || !out_affine)) return fail(CURDLE_EINVAL, "null argument");
   if (n == 0) return CURDLE_OK;
   if (n_scalars != n && n_scalars != 1) return fail(CURDLE_EINVAL, "n_scalars must be n or 1");
   if (n > ((size_t)1 << 24)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^24 points", n);
   int idx;
-  int rc = acquire_slot(true, &idx);
+  int rc = acquire_slot(cx, true, &idx);
   if (rc) return rc;
-  Slot& S = g_ctx.slots[idx];
+  Slot& S = cx.slots[idx];
   auto body = [&]() -> int {
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    HIP_TRY(hipSetDevice(cx.device));
     int r;
     if ((r = ensure(S.points, n * 96))) return r;
     if ((r = ensure(S.scalars, n_scalars * 32))) return r;
@@ -1149,26 +1286,16 @@ extern "C" int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t
   };
   rc = body();
   if (rc) (void)hipStreamSynchronize(S.stream);  // `res` is a local: nothing may still be copying into it
-  release_slot(idx);
+  release_slot(cx, idx);
   return rc;
 }
 
 // ---------------------------------------------------------------------------
 // Life cycle
 // ---------------------------------------------------------------------------
-extern "C" int curdle_init(int device) {
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  return init_locked(device);
-}
-
-extern "C" int curdle_shutdown(void) {
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  Ctx& C = g_ctx;
-  if (!C.inited) return CURDLE_OK;
-  for (Slot& S : C.slots)
-    if (S.busy) return fail(CURDLE_EBUSY, "an MSM is still in flight");
-  for (DSlot& d : C.dslots)
-    if (d.busy) return fail(CURDLE_EBUSY, "a point decoding is still in flight");
+namespace {
+// Everything a context owns; the caller holds cx.mu and has checked that nothing is in flight.
+void teardown_locked(Ctx& C) {
   (void)hipSetDevice(C.device);
   for (DSlot& d : C.dslots) {
     if (d.stream) (void)hipStreamSynchronize(d.stream);
@@ -1245,7 +1372,78 @@ extern "C" int curdle_shutdown(void) {
   (void)hipStreamDestroy(C.h2d_stream);
   C.h2d_stream = nullptr;
   C.inited = false;
+  C.dstreams_ready.store(false, std::memory_order_release);
   C.epoch++;  // device memory of curdle_dbases handles made under this context is gone with it
+}
+}  // namespace
+
+extern "C" int curdle_init(int device) {
+  std::lock_guard<std::mutex> cfg(g_cfg_mu);
+  Ctx& cx = g_ctxs[0];
+  std::lock_guard<std::mutex> g(cx.mu);
+  return init_locked(cx, device);
+}
+
+extern "C" int curdle_init_devices(const int* devices, int n) {
+  if (!devices || n < 1 || n > kMaxDevices) return fail(CURDLE_EINVAL, "devices[] of 1..%d entries expected", kMaxDevices);
+  std::lock_guard<std::mutex> cfg(g_cfg_mu);
+  const int have = g_ndev.load(std::memory_order_acquire);
+  bool any = false;
+  for (int i = 0; i < have; i++) {
+    std::lock_guard<std::mutex> g(g_ctxs[i].mu);
+    any = any || g_ctxs[i].inited;
+  }
+  if (any && have > 1) {  // a multi-device configuration stands until curdle_shutdown
+    bool same = have == n;
+    for (int i = 0; same && i < n; i++) same = g_ctxs[i].device == devices[i];
+    if (!same) return fail(CURDLE_EINVAL, "already initialised on %d device(s); curdle_shutdown first", have);
+    return CURDLE_OK;
+  }
+  for (int i = 0; i < n; i++) {
+    Ctx& cx = g_ctxs[i];
+    std::lock_guard<std::mutex> g(cx.mu);
+    int rc = init_locked(cx, devices[i]);  // context 0 may be up already (curdle_init): same device or CURDLE_EINVAL
+    if (rc) return rc;
+  }
+  if (n > 1)
+    for (int i = 0; i < n; i++)
+      if (!g_ctxs[i].worker) g_ctxs[i].worker = new DevWorker(i);
+  g_ndev.store(n, std::memory_order_release);
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_device_count(void) { return g_ndev.load(std::memory_order_acquire); }
+
+extern "C" int curdle_set_device(int ordinal) {
+  if (ordinal < 0 || ordinal >= g_ndev.load(std::memory_order_acquire))
+    return fail(CURDLE_EINVAL, "device ordinal %d outside [0, %d)", ordinal, g_ndev.load());
+  tl_dev = ordinal;
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_get_device(void) { return cur().ordinal; }
+
+extern "C" int curdle_shutdown(void) {
+  std::lock_guard<std::mutex> cfg(g_cfg_mu);
+  const int have = g_ndev.load(std::memory_order_acquire);
+  for (int i = 0; i < have; i++) {  // all or nothing: first make sure no context has work in flight
+    Ctx& C = g_ctxs[i];
+    std::lock_guard<std::mutex> g(C.mu);
+    if (!C.inited) continue;
+    for (Slot& S : C.slots)
+      if (S.busy) return fail(CURDLE_EBUSY, "an MSM is still in flight");
+    for (DSlot& d : C.dslots)
+      if (d.busy) return fail(CURDLE_EBUSY, "a point decoding is still in flight");
+  }
+  for (int i = 0; i < have; i++) {
+    Ctx& C = g_ctxs[i];
+    delete C.worker;  // joins the device's host thread (its queue is empty: nothing is in flight)
+    C.worker = nullptr;
+    std::lock_guard<std::mutex> g(C.mu);
+    if (C.inited) teardown_locked(C);
+    C.device = 0;
+  }
+  g_ndev.store(1, std::memory_order_release);
   return CURDLE_OK;
 }
 
@@ -1278,6 +1476,79 @@ extern "C" int curdle_msm_window_widths(size_t n, int window_bits, int widths[64
 
 extern "C" int curdle_msm_num_windows(size_t n, int window_bits) { return curdle_msm_window_widths(n, window_bits, nullptr); }
 
+namespace {
+// One MSM from host buffers on the calling thread's context.
+int msm_host_one_device(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
+  if (n == 0) {
+    set_out_infinity(out_jac);
+    return CURDLE_OK;
+  }
+  if (n >= kHostChunkMin && !getenv("CURDLE_HOST_ONE_COPY")) return run_host_chunked(points, scalars, n, out_jac);
+  const uint32_t off[2] = {0, (uint32_t)n};
+  return run_host(points, scalars, off, 1, out_jac);
+}
+
+// share(d, out18) runs on the host thread of context d (whose current context is d) for every
+// d < D, all at once; the D partial sums are added on the host (what curdle_g1_sum does).  The
+// exchange of north_star's "RCCL reduce of 8 partial points" inside ONE process: 144 bytes per
+// device through host memory, no collective.
+int run_on_devices(int D, const std::function<int(int, uint64_t*)>& share, uint64_t out_jac[18]) {
+  struct Part {
+    uint64_t jac[18];
+    int rc = CURDLE_OK;
+    char err[256] = "";
+  };
+  std::vector<Part> parts((size_t)D);
+  std::mutex mu;
+  std::condition_variable cv;
+  int left = D;
+  for (int d = 0; d < D; d++) {
+    DevWorker* w = g_ctxs[d].worker;
+    if (!w) return fail(CURDLE_EINVAL, "context %d has no host thread (curdle_init_devices was not called)", d);
+    w->post([&, d] {
+      Part& p = parts[(size_t)d];
+      p.rc = share(d, p.jac);
+      if (p.rc) snprintf(p.err, sizeof(p.err), "%s", g_err);  // the worker's thread-local text
+      std::lock_guard<std::mutex> g(mu);
+      if (--left == 0) cv.notify_one();
+    });
+  }
+  {
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return left == 0; });
+  }
+  G1XYZZ total;
+  g1_set_inf(total);
+  for (int d = 0; d < D; d++) {
+    if (parts[(size_t)d].rc) return fail(parts[(size_t)d].rc, "device %d: %s", d, parts[(size_t)d].err);
+    G1Jac j;
+    memcpy(&j, parts[(size_t)d].jac, sizeof(j));
+    G1XYZZ t;
+    g1_from_jac(t, j);
+    g1_add(total, t);
+  }
+  g1_to_canonical_jac(out_jac, total);
+  return CURDLE_OK;
+}
+
+// contiguous, as-even-as-possible split of [0, n) over D parts (curdlemsm/distributed.py window_partition)
+inline void even_range(size_t n, int D, int d, size_t* lo, size_t* hi) {
+  const size_t base = n / (size_t)D, extra = n % (size_t)D;
+  *lo = (size_t)d * base + ((size_t)d < extra ? (size_t)d : extra);
+  *hi = *lo + base + ((size_t)d < extra ? 1 : 0);
+}
+
+// Below this many pairs a host-buffer MSM stays on the calling thread's device: the hand-off to
+// D host threads and D separate small MSMs (each a fixed ~0.3 ms chain) cost more than they save.
+size_t multi_device_min() {
+  static const size_t v = [] {
+    const char* e = getenv("CURDLE_MULTI_DEVICE_MIN");
+    return e ? (size_t)atoll(e) : (size_t)1 << 16;
+  }();
+  return v;
+}
+}  // namespace
+
 extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
   if (!out_jac) return fail(CURDLE_EINVAL, "out_jac is null");
   if (n == 0) {
@@ -1286,9 +1557,56 @@ extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, si
   }
   if (!points || !scalars) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
-  if (n >= kHostChunkMin && !getenv("CURDLE_HOST_ONE_COPY")) return run_host_chunked(points, scalars, n, out_jac);
-  const uint32_t off[2] = {0, (uint32_t)n};
-  return run_host(points, scalars, off, 1, out_jac);
+  const int D = g_ndev.load(std::memory_order_acquire);
+  if (D > 1 && n >= multi_device_min()) {
+    // Several GPUs behind this one call (curdle_init_devices): by POINT RANGES -- from host buffers
+    // the copy is most of the call (128 MiB at N = 2^20 over one GPU's PCIe link), and only a point
+    // range divides it: every device copies its own n / D pairs over its own link and runs all
+    // windows over them (a window range would send all n pairs to every device).
+    return run_on_devices(D, [&](int d, uint64_t* part) {
+      size_t lo, hi;
+      even_range(n, D, d, &lo, &hi);
+      return msm_host_one_device(points + 12 * lo, scalars + 4 * lo, hi - lo, part);
+    }, out_jac);
+  }
+  return msm_host_one_device(points, scalars, n, out_jac);
+}
+
+extern "C" int curdle_msm_g1_replicated(const void* const* d_points, const void* const* d_scalars, size_t n, int split,
+                                        uint64_t out_jac[18]) {
+  if (!out_jac) return fail(CURDLE_EINVAL, "out_jac is null");
+  if (split < 0 || split > 2) return fail(CURDLE_EINVAL, "split must be 0 (library's choice), 1 (windows) or 2 (points)");
+  if (n == 0) {
+    set_out_infinity(out_jac);
+    return CURDLE_OK;
+  }
+  if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
+  const int D = g_ndev.load(std::memory_order_acquire);
+  if (!d_points || !d_scalars) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
+  for (int d = 0; d < D; d++)
+    if (!d_points[d] || !d_scalars[d]) return fail(CURDLE_EINVAL, "device %d: null input pointer", d);
+  if (D == 1) {
+    const uint32_t off[2] = {0, (uint32_t)n};
+    return run_device(d_points[0], d_scalars[0], off, 1, 0, 0, -1, out_jac, nullptr);
+  }
+  // which partition pays at which size: DESIGN.md section 5 (per-rank step times on one MI355X)
+  if (split == 0) split = n >= ((size_t)1 << 22) ? 2 : 1;
+  const int c = choose_window_bits(n);
+  uint8_t bits[kMaxWindows];
+  const int W = window_widths(c, bits);
+  return run_on_devices(D, [&](int d, uint64_t* part) {
+    if (split == 1) {  // windows [wb, we) of the plan for all n pairs; a device beyond the last window adds infinity
+      size_t wb, we;
+      even_range((size_t)W, D, d, &wb, &we);
+      const uint32_t off[2] = {0, (uint32_t)n};
+      return run_device(d_points[d], d_scalars[d], off, 1, c, (int)wb, (int)we, part, nullptr);
+    }
+    size_t lo, hi;
+    even_range(n, D, d, &lo, &hi);
+    const uint32_t off[2] = {0, (uint32_t)(hi - lo)};
+    return run_device((const char*)d_points[d] + lo * 96, (const char*)d_scalars[d] + lo * 32, off, 1, 0, 0, -1, part,
+                      nullptr);
+  }, out_jac);
 }
 
 extern "C" int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, size_t n, int window_bits,
@@ -1310,55 +1628,66 @@ extern "C" int curdle_msm_g1_device(const void* d_points, const void* d_scalars,
 // the host.  Up to CURDLE_MSM_SLOTS calls can be in flight.
 extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_scalars, size_t n, int window_bits,
                                            int win_begin, int win_end, int* ticket) {
+  Ctx& cx = cur();
   if (!ticket) return fail(CURDLE_EINVAL, "ticket is null");
   if (n && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
   int idx;
-  int rc = acquire_slot(false, &idx);
+  int rc = acquire_slot(cx, false, &idx);
   if (rc) return rc;
-  Slot& S = g_ctx.slots[idx];
-  hipError_t he = hipSetDevice(g_ctx.device);
+  Slot& S = cx.slots[idx];
+  hipError_t he = hipSetDevice(cx.device);
   if (he != hipSuccess) {
-    release_slot(idx);
+    release_slot(cx, idx);
     return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
   }
   const uint32_t off[2] = {0, (uint32_t)n};
-  const unsigned seq = g_ctx.submit_count.fetch_add(1, std::memory_order_relaxed);
-  const unsigned turn = seq % (unsigned)g_ctx.main_streams;
-  hipStream_t main = turn == 0 ? g_ctx.main_stream : g_ctx.main_extra[turn - 1];
+  const unsigned seq = cx.submit_count.fetch_add(1, std::memory_order_relaxed);
+  const unsigned turn = seq % (unsigned)cx.main_streams;
+  hipStream_t main = turn == 0 ? cx.main_stream : cx.main_extra[turn - 1];
   const bool partial = win_begin > 0 || (win_end >= 0 && win_end < curdle_msm_num_windows(n, window_bits));
-  hipStream_t pre = partial && g_ctx.pre_streams == 2 && (seq & 1u) ? g_ctx.pre_stream2 : g_ctx.pre_stream;
-  rc = enqueue_slot(S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, pre, main,
+  hipStream_t pre = partial && cx.pre_streams == 2 && (seq & 1u) ? cx.pre_stream2 : cx.pre_stream;
+  rc = enqueue_slot(cx, S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, pre, main,
                     S.stream, /*latency_mode=*/false);
   if (rc) {
-    drain_slot(S);
-    release_slot(idx);
+    drain_slot(cx, S);
+    release_slot(cx, idx);
     return rc;
   }
-  *ticket = make_ticket(idx, S.gen);
+  *ticket = make_ticket(cx, idx, S.gen);
   return CURDLE_OK;
 }
 
 extern "C" int curdle_msm_wait(int ticket, uint64_t out_jac[18]) {
-  if (ticket < 0 || ticket_index(ticket) >= kSlots || !out_jac) return fail(CURDLE_EINVAL, "bad ticket or null output");
+  Ctx* cp = ticket_ctx(ticket);
+  if (!cp || ticket_index(ticket) >= kSlots || !out_jac) return fail(CURDLE_EINVAL, "bad ticket or null output");
+  Ctx& cx = *cp;
   const int idx = ticket_index(ticket);
   {
-    std::lock_guard<std::mutex> g(g_ctx.mu);
-    Slot& S = g_ctx.slots[idx];
-    if (!g_ctx.inited || !S.busy || S.claimed || (S.gen & 0x7fffffu) != ticket_gen(ticket))
+    std::lock_guard<std::mutex> g(cx.mu);
+    Slot& S = cx.slots[idx];
+    if (!cx.inited || !S.busy || S.claimed || (S.gen & 0x7fffffu) != ticket_gen(ticket))
       return fail(CURDLE_EINVAL, "ticket %d is not in flight (stale or already waited for)", ticket);
     S.claimed = true;
   }
-  hipError_t he = hipSetDevice(g_ctx.device);
+  hipError_t he = hipSetDevice(cx.device);
   if (he != hipSuccess) {
-    std::lock_guard<std::mutex> g(g_ctx.mu);
-    g_ctx.slots[idx].claimed = false;  // the call is still in flight: the caller may wait again
+    std::lock_guard<std::mutex> g(cx.mu);
+    cx.slots[idx].claimed = false;  // the call is still in flight: the caller may wait again
     return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
   }
-  int rc = finish_slot(g_ctx.slots[idx], out_jac);
-  if (rc) drain_slot(g_ctx.slots[idx]);
-  release_slot(idx);
+  int rc = finish_slot(cx, cx.slots[idx], out_jac);
+  if (rc) drain_slot(cx, cx.slots[idx]);
+  release_slot(cx, idx);
   return rc;
+}
+
+extern "C" int curdle_msm_free_slots(void) {
+  Ctx& cx = cur();
+  std::lock_guard<std::mutex> g(cx.mu);
+  int n = 0;
+  for (const Slot& S : cx.slots) n += S.busy ? 0 : 1;
+  return n;
 }
 
 // k MSMs in one pass of the pipeline; inputs resident on the device.
@@ -1417,6 +1746,7 @@ extern "C" int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scala
 // reduce kernels read the shared fragment bookkeeping with a per-set fragment offset.
 extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k, const uint64_t* scalars, size_t n,
                                    uint64_t* out_jac) {
+  Ctx& cx = cur();
   if ((k && !out_jac) || (k && !points_sets)) return fail(CURDLE_EINVAL, "null argument");
   if (k == 0) return CURDLE_OK;
   if (n == 0) {
@@ -1428,27 +1758,27 @@ extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k,
   for (size_t j = 0; j < k; j++)
     if (!points_sets[j]) return fail(CURDLE_EINVAL, "points_sets[%zu] is null", j);
   int idx;
-  int rc = acquire_slot(true, &idx);
+  int rc = acquire_slot(cx, true, &idx);
   if (rc) return rc;
-  Slot& S = g_ctx.slots[idx];
+  Slot& S = cx.slots[idx];
   auto body = [&]() -> int {
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    HIP_TRY(hipSetDevice(cx.device));
     int r;
     if ((r = ensure(S.points, k * n * 96))) return r;
     if ((r = ensure(S.scalars, n * 32))) return r;
-    const SyncStreams st = sync_streams(S);
+    const SyncStreams st = sync_streams(cx, S);
     for (size_t j = 0; j < k; j++)
       HIP_TRY(hipMemcpyAsync((char*)S.points.p + j * n * 96, points_sets[j], n * 96, hipMemcpyHostToDevice, st.pre));
     HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st.pre));
     const uint32_t off[2] = {0, (uint32_t)n};
-    if ((r = enqueue_slot(S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, st.pre, st.main, st.tail,
+    if ((r = enqueue_slot(cx, S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, st.pre, st.main, st.tail,
                           /*latency_mode=*/true, /*points28_ready=*/false, /*sets=*/k)))
       return r;
-    return finish_slot(S, out_jac);
+    return finish_slot(cx, S, out_jac);
   };
   rc = body();
-  if (rc) drain_slot(S);
-  release_slot(idx);
+  if (rc) drain_slot(cx, S);
+  release_slot(cx, idx);
   return rc;
 }
 
@@ -1456,13 +1786,19 @@ extern "C" int curdle_msm_g1_multi(const uint64_t* const* points_sets, size_t k,
 // Accumulator on the device
 // ---------------------------------------------------------------------------
 struct curdle_dbases {
-  void* d28 = nullptr;  // n internal-form points, kA28Bytes apart
   size_t n = 0;
-  unsigned epoch = 0;   // the context generation the memory belongs to
+  std::vector<uint64_t> host;  // the n gnark points: a context that has not used the set yet converts its own copy from here
+  std::mutex mu;
+  void* d28[kMaxDevices] = {};       // per context: n internal-form points (P and phi(P) each), kA28Bytes apart
+  unsigned epoch[kMaxDevices] = {};  // the context generation each copy belongs to
+  int users = 0;                     // accumulations in flight that copy from this set
+  bool dead = false;                 // curdle_dbases_free came while users > 0: the last user deletes
 };
 struct curdle_dacc {
+  Ctx* ctx = nullptr;  // the context the accumulation runs on (the beginning thread's current one)
   int slot = -1;
-  const curdle_dbases* crs = nullptr;
+  curdle_dbases* crs = nullptr;
+  size_t n_crs = 0;
   size_t n_inst = 0;
   // after curdle_dacc_submit
   bool submitted = false;
@@ -1471,73 +1807,124 @@ struct curdle_dacc {
   size_t export_off = 0;               // where they wait in the slot's pinned staging
 };
 
+namespace {
+void dbases_destroy(curdle_dbases* b) {  // nobody else holds b any more
+  for (int i = 0; i < kMaxDevices; i++) {
+    if (!b->d28[i]) continue;
+    Ctx& cx = g_ctxs[i];
+    std::lock_guard<std::mutex> g(cx.mu);
+    if (cx.inited && b->epoch[i] == cx.epoch) {  // after curdle_shutdown the context's memory is gone with it
+      (void)hipSetDevice(cx.device);
+      (void)hipFree(b->d28[i]);
+    }
+  }
+  delete b;
+}
+
+// The set's copy on context cx, converted on first use (and again after a shutdown); takes a
+// user reference that dbases_release gives back.
+int dbases_acquire(Ctx& cx, curdle_dbases* b, void** d28) {
+  std::lock_guard<std::mutex> gb(b->mu);
+  if (b->dead) return fail(CURDLE_EINVAL, "resident bases were freed");
+  const int o = cx.ordinal;
+  std::lock_guard<std::mutex> g(cx.mu);
+  int rc = init_default_locked(cx);
+  if (rc) return rc;
+  if (b->d28[o] && b->epoch[o] != cx.epoch) b->d28[o] = nullptr;  // that memory went with the old context
+  if (!b->d28[o] && b->n) {
+    HIP_TRY(hipSetDevice(cx.device));
+    void *dst = nullptr, *tmp = nullptr;
+    hipError_t e = hipMalloc(&dst, 2 * b->n * kA28Bytes);  // P and phi(P) per base (launch_convert_points_raw)
+    if (e == hipSuccess) e = hipMalloc(&tmp, b->n * 96);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp, b->host.data(), b->n * 96, hipMemcpyHostToDevice, cx.util_stream);
+    if (e == hipSuccess) e = launch_convert_points_raw(tmp, (uint32_t)b->n, dst, cx.util_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(cx.util_stream);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) {
+      if (dst) (void)hipFree(dst);
+      return fail(e == hipErrorOutOfMemory ? CURDLE_ENOMEM : CURDLE_EHIP, "resident bases: %s", hipGetErrorString(e));
+    }
+    b->d28[o] = dst;
+    b->epoch[o] = cx.epoch;
+  }
+  b->users++;
+  *d28 = b->d28[o];
+  return CURDLE_OK;
+}
+
+void dbases_release(curdle_dbases* b) {
+  bool last = false;
+  {
+    std::lock_guard<std::mutex> g(b->mu);
+    last = --b->users == 0 && b->dead;
+  }
+  if (last) dbases_destroy(b);
+}
+}  // namespace
+
 extern "C" int curdle_dbases_create(const uint64_t* points, size_t n, curdle_dbases** out) {
   if (!out || (n && !points)) return fail(CURDLE_EINVAL, "null argument");
   *out = nullptr;
   if (n > ((size_t)1 << 24)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^24 resident bases", n);
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  int rc = init_default_locked();
-  if (rc) return rc;
-  HIP_TRY(hipSetDevice(g_ctx.device));
   curdle_dbases* b = new (std::nothrow) curdle_dbases();
   if (!b) return fail(CURDLE_ENOMEM, "out of memory");
   b->n = n;
-  b->epoch = g_ctx.epoch;
-  if (n) {
-    void* tmp = nullptr;
-    hipError_t e = hipMalloc(&b->d28, 2 * n * kA28Bytes);  // P and phi(P) per base (launch_convert_points_raw)
-    if (e == hipSuccess) e = hipMalloc(&tmp, n * 96);
-    if (e == hipSuccess) e = hipMemcpyAsync(tmp, points, n * 96, hipMemcpyHostToDevice, g_ctx.util_stream);
-    if (e == hipSuccess) e = launch_convert_points_raw(tmp, (uint32_t)n, b->d28, g_ctx.util_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.util_stream);
-    if (tmp) (void)hipFree(tmp);
-    if (e != hipSuccess) {
-      if (b->d28) (void)hipFree(b->d28);
-      delete b;
-      return fail(e == hipErrorOutOfMemory ? CURDLE_ENOMEM : CURDLE_EHIP, "resident bases: %s", hipGetErrorString(e));
-    }
+  try {
+    b->host.assign(points, points + 12 * n);
+  } catch (const std::bad_alloc&) {
+    delete b;
+    return fail(CURDLE_ENOMEM, "out of memory");
   }
+  // resident on the creating thread's context now (a failure here is the caller's to see); on
+  // every other context when an accumulation there first names the set
+  void* d = nullptr;
+  int rc = dbases_acquire(cur(), b, &d);
+  if (rc) {
+    delete b;
+    return rc;
+  }
+  dbases_release(b);
   *out = b;
   return CURDLE_OK;
 }
 
 extern "C" void curdle_dbases_free(curdle_dbases* b) {
   if (!b) return;
-  if (b->d28) {
-    std::lock_guard<std::mutex> g(g_ctx.mu);
-    if (g_ctx.inited && b->epoch == g_ctx.epoch) {  // after curdle_shutdown the context's memory is gone with it
-      (void)hipSetDevice(g_ctx.device);
-      (void)hipFree(b->d28);
+  {
+    std::lock_guard<std::mutex> g(b->mu);
+    if (b->users > 0) {  // an accumulation is still copying from the set: its end deletes it
+      b->dead = true;
+      return;
     }
   }
-  delete b;
+  dbases_destroy(b);
 }
 
 extern "C" size_t curdle_dbases_size(const curdle_dbases* b) { return b ? b->n : 0; }
 
-extern "C" int curdle_dbases_valid(const curdle_dbases* b) {
-  if (!b) return 0;
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  return g_ctx.inited && b->epoch == g_ctx.epoch ? 1 : 0;
-}
-
-namespace {
-}  // namespace
+// A handle keeps its points and re-creates its device copies as needed (another context, a
+// context re-initialised after curdle_shutdown): it stays usable until it is freed.
+extern "C" int curdle_dbases_valid(const curdle_dbases* b) { return b ? 1 : 0; }
 
 extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_points, size_t n_inst, curdle_dacc** out) {
+  Ctx& cx = cur();
   if (!crs || !out || (n_inst && !inst_points)) return fail(CURDLE_EINVAL, "null argument");
   *out = nullptr;
   if (crs->n + n_inst + CURDLE_DACC_MAX_EXTRA > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "too many bases");
-  int idx;
-  int rc = acquire_slot(true, &idx);
+  // this context's copy of the set (made on first use), held until the accumulation ends
+  curdle_dbases* set = const_cast<curdle_dbases*>(crs);
+  void* crs28 = nullptr;
+  int rc = dbases_acquire(cx, set, &crs28);
   if (rc) return rc;
-  if (crs->epoch != g_ctx.epoch) {
-    release_slot(idx);
-    return fail(CURDLE_EINVAL, "resident bases belong to a context that was shut down; create them again");
+  int idx;
+  rc = acquire_slot(cx, true, &idx);
+  if (rc) {
+    dbases_release(set);
+    return rc;
   }
-  Slot& S = g_ctx.slots[idx];
+  Slot& S = cx.slots[idx];
   auto body = [&]() -> int {
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    HIP_TRY(hipSetDevice(cx.device));
     const size_t cap = crs->n + n_inst + CURDLE_DACC_MAX_EXTRA;
     int r;
     // sized for the whole accumulation now: the MSM pipeline's own ensure() must not move them later
@@ -1546,7 +1933,7 @@ extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_
     if ((r = ensure(S.points, (n_inst + CURDLE_DACC_MAX_EXTRA) * 96))) return r;
     if ((r = ensure_pinned(S, 0, n_inst * 96))) return r;
     if (crs->n)
-      HIP_TRY(hipMemcpyAsync(S.points28.p, crs->d28, 2 * crs->n * kA28Bytes, hipMemcpyDeviceToDevice, S.stream));
+      HIP_TRY(hipMemcpyAsync(S.points28.p, crs28, 2 * crs->n * kA28Bytes, hipMemcpyDeviceToDevice, S.stream));
     if (n_inst) {
       memcpy(S.h_stage[0], inst_points, n_inst * 96);  // pinned: the copy below is truly asynchronous
       HIP_TRY(hipMemcpyAsync(S.points.p, S.h_stage[0], n_inst * 96, hipMemcpyHostToDevice, S.stream));
@@ -1555,30 +1942,37 @@ extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_
     return CURDLE_OK;
   };
   rc = body();
-  if (rc) {
-    (void)hipStreamSynchronize(S.stream);
-    release_slot(idx);
-    return rc;
-  }
-  curdle_dacc* a = new (std::nothrow) curdle_dacc();
+  curdle_dacc* a = rc ? nullptr : new (std::nothrow) curdle_dacc();
   if (!a) {
     (void)hipStreamSynchronize(S.stream);
-    release_slot(idx);
-    return fail(CURDLE_ENOMEM, "out of memory");
+    release_slot(cx, idx);
+    dbases_release(set);
+    return rc ? rc : fail(CURDLE_ENOMEM, "out of memory");
   }
+  a->ctx = &cx;
   a->slot = idx;
-  a->crs = crs;
+  a->crs = set;
+  a->n_crs = crs->n;
   a->n_inst = n_inst;
   *out = a;
   return CURDLE_OK;
 }
 
+namespace {
+// the end of an accumulation, however it ends: the slot and the base set go back
+void dacc_end(curdle_dacc* acc) {
+  release_slot(*acc->ctx, acc->slot);
+  dbases_release(acc->crs);
+  delete acc;
+}
+}  // namespace
+
 extern "C" void curdle_dacc_abort(curdle_dacc* acc) {
   if (!acc) return;
-  (void)hipSetDevice(g_ctx.device);
-  (void)hipStreamSynchronize(g_ctx.slots[acc->slot].stream);
-  release_slot(acc->slot);
-  delete acc;
+  Ctx& cx = *acc->ctx;
+  (void)hipSetDevice(cx.device);
+  (void)hipStreamSynchronize(cx.slots[acc->slot].stream);
+  dacc_end(acc);
 }
 
 extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
@@ -1586,9 +1980,10 @@ extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* che
                                   size_t n_extra, uint64_t* export_scalars) {
   if (!acc) return fail(CURDLE_EINVAL, "null accumulator");
   if (acc->submitted) return fail(CURDLE_EINVAL, "accumulation already submitted");
+  Ctx& cx = *acc->ctx;
   const int idx = acc->slot;
-  Slot& S = g_ctx.slots[idx];
-  const size_t n_crs = acc->crs->n, n_inst = acc->n_inst, n_res = n_crs + n_inst, n = n_res + n_extra;
+  Slot& S = cx.slots[idx];
+  const size_t n_crs = acc->n_crs, n_inst = acc->n_inst, n_res = n_crs + n_inst, n = n_res + n_extra;
   auto body = [&]() -> int {
     if ((n_checks && !checks) || (pool_len && !pool) || (n_extra && (!extra_points || !extra_scalars)))
       return fail(CURDLE_EINVAL, "null argument");
@@ -1611,7 +2006,7 @@ extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* che
           return fail(CURDLE_EINVAL, "check %zu: segment %u out of range", c, s);
       }
     }
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    HIP_TRY(hipSetDevice(cx.device));
     acc->export_scalars = export_scalars;
     acc->n_total = n;
     if (n == 0) {
@@ -1644,7 +2039,7 @@ extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* che
     if (export_scalars && n_res)
       HIP_TRY(hipMemcpyAsync(h + bytes, S.scalars.p, n_res * 32, hipMemcpyDeviceToHost, st));
     const uint32_t off[2] = {0, (uint32_t)n};
-    if ((r = enqueue_slot(S, nullptr, S.scalars.p, off, 1, 0, 0, -1, st, st, st, /*latency_mode=*/true,
+    if ((r = enqueue_slot(cx, S, nullptr, S.scalars.p, off, 1, 0, 0, -1, st, st, st, /*latency_mode=*/true,
                           /*points28_ready=*/true)))
       return r;
     acc->export_off = bytes;
@@ -1654,8 +2049,7 @@ extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* che
   int rc = body();
   if (rc) {  // a failed submission ends the accumulation, like a failed run
     (void)hipStreamSynchronize(S.stream);
-    release_slot(idx);
-    delete acc;
+    dacc_end(acc);
   }
   return rc;
 }
@@ -1663,10 +2057,11 @@ extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* che
 extern "C" int curdle_dacc_poll(curdle_dacc* acc, int* done) {
   if (!acc || !done) return fail(CURDLE_EINVAL, "null argument");
   if (!acc->submitted) return fail(CURDLE_EINVAL, "accumulation not submitted");
+  Ctx& cx = *acc->ctx;
   *done = 1;
   if (acc->n_total == 0) return CURDLE_OK;
-  Slot& S = g_ctx.slots[acc->slot];
-  (void)hipSetDevice(g_ctx.device);
+  Slot& S = cx.slots[acc->slot];
+  (void)hipSetDevice(cx.device);
   const hipError_t e = hipStreamQuery(S.run_stream);
   if (e == hipErrorNotReady) {
     *done = 0;
@@ -1679,25 +2074,25 @@ extern "C" int curdle_dacc_poll(curdle_dacc* acc, int* done) {
 extern "C" int curdle_dacc_wait(curdle_dacc* acc, uint64_t out_jac[18]) {
   if (!acc) return fail(CURDLE_EINVAL, "null accumulator");
   if (!acc->submitted) return fail(CURDLE_EINVAL, "accumulation not submitted");
+  Ctx& cx = *acc->ctx;
   const int idx = acc->slot;
-  Slot& S = g_ctx.slots[idx];
+  Slot& S = cx.slots[idx];
   auto body = [&]() -> int {
     if (!out_jac) return fail(CURDLE_EINVAL, "null argument");
     if (acc->n_total == 0) {
       set_out_infinity(out_jac);
       return CURDLE_OK;
     }
-    HIP_TRY(hipSetDevice(g_ctx.device));
+    HIP_TRY(hipSetDevice(cx.device));
     int r;
-    if ((r = finish_slot(S, out_jac))) return r;
-    const size_t n_res = acc->crs->n + acc->n_inst;
+    if ((r = finish_slot(cx, S, out_jac))) return r;
+    const size_t n_res = acc->n_crs + acc->n_inst;
     if (acc->export_scalars && n_res) memcpy(acc->export_scalars, (char*)S.h_stage[1] + acc->export_off, n_res * 32);
     return CURDLE_OK;
   };
   int rc = body();
   if (rc) (void)hipStreamSynchronize(S.stream);
-  release_slot(idx);
-  delete acc;
+  dacc_end(acc);
   return rc;
 }
 
@@ -1718,13 +2113,14 @@ extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks
 // Synthetic inputs
 // ---------------------------------------------------------------------------
 extern "C" int curdle_synth_points_walk_device(const uint64_t k[4], const uint64_t q[4], size_t n, void* d_out) {
+  Ctx& cx = cur();
   if (!k || !q || (n && !d_out)) return fail(CURDLE_EINVAL, "null argument");
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 points", n);
   if (n == 0) return CURDLE_OK;
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  std::lock_guard<std::mutex> g(cx.mu);
+  int rc = init_default_locked(cx);
   if (rc) return rc;
-  HIP_TRY(hipSetDevice(g_ctx.device));
+  HIP_TRY(hipSetDevice(cx.device));
   G1Affine gen;
   g1_generator(gen);
   G1XYZZ gx, t;
@@ -1739,9 +2135,9 @@ extern "C" int curdle_synth_points_walk_device(const uint64_t k[4], const uint64
   }
   void* d_table = nullptr;
   HIP_TRY(hipMalloc(&d_table, sizeof(table)));
-  HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, g_ctx.util_stream));
-  HIP_TRY(launch_synth_walk((const G1Affine*)d_table, p0, (uint32_t)n, d_out, g_ctx.util_stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.util_stream));
+  HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, cx.util_stream));
+  HIP_TRY(launch_synth_walk((const G1Affine*)d_table, p0, (uint32_t)n, d_out, cx.util_stream));
+  HIP_TRY(hipStreamSynchronize(cx.util_stream));
   HIP_TRY(hipFree(d_table));
   return CURDLE_OK;
 }
@@ -1750,29 +2146,39 @@ extern "C" int curdle_synth_points_walk_device(const uint64_t k[4], const uint64
 // Profiling / self-test
 // ---------------------------------------------------------------------------
 extern "C" int curdle_profile_enable(int on) {
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  g_ctx.profile = on < 0 || on > 2 ? 1 : on;
+  Ctx& cx = cur();
+  std::lock_guard<std::mutex> g(cx.mu);
+  cx.profile = on < 0 || on > 2 ? 1 : on;
   return CURDLE_OK;
 }
 
 extern "C" int curdle_profile_last(curdle_profile* out) {
+  Ctx& cx = cur();
   if (!out) return fail(CURDLE_EINVAL, "null argument");
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  *out = g_ctx.last;
+  std::lock_guard<std::mutex> g(cx.mu);
+  *out = cx.last;
   return CURDLE_OK;
 }
 
 extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64_t* out64, int on_device) {
-  if (op < 0 || op > 10 || !in64 || !out64) return fail(CURDLE_EINVAL, "bad selftest arguments");
+  Ctx& cx = cur();
+  if (op < 0 || op > 11 || !in64 || !out64) return fail(CURDLE_EINVAL, "bad selftest arguments");
   const uint32_t* in = reinterpret_cast<const uint32_t*>(in64);
   uint32_t* out = reinterpret_cast<uint32_t*>(out64);
-  const size_t in_w = op <= 3 ? 24 : (op == 4 ? 16 : 96);
-  const size_t out_w = op <= 3 ? 12 : (op == 4 ? 8 : 48);
+  const size_t in_w = op <= 3 ? 24 : (op == 4 ? 16 : op == 11 ? 8 : 96);
+  const size_t out_w = op <= 3 ? 12 : (op == 4 ? 8 : op == 11 ? 10 : 48);
   if (!on_device) {
     for (size_t i = 0; i < n; i++) {
       const uint32_t* s = in + i * in_w;
       uint32_t* d = out + i * out_w;
-      if (op <= 3) {
+      if (op == 11) {  // the GLV split of a canonical scalar: |k1| (4 words), k2 (4 words), the two signs
+        Fr k;
+        memcpy(&k, s, 32);
+        u32 sa = 0, sb = 0;
+        glv_split(k, d, d + 4, sa, sb);
+        d[8] = sa;
+        d[9] = sb;
+      } else if (op <= 3) {
         Fp a, b, r;
         memcpy(&a, s, 48);
         memcpy(&b, s + 12, 48);
@@ -1805,17 +2211,17 @@ extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64
     }
     return CURDLE_OK;
   }
-  std::lock_guard<std::mutex> g(g_ctx.mu);
-  int rc = init_locked(g_ctx.inited ? g_ctx.device : 0);
+  std::lock_guard<std::mutex> g(cx.mu);
+  int rc = init_default_locked(cx);
   if (rc) return rc;
-  HIP_TRY(hipSetDevice(g_ctx.device));
+  HIP_TRY(hipSetDevice(cx.device));
   void *d_in = nullptr, *d_out = nullptr;
   HIP_TRY(hipMalloc(&d_in, n * in_w * 4));
   HIP_TRY(hipMalloc(&d_out, n * out_w * 4));
-  HIP_TRY(hipMemcpyAsync(d_in, in, n * in_w * 4, hipMemcpyHostToDevice, g_ctx.util_stream));
-  HIP_TRY(launch_selftest(op, (const uint32_t*)d_in, n, (uint32_t*)d_out, g_ctx.util_stream));
-  HIP_TRY(hipMemcpyAsync(out, d_out, n * out_w * 4, hipMemcpyDeviceToHost, g_ctx.util_stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.util_stream));
+  HIP_TRY(hipMemcpyAsync(d_in, in, n * in_w * 4, hipMemcpyHostToDevice, cx.util_stream));
+  HIP_TRY(launch_selftest(op, (const uint32_t*)d_in, n, (uint32_t*)d_out, cx.util_stream));
+  HIP_TRY(hipMemcpyAsync(out, d_out, n * out_w * 4, hipMemcpyDeviceToHost, cx.util_stream));
+  HIP_TRY(hipStreamSynchronize(cx.util_stream));
   (void)hipFree(d_in);
   (void)hipFree(d_out);
   return CURDLE_OK;

@@ -835,7 +835,7 @@ hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32
 // runs in the internal radix-2^28 form the MSM kernels use.
 __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __restrict__ in, size_t n, u32* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (op >= 8) {  // lane-distributed point operations (quad28.h): four lanes per element
+  if (op >= 8 && op <= 10) {  // lane-distributed point operations (quad28.h): four lanes per element
     i >>= 2;
     if (i >= n) return;  // whole quads leave together
     G1XYZZ ga, gb;
@@ -864,6 +864,19 @@ __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __res
     return;
   }
   if (i >= n) return;
+  if (op == 11) {  // the GLV split exactly as k_digits runs it
+    Fr k;
+    for (int j = 0; j < 8; j++) k.l[j] = in[i * 8 + j];
+    u32 a[4], b[4], sa, sb;
+    glv_split(k, a, b, sa, sb);
+    for (int j = 0; j < 4; j++) {
+      out[i * 10 + j] = a[j];
+      out[i * 10 + 4 + j] = b[j];
+    }
+    out[i * 10 + 8] = sa;
+    out[i * 10 + 9] = sb;
+    return;
+  }
   if (op <= 3) {
     u32 w[24];
     for (int k = 0; k < 24; k++) w[k] = in[i * 24 + k];
@@ -910,7 +923,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __res
 }
 
 hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream) {
-  const size_t lanes = op >= 8 ? 4 * n : n;
+  const size_t lanes = op >= 8 && op <= 10 ? 4 * n : n;
   hipLaunchKernelGGL(k_selftest, dim3(cdiv(lanes, kBlock)), dim3(kBlock), 0, stream, op, d_in, n, d_out);
   return hipGetLastError();
 }

@@ -41,6 +41,7 @@ MSM_SLOTS = 8
 # Every symbol include/curdle_msm.h declares (tests check they are all exported).
 SYMBOLS = [
     "curdle_init", "curdle_shutdown", "curdle_last_error", "curdle_device_available",
+    "curdle_init_devices", "curdle_device_count", "curdle_set_device", "curdle_get_device", "curdle_msm_g1_replicated",
     "curdle_msm_g1", "curdle_msm_g1_device", "curdle_msm_g1_device_windows",
     "curdle_msm_g1_device_submit", "curdle_msm_wait",
     "curdle_msm_window_bits", "curdle_msm_num_windows", "curdle_msm_window_widths", "curdle_g1_sum",
@@ -50,7 +51,7 @@ SYMBOLS = [
     "curdle_acc_new", "curdle_acc_free", "curdle_acc_accumulate_check", "curdle_acc_accumulate_check_deferred",
     "curdle_acc_verify",
     "curdle_acc_get_A_c", "curdle_acc_num_bases", "curdle_acc_export",
-    "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op",
+    "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op", "curdle_msm_free_slots",
     "curdle_synth_points_walk_device",
     "curdle_crs_generate", "curdle_crs_free", "curdle_crs_size", "curdle_shuffle_permute_commit",
     "curdle_prove", "curdle_verify", "curdle_proof_from_bytes", "curdle_proof_free", "curdle_verify_proof",
@@ -84,6 +85,12 @@ def _sig(name, restype, *argtypes):
 
 _init = _sig("curdle_init", C.c_int, C.c_int)
 _shutdown = _sig("curdle_shutdown", C.c_int)
+_init_devices = _sig("curdle_init_devices", C.c_int, C.POINTER(C.c_int), C.c_int)
+_device_count = _sig("curdle_device_count", C.c_int)
+_set_device = _sig("curdle_set_device", C.c_int, C.c_int)
+_get_device = _sig("curdle_get_device", C.c_int)
+_msm_g1_replicated = _sig("curdle_msm_g1_replicated", C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t,
+                          C.c_int, _vp)
 _last_error = _sig("curdle_last_error", C.c_int, C.c_char_p, C.c_size_t)
 _device_available = _sig("curdle_device_available", C.c_int)
 _msm_g1 = _sig("curdle_msm_g1", C.c_int, _vp, _vp, C.c_size_t, _vp)
@@ -183,6 +190,42 @@ def init(device: int = 0) -> None:
 
 def shutdown() -> None:
     _check(_shutdown())
+
+
+def init_devices(devices) -> None:
+    """One process, several GPUs: one context per entry of `devices` (HIP device ids; an id may
+    repeat).  See curdle_init_devices in include/curdle_msm.h."""
+    arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+    _check(_init_devices(arr, len(devices)))
+
+
+def device_count() -> int:
+    return int(_device_count())
+
+
+def set_device(ordinal: int) -> None:
+    """The calling thread's current context (0 <= ordinal < device_count())."""
+    _check(_set_device(int(ordinal)))
+
+
+def get_device() -> int:
+    return int(_get_device())
+
+
+SPLIT_AUTO, SPLIT_WINDOWS, SPLIT_POINTS = 0, 1, 2
+
+
+def msm_g1_replicated(d_points, d_scalars, n: int, split: int = SPLIT_AUTO) -> np.ndarray:
+    """One MSM over inputs resident on EVERY configured context (d_points[i] / d_scalars[i]: raw
+    device pointers on context i's GPU), split by Pippenger windows or point ranges, one host
+    thread per device, partials summed on the host."""
+    k = device_count()
+    assert len(d_points) == k and len(d_scalars) == k, "one pointer per configured device"
+    pp = (C.c_void_p * k)(*[int(p) for p in d_points])
+    ps = (C.c_void_p * k)(*[int(p) for p in d_scalars])
+    out = np.zeros(18, dtype=np.uint64)
+    _check(_msm_g1_replicated(pp, ps, n, int(split), _ptr(out)))
+    return out
 
 
 def device_available() -> bool:
@@ -392,7 +435,7 @@ def profile_last() -> dict:
 
 
 _SELFTEST_W = {0: (24, 12), 1: (24, 12), 2: (24, 12), 3: (24, 12), 4: (16, 8), 5: (96, 48), 6: (96, 48), 7: (96, 48),
-               8: (96, 48), 9: (96, 48), 10: (96, 48)}
+               8: (96, 48), 9: (96, 48), 10: (96, 48), 11: (8, 10)}
 
 
 def selftest_op(op: int, inp: np.ndarray, on_device: bool) -> np.ndarray:

@@ -1429,9 +1429,17 @@ bool VerifyStarted(VerifyPrelude& pre, const Proof& proof, const CRS& crs, const
       return e && *e && *e != '0';
     }();
     const auto t0 = std::chrono::steady_clock::now();
-    DeviceSink sink(crs, Rs, Ss, Ts, Us);
+    // The accumulation takes its workspace slot NOW -- the instance points are uploaded and
+    // converted while the host hashes -- unless slots are scarce: with more verifying threads
+    // than slots, a slot held idle through the host's transcript phase (most of a verification)
+    // caps the throughput and stalls plain MSM callers, so the accumulation then starts after the
+    // host algebra, as VerifyWhileDecoding does.
+    DeviceSink sink(crs);
+    const bool early = curdle_msm_free_slots() > CURDLE_MSM_SLOTS / 2;
+    if (early) sink.Begin(Rs, Ss, Ts, Us);
     const auto t1 = std::chrono::steady_clock::now();
     if (!VerifyWithSink(proof, crs, Rs, Ss, Ts, Us, M, rand, sink, &pre)) return false;
+    if (!early) sink.Begin(Rs, Ss, Ts, Us);
     const auto t2 = std::chrono::steady_clock::now();
     const bool ok = sink.Verify();  // the batched MSM on the GPU, == A_c
     if (trace) {
@@ -1485,6 +1493,7 @@ std::vector<int> VerifyBatch(const CRS& crs, const std::vector<BatchItem>& items
       } catch (const std::runtime_error&) {
       }
     }
+    bool Ready(size_t i) { return ahead->Ready(i); }
     bool Usable(size_t i) {
       ahead->Wait(i);
       return parses[i] != 0;

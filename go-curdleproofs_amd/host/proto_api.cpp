@@ -6,6 +6,7 @@
 #include <exception>
 #include <new>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "../../include/curdle_msm.h"
@@ -231,6 +232,46 @@ extern "C" int curdle_verify_export_accumulator(const curdle_crs* crs, const cur
   });
 }
 
+// A batch over SEVERAL devices (curdle_init_devices): contiguous shards of the k proofs, one
+// per context, each verified by its own group of host threads that select the shard's device
+// first -- BASELINE config 5 (many independent verifications) is replicas: no data moves
+// between devices, and the accept bits are exactly those of the single-device call.  run(lo,
+// hi, rand, threads) verifies proofs [lo, hi) on the calling thread's device.
+template <class Run>
+static std::vector<int> ShardOverDevices(size_t k, common::Rand& rand, int nthreads, Run run) {
+  const int D = curdle_device_count();
+  if (D <= 1 || k < (size_t)(2 * D)) return run((size_t)0, k, rand, nthreads);
+  if (nthreads < 1) nthreads = 1;
+  std::vector<uint64_t> seeds((size_t)D);
+  for (auto& sd : seeds) {  // each shard its own verifier randomness, drawn from the caller's
+    Fr f;
+    rand.GetFr(f);
+    sd = (uint64_t)f.l[0] | ((uint64_t)f.l[1] << 32);
+  }
+  const int per = nthreads / D > 2 ? nthreads / D : 2;
+  std::vector<std::vector<int>> res((size_t)D);
+  std::vector<std::exception_ptr> errs((size_t)D);
+  std::vector<std::thread> th;
+  for (int d = 0; d < D; d++)
+    th.emplace_back([&, d] {
+      try {
+        if (curdle_set_device(d) != CURDLE_OK) throw std::runtime_error("selecting a device for a batch shard");
+        const size_t lo = k * (size_t)d / (size_t)D, hi = k * (size_t)(d + 1) / (size_t)D;
+        common::Rand r(seeds[(size_t)d]);
+        res[(size_t)d] = run(lo, hi, r, per);
+      } catch (...) {
+        errs[(size_t)d] = std::current_exception();
+      }
+    });
+  for (auto& t : th) t.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+  std::vector<int> all;
+  all.reserve(k);
+  for (auto& r : res) all.insert(all.end(), r.begin(), r.end());
+  return all;
+}
+
 extern "C" int curdle_verify_batch(const curdle_crs* crs, size_t k, const uint8_t* const* proofs, const size_t* proof_lens,
                                    const uint64_t* const* Rs, const uint64_t* const* Ss, const uint64_t* const* Ts,
                                    const uint64_t* const* Us, size_t ell, const uint64_t* Ms, curdle_rand* rand,
@@ -251,7 +292,11 @@ extern "C" int curdle_verify_batch(const curdle_crs* crs, size_t k, const uint8_
                                   ell,
                                   Ms + 18 * i};
     }
-    std::vector<int> res = proto::VerifyBatch(crs->crs, items, rand->r, nthreads);
+    std::vector<int> res = ShardOverDevices(k, rand->r, nthreads, [&](size_t lo, size_t hi, common::Rand& r, int threads) {
+      if (lo == 0 && hi == k) return proto::VerifyBatch(crs->crs, items, r, threads);
+      std::vector<proto::BatchItem> shard(items.begin() + lo, items.begin() + hi);
+      return proto::VerifyBatch(crs->crs, shard, r, threads);
+    });
     for (size_t i = 0; i < k; i++) oks[i] = res[i];
     return CURDLE_OK;
   });
@@ -293,7 +338,11 @@ extern "C" int curdle_whisk_is_valid_shuffle_proof_batch(const curdle_crs* crs, 
       items[i] = whisk::ShuffleBatchItem{reinterpret_cast<const whisk::WhiskTracker*>(pre_trackers[i]),
                                          reinterpret_cast<const whisk::WhiskTracker*>(post_trackers[i]), n, proofs[i]};
     }
-    std::vector<int> res = whisk::IsValidWhiskShuffleProofBatch(crs->crs, items, rand->r, nthreads);
+    std::vector<int> res = ShardOverDevices(k, rand->r, nthreads, [&](size_t lo, size_t hi, common::Rand& r, int threads) {
+      if (lo == 0 && hi == k) return whisk::IsValidWhiskShuffleProofBatch(crs->crs, items, r, threads);
+      std::vector<whisk::ShuffleBatchItem> shard(items.begin() + lo, items.begin() + hi);
+      return whisk::IsValidWhiskShuffleProofBatch(crs->crs, shard, r, threads);
+    });
     for (size_t i = 0; i < k; i++) oks[i] = res[i];
     return CURDLE_OK;
   });

@@ -52,7 +52,14 @@ class DecodeAhead {
     ready_.assign(nchunks, 0);
     if (producers < 1) producers = 1;
     if ((size_t)producers > nchunks) producers = (int)nchunks;
-    for (int t = 0; t < producers; t++) threads_.emplace_back([this] { Produce(); });
+    // the producers decode on the device of the thread that started the batch (a shard of a
+    // multi-device batch lives on one device: every thread of it selects that device first)
+    const int device = curdle_get_device();
+    for (int t = 0; t < producers; t++)
+      threads_.emplace_back([this, device] {
+        (void)curdle_set_device(device);
+        Produce();
+      });
   }
   ~DecodeAhead() {
     stop_.store(true);
@@ -68,6 +75,11 @@ class DecodeAhead {
     cv_.wait(g, [&] { return ready_[c] != 0 || error_ != nullptr; });
     if (!ready_[c]) std::rethrow_exception(error_);
     return *decs_[c];
+  }
+  // Is proof i's chunk decoded already (or has a producer failed, so that Wait would not block)?
+  bool Ready(size_t i) {
+    std::lock_guard<std::mutex> g(mu_);
+    return ready_[i / chunk_] != 0 || error_ != nullptr;
   }
   void Abandon() { stop_.store(true); }  // the workers gave up: producers stop after their current chunk
 
@@ -230,6 +242,11 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
         CheckRecorder rec;  // joins the group only if the proof's direct checks pass
         std::vector<G1Affine> Rs, Ss, Ts, Us;
         bool pre = false;
+        // Never wait for a decoding while holding a workspace slot: the queued group keeps its slot
+        // until collect(), and the producer that decodes proof i's chunk may itself need a slot
+        // (chunks beyond the two-kernel size, or every decode context taken) -- with all eight
+        // slots held by waiting workers nobody would move.  The group's verdict is taken first.
+        if (run.Active() && !src.Ready(i)) collect();
         try {
           if (!src.Usable(i)) throw std::runtime_error("malformed proof or instance");
           Proof p = src.DecodeProof(i);
@@ -347,7 +364,12 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
     }
   };
   std::vector<std::thread> th;
-  for (int t = 1; t < nthreads; t++) th.emplace_back(worker);
+  const int device = curdle_get_device();  // the batch runs where its caller is
+  for (int t = 1; t < nthreads; t++)
+    th.emplace_back([&worker, device] {
+      (void)curdle_set_device(device);
+      worker();
+    });
   worker();
   for (auto& x : th) x.join();
   if (failed.load()) throw alg::MsmError("batch verification: " + first_error, first_rc);

@@ -216,6 +216,7 @@ std::vector<int> IsValidWhiskShuffleProofBatch(const proto::CRS& crs, const std:
         dec.Add(items[i].postST[t].krG);
       }
     }
+    bool Ready(size_t i) { return ahead->Ready(i); }
     bool Usable(size_t i) {
       ahead->Wait(i);
       return parses[i] != 0;

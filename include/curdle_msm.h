@@ -59,6 +59,29 @@ extern "C" {
  * first MSM call.  Replaces: common.MultiExpConf (common/util.go:14), the
  * reference's only configuration knob. */
 int curdle_init(int device);
+/* One process driving SEVERAL GPUs (the reference's caller is one
+ * process making synchronous MultiExp calls, msmaccumulator/msmaccumulator.go:59): configures
+ * one context per entry of devices[] (HIP device ids; an id may repeat, which puts two
+ * contexts on one GPU -- how the multi-device code is tested on a one-GPU machine), each with
+ * its own streams, workspace slots and one host worker thread.  After it
+ *   - every entry point runs on the calling thread's CURRENT context: curdle_set_device(i)
+ *     selects context i for this thread (default 0), like hipSetDevice; tickets and handles
+ *     (curdle_dacc, decode tickets) remember their context; a curdle_dbases / curdle_crs is
+ *     made resident lazily on every context that uses it;
+ *   - curdle_msm_g1 splits a large host-buffer MSM by POINT RANGES over all contexts (each GPU
+ *     copies and runs its own n / D pairs, the host thread of each device drives it, the D
+ *     partial sums are added on the host with the code of curdle_g1_sum: no collective);
+ *   - curdle_msm_g1_replicated does the same for inputs the caller keeps resident on every
+ *     GPU, by Pippenger windows (north_star's partition) or point ranges;
+ *   - curdle_verify_batch and curdle_whisk_is_valid_shuffle_proof_batch shard their proofs
+ *     over the contexts (BASELINE config 5: replicas, no data-path exchange).
+ * n = 1 is curdle_init(devices[0]).  Fails with CURDLE_EINVAL if the library is already
+ * initialised on a different list. */
+#define CURDLE_MAX_DEVICES 16
+int curdle_init_devices(const int* devices, int n);
+int curdle_device_count(void);      /* contexts configured (1 unless curdle_init_devices said more) */
+int curdle_set_device(int ordinal); /* this thread's current context, 0 <= ordinal < curdle_device_count() */
+int curdle_get_device(void);
 int curdle_shutdown(void);
 /* Copies the calling thread's last error text (NUL-terminated) into buf. */
 int curdle_last_error(char* buf, size_t len);
@@ -74,6 +97,17 @@ int curdle_device_available(void);
  * are copied to the device on every call: the prover mutates bases in place
  * between calls (innerproductargument.go:155-166), so nothing is cached by
  * pointer.
+ * PRECONDITION (differs from gnark): every base must lie in the prime-order subgroup G1 (or be
+ * the point at infinity).  The kernels split every scalar as k P = k1 P + k2 phi(P) with the
+ * curve endomorphism phi(x, y) = (beta x, y), which is multiplication by lambda only on G1;
+ * gnark's MultiExp does not use the endomorphism and is defined for any curve point.  Every
+ * base the reference feeds this path is in G1 (CRS points are multiples of the generator,
+ * proof and tracker points pass gnark's Decoder / SetBytes subgroup check).  For an on-curve
+ * point outside G1 -- e.g. one taken from curdle_g1_decompress with subgroup_check = 0, or from
+ * the begin / points decoding steps before the subgroup verdict -- the result is the well-defined
+ * but different point k1 P + k2 (beta x, y)
+ * (tests/test_msm_gpu.py::test_bases_outside_the_prime_order_subgroup_...).  The same holds for
+ * curdle_g1_scalar_mul_batch and the device accumulator.
  * ------------------------------------------------------------------------- */
 int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n,
                   uint64_t out_jac[CURDLE_G1_JAC_U64]);
@@ -83,6 +117,16 @@ int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n,
  * library's own stream.  This is what bench.py times. */
 int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n,
                          uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
+
+/* The same MSM over inputs the caller keeps resident on EVERY configured context:
+ * d_points[i] / d_scalars[i] are device pointers on context i's GPU, each holding all n pairs
+ * (curdle_device_count() entries).  split: 1 = Pippenger windows [w_i, w_i+1) per context
+ * (north_star's partition: every GPU walks all n pairs for its windows), 2 = point ranges
+ * (every GPU runs all windows over its n / D pairs), 0 = the library's choice (windows up to
+ * 2^21 pairs, point ranges beyond: the per-rank step times of DESIGN.md section 5).  One host
+ * thread per device; the D 144-byte partials are summed on the host. */
+int curdle_msm_g1_replicated(const void* const* d_points, const void* const* d_scalars, size_t n, int split,
+                             uint64_t out_jac[CURDLE_G1_JAC_U64]);
 
 /* Asynchronous form of the device-resident MSM.  submit() enqueues every GPU phase
  * of one MSM (window range as below; window_bits = 0, win_begin = 0, win_end = -1 for
@@ -95,6 +139,11 @@ int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n,
 int curdle_msm_g1_device_submit(const void* d_points, const void* d_scalars, size_t n,
                                 int window_bits, int win_begin, int win_end, int* ticket);
 int curdle_msm_wait(int ticket, uint64_t out_jac[CURDLE_G1_JAC_U64]);
+/* How many of the CURDLE_MSM_SLOTS workspace slots are free right now (a hint: other threads
+ * take and release slots concurrently).  A caller that would hold a slot across host work of
+ * its own (the verifier starts its accumulation before it hashes) uses it to decide whether
+ * to take the slot early or late. */
+int curdle_msm_free_slots(void);
 
 /* Partial MSM over Pippenger windows [win_begin, win_end) of the
 * decomposition the library would use for (n, window_bits); the partial is
@@ -445,7 +494,11 @@ int curdle_synth_points_walk_device(const uint64_t k[4], const uint64_t q[4], si
  *   op 8 / 9: the same add / dbl through the lane-distributed ("quad") point operations the
  *             latency-bound kernels use (csrc/quad28.h); op 10: k * (second point) with a
  *             20-bit k derived from the element index, by the quads' double-and-add
- * (limbs are passed as uint32 little-endian; 24/16/96 in and 12/8/48 out per item)
+ *   op 11: the GLV split every scalar goes through (csrc/bls12_381.h glv_split, run by k_digits and by
+ *          the host's scalar multiplication): in: n x 8 words of a CANONICAL scalar k < r,
+ *          out: n x (|k1| 4 words | k2 4 words | sign of the k1 term | sign of the k2 term,
+ *          0x80000000 = negative), with k = +-|k1| +- k2 * lambda (mod r), both halves < 2^127
+ * (limbs are passed as uint32 little-endian; 24/16/96/8 in and 12/8/48/10 out per item)
  * on_device = 0 runs the same header code on the host CPU. */
 int curdle_selftest_op(int op, const uint64_t* in, size_t n, uint64_t* out, int on_device);
 

@@ -326,6 +326,92 @@ static int Flow(size_t ell) {
   return 0;
 }
 
+// Batch verification against a finite slot pool (stub_backend.cpp, CURDLE_STUB_SLOTS): more
+// workers than workspace slots, every group a single proof (so every worker holds a queued
+// group's slot when it asks for its next proof), chunks of one proof decoded by producers that
+// need a slot themselves (CURDLE_TWO_KERNEL_MAX=0) and are slow.  A worker that waited for a
+// decoding while holding its slot would leave the producers without one: this run must finish.
+static int BatchSlots(size_t ell) {
+  Instance a = Make(ell, 7), b = Make(ell, 21, &a.crs);
+  uint64_t Mj[2][18];
+  a.M.Jac(Mj[0]);
+  b.M.Jac(Mj[1]);
+  std::vector<proto::BatchItem> items;
+  std::vector<int> want;
+  for (int i = 0; i < 48; i++) {
+    const Instance& in = i % 2 ? b : a;
+    const bool bad = i % 11 == 5;
+    const Instance& inst = bad ? (i % 2 ? a : b) : in;  // another proof's instance
+    items.push_back(proto::BatchItem{in.proof.data(), in.proof.size(), inst.Rs.data(), inst.Ss.data(), inst.Ts.data(),
+                                     inst.Us.data(), ell, Mj[(i % 2) ^ (bad ? 1 : 0)]});
+    want.push_back(bad ? 0 : 1);
+  }
+  common::Rand br(5);
+  const std::vector<int> got = proto::VerifyBatch(a.crs, items, br, 16);
+  CHECK(got == want);
+  CHECK(curdle_msm_free_slots() == CURDLE_MSM_SLOTS);  // every slot handed back
+  printf("batch with 16 threads over %d slots: ok\n", CURDLE_MSM_SLOTS);
+  return 0;
+}
+
+// The batch entry point of the C ABI over SEVERAL devices: the stub poses as CURDLE_STUB_DEVICES
+// contexts and counts the device-entry-point calls each one sees.  The k proofs are sharded over
+// the contexts (host/proto_api.cpp ShardOverDevices), every thread of a shard selects its device
+// first, and the accept bits are those of the single-device run.
+struct curdle_rand {  // same layout as in msm_api.hip / proto_api.cpp
+  common::Rand r;
+  explicit curdle_rand(uint64_t seed) : r(seed) {}
+};
+struct curdle_crs {
+  proto::CRS crs;
+};
+extern "C" unsigned long long curdle_stub_calls_on(int ordinal);
+static int BatchDevices(size_t ell) {
+  const int D = curdle_device_count();
+  CHECK(D >= 2);
+  CHECK(curdle_set_device(D) == CURDLE_EINVAL && curdle_set_device(-1) == CURDLE_EINVAL);
+  CHECK(curdle_set_device(D - 1) == CURDLE_OK && curdle_get_device() == D - 1);
+  CHECK(curdle_set_device(0) == CURDLE_OK);
+  Instance a = Make(ell, 7), b = Make(ell, 21, &a.crs);
+  curdle_crs crs{a.crs};
+  uint64_t Mj[2][18];
+  a.M.Jac(Mj[0]);
+  b.M.Jac(Mj[1]);
+  const size_t k = 26;
+  std::vector<const uint8_t*> proofs(k);
+  std::vector<size_t> lens(k);
+  std::vector<const uint64_t*> Rs(k), Ss(k), Ts(k), Us(k);
+  std::vector<uint64_t> Ms(18 * k);
+  std::vector<int> want(k), got(k, -1);
+  for (size_t i = 0; i < k; i++) {
+    const Instance& in = i % 2 ? b : a;
+    const bool bad = i % 7 == 3;
+    const Instance& inst = bad ? (i % 2 ? a : b) : in;  // another proof's instance
+    proofs[i] = in.proof.data();
+    lens[i] = in.proof.size();
+    Rs[i] = reinterpret_cast<const uint64_t*>(inst.Rs.data());
+    Ss[i] = reinterpret_cast<const uint64_t*>(inst.Ss.data());
+    Ts[i] = reinterpret_cast<const uint64_t*>(inst.Ts.data());
+    Us[i] = reinterpret_cast<const uint64_t*>(inst.Us.data());
+    memcpy(&Ms[18 * i], Mj[(i % 2) ^ (bad ? 1 : 0)], sizeof(Mj[0]));
+    want[i] = bad ? 0 : 1;
+  }
+  curdle_rand r(5);
+  CHECK(curdle_verify_batch(&crs, k, proofs.data(), lens.data(), Rs.data(), Ss.data(), Ts.data(), Us.data(), ell, Ms.data(), &r,
+                            2 * D, got.data()) == CURDLE_OK);
+  CHECK(got == want);
+  for (int d = 0; d < D; d++) CHECK(curdle_stub_calls_on(d) > 0);  // every posed device took part
+  // fewer proofs than two per device: the batch stays on the caller's device
+  const unsigned long long before = curdle_stub_calls_on(D - 1);
+  std::vector<int> few(3, -1);
+  CHECK(curdle_verify_batch(&crs, 3, proofs.data(), lens.data(), Rs.data(), Ss.data(), Ts.data(), Us.data(), ell, Ms.data(), &r, 2,
+                            few.data()) == CURDLE_OK);
+  CHECK(few == (std::vector<int>{1, 1, 1}));
+  CHECK(curdle_stub_calls_on(D - 1) == before);
+  printf("batch sharded over %d devices: ok\n", D);
+  return 0;
+}
+
 // the Whisk byte API end to end (whisk.go:20, :63) over Whisk's own CRS size: the route that
 // verifies while the points are being decoded (device accumulator) and the two-pass one
 static int WhiskFlow() {
@@ -515,6 +601,8 @@ int main(int argc, char** argv) {
     if (mode == "flow") return Flow(ell);
     if (mode == "whisk") return WhiskFlow();
     if (mode == "compress") return CompressCheck();
+    if (mode == "slots") return BatchSlots(ell);
+    if (mode == "devices") return BatchDevices(ell);
     if (mode == "fuzz") return Fuzz(ell, argc > 3 ? atoi(argv[3]) : 200);
     if (mode == "time") return Time(ell, argc > 3 ? atoi(argv[3]) : 20);
     if (mode == "timedev") return TimeDevicePath(ell, argc > 3 ? atoi(argv[3]) : 20);

@@ -8,8 +8,13 @@
 // has no CPU MSM: libcurdlemsm.so's entry points fail with CURDLE_ENODEV without a device
 // (tests/test_abi.py).  The sums below are textbook double-and-add over host_math.h.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/curdle_msm.h"
@@ -28,6 +33,78 @@ extern "C" int curdle_last_error(char* buf, size_t len) {
   if (!buf || !len) return CURDLE_EINVAL;
   snprintf(buf, len, "%s", g_err);
   return CURDLE_OK;
+}
+
+// The library's eight workspace slots, modelled (CURDLE_STUB_SLOTS=1) so that the host layer's
+// slot discipline can be tested without a GPU: an accumulation holds a slot from begin to wait /
+// abort, an MSM for the duration of the call, and a one-shot decoding takes one when the device
+// would (CURDLE_TWO_KERNEL_MAX=0: every chunk goes to the fused kernel).  A caller that waits
+// for a decoding while holding a slot deadlocks here exactly as it would on the device.
+namespace {
+struct SlotPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  int free_slots = CURDLE_MSM_SLOTS;
+  bool on() const {
+    static const bool v = getenv("CURDLE_STUB_SLOTS") != nullptr;
+    return v;
+  }
+  void acquire() {
+    if (!on()) return;
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return free_slots > 0; });
+    free_slots--;
+  }
+  void release() {
+    if (!on()) return;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      free_slots++;
+    }
+    cv.notify_one();
+  }
+};
+SlotPool g_slots;
+struct SlotHold {
+  SlotHold() { g_slots.acquire(); }
+  ~SlotHold() { g_slots.release(); }
+};
+}  // namespace
+
+// Contexts: the stub poses as CURDLE_STUB_DEVICES devices (default 1) so that the sharding of
+// the batch entry points and the per-thread device selection can be exercised without a GPU;
+// it records which "device" every accumulation and decoding ran on.
+static int stub_devices() {
+  static const int v = [] {
+    const char* e = getenv("CURDLE_STUB_DEVICES");
+    const int n = e ? atoi(e) : 1;
+    return n < 1 ? 1 : n > CURDLE_MAX_DEVICES ? CURDLE_MAX_DEVICES : n;
+  }();
+  return v;
+}
+static thread_local int tl_stub_dev = 0;
+static std::mutex g_stub_count_mu;
+static unsigned long long g_stub_calls[CURDLE_MAX_DEVICES] = {0};
+static void stub_count_call() {
+  std::lock_guard<std::mutex> g(g_stub_count_mu);
+  g_stub_calls[tl_stub_dev]++;
+}
+extern "C" int curdle_device_count(void) { return stub_devices(); }
+extern "C" int curdle_set_device(int ordinal) {
+  if (ordinal < 0 || ordinal >= stub_devices()) return curdle_set_last_error(CURDLE_EINVAL, "device ordinal out of range");
+  tl_stub_dev = ordinal;
+  return CURDLE_OK;
+}
+extern "C" int curdle_get_device(void) { return tl_stub_dev; }
+// test hook of the stub only: device-entry-point calls seen per posed device
+extern "C" unsigned long long curdle_stub_calls_on(int ordinal) {
+  std::lock_guard<std::mutex> g(g_stub_count_mu);
+  return ordinal >= 0 && ordinal < CURDLE_MAX_DEVICES ? g_stub_calls[ordinal] : 0;
+}
+
+extern "C" int curdle_msm_free_slots(void) {
+  std::lock_guard<std::mutex> g(g_slots.mu);
+  return g_slots.free_slots;
 }
 
 static void msm_naive(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out[18]) {
@@ -50,6 +127,7 @@ static void msm_naive(const uint64_t* points, const uint64_t* scalars, size_t n,
 
 extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
   if (!out_jac || (n && (!points || !scalars))) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  SlotHold hold;
   msm_naive(points, scalars, n, out_jac);
   return CURDLE_OK;
 }
@@ -57,6 +135,7 @@ extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, si
 extern "C" int curdle_msm_g1_batch(const uint64_t* points, const uint64_t* scalars, const size_t* offsets, size_t k,
                                    uint64_t* out_jac) {
   if (!offsets || (k && !out_jac)) return curdle_set_last_error(CURDLE_EINVAL, "null argument");
+  SlotHold hold;
   for (size_t j = 0; j < k; j++)
     msm_naive(points + 12 * offsets[j], scalars + 4 * offsets[j], offsets[j + 1] - offsets[j], out_jac + 18 * j);
   return CURDLE_OK;
@@ -104,7 +183,15 @@ static void decode_all(const uint8_t* in, size_t n, int subgroup_check, uint64_t
 
 extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgroup_check, uint64_t* out_affine,
                                           uint8_t* status) {
+  // the device's one-shot decoding takes a workspace slot whenever the batch is beyond the
+  // two-kernel size (msm_api.hip: kTwoKernelMax) or every decode context is taken
+  stub_count_call();
+  const char* tk = getenv("CURDLE_TWO_KERNEL_MAX");
+  const bool needs_slot = tk && (size_t)atoll(tk) < n;
+  if (const char* d = getenv("CURDLE_STUB_DECODE_DELAY_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(d)));
+  if (needs_slot) g_slots.acquire();
   decode_all(in, n, subgroup_check, out_affine, status);
+  if (needs_slot) g_slots.release();
   return CURDLE_OK;
 }
 
@@ -178,6 +265,8 @@ extern "C" void curdle_dbases_free(curdle_dbases* b) { delete b; }
 extern "C" size_t curdle_dbases_size(const curdle_dbases* b) { return b ? b->pts.size() : 0; }
 extern "C" int curdle_dbases_valid(const curdle_dbases* b) { return b ? 1 : 0; }
 extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_points, size_t n_inst, curdle_dacc** out) {
+  stub_count_call();
+  g_slots.acquire();  // held until wait / abort / a failed submit
   curdle_dacc* a = new curdle_dacc();
   a->crs = crs;
   a->inst.resize(n_inst);
@@ -185,7 +274,11 @@ extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_
   *out = a;
   return CURDLE_OK;
 }
-extern "C" void curdle_dacc_abort(curdle_dacc* acc) { delete acc; }
+extern "C" void curdle_dacc_abort(curdle_dacc* acc) {
+  if (!acc) return;
+  g_slots.release();
+  delete acc;
+}
 // submit computes at once (there is nothing to overlap with on the host backend); poll is always
 // done; wait hands the stored result out
 extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
@@ -242,6 +335,7 @@ extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* che
     if (export_scalars && n_res) memcpy(export_scalars, slots.data(), n_res * 32);
     acc->submitted = true;
   } else {
+    g_slots.release();
     delete acc;  // a failed submission ends the accumulation
   }
   return rc;
@@ -254,6 +348,7 @@ extern "C" int curdle_dacc_poll(curdle_dacc* acc, int* done) {
 extern "C" int curdle_dacc_wait(curdle_dacc* acc, uint64_t out_jac[18]) {
   if (!acc || !out_jac || !acc->submitted) return curdle_set_last_error(CURDLE_EINVAL, "accumulation not submitted");
   memcpy(out_jac, acc->result, sizeof(acc->result));
+  g_slots.release();
   delete acc;
   return CURDLE_OK;
 }

@@ -130,6 +130,65 @@ def test_digit_recoding_covers_every_scalar(cm, oracle):
                         assert abs(d) <= 1 << (widths[w] - 1), (c, w)   # 2^(b-1) slots
 
 
+def glv_split_cases(R, n_random, seed):
+    """Scalars for the direct test of the C routine: every branch boundary of the split (the sign
+    flip at (r - 1) / 2, the rounding of k' / lambda at every multiple of lambda +- lambda / 2
+    near both ends and in the middle, the Barrett quotient's correction steps) plus n_random
+    uniform ones."""
+    lam = GLV_LAMBDA
+    vals = {0, 1, 2, R - 1, R - 2, (R - 1) // 2, (R - 1) // 2 + 1, (R - 1) // 2 - 1, (R + 1) // 2 + 1}
+    mults = list(range(0, 40)) + [lam // 2 - 1, lam // 2, lam // 2 + 1, lam - 2, lam - 1, lam, (R // 2) // lam - 1,
+                                  (R // 2) // lam, 1 << 126, (1 << 126) - 1, (1 << 127) % lam]
+    for q in mults:
+        for d in (-2, -1, 0, 1, 2):
+            for base in (q * lam, q * lam + (lam >> 1), q * lam + (lam >> 1) + 1):
+                v = base + d
+                if 0 <= v < R:
+                    vals.add(v)
+                    vals.add(R - 1 - v)
+    for e in range(1, 255):
+        for d in (-1, 0, 1):
+            vals.add(((1 << e) + d) % R)
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(0, 1 << 32, size=(n_random, 8), dtype=np.uint64)
+    rnd = [sum(int(x) << (32 * j) for j, x in enumerate(row)) % R for row in raw]
+    return sorted(vals) + rnd
+
+
+def check_glv_split_outputs(vals, out, R):
+    """out[i] = curdle_selftest_op(11) of vals[i]: compared with big-integer division."""
+    lam = GLV_LAMBDA
+    worst = 0
+    for s, o in zip(vals, out):
+        a = sum(int(o[j]) << (32 * j) for j in range(4))
+        b = sum(int(o[4 + j]) << (32 * j) for j in range(4))
+        assert int(o[8]) in (0, 0x80000000) and int(o[9]) in (0, 0x80000000), hex(s)
+        k1 = -a if int(o[8]) else a
+        k2 = -b if int(o[9]) else b
+        e1, e2 = glv_split(s, R)                  # floor division on Python integers
+        assert (k1, k2) == (e1, e2) or (a == 0 and abs(k1) == abs(e1) and k2 == e2), hex(s)
+        assert (k1 + k2 * lam - s) % R == 0, hex(s)
+        assert a < 1 << 127 and b < 1 << 127, hex(s)      # the top window's bucket index stays in range
+        worst = max(worst, a, b)
+    return worst
+
+
+def scalars_as_words(vals):
+    return np.array([[(v >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for v in vals], dtype=np.uint32)
+
+
+def test_the_c_split_routine_against_big_integer_division(cm, oracle):
+    """glv_split itself (csrc/bls12_381.h: Barrett division with two correction steps, shared by
+    k_digits and the host's scalar multiplication) -- not a Python restatement of it -- against
+    big-integer division on 300,000 random scalars and every boundary: an out-of-range half would
+    index past the LDS histogram of k_hist, not merely give a wrong sum.  Host build here, the
+    device build in tests/test_msm_gpu.py::test_the_split_on_the_device."""
+    vals = glv_split_cases(oracle.R, 300_000, 11)
+    out = cm.selftest_op(11, scalars_as_words(vals), False)
+    worst = check_glv_split_outputs(vals, out, oracle.R)
+    assert worst < int(1.35 * (1 << 126))             # the bound DESIGN.md quotes
+
+
 def test_host_scalar_multiplication_through_the_split(cm, oracle):
     """curdle_host_scalar_mul (host code: every single scalar multiplication of the protocol
     layers) runs on the same GLV split as the kernels: the scalars where the split's branches

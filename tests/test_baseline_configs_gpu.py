@@ -3,6 +3,8 @@ exercised at reduced size in -m gpu): the full Prove -> Verify at n = 256 (ell =
 curdleproof_test.go:184-237 benches exactly this size) and n = 512 in both check modes with
 the soundness flips of curdleproof_test.go:48-182; the 1,024 x 628-pair MSM batch of config 5
 against the C oracle; cross-proof batch verification at k = 256 with planted bad proofs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -62,8 +64,8 @@ def test_config5_msm_batch_1024_x_628(gpu, oracle, coracle):
     assert len(sample) >= 32
     for j in sample:
         lo, hi = int(offs[j]), int(offs[j + 1])
-        assert (out[j] == coracle.msm_fast(pts[lo:hi], sc[lo:hi], threads=4)).all(), j
-    inf = coracle.msm_fast(pts[:0], sc[:0])
+        assert (out[j] == coracle.msm_pippenger(pts[lo:hi], sc[lo:hi], threads=4)).all(), j
+    inf = coracle.msm_pippenger(pts[:0], sc[:0])
     assert (out[17] == inf).all() and (out[33] == inf).all()
     d_p = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
     d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
@@ -102,3 +104,103 @@ def test_cross_proof_batch_verification_at_k_256(gpu):
     cols = [list(c) for c in zip(*items)]
     got = gpu.verify_batch(crs, *cols, gpu.Rand(9), nthreads=8)
     assert got == expect
+
+
+def test_config5_1024_whisk_shuffle_proofs_in_one_batch(gpu, oracle):
+    """BASELINE config 5 as stated: 1,024 IsValidWhiskShuffleProof verifications (whisk.go:20-61)
+    in one curdle_whisk_is_valid_shuffle_proof_batch call, over 8 distinct honest shuffles
+    (whisk_test.go:13-90 generates one; here eight, repeated) with planted bad members -- post
+    trackers of another shuffle, pre and post swapped, one post tracker replaced, a tracker that
+    is not a curve point, a tracker point outside the prime-order subgroup, a proof cut off half way, a
+    proof with one bit flipped, a proof that does not parse -- and the accept bits exact; then
+    the same batch with every member honest."""
+    from test_whisk import shuffle_trackers
+    crs = gpu.CRS(gpu.WHISK_ELL, gpu.Rand(4))
+    sets = []
+    for j in range(8):
+        pre = shuffle_trackers(gpu, oracle, gpu.Rand(300 + j), gpu.WHISK_ELL)
+        post, proof = gpu.whisk_generate_shuffle_proof(crs, pre, gpu.Rand(600 + j))
+        assert gpu.whisk_is_valid_shuffle_proof(crs, pre, post, proof, gpu.Rand(j)) is True
+        sets.append((pre, post, proof))
+    assert len({s[2] for s in sets}) == 8
+    k = 1024
+    pres = [sets[i % 8][0] for i in range(k)]
+    posts = [sets[i % 8][1] for i in range(k)]
+    proofs = [sets[i % 8][2] for i in range(k)]
+    assert gpu.whisk_is_valid_shuffle_proof_batch(crs, pres, posts, proofs, gpu.Rand(1), nthreads=16) == [True] * k
+    expect = [True] * k
+    # a point on the curve outside G1 (SetBytes rejects it, types.go:85-95)
+    p = oracle.P
+    x = 6
+    while True:
+        rhs = (x * x * x + 4) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p == rhs and oracle.scalar_mul(oracle.R, (x, y)) is not None:
+            break
+        x += 1
+    rogue = oracle.compress((x, y))
+
+    def plant(i, pre=None, post=None, proof=None):
+        if pre is not None:
+            pres[i] = pre
+        if post is not None:
+            posts[i] = post
+        if proof is not None:
+            proofs[i] = proof
+        expect[i] = False
+
+    plant(0, post=sets[1][1])                                         # another shuffle's post trackers
+    plant(9, pre=sets[1][1], post=sets[1][0])                         # swapped
+    swapped = list(sets[2][1])
+    swapped[5] = swapped[6]
+    plant(130, post=swapped)
+    notcurve = list(sets[3][1])
+    notcurve[3] = b"\x01" * 96
+    plant(259, post=notcurve)
+    outside = list(sets[4][0])
+    outside[7] = outside[7][:48] + rogue
+    plant(516, pre=outside)
+    plant(645, proof=sets[5][2][:2000] + b"\x00" * 2576)               # cut off inside the fixed 4,576-byte array (types.go:67-69)
+    flipped = bytearray(sets[6][2])
+    flipped[4536 - 20] ^= 0x10                                        # inside the last scalar of the proof
+    plant(774, proof=bytes(flipped))
+    plant(1023, proof=b"\x00" * 4576)
+    plant(1022, proof=rogue + sets[6][2][48:])                        # M outside the subgroup
+    for nthreads in (16, 3):
+        assert gpu.whisk_is_valid_shuffle_proof_batch(crs, pres, posts, proofs, gpu.Rand(2), nthreads=nthreads) == expect
+
+
+@pytest.mark.parametrize("k,size", [(1024, 2548), (2100, 628)])
+def test_batches_beyond_one_pass_of_bucket_slots(gpu, oracle, coracle, k, size):
+    """A batch whose bucket slots exceed what the slot scans hold in one pass (4,194,304: 1,024
+    verifier MSMs at ell = 508, or 2,100 Whisk ones) runs in passes inside
+    curdle_msm_g1_batch[_device] instead of being refused: sampled members against the C oracle,
+    the first and last member of every pass boundary region, and the sum of all results against
+    one MSM over all pairs."""
+    import torch
+    kk, q = oracle.Rand(77).get_frs(2)
+    sizes = [size] * k
+    sizes[5], sizes[k - 2] = 0, 3
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(offs[-1])
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(kk, q, n, d_pts.data_ptr())
+    sc = rand_scalars(np.random.default_rng(k), n, oracle)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    out = gpu.msm_g1_batch_device(d_pts.data_ptr(), d_sc.data_ptr(), offs)
+    assert out.shape == (k, 18)
+    pts = d_pts.cpu().numpy().view(np.uint64)
+    rng = np.random.default_rng(size)
+    sample = sorted(set([0, 1, 5, k - 2, k - 1]) | set(int(v) for v in rng.integers(0, k, 24)))
+    for j in sample:
+        lo, hi = int(offs[j]), int(offs[j + 1])
+        assert (out[j] == coracle.msm_pippenger(pts[lo:hi], sc[lo:hi], threads=4)).all(), j
+    assert (gpu.g1_sum(out) == gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n)).all()
+    # the same batch forced into many small passes, and from host buffers
+    try:
+        os.environ["CURDLE_MAX_MSMS_PER_PASS"] = "300"
+        assert (gpu.msm_g1_batch_device(d_pts.data_ptr(), d_sc.data_ptr(), offs) == out).all()
+    finally:
+        os.environ.pop("CURDLE_MAX_MSMS_PER_PASS", None)
+    if k == 2100:
+        assert (gpu.msm_g1_batch(pts, sc, offs) == out).all()

@@ -48,6 +48,33 @@ def test_batch_threads_under_tsan(tsan_harness):
         assert "ok" in p.stdout
 
 
+def test_batch_workers_never_wait_for_a_decoding_while_holding_a_slot(tsan_harness):
+    """a batch worker kept its queued group's workspace slot while it blocked on a
+    chunk the producers had not decoded yet, and a producer whose decoding needs a slot of its
+    own (chunk beyond the two-kernel size, or all decode contexts taken) could then find all
+    eight held by waiting workers.  Run with 16 threads over the stub's eight modelled slots,
+    groups and chunks of one proof, slow slot-taking decodings: it must finish (the harness is
+    killed after the timeout otherwise) with exact accept bits and every slot returned."""
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", CURDLE_STUB_SLOTS="1", CURDLE_TWO_KERNEL_MAX="0",
+               CURDLE_BATCH_GROUP="1", CURDLE_BATCH_CHUNK="1", CURDLE_STUB_DECODE_DELAY_MS="20")
+    p = subprocess.run([tsan_harness, "slots", "12"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "ThreadSanitizer" not in p.stderr, p.stderr
+    assert "over 8 slots: ok" in p.stdout
+
+
+def test_batch_is_sharded_over_the_configured_devices(tsan_harness):
+    """curdle_verify_batch through the C ABI with the stub backend posing as three devices: the
+    proofs are sharded over the contexts (config 5: replicas), every thread of a shard selects
+    its device first, each posed device sees work, the accept bits are exact -- under
+    ThreadSanitizer."""
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", CURDLE_STUB_DEVICES="3", CURDLE_BATCH_CHUNK="2", CURDLE_BATCH_GROUP="3")
+    p = subprocess.run([tsan_harness, "devices", "12"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "ThreadSanitizer" not in p.stderr, p.stderr
+    assert "sharded over 3 devices: ok" in p.stdout
+
+
 def test_protocol_flow_under_asan_ubsan(harness):
     out = _run(harness, "flow", "12")
     assert "mirror == device accumulator, batch: ok" in out

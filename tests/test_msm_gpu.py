@@ -68,6 +68,18 @@ def test_device_primitives_match_host(gpu, oracle):
             assert xyzz_to_affine(oracle, dev[i]) == xyzz_to_affine(oracle, host[i]), (op, i)
 
 
+def test_the_split_on_the_device(gpu, oracle):
+    """The device build of glv_split (what k_digits runs) on the same 300,000 random and boundary
+    scalars as the host build (tests/test_abi.py), against big-integer division, and word for
+    word equal to the host build."""
+    from test_abi import check_glv_split_outputs, glv_split_cases, scalars_as_words
+    vals = glv_split_cases(oracle.R, 300_000, 12)
+    words = scalars_as_words(vals)
+    dev = gpu.selftest_op(11, words, True)
+    check_glv_split_outputs(vals, dev, oracle.R)
+    assert (dev == gpu.selftest_op(11, words, False)).all()
+
+
 # -------------------------------------------------------------- golden vectors ---
 def test_golden_vectors_bit_exact(gpu, golden):
     names = golden_case_names(golden)
@@ -283,6 +295,51 @@ def test_scalars_at_the_boundaries_of_the_split(gpu, oracle, coracle):
         assert (gpu.msm_g1(pts[i:i + 1], sc[i:i + 1]) == coracle.msm_naive(pts[i:i + 1], sc[i:i + 1])).all(), hex(vals[i])
 
 
+def test_bases_outside_the_prime_order_subgroup_are_a_documented_precondition(gpu, oracle):
+    """Every scalar goes through the GLV split k P = k1 P + k2 phi(P), phi(x, y) = (beta x, y),
+    which equals [lambda] only on the prime-order subgroup.  gnark's MultiExp does not use the
+    endomorphism, so for a curve point OUTSIDE G1 this library's result differs from k P --
+    include/curdle_msm.h states the precondition (bases in G1, which every decoded proof point and
+    CRS point is: gnark's Decoder / SetBytes check it).  This pins what happens instead: the
+    result is exactly k1 P + k2 (beta x, y), a point on the curve, never a fault."""
+    from test_abi import GLV_LAMBDA, glv_split
+    p, R = oracle.P, oracle.R
+    # beta: the cube root of unity with (beta x, y) = [lambda] (x, y) on G1
+    s3 = pow(p - 3, (p + 1) // 4, p)
+    assert s3 * s3 % p == p - 3
+    betas = [(-1 + s3) * pow(2, -1, p) % p, (-1 - s3) * pow(2, -1, p) % p]
+    gx, gy = oracle.G1
+    beta = [b for b in betas if oracle.scalar_mul(GLV_LAMBDA, oracle.G1) == (b * gx % p, gy)]
+    assert len(beta) == 1
+    beta = beta[0]
+    x = 6
+    while True:
+        rhs = (x * x * x + 4) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p == rhs and oracle.scalar_mul(R, (x, y)) is not None:
+            break
+        x += 1
+    P = (x, y)                                                   # on the curve, not in G1
+    for k in (5, GLV_LAMBDA + 1, 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % R, R - 2):
+        pts = np.array([oracle.affine_to_mont_limbs(P)], dtype=np.uint64)
+        sc = np.array([oracle.fr_to_mont_limbs(k)], dtype=np.uint64)
+        got = gpu.msm_g1(pts, sc)
+        k1, k2 = glv_split(k, R)
+        phiP = (beta * x % p, y)
+        neg = lambda pt: (pt[0], (p - pt[1]) % p)
+        t1 = oracle.scalar_mul(abs(k1), P if k1 >= 0 else neg(P))
+        t2 = oracle.scalar_mul(abs(k2), phiP if k2 >= 0 else neg(phiP))
+        want = oracle.add(t1, t2)
+        assert [int(v) for v in got] == oracle.jac_to_mont_limbs(want), hex(k)
+        if k > 5:
+            assert want != oracle.scalar_mul(k, P)               # ... which is NOT k P here
+    # in G1 the same construction IS k P (the identity the kernels rely on)
+    Q = oracle.scalar_mul(12345, oracle.G1)
+    k = R - 2
+    got = gpu.msm_g1(np.array([oracle.affine_to_mont_limbs(Q)], dtype=np.uint64), np.array([oracle.fr_to_mont_limbs(k)], dtype=np.uint64))
+    assert [int(v) for v in got] == oracle.jac_to_mont_limbs(oracle.scalar_mul(k, Q))
+
+
 def test_sizes_at_the_steps_of_the_plan_tables(gpu, oracle, coracle):
     """The window width, the reduce segments and the positions per accumulate lane are stepwise
     rules of n (make_plan, choose_window_bits): both sides of every step, synchronous and
@@ -359,6 +416,38 @@ def test_window_partials_sum_to_full_msm(gpu, oracle, coracle):
             assert (gpu.g1_sum(np.stack(parts)) == exp).all(), (c, world)
 
 
+def test_partials_of_the_headline_plan_sum_to_the_full_msm(gpu, oracle, coracle):
+    """BASELINE config 4 at its real size: N = 2^20, the plan that size takes (c = 16: eight
+    windows of the 127-bit halves, one per rank at world size 8).  The 8 / 4 / 2 window-range
+    partials AND the 8 / 4 / 2 point-range partials, each summed with curdle_g1_sum, equal the
+    full result, which equals the closed form of the known-discrete-log inputs."""
+    import torch
+    from curdlemsm.distributed import point_partition, window_partition
+    n = 1 << 20
+    k, q = oracle.Rand(1).get_frs(2)
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    sc = rand_scalars(np.random.default_rng(2020), n, oracle)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    exp = _walk_expected(oracle, coracle, k, q, sc)
+    assert gpu.window_bits(n) == 16
+    W = gpu.num_windows(n, 0)
+    assert W == 8
+    assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == exp).all()
+    for world in (8, 4, 2):
+        parts = []
+        for rank in range(world):
+            b, e = window_partition(W, world, rank)
+            assert e - b == W // world
+            parts.append(gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, win_begin=b, win_end=e))
+        assert (gpu.g1_sum(np.stack(parts)) == exp).all(), ("windows", world)
+        parts = []
+        for rank in range(world):
+            b, e = point_partition(n, world, rank)
+            parts.append(gpu.msm_g1_device(d_pts.data_ptr() + 96 * b, d_sc.data_ptr() + 32 * b, e - b))
+        assert (gpu.g1_sum(np.stack(parts)) == exp).all(), ("points", world)
+
+
 # ------------------------------------------------------------------ batch / multi ---
 def test_batch_and_multi_entry_points(gpu, oracle, coracle):
     k, q = oracle.Rand(9).get_frs(2)
@@ -385,7 +474,7 @@ def test_batch_and_multi_entry_points(gpu, oracle, coracle):
         s = rand_scalars(np.random.default_rng(n), n, oracle)
         out = gpu.msm_g1_multi(sets, s)
         for j in range(nsets):
-            assert (out[j] == coracle.msm_fast(sets[j], s, threads=4)).all(), (n, j)
+            assert (out[j] == coracle.msm_pippenger(sets[j], s, threads=4)).all(), (n, j)
     n = 3000
     sets = [coracle.points_walk(k + 5 * j, q, n) for j in range(3)]
     fams = {"all_equal": [123456789123456789] * n, "small": [i % 300 for i in range(n)],
@@ -398,7 +487,7 @@ def test_batch_and_multi_entry_points(gpu, oracle, coracle):
                     os.environ["CURDLE_WINDOW_BITS"] = str(c)
                 out = gpu.msm_g1_multi(sets, s)
                 for j in range(3):
-                    assert (out[j] == coracle.msm_fast(sets[j], s, threads=4)).all(), (name, c, j)
+                    assert (out[j] == coracle.msm_pippenger(sets[j], s, threads=4)).all(), (name, c, j)
     finally:
         os.environ.pop("CURDLE_WINDOW_BITS", None)
 

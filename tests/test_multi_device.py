@@ -1,0 +1,151 @@
+"""One process driving several GPUs through the C ABI (curdle_init_devices; SURVEY.md sections
+8b / 8e).  A one-GPU box cannot hold two devices, so the multi-device code is
+run with devices = {0, 0}: two contexts -- each with its own streams, workspace slots, decode
+contexts, resident copies of the CRS and host thread -- on the one GPU.  Everything below goes
+through the same entry points a Go host would bind (go/curdlemsm/curdlemsm.go)."""
+import threading
+
+import numpy as np
+import pytest
+
+from test_msm_gpu import _walk_expected, rand_scalars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def two(gpu):
+    gpu.init_devices([0, 0])
+    assert gpu.device_count() == 2
+    yield gpu
+    gpu.set_device(0)
+    gpu.shutdown()
+    gpu.init(0)
+    assert gpu.device_count() == 1
+
+
+def on_device(cm, ordinal, fn):
+    """fn() on a thread whose current context is `ordinal`."""
+    box = {}
+
+    def run():
+        try:
+            cm.set_device(ordinal)
+            box["v"] = fn()
+        except BaseException as e:          # noqa: BLE001 -- handed to the caller's thread
+            box["e"] = e
+
+    t = threading.Thread(target=run)
+    t.start()
+    t.join()
+    if "e" in box:
+        raise box["e"]
+    return box["v"]
+
+
+def test_contexts_and_tickets(two, oracle, coracle):
+    import torch
+    cm = two
+    with pytest.raises(cm.CurdleError):
+        cm.set_device(2)
+    with pytest.raises(cm.CurdleError):
+        cm.init_devices([0])                                   # a standing configuration is not silently replaced
+    cm.init_devices([0, 0])                                    # the same list again is fine
+    assert cm.get_device() == 0
+    assert on_device(cm, 1, cm.get_device) == 1 and cm.get_device() == 0     # the selection is per thread
+    k, q = oracle.Rand(3).get_frs(2)
+    n = 3000
+    pts = coracle.points_walk(k, q, n)
+    sc = rand_scalars(np.random.default_rng(3), n, oracle)
+    exp = coracle.msm_pippenger(pts, sc, threads=4)
+    assert (on_device(cm, 1, lambda: cm.msm_g1(pts, sc)) == exp).all()
+    # a ticket names its context: submitted on context 1, waited for from a thread on context 0
+    d_p = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
+    d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    t1 = on_device(cm, 1, lambda: cm.msm_g1_device_submit(d_p.data_ptr(), d_s.data_ptr(), n))
+    t0 = cm.msm_g1_device_submit(d_p.data_ptr(), d_s.data_ptr(), n)
+    assert (t1 >> 3) & 0x1F == 1 and (t0 >> 3) & 0x1F == 0
+    assert (cm.msm_wait(t1) == exp).all() and (cm.msm_wait(t0) == exp).all()
+    with pytest.raises(cm.CurdleError):
+        cm.msm_wait(t1)                                        # already waited for
+    # every slot of BOTH contexts can be in flight at once
+    tickets = [on_device(cm, d, lambda: [cm.msm_g1_device_submit(d_p.data_ptr(), d_s.data_ptr(), n) for _ in range(cm.MSM_SLOTS)])
+               for d in (0, 1)]
+    for ts in tickets:
+        for t in ts:
+            assert (cm.msm_wait(t) == exp).all()
+
+
+def test_one_msm_over_both_contexts(two, oracle, coracle):
+    """curdle_msm_g1 (host buffers: point ranges, one host thread per device) and
+    curdle_msm_g1_replicated (resident inputs: Pippenger windows or point ranges) against the
+    single-context result and the closed form, at a size below the split threshold, at 2^17
+    and at the headline 2^20."""
+    import torch
+    cm = two
+    k, q = oracle.Rand(1).get_frs(2)
+    for n in (1000, (1 << 17) + 3, 1 << 20):
+        d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+        cm.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+        sc = rand_scalars(np.random.default_rng(n), n, oracle)
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        exp = _walk_expected(oracle, coracle, k, q, sc)
+        assert (cm.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == exp).all()
+        assert (cm.msm_g1(d_pts.cpu().numpy().view(np.uint64), sc) == exp).all(), n
+        ptrs, sptrs = [d_pts.data_ptr()] * 2, [d_sc.data_ptr()] * 2
+        for split in (cm.SPLIT_AUTO, cm.SPLIT_WINDOWS, cm.SPLIT_POINTS):
+            assert (cm.msm_g1_replicated(ptrs, sptrs, n, split) == exp).all(), (n, split)
+    with pytest.raises(cm.CurdleError):
+        cm.msm_g1_replicated([d_pts.data_ptr(), 0], sptrs, n)
+
+
+def test_verification_on_the_second_context(two, oracle):
+    """A CRS made resident by a thread on context 0 is used by verifications on context 1 (its
+    copy there is made on first use), and a batch is sharded over both contexts."""
+    cm = two
+    ell = 60
+    rand = cm.Rand(0)
+    crs = cm.CRS(ell, rand)
+    base = []
+    for j in range(3):
+        perm = cm.Rand(100 + j).generate_permutation(ell)
+        kk = rand.get_fr()
+        Rs, Ss = rand.get_g1_affines(ell), rand.get_g1_affines(ell)
+        Ts, Us, M, rs_m = cm.shuffle_permute_commit(crs, Rs, Ss, perm, kk, rand)
+        base.append([cm.prove(crs, Rs, Ss, Ts, Us, M, perm, kk, rs_m, cm.Rand(42 + j)), Rs, Ss, Ts, Us, M])
+    p0 = base[0]
+    assert cm.verify(crs, *p0, cm.Rand(7)) is True
+    assert on_device(cm, 1, lambda: cm.verify(crs, *p0, cm.Rand(8))) is True
+    assert on_device(cm, 1, lambda: cm.verify(crs, p0[0], p0[2], p0[1], p0[3], p0[4], p0[5], cm.Rand(9))) is False
+    items = [list(base[i % 3]) for i in range(96)]
+    expect = [True] * 96
+    items[5][1], items[5][2] = base[1][1], base[1][2]            # instance of another proof, first shard
+    expect[5] = False
+    items[70][0] = items[70][0][:-9]                             # truncated, second shard
+    expect[70] = False
+    items[95][3] = base[(95 + 1) % 3][3]
+    expect[95] = False
+    cols = [list(c) for c in zip(*items)]
+    assert cm.verify_batch(crs, *cols, cm.Rand(9), nthreads=8) == expect
+
+
+def test_whisk_batch_over_both_contexts(two, oracle):
+    from test_whisk import shuffle_trackers
+    cm = two
+    crs = cm.CRS(cm.WHISK_ELL, cm.Rand(4))
+    sets = []
+    for j in range(2):
+        pre = shuffle_trackers(cm, oracle, cm.Rand(30 + j), cm.WHISK_ELL)
+        post, proof = cm.whisk_generate_shuffle_proof(crs, pre, cm.Rand(60 + j))
+        sets.append((pre, post, proof))
+    k = 64
+    pres = [sets[i % 2][0] for i in range(k)]
+    posts = [sets[i % 2][1] for i in range(k)]
+    proofs = [sets[i % 2][2] for i in range(k)]
+    expect = [True] * k
+    posts[3] = sets[0][1]                                        # proof 3 is shuffle 1's: wrong post trackers
+    expect[3] = False
+    proofs[40] = b"\x00" * 4576
+    expect[40] = False
+    assert cm.whisk_is_valid_shuffle_proof_batch(crs, pres, posts, proofs, cm.Rand(1), nthreads=8) == expect
+    assert on_device(cm, 1, lambda: cm.whisk_is_valid_shuffle_proof(crs, sets[0][0], sets[0][1], sets[0][2], cm.Rand(2))) is True
