@@ -656,6 +656,17 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   }
   // counts are cleared by k_digits, the large-bucket counter by the scan
   Prof prof(S, pre, cx.profile);
+  // Two ways of overlapping the phases INSIDE one synchronous call were built and measured in
+  // round 3, and removed again (profiles/r03_sync_groups_experiment.txt).  (1) The windows of one
+  // call in G groups with their own sort -> accumulate -> reduce chains on three streams, so that
+  // group g + 1 is sorted and group g - 1 reduced while group g accumulates: 3.64 ms as one
+  // chain, 3.88 / 4.55 / 5.18 ms in 2 / 4 / 8 groups -- the latency-bound kernels crawl beside a
+  // full-chip accumulation (a single-block scan 0.26-0.6 ms instead of 0.04, window sums 0.3-0.4
+  // instead of 0.05, every group's reduce 0.45-0.67), the accumulations stretch from 2.65 to
+  // 3.37 ms in all and the tails queue up behind each other.  (2) The point conversion on a
+  // second stream beside the sort, which never reads a point: 3.53 -> 3.67 ms at 2^20, nothing
+  // at 2^17..2^19 -- conversion and sort are both HBM-bound, so side by side they take as long
+  // as one after the other, plus two event hops.
   if (!points28_ready) {  // the device accumulator fills S.points28 itself (resident bases: no conversion here)
     HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre));
     prof.mark("convert_points");
