@@ -100,8 +100,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["msm", "verify"], default="msm",
-                    help="msm: the pairs/s line (with the verify figures attached); verify: the verifies/s line only")
+    ap.add_argument("--mode", choices=["msm", "verify", "whisk-batch"], default="msm",
+                    help="msm: the pairs/s line (with the verify and config-5 figures attached); verify: the verifies/s "
+                         "line only; whisk-batch: BASELINE config 5 -- 1,024 IsValidWhiskShuffleProof verifications, "
+                         "replicas over the ranks, every rank working")
+    ap.add_argument("--sweep", action="store_true",
+                    help="north_star's size sweep as one artifact: N = 2^10..2^20 (one GPU), per size the synchronous "
+                         "call's wall time, pairs/s, the dominant kernel with its HBM and multiply-issue fractions, "
+                         "and the CPU port on the same inputs")
+    ap.add_argument("--proofs", type=int, default=1024, help="whisk-batch: proofs per step (all ranks together)")
     ap.add_argument("--logn", type=int, default=20, help="log2 of the MSM size (default: the headline 2^20)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="MSMs in flight (curdle_msm_g1_device_submit/wait); 1 = strictly one after the other; "
@@ -141,6 +148,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     cm.init(local_rank)
+
+    if args.sweep:
+        if rank == 0:
+            sweep(cm, torch, dev, args)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    if args.mode == "whisk-batch":
+        line = whisk_batch_leg(cm, torch, dist, dev, rank, world, args.proofs, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if args.mode == "verify":
         if rank == 0:
@@ -360,6 +384,24 @@ def main():
         # the verification leg BEFORE the CPU baseline: sixteen saturated host threads right in
         # front of a latency measurement run into the box's CPU quota (observed: 12 % fewer
         # verifies/s)
+        if world == 1 and args.logn <= 22:
+            # PCIe-inclusive: the entry point a cgo caller binds takes HOST slices (pageable memory);
+            # reported beside the headline, never as `value`
+            pts_h = d_pts.cpu().numpy().view(np.uint64)
+            hb = []
+            for _ in range(6):
+                t1 = time.perf_counter()
+                r_h = cm.msm_g1(pts_h, sc)
+                hb.append((time.perf_counter() - t1) * 1e3)
+            if not (r_h == result).all():
+                ok = False
+            hb_ms = float(np.median(hb[1:]))
+            out["config"]["host_buffers"] = {"entry_point": "curdle_msm_g1 (pageable host slices, H2D inside the call)",
+                                             "ms_per_call": round(hb_ms, 4), "pairs_per_s": round(n / hb_ms * 1e3, 1)}
+            out["config"]["single_call"] = {"entry_point": "curdle_msm_g1_device (synchronous, inputs resident)",
+                                            "ms_per_call": round(single_call_ms, 4),
+                                            "pairs_per_s": round(n / single_call_ms * 1e3, 1)}
+            del pts_h
         if world == 1 and not args.no_verify and args.logn == 20:
             out["verify"] = verify_leg(cm, 200, 20)
         if world == 1 and not args.no_cpu_baseline:
@@ -367,12 +409,209 @@ def main():
             ok = out["cpu_baseline"]["gpu_matches_cpu"] and out["cpu_baseline"]["gpu_full_size_verified"]
         if not ok:
             out["value"] = None   # a wrong result has no throughput
+    # BASELINE config 5 beside the headline at every N (replicas: every rank verifies its share of
+    # 1,024 Whisk shuffle proofs; collective calls, so all ranks take part)
+    c5 = None
+    if not args.no_verify and args.logn == 20 and not args.emulate_world:
+        c5 = whisk_batch_leg(cm, torch, dist, dev, rank, world, 1024, 3, 1)
+    if rank == 0:
+        if c5 is not None:
+            out["config5"] = {k_: c5[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "config", "accept_bits_exact")}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("bench.py: the GPU result failed verification (see cpu_baseline in the line above)")
+
+
+def whisk_batch_leg(cm, torch, dist, dev, rank, world, k, steps, warmup):
+    """BASELINE config 5: k IsValidWhiskShuffleProof verifications (whisk.go:20-61) per step, as
+    replicas over the ranks -- rank r verifies proofs r, r + world, ... with ONE
+    curdle_whisk_is_valid_shuffle_proof_batch call on its GPU (everything from bytes: tracker and
+    proof points decoded on the GPU, host threads hashing, one device accumulation per group of
+    proofs) and the accept bits are exchanged with one all_gather of ceil(k / world) bytes
+    (curdlemsm.distributed.verify_replicas).  Eight distinct honest shuffles; the timed steps
+    verify honest proofs (a rejected group of 32 is re-verified member by member, which is the
+    price of exact bits, not the steady state), and one more untimed step with every 61st member
+    a planted reject must return the exact bits on every rank.  The k proofs are fixed as the
+    ranks grow: STRONG scaling of one batch."""
+    from curdlemsm.distributed import replica_shard, verify_replicas
+    ONE = np.array(cm_one_limbs(), dtype=np.uint64)
+    compress = lambda aff: cm.g1_compress(np.concatenate([aff, ONE]))
+    crs = cm.CRS(cm.WHISK_ELL, cm.Rand(0))
+    sets = []
+    for j in range(8):                                  # the same eight shuffles on every rank (seeded)
+        r = cm.Rand(10 + j)
+        pts = r.get_g1_affines(2 * cm.WHISK_ELL)
+        pre = [compress(pts[2 * i]) + compress(pts[2 * i + 1]) for i in range(cm.WHISK_ELL)]
+        post, proof = cm.whisk_generate_shuffle_proof(crs, pre, r)
+        sets.append((pre, post, proof))
+    mine = replica_shard(k, world, rank)
+
+    def prepare(planted):
+        expect = np.ones(k, dtype=np.uint8)
+        pres, posts, proofs = [], [], []
+        for i in mine:
+            pre, post, proof = sets[i % 8]
+            if planted and i % 61 == 60:                # another shuffle's post trackers
+                post = sets[(i + 1) % 8][1]
+            pres.append(pre), posts.append(post), proofs.append(proof)
+        if planted:
+            expect[60::61] = 0
+        return cm.PreparedWhiskBatch(pres, posts, proofs), expect
+
+    honest, all_ones = prepare(False)
+    with_rejects, expect_rejects = prepare(True)
+    threads = min(16, host_cores())
+    seed = [100]
+
+    def step(batch=None):
+        batch = batch or honest
+
+        def shard_bits(idx):
+            assert len(idx) == len(mine)
+            seed[0] += 1
+            return np.array(batch.run(crs, cm.Rand(seed[0] * 1000 + rank), nthreads=threads), dtype=np.uint8)
+
+        if world == 1:
+            return shard_bits(mine)
+        return verify_replicas(k, shard_bits, device=dev if dist.get_backend() == "nccl" else None)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    exact = True
+    for _ in range(warmup):
+        exact = exact and bool((step() == all_ones).all())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        exact = exact and bool((step() == all_ones).all())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    exact = exact and bool((step(with_rejects) == expect_rejects).all())     # untimed: exact bits with bad members
+    barrier()
+    rejects_ms = (time.perf_counter() - t1) * 1e3
+    if dist is not None:
+        t = torch.tensor([elapsed, 0.0 if exact else 1.0], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, exact = float(t[0].item()), float(t[1].item()) == 0.0
+    return {"metric": "Whisk shuffle proofs verified/sec (BASELINE config 5)", "value": k * steps / elapsed if exact else None,
+            "unit": "proofs/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed * 1e3 / steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{k} IsValidWhiskShuffleProof verifications per step (ell = {cm.WHISK_ELL}, 4,576-byte proofs, "
+                                   f"496 tracker points each), replicas round-robin over {world} rank(s), "
+                                   f"{threads} host threads per rank, 8 distinct shuffles, all honest in the timed steps",
+                       "parallelism": "single GPU" if world == 1 else f"replicas x{world}, all_gather of accept bits",
+                       "step_with_planted_rejects": {"rejects": int(k - expect_rejects.sum()), "ms": round(rejects_ms, 2)}},
+            "accept_bits_exact": exact}
+
+
+def sweep(cm, torch, dev, args):
+    """north_star: "MSM throughput on synthetic random scalars/points at N in {2^10 .. 2^20} ... as
+    absolute numbers and as fraction of HBM roofline, next to the ... CPU MultiExp timed on the
+    GPU box's own host cores (core count stated) in the same run" -- one JSON object, one entry
+    per size: the synchronous call's wall time on resident inputs (median of 9) and from host
+    slices, every kernel's own duration (HIP events), the dominant kernel with its HBM fraction
+    (128 B x N / its duration / 8 TB/s) and, for the accumulation, the multiply-issue fraction,
+    and the CPU port (oracle/cpu_msm_fast.c, all granted cores) on the SAME inputs with its
+    result compared bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+    import coracle as co
+    cores = host_cores()
+    native = False
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "native"], check=True, capture_output=True, timeout=120)
+        native = True
+    except Exception:
+        native = False
+    r1 = cm.Rand(1)
+    k = limbs_to_int(r1.get_fr()) * R_INV % R_MOD
+    q = limbs_to_int(r1.get_fr()) * R_INV % R_MOD
+    nmax = 1 << 20
+    d_all = torch.empty((nmax, 12), dtype=torch.int64, device=dev)
+    cm.synth_points_walk_device(k, q, nmax, d_all.data_ptr())
+    pts_all = d_all.cpu().numpy().view(np.uint64)
+    sc_all = uniform_scalars(np.random.default_rng(2), nmax)
+    d_sc_all = torch.from_numpy(sc_all.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    peak_mads = 1024 * 64 * 2.4e9 / 4.9
+    rows, all_ok = [], True
+    sizes = [8, 32, 64, 128, 256, 512] + [1 << e for e in range(10, 21)]   # the protocol's small MSMs, then north_star's sweep
+    for n in sizes:
+        logn = int(np.log2(n))
+        pp, sp = d_all.data_ptr(), d_sc_all.data_ptr()
+        cm.profile_enable(0)
+        for _ in range(3):
+            res = cm.msm_g1_device(pp, sp, n)
+        lat = []
+        for _ in range(9):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cm.msm_g1_device(pp, sp, n)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        hb = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            r_h = cm.msm_g1(pts_all[:n], sc_all[:n])
+            hb.append((time.perf_counter() - t1) * 1e3)
+        cm.profile_enable(1)
+        ks, counts = {}, {}
+        for _ in range(5):
+            cm.msm_g1_device(pp, sp, n)
+            pr = cm.profile_last()
+            for name, ms in pr["kernels"].items():
+                if not name.startswith("("):
+                    ks.setdefault(name, []).append(ms)
+            counts = {"entries": pr["entries"], "fragments": pr["fragments"]}
+        cm.profile_enable(0)
+        ks = {a: round(float(np.mean(b)), 4) for a, b in ks.items()}
+        dom = max(ks, key=ks.get)
+        threads = min(cores, 256)
+        co.msm_fast(pts_all[:min(n, 4096)], sc_all[:min(n, 4096)], threads=threads, native=native)
+        best, best_threads = None, threads
+        for th in ([threads] if n >= 4096 else [1, threads]):   # a small MSM is faster on one core than fanned out
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ref = co.msm_fast(pts_all[:n], sc_all[:n], threads=th, native=native)
+                dt = time.perf_counter() - t1
+                if best is None or dt < best:
+                    best, best_threads = dt, th
+        same = bool((res == ref).all()) and bool((r_h == ref).all())
+        all_ok = all_ok and same
+        wall = float(np.median(lat))
+        row = {"logn": logn if n >= 1024 else None, "n_pairs": n, "window_bits": cm.window_bits(n), "num_windows": cm.num_windows(n, 0),
+               "wall_ms": round(wall, 4), "pairs_per_s": round(n / wall * 1e3, 1),
+               "host_buffers_ms": round(float(np.median(hb[1:])), 4),
+               "kernel_ms_alone": ks, "dominant_kernel": dom,
+               "hbm_frac_dominant": round(BYTES_PER_PAIR * n / (ks[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+               "hbm_frac_whole_call": round(BYTES_PER_PAIR * n / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+               "valu_frac_accumulate": (round((counts["entries"] - counts["fragments"]) * MADS_PER_MADD
+                                              / (ks["accumulate"] * 1e-3) / peak_mads, 4)
+                                        if counts.get("entries") and "accumulate" in ks else None),
+               "cpu_port_ms": round(best * 1e3, 4), "cpu_port_pairs_per_s": round(n / best, 1), "cpu_cores": best_threads,
+               "gpu_over_cpu": round(best * 1e3 / wall, 2), "gpu_matches_cpu": same}
+        rows.append(row)
+        print(json.dumps(row), file=sys.stderr, flush=True)
+    # where a Go caller should route a MultiExp to gnark's CPU path instead: the smallest size from
+    # which the GPU's synchronous call from HOST slices beats the CPU port for good
+    cross = None
+    for r in reversed(rows):
+        if r["host_buffers_ms"] < r["cpu_port_ms"]:
+            cross = r["n_pairs"]
+        else:
+            break
+    print(json.dumps({"metric": "BLS12-381 G1 MSM size sweep N=2^10..2^20 (north_star), with the protocol's small sizes in front", "n_gpus": 1, "unit": "pairs/s",
+                      "dtype": "u32", "data": "synthetic", "hbm_peak_GBs": HBM_PEAK_GBS, "bytes_per_pair": BYTES_PER_PAIR,
+                      "cpu_baseline": {"kind": "port", "cores": min(cores, 256),
+                                       "what": f"oracle/cpu_msm_fast.c ({'-march=native' if native else 'portable'}), best of 3 per size"},
+                      "gpu_beats_cpu_from_host_slices_from_n": cross, "all_results_match_cpu": all_ok, "sweep": rows}), flush=True)
+    if not all_ok:
+        raise SystemExit("bench.py --sweep: a GPU result differs from the CPU port's")
 
 
 def cpu_baseline(cm, k, q, n, sc, gpu_result, d_pts):
@@ -442,7 +681,15 @@ def verify_leg(cm, reps, warmup):
     # (points decoded ahead in chunks, host threads verifying, one device accumulation per 32
     # proofs).  Reported beside the headline, which stays the one-after-the-other figure.
     kb, threads = 1024, min(16, host_cores())
-    batch = cm.PreparedVerifyBatch([proof_bytes] * kb, [Rs] * kb, [Ss] * kb, [Ts] * kb, [Us] * kb, [M] * kb)
+    distinct = [(proof_bytes, Rs, Ss, Ts, Us, M)]
+    for j in range(7):                                  # eight distinct (proof, instance) pairs, not one repeated
+        pj = cm.Rand(50 + j).generate_permutation(ell)
+        kj = rand.get_fr()
+        Rj, Sj = rand.get_g1_affines(ell), rand.get_g1_affines(ell)
+        Tj, Uj, Mj, rsj = cm.shuffle_permute_commit(crs, Rj, Sj, pj, kj, rand)
+        distinct.append((cm.prove(crs, Rj, Sj, Tj, Uj, Mj, pj, kj, rsj, cm.Rand(60 + j)), Rj, Sj, Tj, Uj, Mj))
+    cols = [[distinct[i % 8][c] for i in range(kb)] for c in range(6)]
+    batch = cm.PreparedVerifyBatch(*cols)
     if not all(batch.run(crs, cm.Rand(7), nthreads=threads)):
         raise SystemExit("bench.py: an honest proof was rejected by the batch verifier")
     tb = []
@@ -477,7 +724,7 @@ def verify_leg(cm, reps, warmup):
             "proof_bytes": len(proof_bytes), "rejects_swapped_instance": bool(rejects),
             "batch": {"value": kb / min(tb), "unit": "verifies/s", "proofs": kb, "host_threads": threads,
                       "ms_per_batch": [round(t * 1e3, 2) for t in tb],
-                      "workload": "curdle_verify_batch: 1,024 proofs from bytes in one call (best of 3)"},
+                      "workload": "curdle_verify_batch: 1,024 proofs (8 distinct) from bytes in one call (best of 3)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 8), "traffic": None,
                          "algorithmic_bytes_per_verify": abytes, "kernel_ms_alone": ks,
