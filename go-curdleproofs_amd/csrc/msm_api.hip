@@ -359,7 +359,7 @@ int window_widths(int c, uint8_t bits[kMaxWindows]) {
 
 // Plan for k MSMs of n_total pairs in all, the largest having n_max pairs.
 int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end,
-              bool latency_mode, size_t sets = 1, bool many = false) {
+              bool latency_mode, size_t sets = 1, bool many = false, uint32_t seg_override = 0) {
   if (n_total > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n_total);
   many = many || k * sets >= kGpuCombineMin;  // a pass of a larger batch keeps the batch's rules
   if (c == 0) c = choose_window_bits(n_max, many);
@@ -431,6 +431,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
     while (nbk / seg * 4 > lanes && seg < 64) seg *= 2;
     p.seg = seg;
   }
+  if (seg_override) p.seg = seg_override;
   if (const char* env = getenv("CURDLE_REDUCE_SEG")) p.seg = (uint32_t)atoi(env);
   if (p.seg < 1) p.seg = 1;
   while (p.seg > min_nbkt || (p.seg & (p.seg - 1))) p.seg >>= 1;
@@ -575,12 +576,23 @@ struct Prof {
   }
 };
 
+// One MSM accumulated in CHUNKS over one plan (run_host_chunked): a chunk that is not the last
+// stops after its accumulation (its fragments stay in its slot; `frags_done` on its tail stream
+// says when), the last one waits for the earlier chunks' events and folds their fragment lists
+// into its own bucket reduction (FragSources, msm_kernels.h).
+struct ChunkJoin {
+  bool accumulate_only = false;       // an earlier chunk: no reduce, no window sums, no D2H
+  std::vector<Slot*> earlier;         // the last chunk: the slots of the chunks before it
+  uint32_t seg = 0;                   // buckets per reduce segment, the same for every chunk (0: the plan's rule)
+};
+
 // Enqueue every GPU phase of k MSMs on the slot's stream (no host synchronisation).
 // d_points / d_scalars are device pointers holding the pairs of all MSMs back to back
 // and must stay valid until the matching finish_slot(); h_off has k + 1 entries.
 int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                  int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail,
-                 bool latency_mode = true, bool points28_ready = false, size_t sets = 1, bool many = false) {
+                 bool latency_mode = true, bool points28_ready = false, size_t sets = 1, bool many = false,
+                 const ChunkJoin* join = nullptr) {
   // sets > 1 (curdle_msm_g1_multi): d_points holds `sets` base sets of h_off[k] points each, all
   // multiplied by the SAME scalars: recoded and sorted once, accumulated per set
   const size_t n_pairs = h_off[k];
@@ -590,7 +602,7 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
     if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
   }
   MsmPlan& p = S.plan;
-  int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets, many);
+  int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets, many, join ? join->seg : 0);
   if (rc) return rc;
   // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
   const size_t n = 2 * n_pairs;
@@ -696,7 +708,27 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   }
   HIP_TRY(launch_merge_large(p, ws, stream));
   prof.mark("merge_large");
-  HIP_TRY(launch_bucket_reduce(p, ws, stream));
+  if (join && join->accumulate_only) {
+    HIP_TRY(hipEventRecord(S.acc_done, stream));  // the fragments are complete (the last chunk waits for this)
+    return CURDLE_OK;
+  }
+  FragSources extra;
+  memset(&extra, 0, sizeof(extra));
+  if (join) {
+    for (Slot* E : join->earlier) {
+      if (extra.n >= (uint32_t)kMaxFragSources - 1) return fail(CURDLE_EINVAL, "too many chunks for one reduction");
+      const MsmPlan& q = E->plan;
+      if (q.c != p.c || q.NB != p.NB || q.seg != p.seg || q.k != 1 || p.k != 1 || sets != 1 || q.win_begin != p.win_begin ||
+          q.win_end != p.win_end)
+        return fail(CURDLE_EINVAL, "chunks of one MSM must share the plan");
+      extra.frags[extra.n] = E->frags.p;
+      extra.foff[extra.n] = (const uint32_t*)E->foff.p;
+      extra.fragcnt[extra.n] = (const uint32_t*)E->fragcnt.p;
+      extra.n++;
+      HIP_TRY(hipStreamWaitEvent(stream, E->acc_done, 0));
+    }
+  }
+  HIP_TRY(launch_bucket_reduce(p, ws, stream, extra.n ? &extra : nullptr));
   prof.mark("bucket_reduce");
   HIP_TRY(launch_window_sum(p, ws, stream));
   prof.mark("window_sum");
@@ -895,48 +927,48 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
 constexpr size_t kHostChunkMin = (size_t)1 << 19;  // below this a call is one chunk
 int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out) {
   Ctx& cx = cur();
-  // measured (tools/bench_host_buffers.py, pageable memory, ~29 GB/s at best): N = 2^20 6.4 ms in
-  // one copy, 5.8 in two chunks, 6.5 in four (32 MiB copies run below that rate); N = 2^22 23.1 ms
-  // in one copy, 18.3-18.5 in two to eight chunks -- the copy itself is what is left
-  size_t nchunks = n >= ((size_t)1 << 21) ? 4 : 2;
+  // Round 2 ran every chunk as an MSM of its own and added the results: 6.4 ms in one copy, 5.8
+  // in two chunks, 6.5 in four at N = 2^20 on a 29 GB/s link -- two half-size MSMs cost more than
+  // one whole (each has the full set of buckets to reduce).  Now the chunks share ONE plan (the
+  // whole call's window width) and ONE bucket reduction: a chunk is sorted and accumulated into
+  // fragments while the next one is copied, and the last chunk's reduction folds in the fragment
+  // lists of all of them.  tools/bench_sync_call.py --variants CURDLE_HOST_CHUNKS=...:
+  // see profiles/r03_host_buffer_chunks.txt.
+  size_t nchunks = n >= ((size_t)1 << 21) ? 4 : (n >= ((size_t)1 << 20) ? 4 : 2);
   if (const char* e = getenv("CURDLE_HOST_CHUNKS")) nchunks = atoi(e) < 1 ? 1 : (size_t)atoi(e);
-  const size_t per = (n + nchunks - 1) / nchunks;
-  std::vector<int> pending;  // slots with a chunk in flight, oldest first
-  G1XYZZ total;
-  g1_set_inf(total);
-  auto collect_oldest = [&]() -> int {
-    const int idx = pending.front();
-    pending.erase(pending.begin());
-    uint64_t part[18];
-    int rc = finish_slot(cx, cx.slots[idx], part);
-    if (rc) drain_slot(cx, cx.slots[idx]);
-    release_slot(cx, idx);
+  if (nchunks > (size_t)kMaxFragSources) nchunks = kMaxFragSources;
+  // every chunk needs a slot until the reduction has read its fragments: take what is free now
+  // (never wait for a slot while holding one), at least one
+  std::vector<int> slots;
+  {
+    int idx = -1;
+    int rc = acquire_slot(cx, true, &idx);
     if (rc) return rc;
-    G1Jac j;
-    memcpy(&j, part, sizeof(j));
-    G1XYZZ t;
-    g1_from_jac(t, j);
-    g1_add(total, t);
-    return CURDLE_OK;
-  };
+    slots.push_back(idx);
+    while (slots.size() < nchunks && acquire_slot(cx, false, &idx) == CURDLE_OK) slots.push_back(idx);
+    // ... and leave other callers some: with fewer than three slots free afterwards, two chunks do
+    size_t busy = 0;
+    {
+      std::lock_guard<std::mutex> g(cx.mu);
+      for (const Slot& x : cx.slots) busy += x.busy ? 1 : 0;
+    }
+    while (slots.size() > 2 && kSlots - busy < 3) {
+      release_slot(cx, slots.back());
+      slots.pop_back();
+      busy--;
+    }
+    nchunks = slots.size();
+  }
+  const int c = choose_window_bits(n);
+  const size_t per = (n + nchunks - 1) / nchunks;
   auto body = [&]() -> int {
-    for (size_t lo = 0; lo < n; lo += per) {
+    HIP_TRY(hipSetDevice(cx.device));
+    ChunkJoin last;
+    size_t used = 0;
+    for (size_t lo = 0, i = 0; lo < n; lo += per, i++) {
       const size_t m = n - lo < per ? n - lo : per;
-      // never wait for a slot while holding one: another chunked caller may be doing the same
-      int idx = -1;
-      int rc = acquire_slot(cx, false, &idx);
-      while (rc == CURDLE_EBUSY) {
-        if (pending.empty()) {
-          rc = acquire_slot(cx, true, &idx);
-          break;
-        }
-        if ((rc = collect_oldest())) return rc;
-        rc = acquire_slot(cx, false, &idx);
-      }
-      if (rc) return rc;
-      Slot& S = cx.slots[idx];
-      pending.push_back(idx);
-      HIP_TRY(hipSetDevice(cx.device));
+      Slot& S = cx.slots[slots[i]];
+      used = i + 1;
       int r;
       if ((r = ensure(S.points, m * 96))) return r;
       if ((r = ensure(S.scalars, m * 32))) return r;
@@ -944,38 +976,31 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       const unsigned turn = seq % (unsigned)cx.main_streams;
       hipStream_t main = turn == 0 ? cx.main_stream : cx.main_extra[turn - 1];
       // every chunk's copy on ONE stream, so that the first chunk arrives at the full PCIe rate
-      // instead of sharing it with the ones behind it (from page-locked memory all the copies are
-      // queued at once; measured, such memory buys nothing else here: the link gives ~29 GB/s to
-      // pageable and page-locked sources alike), the pipeline behind its own chunk's copy
+      // instead of sharing it with the ones behind it; the scalars first: the sort needs only them
       HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars + 4 * lo, m * 32, hipMemcpyHostToDevice, cx.h2d_stream));
       HIP_TRY(hipMemcpyAsync(S.points.p, points + 12 * lo, m * 96, hipMemcpyHostToDevice, cx.h2d_stream));
       HIP_TRY(hipEventRecord(S.pre_done, cx.h2d_stream));
       HIP_TRY(hipStreamWaitEvent(cx.pre_stream, S.pre_done, 0));
       const uint32_t off[2] = {0, (uint32_t)m};
-      if ((r = enqueue_slot(cx, S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, cx.pre_stream, main, S.stream,
-                            /*latency_mode=*/false)))
+      const bool is_last = lo + per >= n;
+      ChunkJoin mine;
+      // with three or four fragment lists per bucket the reduction's chain is fragments, not
+      // running sums: half as many buckets per quad (N = 2^20, four chunks: 5.30 -> 5.02 ms)
+      mine.seg = nchunks >= 3 ? 8 : 0;
+      mine.accumulate_only = !is_last;
+      if (is_last) mine.earlier = last.earlier;
+      // the last chunk's tail is what the caller waits for: the synchronous rule for its segments
+      // (every chunk must take the same rule: the reduction walks all of them with one plan)
+      if ((r = enqueue_slot(cx, S, S.points.p, S.scalars.p, off, 1, c, 0, -1, cx.pre_stream, main, S.stream,
+                            /*latency_mode=*/true, false, 1, false, &mine)))
         return r;
-      // at most three chunks in flight, two while other callers hold slots: two or three
-      // concurrent large calls would otherwise take all eight slots between them and queue
-      // every other caller behind their copies
-      size_t busy_slots = 0;
-      {
-        std::lock_guard<std::mutex> g(cx.mu);
-        for (const Slot& x : cx.slots) busy_slots += x.busy ? 1 : 0;
-      }
-      const size_t cap = busy_slots > pending.size() ? 1 : 2;
-      if (pending.size() > cap && (r = collect_oldest())) return r;
+      last.earlier.push_back(&S);
     }
-    while (!pending.empty()) {
-      int r = collect_oldest();
-      if (r) return r;
-    }
-    g1_to_canonical_jac(out, total);
-    return CURDLE_OK;
+    return finish_slot(cx, cx.slots[slots[used - 1]], out);  // the last chunk's slot holds the window sums
   };
   int rc = body();
-  for (int idx : pending) {  // only after a failure
-    drain_slot(cx, cx.slots[idx]);
+  for (int idx : slots) {
+    if (rc) drain_slot(cx, cx.slots[idx]);
     release_slot(cx, idx);
   }
   return rc;

@@ -71,6 +71,18 @@ struct MsmWorkspace {
   G1XYZZ* results;    // [k]       XYZZ results of a batched call, gnark form (normalised by the host)
 };
 
+// The fragment lists the bucket reduction folds in: one per CHUNK of an MSM whose pairs were
+// accumulated in several pieces over the same plan (host-buffer calls: a piece is accumulated
+// while the next one crosses PCIe; msm_api.hip run_host_chunked) -- the pieces share the bucket
+// slots, so their fragments meet in ONE reduction instead of one reduction per piece.
+static constexpr int kMaxFragSources = 4;
+struct FragSources {
+  const void* frags[kMaxFragSources];        // d28::X28
+  const uint32_t* foff[kMaxFragSources];     // [nb + 1]
+  const uint32_t* fragcnt[kMaxFragSources];  // [nb]
+  uint32_t n;
+};
+
 // Every launcher enqueues on `stream` and returns the launch status.
 // n gnark affine points -> internal form at d_out28 (kA28Bytes apart), outside a plan: the device accumulator
 // converts its resident base sets once and per-verification points as they arrive.
@@ -81,7 +93,8 @@ hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t str
 hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
-hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
+// extra: fragment lists of earlier chunks (same plan) to fold in besides ws's own; may be null
+hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, const FragSources* extra = nullptr);
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 // Batched calls only: Horner over each MSM's window sums, one quad per MSM.
 hipError_t launch_combine(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);

@@ -24,6 +24,7 @@
 // This is 381-bit integer arithmetic: no MFMA, no floating point.  Wave size 64.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "msm_kernels.h"
 
@@ -510,8 +511,7 @@ __device__ __forceinline__ void group_sum_quad(F28& acc, u32 G, F28 (*wave_parti
 // buckets have different fragment counts do not wait for each other bucket by bucket, and
 // the kernel has a single copy of the addition in its main loop.
 __global__ void __launch_bounds__(kBlock, 2)
-    k_bucket_reduce_quad(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
-                         X28* __restrict__ partials, MsmPlan p) {
+    k_bucket_reduce_quad(FragSources src, X28* __restrict__ partials, MsmPlan p) {
   __shared__ F28 sh[4][4];
   const u32 tid = threadIdx.x;
   const u32 q = blockIdx.x * (kBlock / 4) + (tid >> 2);  // logical lane
@@ -523,35 +523,42 @@ __global__ void __launch_bounds__(kBlock, 2)
     const u32 jr = q / p.NS;            // result index = set * k + j
     const u32 r = q - jr * p.NS;
     const u32 set = jr / p.k, j = jr - set * p.k;
-    frags += (size_t)set * p.frag_stride;
+    const size_t set_off = (size_t)set * p.frag_stride;  // base sets of a shared-scalar call: one source only
     int w = p.win_begin;
     while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
     const u32 lo = (r - p.base[w] / p.seg) * p.seg;
     const u32 g0 = j * p.NB + p.base[w] + lo;
     int u = (int)p.seg - 1;
-    u32 m = fragcnt[g0 + u], k = 0;
-    if (m > p.max_small) m = 1;  // pre-merged by k_merge_large into its first slot
-    const X28* f = frags + foff[g0 + u];
+    // the bucket's fragments: those of source 0, then source 1, ... (one source but for chunked calls)
+    u32 s = 0, m = 0, k = 0;
+    const X28* f = nullptr;
+    auto open = [&]() {
+      m = src.fragcnt[s][g0 + u];
+      if (m > p.max_small) m = 1;  // pre-merged by k_merge_large into its first slot
+      f = reinterpret_cast<const X28*>(src.frags[s]) + set_off + src.foff[s][g0 + u];
+      k = 0;
+    };
+    open();
     while (u >= 0) {
+      while (k >= m && s + 1 < src.n) {  // this source has nothing (more) for the bucket: the next one
+        s++;
+        open();
+      }
       const bool take = k < m;  // uniform over the quad
       if (take) {
         q28::load(b, &f[k]);
         k++;
       }
-      F28 dst, src;
+      F28 dst, from;
       q28::sel(dst, take, run, acc);
-      q28::sel(src, take, b, run);
-      q28::add(dst, src);
+      q28::sel(from, take, b, run);
+      q28::add(dst, from);
       q28::sel(run, take, dst, run);
       q28::sel(acc, take, acc, dst);
       if (!take) {
         u--;
-        if (u >= 0) {
-          m = fragcnt[g0 + u];
-          if (m > p.max_small) m = 1;
-          f = frags + foff[g0 + u];
-          k = 0;
-        }
+        s = 0;
+        if (u >= 0) open();
       }
     }
     // lo * (segment total): every quad of the window runs the same number of steps
@@ -749,10 +756,18 @@ hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStrea
   return hipGetLastError();
 }
 
-hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
+hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, const FragSources* extra) {
   const u64 lanes = (u64)p.kr * p.NS;  // quads
-  hipLaunchKernelGGL(k_bucket_reduce_quad, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.partials), p);
+  FragSources src;
+  memset(&src, 0, sizeof(src));
+  if (extra) src = *extra;  // the earlier chunks first (any order gives the same bucket sums)
+  if (src.n >= (u32)kMaxFragSources) return hipErrorInvalidValue;
+  src.frags[src.n] = ws.frags;
+  src.foff[src.n] = ws.foff;
+  src.fragcnt[src.n] = ws.fragcnt;
+  src.n++;
+  hipLaunchKernelGGL(k_bucket_reduce_quad, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream, src,
+                     reinterpret_cast<X28*>(ws.partials), p);
   return hipGetLastError();
 }
 
