@@ -9,6 +9,7 @@
 // About 570 field products for the square root and 1,300 for the subgroup test per point;
 // the same lazily-reduced 14 x 28-bit arithmetic as the MSM kernels (fp28.h).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/curdle_msm.h"
 #include "fp28.h"
@@ -16,6 +17,16 @@
 #include "msm_kernels.h"
 
 namespace curdle {
+// Up to this many lanes the latency-bound kernels of this file run on quads (four lanes per
+// point, quad28.h); beyond it on one lane per point.  CURDLE_QUAD_MAX_LANES overrides (tuning).
+static inline uint64_t quad_max_lanes() {
+  static const uint64_t v = [] {
+    const char* e = getenv("CURDLE_QUAD_MAX_LANES");
+    return e ? (uint64_t)atoll(e) : (uint64_t)131072;
+  }();
+  return v;
+}
+
 
 using d28::F28;
 using d28::X28;
@@ -320,7 +331,7 @@ __global__ void __launch_bounds__(kBlock, 2)
 
 hipError_t launch_g1_subgroup_from_bytes(const uint8_t* in, uint32_t n, uint8_t* sub, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  if ((uint64_t)n * 4 <= 131072)
+  if ((uint64_t)n * 4 <= quad_max_lanes())
     hipLaunchKernelGGL(k_g1_subgroup_from_x<true>, dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n, sub);
   else
     hipLaunchKernelGGL(k_g1_subgroup_from_x<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n, sub);
@@ -331,7 +342,7 @@ hipError_t launch_g1_decompress(const uint8_t* in, uint32_t n, int subgroup_chec
                                 hipStream_t stream) {
   if (n == 0) return hipSuccess;
   // four lanes per point while even that is at most one round of the chip (2 waves per SIMD)
-  if (subgroup_check && (uint64_t)n * 4 <= 131072)
+  if (subgroup_check && (uint64_t)n * 4 <= quad_max_lanes())
     hipLaunchKernelGGL((k_g1_decompress<true, true>), dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, n, out,
                        status);
   else if (subgroup_check)

@@ -13,12 +13,23 @@
 // launch is at most one round of the chip.  Results leave as XYZZ in gnark's limb format;
 // the host normalises the batch with one shared inversion.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "fp28.h"
 #include "quad28.h"
 #include "msm_kernels.h"
 
 namespace curdle {
+// Up to this many lanes the latency-bound kernels of this file run on quads (four lanes per
+// point, quad28.h); beyond it on one lane per point.  CURDLE_QUAD_MAX_LANES overrides (tuning).
+static inline uint64_t quad_max_lanes() {
+  static const uint64_t v = [] {
+    const char* e = getenv("CURDLE_QUAD_MAX_LANES");
+    return e ? (uint64_t)atoll(e) : (uint64_t)131072;
+  }();
+  return v;
+}
+
 
 using d28::F28;
 using d28::X28;
@@ -175,7 +186,10 @@ __global__ void __launch_bounds__(kBlock, 2)
 hipError_t launch_scalar_mul_batch(const void* points, const void* scalars, int shared_scalar, const void* addends,
                                    uint32_t n, void* out_xyzz, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  if ((uint64_t)n * 4 <= 131072)
+  // quads up to TWO rounds of lanes here (tools/bench_quad_vs_lane.py, profiles/r03_quad_vs_lane.txt:
+  // 40,000 points 11.6 ms on quads against 12.7 on single lanes, 65,536 points 18.3 against 27.3,
+  // 262,144 points 75.7 against 75.0: the single-lane build spills 131 of its 256 registers)
+  if ((uint64_t)n * 4 <= 2 * quad_max_lanes())
     hipLaunchKernelGGL(k_scalar_mul_batch_quad, dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                        (const uint4*)points, (const uint4*)scalars, (u32)shared_scalar, (const uint4*)addends, n,
                        (G1XYZZ*)out_xyzz);

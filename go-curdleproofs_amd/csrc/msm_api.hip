@@ -302,6 +302,12 @@ int init_locked(Ctx& cx, int device) {
   // MSMs (measured: 0.93 vs 0.84 ms per 2-window partial).  CURDLE_TAIL_PRIO=1 restores it.
   const char* tp = getenv("CURDLE_TAIL_PRIO");
   const int tail_prio = (tp && atoi(tp) == 1) ? prio_greatest : prio_least;
+  // (Confining the tail streams to 32 / 64 / 128 compute units with hipExtStreamCreateWithCUMask --
+  // so that the latency-bound bucket reductions, whose waves sit on their SIMDs for 0.3-0.7 ms
+  // and leave room for only one accumulate wave beside them, stop taking a wave slot on half the
+  // chip -- was measured in round 3: the pipelined step went from 2.69 to 3.87 / 3.18 / 2.80 ms and
+  // an 8-way rank's from 0.60 to 1.04 / 0.69 / 0.63: the confined reductions take 0.86 / 0.47 /
+  // 0.29 ms and the pipeline waits for them.  profiles/r03_pipeline_experiments.txt.)
   for (Slot& s : cx.slots) {
     HIP_TRY(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, tail_prio));
     HIP_TRY(hipEventCreateWithFlags(&s.acc_done, hipEventDisableTiming));
