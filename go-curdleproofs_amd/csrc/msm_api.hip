@@ -92,7 +92,7 @@ struct Slot {
   hipEvent_t acc_done = nullptr;
   hipEvent_t pre_done = nullptr;
   Buf points, scalars, offsets, points28, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials,
-      winsums, winsums28, results, job;
+      winsums, winsums28, results, job, tmp, ccur;
   void* h_stage[2] = {nullptr, nullptr};  // pinned staging of the device accumulator (instance points; job)
   size_t h_stage_cap[2] = {0, 0};
   void* h_buf = nullptr;  // pinned: window sums (host combine) or results (GPU combine)
@@ -111,7 +111,7 @@ struct Slot {
 
   Buf* all_bufs(int i) {
     Buf* b[] = {&points, &scalars, &offsets, &points28, &counts, &starts, &cursor, &fragcnt, &foff, &small,
-                &digits, &sorted,  &frags,   &partials, &winsums, &winsums28, &results, &job};
+                &digits, &sorted,  &frags,   &partials, &winsums, &winsums28, &results, &job,      &tmp,    &ccur};
     return i < (int)(sizeof(b) / sizeof(b[0])) ? b[i] : nullptr;
   }
 };
@@ -488,6 +488,18 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (ch > n_max) ch = n_max ? n_max : 1;
   p.chunk = (uint32_t)ch;
   p.gpu_combine = many ? 1u : 0u;
+  // The scatter in two passes (msm_kernels.hip): one MSM whose windows are whole numbers of
+  // 128-bucket bins (c >= 13) and whose term indices fit the intermediate entries' 24 bits; below
+  // 2^17 terms the extra launches cost more than the stores save.  CURDLE_SCATTER=1 / 2 forces
+  // the one-pass / two-pass form where the shapes allow.
+  {
+    static const int forced = [] {
+      const char* e = getenv("CURDLE_SCATTER");
+      return e ? atoi(e) : 0;
+    }();
+    const bool shapes = k == 1 && min_nbkt >= 4096 && (min_nbkt & 127u) == 0 && p.max_nbkt <= 32768 && p.n <= (1u << 24);
+    p.two_level = shapes && forced != 1 && (forced == 2 || p.n >= (1u << 17)) ? 1u : 0u;
+  }
   // One single-block scan launch instead of six: up to 8,192 slots it is also the faster one; up to
   // 65,536 slots (a two-window partial of the multi-GPU split) it is slower in isolation (0.14 ms:
   // 64 consecutive slots per thread) but a pipelined caller only pays for launches, not latency.
@@ -630,6 +642,10 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   if ((rc = ensure(S.small, (1024 + 1 + (size_t)p.max_large) * 4))) return rc;
   if ((rc = ensure(S.digits, (size_t)nw * n * 4))) return rc;
   if ((rc = ensure(S.sorted, (size_t)nw * n * 4))) return rc;
+  if (p.two_level) {
+    if ((rc = ensure(S.tmp, (size_t)nw * n * 4))) return rc;
+    if ((rc = ensure(S.ccur, ((size_t)nw * 256 * 2 + 1) * 4))) return rc;  // the bins' cursors, and their packed starts + sentinel
+  }
   p.frag_stride = (uint32_t)(nb + nlanes + 1);
   if ((rc = ensure(S.points28, sets * n * kA28Bytes))) return rc;
   if ((rc = ensure(S.frags, sets * (size_t)p.frag_stride * kX28Bytes))) return rc;
@@ -659,6 +675,8 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   ws.large = ws.blocksum + 1025;
   ws.digits = (uint32_t*)S.digits.p;
   ws.sorted = (uint32_t*)S.sorted.p;
+  ws.tmp = p.two_level ? (uint32_t*)S.tmp.p : nullptr;
+  ws.ccur = p.two_level ? (uint32_t*)S.ccur.p : nullptr;
   ws.points28 = S.points28.p;
   ws.frags = S.frags.p;
   ws.partials = S.partials.p;

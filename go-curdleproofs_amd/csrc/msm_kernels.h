@@ -40,6 +40,7 @@ struct MsmPlan {
   uint32_t chunk;      // pairs per sort block
   uint32_t gpu_combine;  // 1: window sums combined on the GPU (large batches), 0: on the host
   uint32_t fuse_scan;    // 1: the bucket-slot scans run as one single-block launch
+  uint32_t two_level;    // 1: the scatter runs in two passes (coarse bins, then buckets): single large MSMs
   uint8_t bits[kMaxWindows];    // width of window w
   uint16_t shift[kMaxWindows];  // bit offset of window w
   uint32_t nbkt[kMaxWindows];   // bucket slots of window w
@@ -63,6 +64,8 @@ struct MsmWorkspace {
   uint32_t* nlarge;   // [1]
   uint32_t* digits;   // [nw][n]   |digit| | sign<<31, window-major
   uint32_t* sorted;   // [nw * n]  pair index | sign<<31, grouped by bucket
+  uint32_t* tmp;      // [nw * n]  two-level scatter: entries grouped by coarse bin (null otherwise)
+  uint32_t* ccur;     // [2 * nw * 256 + 1] two-level scatter: the bins' cursors, then their packed starts
   void* points28;     // [n]       input points in internal form (d28::A28, 112 B)
   void* frags;        // [nb + lanes + 1]  d28::X28 (224 B)
   void* partials;     // [k * NS / G]      d28::X28, one per group of G bucket-reduce lanes

@@ -26,6 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "msm_kernels.h"
 
 #include "fp28.h"
@@ -172,6 +174,237 @@ __global__ void __launch_bounds__(kSortThreads) k_scatter(const u32* __restrict_
       u32 pos = atomicAdd(&lds_cnt[mag - 1], 1u);
       sorted[pos] = i | (d & 0x80000000u);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Two-level scatter (single large MSMs).  k_scatter above writes 4 bytes at a time to positions
+// spread over the whole window's range -- at N = 2^20 a block's 32,768 terms go to ~32,768
+// different buckets of an 8 MB range, every store dirties its own line and the launch writes
+// 587 MB for a 64 MB payload (profiles/pmc_traffic.json, round 2).  Here the terms are first
+// partitioned by the COARSE part of their bucket (bins of 2^kFineBits buckets; a bin's range in
+// the output is known from the fine scan: starts[] at the bin's first bucket), sorted by bin in
+// LDS and written out as contiguous runs; the second pass walks the bin-grouped array in tiles of
+// consecutive positions and hands out the final positions with the old scheme (LDS counters, one
+// returning global atomic per tile and bucket) -- but a tile's stores now land in the few dozen
+// kilobytes its own bins cover, which the L2 merges into whole lines.
+// An entry of the intermediate array: term index (24 bits) | fine bucket (7 bits) << 24 | sign << 31.
+// ---------------------------------------------------------------------------
+static constexpr int kFineBits = 7;
+static constexpr u32 kFineMask = (1u << kFineBits) - 1u;
+static constexpr int kCoarseMax = 256;          // bins per window: 32,768 buckets / 128
+static constexpr int kCoarseThreads = 512;
+static constexpr int kCoarseTile = 8192;        // terms per block of the first pass: 32-entry (one line) runs per bin on average
+static constexpr int kFineTile = 2048;          // positions per block of the second pass
+static constexpr int kFineCap = 1024;           // LDS counters of the second pass (bucket slots per sweep)
+
+// coarse cursors: ccur[lw * kCoarseMax + bin] = global position of the bin's first entry (advanced by
+// the first pass), and the same positions packed over all windows in slot order, with the total
+// behind them, for the second pass: cstart[binbase(lw) + bin]
+__global__ void __launch_bounds__(kBlock)
+    k_coarse_init(const u32* __restrict__ starts, MsmPlan p, u32* __restrict__ ccur, u32* __restrict__ cstart, u32 nb) {
+  const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  const u32 nw = p.win_end - p.win_begin;
+  if (t >= nw * kCoarseMax) return;
+  const u32 lw = t / kCoarseMax, bin = t - lw * kCoarseMax;
+  const u32 w = p.win_begin + lw;
+  const u32 nbins = p.nbkt[w] >> kFineBits;
+  if (bin >= nbins) return;
+  const u32 v = starts[p.base[w] + (bin << kFineBits)];
+  ccur[t] = v;
+  u32 first = 0;
+  for (u32 x = p.win_begin; x < w; x++) first += p.nbkt[x] >> kFineBits;
+  cstart[first + bin] = v;
+  if (lw == nw - 1 && bin == nbins - 1) cstart[first + nbins] = starts[nb];  // the sentinel: every entry lies below it
+}
+
+__global__ void __launch_bounds__(kCoarseThreads)
+    k_scatter_coarse(const u32* __restrict__ digits, MsmPlan p, u32* __restrict__ ccur, u32* __restrict__ tmp) {
+  __shared__ u32 cnt[kCoarseMax], off[kCoarseMax + 1], gbase[kCoarseMax];
+  extern __shared__ u32 lds_cnt[];  // 80 KiB: the tile's entries sorted by bin, and each entry's bin
+  u32* buf = lds_cnt;
+  unsigned char* binof = reinterpret_cast<unsigned char*>(lds_cnt + kCoarseTile);
+  const u32 tid = threadIdx.x, lw = blockIdx.y;
+  const u32 i0 = blockIdx.x * kCoarseTile;
+  if (i0 >= p.n) return;  // block-uniform
+  constexpr int PER = kCoarseTile / kCoarseThreads;
+  if (tid < kCoarseMax) cnt[tid] = 0;
+  __syncthreads();
+  const u32* dw = digits + (size_t)lw * p.n;
+  u32 word[PER], rank[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const u32 i = i0 + j * kCoarseThreads + tid;
+    const u32 d = i < p.n ? dw[i] : 0u;
+    const u32 mag = d & 0x7fffffffu;
+    word[j] = 0xffffffffu;  // no entry
+    rank[j] = 0;
+    if (mag) {
+      const u32 bkt = mag - 1;
+      rank[j] = atomicAdd(&cnt[bkt >> kFineBits], 1u) | ((bkt >> kFineBits) << 16);  // rank inside the bin (< 16,384) | bin
+      word[j] = i | ((bkt & kFineMask) << 24) | (d & 0x80000000u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the bin sizes (256 values: Hillis-Steele in LDS), and the bins' global ranges
+  if (tid < kCoarseMax) off[tid + 1] = cnt[tid];
+  if (tid == 0) off[0] = 0;
+  __syncthreads();
+  for (u32 step = 1; step < kCoarseMax; step <<= 1) {
+    u32 v = 0;
+    if (tid < kCoarseMax && tid + 1 > step) v = off[tid + 1 - step];
+    __syncthreads();
+    if (tid < kCoarseMax) off[tid + 1] += v;
+    __syncthreads();
+  }
+  if (tid < kCoarseMax && cnt[tid]) gbase[tid] = atomicAdd(&ccur[lw * kCoarseMax + tid], cnt[tid]);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    if (word[j] != 0xffffffffu) {
+      const u32 bin = rank[j] >> 16;
+      const u32 pos = off[bin] + (rank[j] & 0xffffu);
+      buf[pos] = word[j];
+      binof[pos] = (unsigned char)bin;
+    }
+  }
+  __syncthreads();
+  const u32 total = off[kCoarseMax];
+  for (u32 pos = tid; pos < total; pos += kCoarseThreads) {
+    const u32 bin = binof[pos];
+    tmp[gbase[bin] + (pos - off[bin])] = buf[pos];  // consecutive lanes, consecutive addresses inside a bin's run
+  }
+}
+
+// Second pass: a tile of consecutive positions of the bin-grouped array -> final positions.
+// cstart: the first position of every bin, bins of all windows in slot order, plus the total as a
+// sentinel (k_coarse_init).  Small blocks (256 threads, 2,048 positions, 4 KiB of counters), many
+// per compute unit: a block is a chain of dependent steps (find the tile's bins, count, reserve
+// with returning global atomics, hand out), so it is the number of blocks in flight that hides
+// their latency -- with 1,024 threads and 8,192 positions per block the launch took 0.10 ms at
+// N = 2^20, however the inside was arranged (entries kept in registers, bin tables in LDS, output
+// staged in LDS for contiguous stores: 0.099-0.152 ms).
+static constexpr int kFineThreads = 256;
+static constexpr int kFineBinsCached = 64;
+__global__ void __launch_bounds__(kFineThreads)
+    k_scatter_fine(const u32* __restrict__ tmp, MsmPlan p, const u32* __restrict__ cstart, u32 nbins, u32* __restrict__ cursor,
+                   u32* __restrict__ sorted) {
+  __shared__ u32 cnt[kFineCap], loff[kFineCap], gb[kFineCap];      // per slot of the sweep: entries, offset in the tile, reserved position
+  __shared__ u32 buf[kFineTile];                                   // the tile's entries ordered by slot
+  __shared__ unsigned short sl[kFineTile];                         // ... and each one's slot - s0
+  __shared__ u32 scan_sh[kFineThreads];
+  __shared__ u32 lb[kFineBinsCached + 1], ls[kFineBinsCached + 1];  // the tile's bins: first position, first slot
+  __shared__ u32 sh_bin[2];
+  const u32 tid = threadIdx.x;
+  const u32 total = cstart[nbins];
+  const u32 a = blockIdx.x * kFineTile;
+  if (a >= total) return;  // block-uniform
+  const u32 b = min(a + kFineTile, total);
+  auto bin_slot = [&](u32 bin) {  // bin index -> first bucket slot of the bin
+    u32 first = 0;
+    int w = p.win_begin;
+    for (;;) {
+      const u32 nbw = p.nbkt[w] >> kFineBits;
+      if (bin < first + nbw) return p.base[w] + ((bin - first) << kFineBits);
+      first += nbw;
+      w++;
+    }
+  };
+  auto bin_of = [&](u32 pos) {  // last bin with cstart[bin] <= pos (empty bins share their start with the next one)
+    u32 lo = 0, hi = nbins;
+    while (lo < hi) {
+      const u32 mid = (lo + hi) >> 1;
+      if (cstart[mid] > pos) hi = mid;
+      else lo = mid + 1;
+    }
+    return lo - 1;
+  };
+  if (tid < 2) sh_bin[tid] = bin_of(tid == 0 ? a : b - 1);
+  __syncthreads();
+  const u32 bin_lo = sh_bin[0], bin_hi = sh_bin[1];  // two or three bins as a rule
+  const u32 nbt = bin_hi - bin_lo + 1;
+  const bool cached = nbt <= (u32)kFineBinsCached;
+  if (cached && tid <= nbt) {
+    lb[tid] = cstart[bin_lo + tid];
+    ls[tid] = tid < nbt ? bin_slot(bin_lo + tid) : 0u;
+  }
+  __syncthreads();
+  const u32 g_lo = bin_slot(bin_lo);
+  const u32 g_end = bin_slot(bin_hi) + (1u << kFineBits);
+  constexpr int PER = kFineTile / kFineThreads;
+  u32 ent[PER], slot[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const u32 pos = a + j * kFineThreads + tid;
+    slot[j] = 0xffffffffu;
+    ent[j] = 0;
+    if (pos < b) {
+      ent[j] = tmp[pos];
+      u32 first_slot;
+      if (cached) {
+        u32 i = 0;
+        while (i + 1 < nbt && lb[i + 1] <= pos) i++;
+        first_slot = ls[i];
+      } else {
+        first_slot = bin_slot(bin_of(pos));
+      }
+      slot[j] = first_slot + ((ent[j] >> 24) & kFineMask);
+    }
+  }
+  // sweeps over the covered slots, kFineCap at a time (one sweep unless the tile's bins are tiny):
+  // count (the atomic's return value is the entry's rank in its bucket), prefix of the counts inside
+  // the tile, one returning global atomic per touched bucket, the entries laid out by bucket in LDS
+  // and written out in that order -- consecutive lanes, consecutive addresses inside a bucket's run
+  u32 rank[PER];
+  for (u32 s0 = g_lo; s0 < g_end; s0 += kFineCap) {
+    const u32 s1 = min(s0 + (u32)kFineCap, g_end);
+    const u32 S = s1 - s0;
+    for (u32 k = tid; k < kFineCap; k += kFineThreads) cnt[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+      if (slot[j] >= s0 && slot[j] < s1) rank[j] = atomicAdd(&cnt[slot[j] - s0], 1u);
+    __syncthreads();
+    constexpr int CPT = kFineCap / kFineThreads;  // consecutive counters per thread
+    u32 c[CPT], sum = 0;
+#pragma unroll
+    for (int x = 0; x < CPT; x++) {
+      c[x] = cnt[tid * CPT + x];
+      sum += c[x];
+    }
+    // exclusive scan of the 256 partial sums
+    scan_sh[tid] = sum;
+    __syncthreads();
+    for (u32 step = 1; step < kFineThreads; step <<= 1) {
+      const u32 t = tid >= step ? scan_sh[tid - step] : 0;
+      __syncthreads();
+      scan_sh[tid] += t;
+      __syncthreads();
+    }
+    const u32 tile_total = scan_sh[kFineThreads - 1];
+    u32 run = scan_sh[tid] - sum;
+#pragma unroll
+    for (int x = 0; x < CPT; x++) {
+      const u32 k = tid * CPT + x;
+      loff[k] = run;
+      run += c[x];
+      if (c[x] && k < S) gb[k] = atomicAdd(&cursor[s0 + k], c[x]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+      if (slot[j] >= s0 && slot[j] < s1) {
+        const u32 k = slot[j] - s0;
+        const u32 at = loff[k] + rank[j];
+        buf[at] = ent[j] & 0x80ffffffu;
+        sl[at] = (unsigned short)k;
+      }
+    __syncthreads();
+    for (u32 i = tid; i < tile_total; i += kFineThreads) {
+      const u32 k = sl[i];
+      sorted[gb[k] + (i - loff[k])] = buf[i];
+    }
+    __syncthreads();
   }
 }
 
@@ -667,16 +900,23 @@ __global__ void __launch_bounds__(kBlock, 2)
 // ---------------------------------------------------------------------------
 static inline u32 cdiv(u64 a, u32 b) { return (u32)((a + b - 1) / b); }
 
-// LDS histograms larger than the default 64 KiB need the opt-in once per process.
+// LDS beyond the default 64 KiB needs an opt-in per kernel -- and per DEVICE (a process may drive
+// several: curdle_init_devices), so it is made once for every device a launch comes from.
 static hipError_t sort_lds_optin() {
-  static hipError_t st = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       32768 * 4);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               32768 * 4);
-  }();
-  return st;
+  static std::atomic<uint32_t> done{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint32_t bit = 1u << (dev & 31);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_coarse), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kCoarseTile * 5);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
 }
 
 hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream) {
@@ -726,6 +966,23 @@ hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t 
   hipError_t e = sort_lds_optin();
   if (e != hipSuccess) return e;
   const u32 nw = p.win_end - p.win_begin;
+  if (p.two_level) {
+    // operand shapes the two passes assume (checked here, on the host): one MSM, every window a
+    // whole number of bins and at most kCoarseMax of them, term indices that fit 24 bits
+    if (p.k != 1 || p.n > (1u << 24) || !ws.tmp || !ws.ccur) return hipErrorInvalidValue;
+    for (int w = p.win_begin; w < p.win_end; w++)
+      if ((p.nbkt[w] & kFineMask) || (p.nbkt[w] >> kFineBits) > (u32)kCoarseMax) return hipErrorInvalidValue;
+    u32 nbins = 0;
+    for (int w = p.win_begin; w < p.win_end; w++) nbins += p.nbkt[w] >> kFineBits;
+    u32* cstart = ws.ccur + (size_t)nw * kCoarseMax;  // [nbins + 1], behind the cursors
+    hipLaunchKernelGGL(k_coarse_init, dim3(cdiv((u64)nw * kCoarseMax, kBlock)), dim3(kBlock), 0, stream, ws.starts, p, ws.ccur,
+                       cstart, p.k * p.NB);
+    hipLaunchKernelGGL(k_scatter_coarse, dim3(cdiv(p.n, kCoarseTile), nw), dim3(kCoarseThreads), kCoarseTile * 5, stream,
+                       ws.digits, p, ws.ccur, ws.tmp);
+    hipLaunchKernelGGL(k_scatter_fine, dim3(cdiv((u64)nw * p.n, kFineTile)), dim3(kFineThreads), 0, stream, ws.tmp, p, cstart,
+                       nbins, ws.cursor, ws.sorted);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_scatter, dim3(cdiv(p.n_max, p.chunk), nw, p.k), dim3(kSortThreads), p.max_nbkt * 4, stream,
                      ws.digits, p, ws.offsets, ws.cursor, ws.sorted);
   return hipGetLastError();

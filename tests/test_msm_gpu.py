@@ -392,6 +392,50 @@ def test_linearity_at_full_size(gpu, oracle):
     assert (gpu.g1_sum(np.stack(res[:2])) == res[2]).all()
 
 
+def test_two_pass_scatter_with_skewed_scalars(gpu, oracle, coracle):
+    """Single MSMs from ~200,000 pairs on sort their terms in two passes (coarse bins of 128
+    buckets, then buckets: msm_kernels.hip k_scatter_coarse / k_scatter_fine).  Uniform scalars
+    fill every bin evenly; these do not: all-equal scalars (one bucket per window holds every
+    term), scalars below 300 (one window, a few bins), a hot top window, 1 % infinity bases, and
+    an odd size -- each against the closed form of the known-discrete-log inputs, for the window
+    widths 15 and 16."""
+    import torch
+    n = (1 << 18) + 77
+    k, q = oracle.Rand(1).get_frs(2)
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    rng = np.random.default_rng(18)
+    uniform = rand_scalars(rng, n, oracle)
+    fams = {"uniform": uniform}
+
+    def from_ints(vals):
+        v = np.asarray([oracle.fr_to_mont_limbs(int(x) % oracle.R) for x in vals], dtype=np.uint64)
+        return v
+
+    fams["all_equal"] = np.tile(from_ints([123456789123456789123456789])[0], (n, 1))
+    small = np.tile(from_ints(range(300)), ((n + 299) // 300, 1))[:n].copy()
+    fams["small"] = small
+    hot = uniform.copy()
+    hot[: n // 2] = np.tile(from_ints([(7 << 250) % oracle.R])[0], (n // 2, 1))      # half the terms share every digit
+    fams["half_equal"] = hot
+    for name, sc in fams.items():
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        exp = _walk_expected(oracle, coracle, k, q, sc)
+        for c in (0, 15, 16):
+            got = gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c)
+            assert (got == exp).all(), (name, c)
+    # infinity bases: their terms are sorted like any other and skipped by the accumulation
+    pts = d_pts.cpu().numpy().view(np.uint64).copy()
+    dead = rng.integers(0, n, n // 100)
+    pts[dead] = 0
+    sc = uniform.copy()
+    sc_dead = sc.copy()
+    sc_dead[dead] = 0                                            # same sum: a zero scalar on the original point
+    d_p2 = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
+    got = gpu.msm_g1_device(d_p2.data_ptr(), torch.from_numpy(sc.view(np.int64)).to("cuda:0").data_ptr(), n)
+    assert (got == _walk_expected(oracle, coracle, k, q, sc_dead)).all()
+
+
 # ------------------------------------------------------------- window partition ---
 def test_window_partials_sum_to_full_msm(gpu, oracle, coracle):
     """The multi-GPU split: partials over a partition of the windows, summed, equal
