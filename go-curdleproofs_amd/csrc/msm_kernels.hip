@@ -3,23 +3,30 @@
 // Replaces the body of gnark-crypto's (*G1Jac).MultiExp as the reference uses it
 // (/root/reference/msmaccumulator/msmaccumulator.go:59 and the call sites in
 // SURVEY.md section 8a).  Phases, one kernel each:
-//   digits      scalar Montgomery->canonical, signed c-bit digits (window-major)
+//   convert     gnark affine points (96 B, R = 2^384) -> internal form (fp28.h: 14 limbs of 28
+//               bits, R = 2^392), TWO 128-byte records per point: P and phi(P) = (beta x, y)
+//   digits      scalar Montgomery->canonical, the GLV split k = k1 + k2 lambda into two
+//               127-bit halves, signed c-bit digits of both (window-major): 2n terms, W =
+//               ceil(127 / c) windows
 //   hist        bucket sizes, per-window histogram staged in LDS
 //   scan        exclusive prefix of the bucket sizes over all (window, bucket)
 //               slots, then of the per-bucket fragment counts
-//   scatter     point indices grouped by (window, bucket): LDS histogram again,
-//               one coalesced returning atomic per (block, bucket) reserves the range
-//   accumulate  one lane per L consecutive sorted positions: gathers the affine
-//               points (96 B each, AoS as gnark stores them), sums them with XYZZ
-//               mixed additions and emits one fragment per bucket it touches, so
-//               the work per lane is the same however skewed the scalars are
+//   scatter     term indices grouped by (window, bucket).  One pass (LDS histogram again, one
+//               returning atomic per (block, bucket) reserves the range) for batches and small
+//               MSMs; two passes for single large MSMs: by coarse bin of 128 buckets, written as
+//               contiguous runs, then by bucket inside the bins
+//   accumulate  one lane per L consecutive sorted positions: gathers the internal affine
+//               points (112 B in one 128-byte line each), sums them with XYZZ mixed additions
+//               and emits one fragment per bucket it touches, so the work per lane is the same
+//               however skewed the scalars are
 //   merge_large block-per-bucket tree sum for buckets with many fragments
 //   reduce      sum_b (b+1)*bucket[b] per window, as running sums over short
-//               segments (the serial chain is what matters: one G1 addition is
-//               ~10-25 us of dependent 32-bit multiply-adds on one lane)
+//               segments on quads (four lanes per point, quad28.h: the serial chain is what
+//               matters); folds in the fragment lists of up to four chunks of one MSM
 //   window_sum  per-window tree sum of the segment results
-// The last 255 doublings (combining the <= 64 window sums) are O(1) work with a
-// serial dependency chain and are done by the host side of the library.
+// The last 127 doublings (combining the <= 32 window sums of the 127-bit halves) are O(1) work
+// with a serial dependency chain and are done by the host side of the library for single MSMs,
+// by k_combine (one quad per MSM) for batches.
 //
 // This is 381-bit integer arithmetic: no MFMA, no floating point.  Wave size 64.
 #include <hip/hip_runtime.h>

@@ -87,10 +87,11 @@ func BenchmarkMultiExp(b *testing.B) {
 			b.ReportMetric(float64(len(points))*float64(b.N)/b.Elapsed().Seconds(), "pairs/s")
 		})
 		b.Run(fmt.Sprintf("gpu/N=2^%d", lg), func(b *testing.B) {
+			cfg := ecc.MultiExpConfig{NbTasks: runtime.NumCPU()}
 			var dst bls12381.G1Jac
 			b.ResetTimer()
 			for i := 0; i < b.N; i++ {
-				if _, err := curdlemsm.MultiExp(&dst, points, scalars); err != nil {
+				if _, err := curdlemsm.MultiExp(&dst, points, scalars, cfg); err != nil {
 					b.Fatal(err)
 				}
 			}
@@ -104,6 +105,7 @@ func TestParity(t *testing.T) {
 		t.Skipf("no MI355X: %v", err)
 	}
 	cfg := ecc.MultiExpConfig{NbTasks: runtime.NumCPU()}
+	curdlemsm.MinGPUPairs = 0 // parity of the GPU path at EVERY size, the small ones included
 	ns := []int{0, 1, 2, 3, 6, 7, 8, 9, 60, 64, 124, 128, 252, 256, 308, 628, 1268, 2548, 1 << 12, 1 << 16}
 	for _, n := range ns {
 		points, scalars := inputs(n)
@@ -114,7 +116,7 @@ func TestParity(t *testing.T) {
 		if _, err := cpu.MultiExp(points, scalars, cfg); err != nil {
 			t.Fatal(err)
 		}
-		if _, err := curdlemsm.MultiExp(&gpu, points, scalars); err != nil {
+		if _, err := curdlemsm.MultiExp(&gpu, points, scalars, cfg); err != nil {
 			t.Fatal(err)
 		}
 		if !cpu.Equal(&gpu) {

@@ -24,6 +24,7 @@ import (
 	"runtime"
 	"unsafe"
 
+	"github.com/consensys/gnark-crypto/ecc"
 	bls12381 "github.com/consensys/gnark-crypto/ecc/bls12-381"
 	"github.com/consensys/gnark-crypto/ecc/bls12-381/fr"
 )
@@ -48,12 +49,69 @@ func Init(device int) error {
 	return locked(func() C.int { return C.curdle_init(C.int(device)) })
 }
 
+// InitDevices configures one context per entry of devices (HIP device ids): ONE Go process
+// driving several GPUs, which is how the reference's single-process callers reach BASELINE
+// configs 4 and 5 (curdle_init_devices in curdle_msm.h).  After it MultiExp splits large
+// inputs by point ranges over all devices (each GPU copies and runs its own share; one host
+// thread per device inside the library; the partial sums are added on the host), and
+// VerifyBatch-style entry points shard their proofs over the devices.  A goroutine that
+// wants a particular device for its own calls uses OnDevice.
+func InitDevices(devices []int) error {
+	if len(devices) == 0 {
+		return errors.New("curdlemsm: InitDevices: no devices")
+	}
+	ids := make([]C.int, len(devices))
+	for i, d := range devices {
+		ids[i] = C.int(d)
+	}
+	return locked(func() C.int { return C.curdle_init_devices(&ids[0], C.int(len(ids))) })
+}
+
+// DeviceCount is the number of configured contexts (1 unless InitDevices said more).
+func DeviceCount() int { return int(C.curdle_device_count()) }
+
+// OnDevice runs f with the calling OS thread's current context set to `ordinal` (the
+// library's selection is per OS thread, like hipSetDevice, so the goroutine is locked to its
+// thread for the duration and the previous selection is restored).
+func OnDevice(ordinal int, f func() error) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	prev := C.curdle_get_device()
+	if rc := C.curdle_set_device(C.int(ordinal)); rc != 0 {
+		return fmt.Errorf("curdlemsm: no device %d (rc=%d)", ordinal, int(rc))
+	}
+	defer C.curdle_set_device(prev)
+	return f()
+}
+
+// MinGPUPairs is the size below which MultiExp stays on gnark's CPU path.  `bench.py --sweep`
+// (profiles/r03_sweep.json) puts one synchronous GPU call from host slices at 0.23-0.30 ms for
+// 8..512 pairs -- a chain of dependent point additions, whatever the size -- against 0.35 ms
+// (8 pairs) .. 1.2 ms (512) for the C port of the bucket method on one core; gnark's own
+// MultiExp is tighter than that port for a handful of points (a 255-bit scalar multiplication is
+// ~70 us on a core), so the verifier's ten size-m calls per Verify (m = 6..9,
+// innerproductargument.go:238-280, samemultiscalarargument.go:196-227) are kept on the CPU and
+// everything from 32 pairs on goes to the GPU.  A variable, so a maintainer with a Go box can
+// set it from go/bench/multiexp_bench_test.go's numbers.
+var MinGPUPairs = 32
+
 // MultiExp is the drop-in for (*bls12381.G1Jac).MultiExp(points, scalars, cfg):
 // dst = sum_i scalars[i] * points[i].  Same contract as gnark: the receiver is
 // overwritten, a length mismatch is an error, an empty input gives infinity.
-func MultiExp(dst *bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Element) (*bls12381.G1Jac, error) {
+//
+// PRECONDITION (differs from gnark): every point must be in the prime-order subgroup G1 or
+// be the point at infinity -- the kernels split every scalar with the curve endomorphism,
+// which is multiplication by lambda only there (curdle_msm.h).  Every point the reference
+// passes is: CRS points are multiples of the generator, proof and tracker points come out of
+// gnark's Decoder / SetBytes, which check the subgroup.
+//
+// Inputs below MinGPUPairs stay on gnark's CPU path (cfg: the reference's common.MultiExpConf).
+func MultiExp(dst *bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Element, cfg ecc.MultiExpConfig) (*bls12381.G1Jac, error) {
 	if len(points) != len(scalars) {
 		return nil, errors.New("len(points) != len(scalars)")
+	}
+	if len(points) < MinGPUPairs {
+		return dst.MultiExp(points, scalars, cfg)
 	}
 	var pp, sp unsafe.Pointer
 	if len(points) > 0 {
