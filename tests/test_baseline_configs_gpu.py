@@ -204,3 +204,37 @@ def test_batches_beyond_one_pass_of_bucket_slots(gpu, oracle, coracle, k, size):
         os.environ.pop("CURDLE_MAX_MSMS_PER_PASS", None)
     if k == 2100:
         assert (gpu.msm_g1_batch(pts, sc, offs) == out).all()
+
+
+def test_plan_tables_have_not_regressed_by_a_factor(gpu, oracle):
+    """The plan rules (window widths, segment lengths, scatter form, chunking) are tables of
+    measured steps; the parity tests catch a wrong result, not a table entry that makes a call
+    twice as slow.  Loose ceilings on one synchronous call at the BASELINE sizes -- about twice
+    what profiles/r03_sweep.json shows on a healthy box -- so that a broken rule fails here
+    instead of in the bench: 1,268 pairs (config 3's final MSM, 0.3-0.4 ms), 2^16 (config 2,
+    0.7 ms), 2^20 (the headline, 3.4-3.6 ms; 5.0-5.6 ms from host slices)."""
+    import time
+    import torch
+    k, q = oracle.Rand(1).get_frs(2)
+    n = 1 << 20
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    sc = rand_scalars(np.random.default_rng(3), n, oracle)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    pts = d_pts.cpu().numpy().view(np.uint64)
+
+    def best_of(fn, reps=5):
+        fn()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t) * 1e3)
+        return min(ts)
+
+    for m, ceiling in ((1268, 0.9), (1 << 16, 1.6), (1 << 20, 7.0)):
+        ms = best_of(lambda: gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), m))
+        assert ms < ceiling, (m, ms)
+    ms = best_of(lambda: gpu.msm_g1(pts, sc), reps=3)
+    assert ms < 11.0, ms

@@ -4,7 +4,7 @@ on host buffers: what the Go drop-in makes) under alternative settings of the li
 knobs, one child process per setting (the knobs are read once per process); every child's
 result must equal the first setting's.
 Usage: python tools/bench_sync_call.py [--variants "A=1;B=2,C=3;..."] [logn ...]
-(default variants: the point conversion in front of the sort, and beside it)"""
+(default variants: the library's defaults, the one-pass scatter, host buffers in one copy)"""
 import json
 import os
 import subprocess
@@ -58,7 +58,7 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
         return child(int(sys.argv[2]))
     args = sys.argv[1:]
-    variants = "CURDLE_CONVERT_ASIDE_MIN=999999999;CURDLE_CONVERT_ASIDE_MIN=1024"
+    variants = "DEFAULTS=1;CURDLE_SCATTER=1;CURDLE_HOST_CHUNKS=1"
     if args and args[0] == "--variants":
         variants, args = args[1], args[2:]
     logns = [int(a) for a in args] or [20, 18, 16]

@@ -24,6 +24,15 @@ python3 $R/tools/pmc_summary.py $(find $O/prof_fetch -name '*counter_collection.
 cp $(find $O/prof_stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/gather_fetch -o gather -- $R/tools/ubench_gather > $O/gather_fetch.log 2>&1
 timeout -k 10 400 python3 $R/tools/sweep.py > $O/sweep.log 2>/dev/null
+timeout -k 10 400 python3 $R/bench.py --sweep > $O/sweep.json 2> $O/sweep_rows.jsonl
+timeout -k 10 300 python3 $R/bench.py --mode whisk-batch --steps 5 --warmup 1 > $O/whisk_batch.json 2> /dev/null
+timeout -k 10 300 python3 $R/bench.py --mode verify --steps 200 --warmup 20 > $O/verify_line.json 2> /dev/null
+for w in 2 4 8; do timeout -k 10 200 python3 $R/bench.py --emulate-world $w --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl; done
+timeout -k 10 200 python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl
+for lg in 22 24; do timeout -k 10 300 python3 $R/bench.py --logn $lg --steps 10 --warmup 2 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 > $O/bench_2p$lg.json; done
+timeout -k 10 400 python3 $R/tools/bench_sync_call.py 20 19 18 16 > $O/sync_call.jsonl 2> /dev/null
+timeout -k 10 120 python3 $R/tools/bench_h2d.py > $O/h2d.txt 2>&1
+timeout -k 10 120 $R/tools/ubench_affine > $O/batched_affine.txt 2>&1
 timeout -k 10 400 python3 $R/tools/bench_configs.py 2> $O/configs.err > $O/configs.json
 timeout -k 10 300 python3 $R/tools/bench_verify.py 2> $O/verify.err > $O/verify.log
 timeout -k 10 300 python3 $R/tools/bench_whisk.py 2> $O/whisk.err > $O/whisk.log
