@@ -958,7 +958,7 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
   // fragments while the next one is copied, and the last chunk's reduction folds in the fragment
   // lists of all of them.  tools/bench_sync_call.py --variants CURDLE_HOST_CHUNKS=...:
   // see profiles/r03_host_buffer_chunks.txt.
-  size_t nchunks = n >= ((size_t)1 << 21) ? 4 : (n >= ((size_t)1 << 20) ? 4 : 2);
+  size_t nchunks = n >= ((size_t)1 << 20) ? 4 : 2;
   if (const char* e = getenv("CURDLE_HOST_CHUNKS")) nchunks = atoi(e) < 1 ? 1 : (size_t)atoi(e);
   if (nchunks > (size_t)kMaxFragSources) nchunks = kMaxFragSources;
   // every chunk needs a slot until the reduction has read its fragments: take what is free now
