@@ -81,6 +81,31 @@ def test_the_split_on_the_device(gpu, oracle):
 
 
 # -------------------------------------------------------------- golden vectors ---
+def test_published_double_of_the_generator_on_the_gpu(gpu, oracle):
+    """EIP-2537's published 2 * G1 (tests/test_oracle.py) out of the GPU's MSM: as 2 * G, as G + G
+    (two terms in one bucket: the accumulation's doubling branch), as (r - 1) * (-2 G) ... every
+    route through the split, the buckets and the host's Horner pass must land on the published
+    coordinates."""
+    from test_oracle import EIP2537_2G_X, EIP2537_2G_Y
+    two_g = (EIP2537_2G_X, EIP2537_2G_Y)
+    want = np.array(oracle.jac_to_mont_limbs(two_g), dtype=np.uint64)
+    g = np.array([oracle.affine_to_mont_limbs(oracle.G1)], dtype=np.uint64)
+    fr = lambda v: oracle.fr_to_mont_limbs(v % oracle.R)
+    assert (gpu.msm_g1(g, np.array([fr(2)], dtype=np.uint64)) == want).all()
+    assert (gpu.msm_g1(np.concatenate([g, g]), np.array([fr(1), fr(1)], dtype=np.uint64)) == want).all()
+    neg_g = np.array([oracle.affine_to_mont_limbs(oracle.neg(oracle.G1))], dtype=np.uint64)
+    assert (gpu.msm_g1(neg_g, np.array([fr(oracle.R - 2)], dtype=np.uint64)) == want).all()
+    # gnark's own spelling of the scalar one (fr SetOne) is taken as 1, and the result's Z is gnark's fp one
+    from test_oracle import GNARK_FP_ONE, GNARK_FR_ONE
+    one_g = gpu.msm_g1(g, np.array([GNARK_FR_ONE], dtype=np.uint64))
+    assert [int(v) for v in one_g] == oracle.jac_to_mont_limbs(oracle.G1) and [int(v) for v in one_g[12:]] == GNARK_FP_ONE
+    # ... and from 1,000 terms whose scalars sum to 2 (mod r)
+    rng = np.random.default_rng(2537)
+    sc = [int.from_bytes(rng.bytes(32), "big") % oracle.R for _ in range(999)]
+    sc.append((2 - sum(sc)) % oracle.R)
+    assert (gpu.msm_g1(np.repeat(g, 1000, axis=0), np.array([fr(v) for v in sc], dtype=np.uint64)) == want).all()
+
+
 def test_golden_vectors_bit_exact(gpu, golden):
     names = golden_case_names(golden)
     assert len(names) >= 17

@@ -31,6 +31,46 @@ def test_compressed_encoding_of_the_generator(oracle):
     assert neg[0] == 0xB7 and neg[1:] == G1_GENERATOR_COMPRESSED[1:]  # same x, the larger root
 
 
+# A published known answer for the group law itself: 2 * G1 as EIP-2537's test vectors give it
+# ("bls_g1add_(g1+g1=2*g1)" / "bls_g1mul_(2*g1)": 128-byte big-endian x | y, each padded to 64
+# bytes).  Written down from the published vector before anything here computed it.
+EIP2537_2G_X = 0x0572CBEA904D67468808C8EB50A9450C9721DB309128012543902D0AC358A62AE28F75BB8F1C7C42C39A8C5529BF0F4E
+EIP2537_2G_Y = 0x166A9D8CABC673A322FDA673779D8E3822BA3ECB8670E461F73BB9021D5FD76A4C56D9D4CD16BD1BBA86881979749D28
+
+
+def test_published_double_of_the_generator(oracle, coracle):
+    """The Python oracle's addition and doubling, the C oracle's Pippenger and its fixed-base
+    scalar multiplication all reproduce the published 2 * G1 -- an anchor for the group law that
+    does not come from this repository."""
+    two_g = (EIP2537_2G_X, EIP2537_2G_Y)
+    assert oracle.is_on_curve(two_g)
+    assert oracle.add(oracle.G1, oracle.G1) == two_g
+    assert oracle.scalar_mul(2, oracle.G1) == two_g
+    want = np.array(oracle.jac_to_mont_limbs(two_g), dtype=np.uint64)
+    g = np.array([oracle.affine_to_mont_limbs(oracle.G1)], dtype=np.uint64)
+    assert (coracle.msm_pippenger(g, np.array([oracle.fr_to_mont_limbs(2)], dtype=np.uint64)) == want).all()
+    assert (coracle.msm_pippenger(np.concatenate([g, g]), np.array([oracle.fr_to_mont_limbs(1)] * 2, dtype=np.uint64)) == want).all()
+    aff = coracle.scalar_mul_gen(2)
+    assert oracle.affine_from_mont_limbs([int(v) for v in aff]) == two_g
+
+
+# gnark-crypto's generated field code spells out "one" limb by limb (bls12-381 fr / fp element.go,
+# SetOne: z[0] = 8589934590 ... / z[0] = 8505329371266088957 ...): the library's in-memory
+# convention in gnark's own constants -- Montgomery form with R = 2^256 resp. 2^384, least
+# significant 64-bit limb first -- which is what every pointer handed across the C ABI assumes.
+GNARK_FR_ONE = [8589934590, 6378425256633387010, 11064306276430008309, 1739710354780652911]
+GNARK_FP_ONE = [8505329371266088957, 17002214543764226050, 6865905132761471162, 8632934651105793861,
+                6631298214892334189, 1582556514881692819]
+
+
+def test_gnark_spells_one_the_way_the_oracle_lays_it_out(oracle):
+    assert oracle.fr_to_mont_limbs(1) == GNARK_FR_ONE
+    assert oracle.fp_to_mont_limbs(1) == GNARK_FP_ONE
+    assert oracle.fr_from_mont_limbs(GNARK_FR_ONE) == 1 and oracle.fp_from_mont_limbs(GNARK_FP_ONE) == 1
+    # the canonical Jacobian representative the ABI returns has Z = gnark's one
+    assert oracle.jac_to_mont_limbs(oracle.G1)[12:] == GNARK_FP_ONE
+
+
 def test_rand_known_answers(oracle):
     # SURVEY.md 8(c) "Derived known-answers for common.Rand"
     assert oracle.Rand(0).get_fr() == 0x119141DCE89807096095D9729B0DA80481A492498E235346EFC58AA73335A351
