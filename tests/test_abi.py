@@ -280,12 +280,12 @@ def test_protocol_layer_has_no_cpu_msm_either(cm):
     assert e.value.code == cm.ENODEV
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="msm_from_c"):
     import subprocess
-    exe = str(tmp_path / "msm_from_c")
+    exe = str(tmp_path / name)
     pkg = os.path.join(ROOT, "go-curdleproofs_amd")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "msm_from_c.c"), "-L" + pkg, "-lcurdlemsm",
+                           os.path.join(ROOT, "examples", name + ".c"), "-L" + pkg, "-lcurdlemsm",
                            "-Wl,-rpath," + pkg, "-o", exe])
     return exe
 
@@ -298,6 +298,29 @@ def test_header_is_plain_c_and_a_c_caller_links(cm, tmp_path):
     if not cm.device_available():
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_multi_device_c_caller_links(cm, tmp_path):
+    """The multi-device boundary as a C program sees it (what the cgo shim's InitDevices /
+    OnDevice bind): strict C99, links, and without a device fails loudly with ENODEV."""
+    import subprocess
+    exe = _build_c_example(tmp_path, "multi_device_from_c")
+    if not cm.device_available():
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_multi_device_c_caller_agrees_across_contexts(gpu, tmp_path):
+    """One C process, two contexts on the one GPU: curdle_msm_g1 on one context, split over both
+    by point ranges, and a batch on the second context selected with curdle_set_device -- the
+    three results are the same bytes (the program compares them and exits non-zero otherwise)."""
+    import subprocess
+    exe = _build_c_example(tmp_path, "multi_device_from_c")
+    r = subprocess.run([exe, "0", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 3 and lines[0][5:] == lines[1][5:] == lines[2][5:]
 
 
 @pytest.mark.gpu
