@@ -20,16 +20,6 @@
 #include "msm_kernels.h"
 
 namespace curdle {
-// Up to this many lanes the latency-bound kernels of this file run on quads (four lanes per
-// point, quad28.h); beyond it on one lane per point.  CURDLE_QUAD_MAX_LANES overrides (tuning).
-static inline uint64_t quad_max_lanes() {
-  static const uint64_t v = [] {
-    const char* e = getenv("CURDLE_QUAD_MAX_LANES");
-    return e ? (uint64_t)atoll(e) : (uint64_t)131072;
-  }();
-  return v;
-}
-
 
 using d28::F28;
 using d28::X28;
@@ -118,85 +108,17 @@ __global__ void __launch_bounds__(kBlock, 2)
   for (int j = 0; j < 12; j++) dst[j] = w12[j];
 }
 
-// One lane per element, for batches beyond one round of the chip.
-__global__ void __launch_bounds__(kBlock, 2)
-    k_scalar_mul_batch(const uint4* __restrict__ points, const uint4* __restrict__ scalars, u32 shared_scalar,
-                       const uint4* __restrict__ addends, u32 n, G1XYZZ* __restrict__ out) {
-  const u32 i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  // the same split; here the two halves' additions stay two mixed additions (their sum is not
-  // affine): 127 doublings and up to 254 mixed additions instead of 255 and 255
-  Fr k;
-  {
-    const size_t si = shared_scalar ? 0 : i;
-    uint4 lo = scalars[2 * si], hi = scalars[2 * si + 1];
-    Fr m;
-    m.l[0] = lo.x; m.l[1] = lo.y; m.l[2] = lo.z; m.l[3] = lo.w;
-    m.l[4] = hi.x; m.l[5] = hi.y; m.l[6] = hi.z; m.l[7] = hi.w;
-    f_from_mont<FrParams>(k, m);
-  }
-  u32 a[4], b[4], neg_a, neg_b;
-  glv_split(k, a, b, neg_a, neg_b);
-  F28 x, y;
-  X28 acc;
-  d28::set_inf(acc);
-  if (load_affine(x, y, points, i)) {
-    F28 yn, z, beta, bx;
-    d28::set_zero(z);
-    d28::sub<4>(yn, z, y);  // 4p - y
-#pragma unroll
-    for (int j = 0; j < d28::N; j++) beta.l[j] = d28::kBeta(j);
-    d28::mul(bx, x, beta);
-    const F28 ya = neg_a ? yn : y, yb = neg_b ? yn : y;
-#pragma unroll
-    for (int j = 3; j > 0; j--) {
-      a[j] = (a[j] << 1) | (a[j - 1] >> 31);
-      b[j] = (b[j] << 1) | (b[j - 1] >> 31);
-    }
-    a[0] <<= 1;
-    b[0] <<= 1;
-    for (int bit = 126; bit >= 0; bit--) {
-      d28::dbl(acc);
-      if (a[3] >> 31) d28::madd(acc, x, ya);
-      if (b[3] >> 31) d28::madd(acc, bx, yb);
-#pragma unroll
-      for (int j = 3; j > 0; j--) {
-        a[j] = (a[j] << 1) | (a[j - 1] >> 31);
-        b[j] = (b[j] << 1) | (b[j - 1] >> 31);
-      }
-      a[0] <<= 1;
-      b[0] <<= 1;
-    }
-  }
-  if (addends && load_affine(x, y, addends, i)) d28::madd(acc, x, y);
-  G1XYZZ o;
-  if (d28::is_inf(acc)) {
-    u32* z = reinterpret_cast<u32*>(&o);
-#pragma unroll
-    for (int j = 0; j < 48; j++) z[j] = 0;  // ZZ = 0
-  } else {
-    d28::to_gnark(o, acc);
-  }
-  u32* dst = reinterpret_cast<u32*>(&out[i]);
-  const u32* src = reinterpret_cast<const u32*>(&o);
-#pragma unroll
-  for (int j = 0; j < 48; j++) dst[j] = src[j];
-}
-
 hipError_t launch_scalar_mul_batch(const void* points, const void* scalars, int shared_scalar, const void* addends,
                                    uint32_t n, void* out_xyzz, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  // quads up to TWO rounds of lanes here (tools/bench_quad_vs_lane.py, profiles/r03_quad_vs_lane.txt:
-  // 40,000 points 11.6 ms on quads against 12.7 on single lanes, 65,536 points 18.3 against 27.3,
-  // 262,144 points 75.7 against 75.0: the single-lane build spills 131 of its 256 registers)
-  if ((uint64_t)n * 4 <= 2 * quad_max_lanes())
-    hipLaunchKernelGGL(k_scalar_mul_batch_quad, dim3((4 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-                       (const uint4*)points, (const uint4*)scalars, (u32)shared_scalar, (const uint4*)addends, n,
-                       (G1XYZZ*)out_xyzz);
-  else
-    hipLaunchKernelGGL(k_scalar_mul_batch, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-                       (const uint4*)points, (const uint4*)scalars, (u32)shared_scalar, (const uint4*)addends, n,
-                       (G1XYZZ*)out_xyzz);
+  // Quads (four lanes per point) at every size.  Until round 3 batches beyond one round of lanes
+  // went to a one-lane-per-point build of the same chain: 256 registers, 131 of them spilled, 528
+  // bytes of scratch per lane -- measured against the quads at those sizes
+  // (tools/bench_quad_vs_lane.py, profiles/r03_quad_vs_lane.txt): 40,000 points 12.7 ms against
+  // 11.6 on quads, 65,536 points 27.3 against 18.3, 262,144 points 75.0 against 75.7.  Removed.
+  hipLaunchKernelGGL(k_scalar_mul_batch_quad, dim3((unsigned)(((uint64_t)4 * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                     (const uint4*)points, (const uint4*)scalars, (u32)shared_scalar, (const uint4*)addends, n,
+                     (G1XYZZ*)out_xyzz);
   return hipGetLastError();
 }
 

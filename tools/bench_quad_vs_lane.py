@@ -2,6 +2,9 @@
 """Large batches of the latency-bound kernels (point decoding with the subgroup test, batched
 scalar multiplication): four lanes per point (quad28.h, no spills) against one lane per point
 (256 VGPRs, 20-131 of them spilled), per batch size.  One child process per setting.
+(Since the end of round 3 only the decoding kernels still have a one-lane build; the scalar
+multiplication's was removed on this tool's numbers -- profiles/r03_quad_vs_lane.txt -- and its
+columns are the same kernel in both settings now.)
     python tools/bench_quad_vs_lane.py"""
 import json
 import os
