@@ -1562,9 +1562,10 @@ int run_on_devices(int D, const std::function<int(int, uint64_t*)>& share, uint6
   std::mutex mu;
   std::condition_variable cv;
   int left = D;
+  for (int d = 0; d < D; d++)  // before anything is posted: the jobs below refer to this frame
+    if (!g_ctxs[d].worker) return fail(CURDLE_EINVAL, "context %d has no host thread (curdle_init_devices was not called)", d);
   for (int d = 0; d < D; d++) {
     DevWorker* w = g_ctxs[d].worker;
-    if (!w) return fail(CURDLE_EINVAL, "context %d has no host thread (curdle_init_devices was not called)", d);
     w->post([&, d] {
       Part& p = parts[(size_t)d];
       p.rc = share(d, p.jac);
