@@ -82,6 +82,9 @@ int curdle_init_devices(const int* devices, int n);
 int curdle_device_count(void);      /* contexts configured (1 unless curdle_init_devices said more) */
 int curdle_set_device(int ordinal); /* this thread's current context, 0 <= ordinal < curdle_device_count() */
 int curdle_get_device(void);
+/* Closes every context (streams, workspaces, host threads).  CURDLE_EBUSY while an MSM or a point
+ * decoding is in flight on a slot.  Like every teardown of a library, it must not run
+ * concurrently with other entry points: a call that has not taken its slot yet is not seen. */
 int curdle_shutdown(void);
 /* Copies the calling thread's last error text (NUL-terminated) into buf. */
 int curdle_last_error(char* buf, size_t len);
