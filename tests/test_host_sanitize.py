@@ -80,6 +80,16 @@ def test_protocol_flow_under_asan_ubsan(harness):
     assert "mirror == device accumulator, batch: ok" in out
 
 
+def test_baseline_config_1_shape_on_the_cpu_only_build(harness):
+    """BASELINE config 1 is "BenchmarkVerifier shuffled_elements=60 on the pure-Go CPU path
+    (plumbing, no GPU)".  There is no Go here; its counterpart is the host restatement at
+    ell = 60 over the test-only CPU backend: Prove, Verify (completeness, the soundness flips of
+    curdleproof_test.go:48-182, both accumulators, batch verification) with no GPU in the
+    process -- under AddressSanitizer + UBSan."""
+    out = _run(harness, "flow", "60")
+    assert "flow ell=60" in out and "batch: ok" in out
+
+
 def test_vectorised_point_compression_matches_scalar(harness):
     out = _run(harness, "compress", "0")
     assert "batch == scalar" in out
