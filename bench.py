@@ -420,6 +420,18 @@ def main():
     if not args.no_verify and args.logn == 20 and not args.emulate_world:
         c5 = whisk_batch_leg(cm, torch, dist, dev, rank, world, 1024, 3, 1)
     if rank == 0:
+        # One process, several GPUs through the C ABI (curdle_init_devices) -- in a CHILD process with
+        # a timeout, after everything above is measured, so that nothing in it can take this line
+        # down: only when a one-rank run sees more than one GPU (never on a one-GPU lease).
+        if world == 1 and not args.no_verify and args.logn == 20 and torch.cuda.device_count() > 1 \
+                and os.environ.get("CURDLE_BENCH_MULTI_DEVICE", "1") != "0":
+            try:
+                cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_multi_device.py")], capture_output=True,
+                                    text=True, timeout=240)
+                lines = [ln for ln in cp.stdout.strip().splitlines() if ln.startswith("{")]
+                out["multi_device_c_abi"] = json.loads(lines[-1]) if lines else {"error": (cp.stderr or "no output")[-400:]}
+            except Exception as e:      # noqa: BLE001 -- a diagnostic leg: its failure is reported, not raised
+                out["multi_device_c_abi"] = {"error": repr(e)[:400]}
         if c5 is not None:
             out["config5"] = {k_: c5[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "config", "accept_bits_exact")}
         print(json.dumps(out), flush=True)
