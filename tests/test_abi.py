@@ -56,6 +56,35 @@ def test_length_mismatch_is_an_error(cm):
 GLV_LAMBDA = 0xac45a4010001a40200000000ffffffff      # z^2 - 1, z = 0xd201000000010000: lambda^2 + lambda + 1 = r
 
 
+def test_device_selection_and_multi_device_entry_points_check_their_arguments(cm, oracle):
+    """The multi-device surface without a device: argument errors are CURDLE_EINVAL whatever the
+    hardware, the empty MSM is the identity, and configuring devices that do not exist fails
+    loudly with CURDLE_ENODEV -- never a silent single-device or CPU fallback."""
+    import ctypes as C
+    lib = C.CDLL(cm.LIB_PATH)
+    lib.curdle_init_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+    lib.curdle_msm_g1_replicated.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    assert lib.curdle_init_devices(None, 0) == cm.EINVAL
+    too_many = (C.c_int * 17)(*([0] * 17))
+    assert lib.curdle_init_devices(too_many, 17) == cm.EINVAL
+    assert cm.device_count() >= 1 and 0 <= cm.get_device() < cm.device_count()
+    with pytest.raises(cm.CurdleError) as e:
+        cm.set_device(cm.device_count())
+    assert e.value.code == cm.EINVAL
+    with pytest.raises(cm.CurdleError):
+        cm.set_device(-1)
+    out = np.zeros(18, dtype=np.uint64)
+    assert lib.curdle_msm_g1_replicated(None, None, 5, 0, None) == cm.EINVAL          # no output
+    assert lib.curdle_msm_g1_replicated(None, None, 5, 3, out.ctypes.data) == cm.EINVAL  # no such split
+    assert lib.curdle_msm_g1_replicated(None, None, 0, 0, out.ctypes.data) == cm.OK      # empty: the identity
+    assert [int(v) for v in out] == oracle.jac_to_mont_limbs(oracle.INF)
+    assert lib.curdle_msm_g1_replicated(None, None, 5, 1, out.ctypes.data) == cm.EINVAL  # null inputs
+    if not cm.device_available():
+        two = (C.c_int * 2)(0, 0)
+        assert lib.curdle_init_devices(two, 2) == cm.ENODEV
+        assert "no HIP device" in cm.last_error()
+
+
 def glv_split(k, R):
     """Host restatement of the kernels' split (msm_kernels.hip glv_split): k = s * (k1 + k2 *
     lambda) mod r with s = -1 for k > (r - 1) / 2, k2 = round(k' / lambda) >= 0 and k1 in
