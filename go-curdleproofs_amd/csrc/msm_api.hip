@@ -442,8 +442,27 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (p.seg < 1) p.seg = 1;
   while (p.seg > min_nbkt || (p.seg & (p.seg - 1))) p.seg >>= 1;
   p.NS = p.NB / p.seg;
-  const uint32_t gmax = 64u;  // quads per block
+  // Single MSMs reduce their buckets without a scalar multiple (msm_kernels.hip, k_reduce_segments):
+  // the window leaves the GPU as bit-positioned points for the host's Horner pass.  Batches and
+  // shared-scalar calls keep k_bucket_reduce_quad: their host pass runs once per RESULT, and ~8 more
+  // additions per window and result cost the host more than the GPU saves.
+  {
+    static const int forced = [] {
+      const char* e = getenv("CURDLE_REDUCE_BITS");
+      return e ? atoi(e) : -1;
+    }();
+    p.reduce_bits = (forced < 0 ? k * sets == 1 : forced != 0) && !many ? 1u : 0u;
+  }
+  const uint32_t gmax = p.reduce_bits ? 16u : 64u;  // quads per group: one wave's, or one block's
   p.G = min_nbkt / p.seg < gmax ? min_nbkt / p.seg : gmax;
+  if (p.reduce_bits) {
+    while ((1u << p.lg_seg) < p.seg) p.lg_seg++;
+    while ((1u << p.lgG) < p.G) p.lgG++;
+    p.NG = p.NS / p.G;
+    uint32_t lgn = 0;
+    while ((p.seg << (lgn + 1)) <= p.max_nbkt) lgn++;
+    p.nout = 2 + lgn;
+  }
   // Sorted positions per accumulate lane: about two full-chip rounds of lanes
   // (256 CUs x 4 SIMDs x 2 waves x 64 lanes) for large inputs, never below 8.
   const uint64_t entries = (uint64_t)(win_end - win_begin) * n_total;
@@ -649,13 +668,15 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   p.frag_stride = (uint32_t)(nb + nlanes + 1);
   if ((rc = ensure(S.points28, sets * n * kA28Bytes))) return rc;
   if ((rc = ensure(S.frags, sets * (size_t)p.frag_stride * kX28Bytes))) return rc;
-  if ((rc = ensure(S.partials, (kr * (size_t)p.NS / p.G + 1) * kX28Bytes))) return rc;
-  if ((rc = ensure(S.winsums, kr * (size_t)nw * sizeof(G1XYZZ)))) return rc;
+  // what leaves the GPU per window: one sum, or the reduce_bits form's nout bit-positioned points
+  const size_t wpts = p.reduce_bits ? p.nout : 1;
+  if ((rc = ensure(S.partials, (kr * (size_t)p.NS / p.G * (p.reduce_bits ? 2 * (2 + p.lgG) : 1) + 2) * kX28Bytes))) return rc;
+  if ((rc = ensure(S.winsums, kr * (size_t)nw * wpts * sizeof(G1XYZZ)))) return rc;
   if (p.gpu_combine) {
     if ((rc = ensure(S.winsums28, kr * (size_t)nw * kX28Bytes))) return rc;
     if ((rc = ensure(S.results, kr * sizeof(G1XYZZ)))) return rc;
   }
-  const size_t host_need = (p.gpu_combine ? kr * sizeof(G1XYZZ) : kr * (size_t)nw * sizeof(G1XYZZ)) + (k + 1) * 4;
+  const size_t host_need = (p.gpu_combine ? kr * sizeof(G1XYZZ) : kr * (size_t)nw * wpts * sizeof(G1XYZZ)) + (k + 1) * 4;
   if (S.h_buf_cap < host_need) {
     if (S.h_buf) HIP_TRY(hipHostFree(S.h_buf));
     S.h_buf = nullptr;
@@ -752,16 +773,23 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
       HIP_TRY(hipStreamWaitEvent(stream, E->acc_done, 0));
     }
   }
-  HIP_TRY(launch_bucket_reduce(p, ws, stream, extra.n ? &extra : nullptr));
-  prof.mark("bucket_reduce");
-  HIP_TRY(launch_window_sum(p, ws, stream));
-  prof.mark("window_sum");
+  if (p.reduce_bits) {
+    HIP_TRY(launch_reduce_segments(p, ws, stream, extra.n ? &extra : nullptr));
+    prof.mark("bucket_reduce");
+    HIP_TRY(launch_reduce_groups(p, ws, stream));
+    prof.mark("window_sum");
+  } else {
+    HIP_TRY(launch_bucket_reduce(p, ws, stream, extra.n ? &extra : nullptr));
+    prof.mark("bucket_reduce");
+    HIP_TRY(launch_window_sum(p, ws, stream));
+    prof.mark("window_sum");
+  }
   if (p.gpu_combine) {
     HIP_TRY(launch_combine(p, ws, stream));
     prof.mark("combine");
     HIP_TRY(hipMemcpyAsync(S.h_buf, ws.results, kr * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
   } else {
-    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.winsums, kr * (size_t)nw * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.winsums, kr * (size_t)nw * wpts * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
   }
   return CURDLE_OK;
 }
@@ -819,6 +847,24 @@ int finish_slot(Ctx& cx, Slot& S, uint64_t* out) {
   // Window combine on the host: Horner from the top window down, each step shifting
   // by the width of the window below, then the 2^shift scaling of a partial
   // (host/host_ops.cpp).
+  if (p.reduce_bits) {
+    // every window arrived as nout points with bit positions (reduce_bits_position; -1 = unused slot,
+    // which holds infinity): one Horner pass over all of them, top bit first, like over window sums
+    int dbls[kMaxWindows * 16];
+    const uint32_t np = nw * p.nout;
+    int prev = 0;
+    for (uint32_t i = 0; i < np; i++) {
+      const int w = p.win_begin + (int)(i / p.nout);
+      const int rel = reduce_bits_position(p, w, i % p.nout);
+      const int pos = rel < 0 ? prev : (int)p.shift[w] + rel;
+      if (pos < prev) return fail(CURDLE_EHIP, "internal: bit positions of the reduction are not monotone");
+      dbls[i] = pos - prev;
+      prev = pos;
+    }
+    for (size_t j = 0; j < k; j++)
+      curdle_window_combine((const G1XYZZ*)S.h_buf + j * np, (int)np, dbls, out + 18 * j);
+    return CURDLE_OK;
+  }
   int dbls[kMaxWindows];
   for (uint32_t lw = 0; lw < nw; lw++) dbls[lw] = lw > 0 ? p.bits[p.win_begin + lw - 1] : p.shift[p.win_begin];
   for (size_t j = 0; j < k; j++)

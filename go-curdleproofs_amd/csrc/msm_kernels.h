@@ -41,6 +41,14 @@ struct MsmPlan {
   uint32_t gpu_combine;  // 1: window sums combined on the GPU (large batches), 0: on the host
   uint32_t fuse_scan;    // 1: the bucket-slot scans run as one single-block launch
   uint32_t two_level;    // 1: the scatter runs in two passes (coarse bins, then buckets): single large MSMs
+  // The bucket reduction without a scalar multiple (single MSMs; k_reduce_segments / k_reduce_groups):
+  // a window's sum_b (b + 1) B_b leaves the GPU as `nout` points with bit positions, which the host's
+  // Horner pass over the windows takes in like window sums.  Then G <= 16 (one wave's quads).
+  uint32_t reduce_bits;  // 1: that form; 0: k_bucket_reduce_quad + window sums (batches, shared-scalar calls)
+  uint32_t lg_seg;       // log2(seg)
+  uint32_t lgG;          // log2(G)
+  uint32_t NG;           // segment groups per MSM = NS / G
+  uint32_t nout;         // points per window handed to the host = 2 + log2(max_nbkt / seg): sum S | - | X_0 ..
   uint8_t bits[kMaxWindows];    // width of window w
   uint16_t shift[kMaxWindows];  // bit offset of window w
   uint32_t nbkt[kMaxWindows];   // bucket slots of window w
@@ -99,6 +107,13 @@ hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStrea
 // extra: fragment lists of earlier chunks (same plan) to fold in besides ws's own; may be null
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, const FragSources* extra = nullptr);
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
+// The reduce_bits form: segments -> groups (ws.partials, room for 2 x kr x NG x (2 + lgG) + 2 points), groups ->
+// nout points per window (ws.winsums), in one or two levels.
+hipError_t launch_reduce_segments(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, const FragSources* extra = nullptr);
+hipError_t launch_reduce_groups(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
+// Bit position (relative to the window's shift) of output point `slot` of window w in the reduce_bits
+// form, or -1 for a slot the window does not use (it holds infinity).  Host and device agree on this.
+int reduce_bits_position(const MsmPlan& p, int w, uint32_t slot);
 // Batched calls only: Horner over each MSM's window sums, one quad per MSM.
 hipError_t launch_combine(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 

@@ -810,6 +810,298 @@ __global__ void __launch_bounds__(kBlock, 2)
   if (((tid >> 2) & (p.G - 1)) == 0 && live) q28::store(&partials[q / p.G], acc);
 }
 
+// ---------------------------------------------------------------------------
+// The bucket reduction WITHOUT a scalar multiple (single MSMs; MsmPlan::reduce_bits).
+//
+// k_bucket_reduce_quad above gives every quad its segment's lo * (segment total) by a 15-bit
+// double-and-add: 105 product steps of the ~290 in a quad's chain at N = 2^20, as much work again
+// as the running sums, and a 6-level tree plus a window-sum launch behind it (0.42 ms
+// for 5 % of the accumulation's additions).  Here nothing is multiplied on the GPU.  With segment
+// totals T_j and segment running sums S_j (j the segment's index inside its window),
+//
+//     sum_b (b + 1) B_b  =  sum_j S_j  +  seg * sum_j j T_j ,      sum_j j T_j = sum_i 2^i X_i ,
+//     X_i = sum of T_j over the j whose bit i is set,
+//
+// and ALL the X_i fall out of ONE butterfly over the T_j at the cost of a plain tree sum: at the level
+// with offset o every quad whose index has bit o clear adds the value of the quad o further up; at
+// the end the quad with index 0 holds the total and the quad with index 2^i holds X_i.  The quads
+// whose bit o is SET are idle in that level, so they carry the plain sum of the S_j towards the
+// group's last quad in the same instruction stream: one addition per level for both trees.
+// A window leaves the GPU as <= 14 points with bit positions (sum S at 0, X_i at log2(seg) + i) and
+// the host's Horner pass over the windows -- 127 doublings it runs anyway -- takes them in like
+// window sums: ~12 additions per window at ~0.3 us each, where the GPU pays ~5 us per dependent
+// addition.  Two launches: segments -> groups of <= 16 quads (one wave, shuffles only), groups ->
+// the window's points (k_reduce_groups).
+// ---------------------------------------------------------------------------
+// S: plain sum over aligned groups of G quads (G a power of two <= 16), result in the group's LAST
+// quad.  T: the butterfly, total in the group's first quad, X_i in the quad with index 2^i.
+__device__ __forceinline__ void group_bits_and_sum(F28& S, F28& T, u32 G) {
+  const u32 idx = ((threadIdx.x & 63u) >> 2) & (G - 1);
+  for (u32 o = 1; o < G; o <<= 1) {
+    F28 up, dn, a, b;
+    q28::shfl_down(up, T, o);
+    q28::shfl_up(dn, S, o);
+    const bool is_t = (idx & o) == 0;
+    const bool is_s = (idx & (2 * o - 1)) == 2 * o - 1;
+    q28::sel(a, is_t, T, S);
+    q28::sel(b, is_t, up, dn);
+    if (!is_t && !is_s) q28::set_inf(b);  // quad-uniform
+    q28::add(a, b);
+    q28::sel(T, is_t, a, T);
+    q28::sel(S, is_t, S, a);
+  }
+}
+
+// One quad per segment of `seg` consecutive buckets, as in k_bucket_reduce_quad: ONE addition per
+// step, the next fragment into the running sum or the running sum into the segment sum.  The
+// fragment a step adds was loaded during the step before it, and a bucket's bookkeeping one bucket
+// ahead (source 0): the loads are off the chain.  Output per group of G quads: 2 + log2(G) points,
+// [sum S | total T | X_0 .. X_(lgG-1)].
+__global__ void __launch_bounds__(kBlock, 2)
+    k_reduce_segments(FragSources src, X28* __restrict__ groups, MsmPlan p) {
+  const u32 tid = threadIdx.x;
+  const u32 q = blockIdx.x * (kBlock / 4) + (tid >> 2);  // logical lane
+  const bool live = q < p.kr * p.NS;
+  F28 acc, run;
+  q28::set_inf(acc);
+  q28::set_inf(run);
+  if (live) {
+    const u32 jr = q / p.NS;            // result index = set * k + j
+    const u32 r = q - jr * p.NS;
+    const u32 set = jr / p.k, j = jr - set * p.k;
+    const size_t set_off = (size_t)set * p.frag_stride;
+    int w = p.win_begin;
+    while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
+    const u32 lo = (r - p.base[w] / p.seg) * p.seg;
+    const u32 g0 = j * p.NB + p.base[w] + lo;
+    int u = (int)p.seg - 1;
+    u32 s = 0, m = 0, k = 0;
+    const X28* f = nullptr;
+    u32 pm = src.fragcnt[0][g0 + u], pf = src.foff[0][g0 + u];  // bucket u of source 0, read ahead
+    auto open = [&]() {
+      u32 fo;
+      if (s == 0) {
+        m = pm;
+        fo = pf;
+        if (u > 0) {
+          pm = src.fragcnt[0][g0 + u - 1];
+          pf = src.foff[0][g0 + u - 1];
+        }
+      } else {
+        m = src.fragcnt[s][g0 + u];
+        fo = src.foff[s][g0 + u];
+      }
+      if (m > p.max_small) m = 1;  // pre-merged by k_merge_large into its first slot
+      f = reinterpret_cast<const X28*>(src.frags[s]) + set_off + fo;
+      k = 0;
+    };
+    F28 nxt;
+    q28::set_inf(nxt);
+    auto seek = [&]() {  // the next fragment of bucket u, if any source has one left: its load is issued here
+      while (k >= m && s + 1 < src.n) {
+        s++;
+        open();
+      }
+      if (k < m) q28::load(nxt, &f[k]);
+    };
+    open();
+    seek();
+    while (u >= 0) {
+      const bool take = k < m;  // uniform over the quad
+      F28 b = nxt;
+      if (take) {
+        k++;
+        seek();
+      } else {
+        u--;
+        s = 0;
+        if (u >= 0) {
+          open();
+          seek();
+        }
+      }
+      F28 dst, from;
+      q28::sel(dst, take, run, acc);
+      q28::sel(from, take, b, run);
+      q28::add(dst, from);
+      q28::sel(run, take, dst, run);
+      q28::sel(acc, take, acc, dst);
+    }
+  }
+  if (p.G > 1) group_bits_and_sum(acc, run, p.G);
+  if (!live) return;  // groups are live or dead as a whole
+  const u32 idx = q & (p.G - 1);
+  X28* out = groups + (size_t)(q / p.G) * (2 + p.lgG);
+  if (idx == p.G - 1) q28::store(&out[0], acc);
+  if (idx == 0)
+    q28::store(&out[1], run);
+  else if ((idx & (idx - 1)) == 0)
+    q28::store(&out[2 + (31 - __clz((int)idx))], run);
+}
+
+// A window's output point `slot`: which bit position it carries, relative to the window's shift;
+// -1 if the window has no such point (msm_kernels.h).  Slot 0 is the sum of the segment sums, slot 1
+// the total of all buckets (bookkeeping of the levels, of no use to the host), slot 2 + i is X_i.
+__host__ __device__ inline int reduce_slot_position(const MsmPlan& p, int w, u32 slot) {
+  if (slot == 0) return 0;
+  if (slot == 1) return -1;
+  u32 lgn = 0;  // log2 of the window's segments
+  while ((p.seg << (lgn + 1)) <= p.nbkt[w]) lgn++;
+  return slot - 2 < lgn ? (int)(p.lg_seg + slot - 2) : -1;
+}
+int reduce_bits_position(const MsmPlan& p, int w, uint32_t slot) { return reduce_slot_position(p, w, slot); }
+
+// This lane's coordinate of a point, gnark form, to the host's array.
+__device__ __forceinline__ void write_point_quad(const F28& c, G1XYZZ* dst) {
+  u32 w12[12];
+  d28::to_gnark(w12, c);
+  u32* d = reinterpret_cast<u32*>(dst) + 12u * q28::role();
+#pragma unroll
+  for (int i = 0; i < 12; i++) d[i] = w12[i];
+}
+
+// One LEVEL above k_reduce_segments: up to 128 consecutive groups of a window -> one group, the same
+// record with log2(128) more bits: [sum S | total A | X_0 .. ].  Block (window lw, result jr and
+// block index, quantity z) of 64 quads; a quad takes TWO consecutive input groups.  z = 0 and z >= 2
+// are plain sums of that slot.  z = 1 weighs the totals A_e by the group index e, as bit sums again:
+// the lowest new bit is the plain sum of the odd groups' totals (it rides on the S side of the dual
+// tree), the pairs' totals go through the butterfly.  One wave reduces its 16 quads by shuffles;
+// the waves' six results (S in the last quad, T in quads 0 1 2 4 8) meet in LDS, where 6 x nwv <= 24
+// quads of waves 0 and 1 reduce them in groups of nwv quads the same way.  Every wave of a block
+// sits on a SIMD of its own (one block of 512 threads per window and quantity took 0.087 ms at
+// N = 2^20 where this takes half: two waves on a SIMD share its multiplier).
+// A window with more than 128 groups takes a second pass (ng_shift = 7: the groups that are left);
+// the last pass writes the host's array (gnark form) instead of records.
+struct ReduceLevel {
+  u32 ng_shift;   // input groups of window w: nbkt[w] / (seg * G) >> ng_shift (at least 1)
+  u32 P_in;       // points per input record
+  u32 P_out;      // points per output record (last pass: nout)
+  u32 nblk_max;   // blocks per window and result in blockIdx.y
+  u32 in_stride;  // input records per result
+  u32 out_stride; // output records per result (not used by the last pass)
+  u32 last;       // 1: write the host's array
+};
+__global__ void __launch_bounds__(kBlock, 2)
+    k_reduce_level(const X28* __restrict__ in, X28* __restrict__ out, G1XYZZ* __restrict__ host_out, MsmPlan p, ReduceLevel lv) {
+  __shared__ F28 sh[4][6][4];
+  const u32 lw = blockIdx.x, jr = blockIdx.y / lv.nblk_max, blk = blockIdx.y - jr * lv.nblk_max, z = blockIdx.z;
+  const int w = p.win_begin + (int)lw;
+  const u32 nw = p.win_end - p.win_begin;
+  const u32 per = p.seg * p.G;
+  u32 ng = (p.nbkt[w] / per) >> lv.ng_shift;  // this window's input groups (a power of two)
+  if (ng == 0) ng = 1;
+  const u32 B = ng < 128u ? ng : 128u;         // input groups per block
+  if (blk * B >= ng) return;                   // block-uniform
+  const u32 Qa = B >= 2u ? B / 2u : 1u;        // quads at work
+  const u32 tid = threadIdx.x, q = tid >> 2, wave = tid >> 6, ql = (tid & 63u) >> 2;
+  // records of window w start where the windows before it end: every window's count is shifted alike
+  u32 first_in = 0, first_out = 0;
+  for (int x = p.win_begin; x < w; x++) {
+    u32 g = (p.nbkt[x] / per) >> lv.ng_shift;
+    if (g == 0) g = 1;
+    first_in += g;
+    first_out += g <= 128u ? 1u : g / 128u;
+  }
+  const X28* base = in + ((size_t)jr * lv.in_stride + first_in + (size_t)blk * B) * lv.P_in;
+  X28* orec = out + ((size_t)jr * lv.out_stride + first_out + blk) * lv.P_out;
+  G1XYZZ* hrec = host_out + ((size_t)jr * nw + lw) * lv.P_out;
+  auto emit = [&](const F28& v, u32 slot) {  // the calling quad's point -> slot of the output record
+    if (lv.last)
+      write_point_quad(v, &hrec[slot]);
+    else
+      q28::store(&orec[slot], v);
+  };
+  F28 S, T, b;
+  q28::set_inf(S);
+  q28::set_inf(T);
+  if (B == 1) {  // nothing to reduce: the record moves on (the host's array gets infinity for the total)
+    if (z >= lv.P_in) return;
+    if (q == 0) {
+      q28::load(S, base + z);
+      if (lv.last && z == 1) q28::set_inf(S);
+      emit(S, z);
+    }
+    if (z == 1 && q >= lv.P_in && q < lv.P_out) emit(S, q);  // S is infinity here: q != 0
+    return;
+  }
+  if (q < Qa) {
+    const X28* e = base + (size_t)(2 * q) * lv.P_in + z;
+    if (z != 1) {
+      q28::load(S, e);
+      q28::load(b, e + lv.P_in);
+      q28::add(S, b);
+    } else {
+      q28::load(T, e);
+      q28::load(S, e + lv.P_in);  // the odd group: bit 0 of the group index
+      q28::add(T, S);
+    }
+  }
+  const u32 G1 = Qa < 16u ? Qa : 16u;
+  u32 lg1 = 0;
+  while ((1u << lg1) < G1) lg1++;
+  if (G1 > 1) group_bits_and_sum(S, T, G1);
+  const u32 nwv = Qa > 16u ? Qa / 16u : 1u;  // 1, 2 or 4 waves hold groups
+  u32 lgw = 0;
+  while ((1u << lgw) < nwv) lgw++;
+  // z = 1: the new bits in order: odd groups | quad bits inside a wave | wave bits
+  const u32 bit0 = lv.P_in;
+  if (nwv == 1) {
+    if (wave == 0) {
+      if (ql == G1 - 1) emit(S, z == 1 ? bit0 : z);
+      if (z == 1) {
+        if (ql == 0) {
+          if (lv.last) q28::set_inf(T);
+          emit(T, 1);
+        } else if (ql < G1 && (ql & (ql - 1)) == 0) {
+          emit(T, bit0 + 1 + (31 - __clz((int)ql)));
+        }
+      }
+    }
+  } else {
+    if (wave < nwv) {
+      if (ql == 15) sh[wave][0][tid & 3u] = S;
+      if (ql == 0) sh[wave][1][tid & 3u] = T;
+      if (ql == 1) sh[wave][2][tid & 3u] = T;
+      if (ql == 2) sh[wave][3][tid & 3u] = T;
+      if (ql == 4) sh[wave][4][tid & 3u] = T;
+      if (ql == 8) sh[wave][5][tid & 3u] = T;
+    }
+    __syncthreads();
+    const u32 slot2 = wave * 16u + ql;    // quad slot of the second stage: quantity c, wave v
+    const u32 c = slot2 / nwv, v = slot2 - c * nwv;
+    if (wave < 2) {
+      q28::set_inf(S);
+      q28::set_inf(T);
+      if (c < 6) {
+        if (c == 1)
+          T = sh[v][1][tid & 3u];
+        else
+          S = sh[v][c][tid & 3u];
+      }
+      group_bits_and_sum(S, T, nwv);
+      if (c == 0) {
+        if (v == nwv - 1) emit(S, z == 1 ? bit0 : z);
+      } else if (z == 1 && c < 6) {
+        if (c == 1) {
+          if (v == 0) {
+            if (lv.last) q28::set_inf(T);
+            emit(T, 1);
+          } else if ((v & (v - 1)) == 0) {
+            emit(T, bit0 + 1 + 4 + (31 - __clz((int)v)));
+          }
+        } else if (v == nwv - 1) {
+          emit(S, bit0 + 1 + (c - 2));
+        }
+      }
+    }
+  }
+  // the bit slots this block's window does not fill hold infinity (z = 1's block owns them)
+  const u32 made = 1 + lg1 + lgw;  // new bits of this level
+  if (z == 1 && q >= bit0 + made && q < lv.P_out) {
+    q28::set_inf(S);
+    emit(S, q);
+  }
+}
 
 // Window sums from the group partials.  A window owns nseg / G consecutive
 // partials.  Wide windows (many partials): one 64-quad block per (window, MSM)
@@ -1032,6 +1324,68 @@ hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStr
   src.n++;
   hipLaunchKernelGGL(k_bucket_reduce_quad, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream, src,
                      reinterpret_cast<X28*>(ws.partials), p);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_segments(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, const FragSources* extra) {
+  // operand shapes the kernels assume: whole groups of <= 16 quads, every window a whole number of groups
+  if (!p.reduce_bits || p.G < 1 || p.G > 16 || (p.G & (p.G - 1)) || (1u << p.lgG) != p.G || (1u << p.lg_seg) != p.seg ||
+      p.NS != p.NB / p.seg || p.NG * p.G != p.NS)
+    return hipErrorInvalidValue;
+  for (int w = p.win_begin; w < p.win_end; w++)
+    if (p.nbkt[w] % (p.seg * p.G) || p.base[w] % (p.seg * p.G)) return hipErrorInvalidValue;
+  const u64 lanes = (u64)p.kr * p.NS;  // quads
+  FragSources src;
+  memset(&src, 0, sizeof(src));
+  if (extra) src = *extra;
+  if (src.n >= (u32)kMaxFragSources) return hipErrorInvalidValue;
+  src.frags[src.n] = ws.frags;
+  src.foff[src.n] = ws.foff;
+  src.fragcnt[src.n] = ws.fragcnt;
+  src.n++;
+  hipLaunchKernelGGL(k_reduce_segments, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream, src,
+                     reinterpret_cast<X28*>(ws.partials), p);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_groups(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
+  const u32 nw = p.win_end - p.win_begin;
+  if (!p.reduce_bits || !p.NG) return hipErrorInvalidValue;
+  // levels of up to 128 groups per block until every window is one record; records ping-pong between
+  // the two halves of ws.partials (the first half holds k_reduce_segments' output)
+  const u32 per = p.seg * p.G;
+  X28* bufs[2] = {reinterpret_cast<X28*>(ws.partials), reinterpret_cast<X28*>(ws.partials) + (size_t)p.kr * p.NG * (2 + p.lgG) + 1};
+  ReduceLevel lv;
+  lv.ng_shift = 0;
+  lv.P_in = 2 + p.lgG;
+  lv.in_stride = p.NG;
+  for (int pass = 0;; pass++) {
+    u32 ng_max = 1, in_recs = 0, out_recs = 0;
+    for (int w = p.win_begin; w < p.win_end; w++) {
+      u32 g = (p.nbkt[w] / per) >> lv.ng_shift;
+      if (g == 0) g = 1;
+      if (g > ng_max) ng_max = g;
+      in_recs += g;
+      out_recs += g <= 128u ? 1u : g / 128u;
+    }
+    if (in_recs != lv.in_stride) return hipErrorInvalidValue;
+    const u32 B = ng_max < 128u ? ng_max : 128u;
+    u32 lgB = 0;
+    while ((1u << lgB) < B) lgB++;
+    lv.last = ng_max <= 128u ? 1u : 0u;
+    lv.P_out = lv.P_in + lgB;
+    lv.nblk_max = ng_max <= 128u ? 1u : ng_max / 128u;
+    lv.out_stride = out_recs;
+    if (lv.last && lv.P_out != p.nout) return hipErrorInvalidValue;
+    if (lv.P_out > 64u) return hipErrorInvalidValue;  // the filler takes one quad per slot
+    hipLaunchKernelGGL(k_reduce_level, dim3(nw, p.kr * lv.nblk_max, lv.P_in), dim3(kBlock), 0, stream, bufs[pass & 1],
+                       bufs[(pass + 1) & 1], ws.winsums, p, lv);
+    if (lv.last) break;
+    lv.ng_shift += 7;
+    lv.P_in = lv.P_out;
+    lv.in_stride = out_recs;
+    if (pass > 4) return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

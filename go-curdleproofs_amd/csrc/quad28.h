@@ -214,6 +214,12 @@ __device__ __forceinline__ void shfl_down(F28& dst, const F28& src, u32 off) {
   for (int i = 0; i < N; i++) dst.l[i] = __shfl_down(src.l[i], off * 4, 64);
 }
 
+// ... and the one `off` quads further down (off < 16).
+__device__ __forceinline__ void shfl_up(F28& dst, const F28& src, u32 off) {
+#pragma unroll
+  for (int i = 0; i < N; i++) dst.l[i] = __shfl_up(src.l[i], off * 4, 64);
+}
+
 // Replicated X28 (every lane holds the whole point) <-> distributed.
 __device__ __forceinline__ void from_x28(F28& c, const X28& p) {
   const u32 r = role();
