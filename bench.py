@@ -117,6 +117,13 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the verifies/s leg")
     ap.add_argument("--split", choices=["windows", "points"], default="windows",
                     help="multi-GPU partition: Pippenger windows (north_star) or point ranges (diagnostic)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N > 1 code path at ANY world size, 1 included: torch.distributed process group on the "
+                         "chosen backend (nccl = RCCL unless CURDLE_DIST_BACKEND says otherwise), partials exchanged by "
+                         "all_gather, accept bits of the config-5 leg too -- so that everything a multi-GPU run executes "
+                         "for the first time can be executed on a one-GPU lease (tests/test_bench_cli.py)")
+    ap.add_argument("--sweep-sizes", default="",
+                    help="--sweep: comma-separated pair counts instead of the default list (tests use a short one)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: on ONE GPU, run only the share rank 0 of an N-rank job would run "
                          "(no collective); prints the per-rank step time, not a bench line")
@@ -132,9 +139,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist or os.environ.get("CURDLE_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:     # a one-rank group needs a rendezvous too
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         backend = os.environ.get("CURDLE_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on one GPU
         if backend != "nccl":
             local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -150,7 +162,9 @@ def main():
     cm.init(local_rank)
 
     if args.sweep:
-        if rank == 0:
+        if dist is not None:
+            sweep_distributed(cm, torch, dist, dev, rank, world, args)
+        elif rank == 0:
             sweep(cm, torch, dev, args)
         if dist is not None:
             dist.barrier()
@@ -216,7 +230,7 @@ def main():
         host_t["submit"] += time.perf_counter() - t_
         return tk
 
-    exchange = PartialExchange(device=dev if dist.get_backend() == "nccl" else None) if world > 1 else None
+    exchange = PartialExchange(device=dev if dist.get_backend() == "nccl" else None) if dist is not None else None
     exchanging = []     # (N > 1) the all_gather of the step before, finished one step later
 
     def collect(ticket):
@@ -227,7 +241,7 @@ def main():
         t_ = time.perf_counter()
         part = cm.msm_wait(ticket)
         host_t["wait"] += time.perf_counter() - t_
-        if world == 1:
+        if dist is None:
             return part
         t_ = time.perf_counter()
         exchanging.append(exchange.start(part))
@@ -255,7 +269,7 @@ def main():
             res = collect(pending.pop(0))
             if on_step:
                 on_step()
-        if world > 1:
+        if dist is not None:
             res = flush()
         return res
 
@@ -303,7 +317,7 @@ def main():
     for _ in range(5):
         barrier()
         collect(submit())
-        if world > 1:
+        if dist is not None:
             flush()
         pr = cm.profile_last()
         for name, ms in pr["kernels"].items():
@@ -381,9 +395,9 @@ def main():
             "config": {"workload": f"single G1 MSM, N=2^{args.logn} random Fr scalars x walk points, inputs resident in HBM",
                        "n_pairs": n, "window_bits": c, "num_windows": W, "in_flight": depth,
                        "single_call_ms": round(single_call_ms, 4), "host_ms_per_step": host_ms,
-                       "parallelism": "single GPU" if world == 1 else
+                       "parallelism": "single GPU" if dist is None else
                        (f"Pippenger windows split x{world}" if args.split == "windows" else f"point ranges x{world}")
-                       + ", all_gather of 144 B partials"},
+                       + f", all_gather of 144 B partials over {dist.get_backend()}"},
             "roofline": roofline,
         }
         # the verification leg BEFORE the CPU baseline: sixteen saturated host threads right in
@@ -409,7 +423,9 @@ def main():
             del pts_h
         if world == 1 and not args.no_verify and args.logn == 20:
             out["verify"] = verify_leg(cm, 200, 20)
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # on rank 0 at every N (north_star: the CPU "in the same run"); the other ranks wait at the
+            # barrier below -- seconds, far inside the collective's timeout
             out["cpu_baseline"] = cpu_baseline(cm, k, q, n, sc, result, d_pts)
             ok = out["cpu_baseline"]["gpu_matches_cpu"] and out["cpu_baseline"]["gpu_full_size_verified"]
         if not ok:
@@ -480,7 +496,9 @@ def whisk_batch_leg(cm, torch, dist, dev, rank, world, k, steps, warmup):
 
     honest, all_ones = prepare(False)
     with_rejects, expect_rejects = prepare(True)
-    threads = min(16, host_cores())
+    # the ranks of one node share its cores (and one cgroup quota): each takes its share
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    threads = max(1, min(16, host_cores() // max(1, local_world)))
     seed = [100]
 
     def step(batch=None):
@@ -491,7 +509,7 @@ def whisk_batch_leg(cm, torch, dist, dev, rank, world, k, steps, warmup):
             seed[0] += 1
             return np.array(batch.run(crs, cm.Rand(seed[0] * 1000 + rank), nthreads=threads), dtype=np.uint8)
 
-        if world == 1:
+        if dist is None:
             return shard_bits(mine)
         return verify_replicas(k, shard_bits, device=dev if dist.get_backend() == "nccl" else None)
 
@@ -523,7 +541,7 @@ def whisk_batch_leg(cm, torch, dist, dev, rank, world, k, steps, warmup):
             "config": {"workload": f"{k} IsValidWhiskShuffleProof verifications per step (ell = {cm.WHISK_ELL}, 4,576-byte proofs, "
                                    f"496 tracker points each), replicas round-robin over {world} rank(s), "
                                    f"{threads} host threads per rank, 8 distinct shuffles, all honest in the timed steps",
-                       "parallelism": "single GPU" if world == 1 else f"replicas x{world}, all_gather of accept bits",
+                       "parallelism": "single GPU" if dist is None else f"replicas x{world}, all_gather of accept bits over {dist.get_backend()}",
                        "step_with_planted_rejects": {"rejects": int(k - expect_rejects.sum()), "ms": round(rejects_ms, 2)}},
             "accept_bits_exact": exact}
 
@@ -559,6 +577,8 @@ def sweep(cm, torch, dev, args):
     peak_mads = 1024 * 64 * 2.4e9 / 4.9
     rows, all_ok = [], True
     sizes = [8, 32, 64, 128, 256, 512] + [1 << e for e in range(10, 21)]   # the protocol's small MSMs, then north_star's sweep
+    if args.sweep_sizes:
+        sizes = [int(x) for x in args.sweep_sizes.split(",")]
     for n in sizes:
         logn = int(np.log2(n))
         pp, sp = d_all.data_ptr(), d_sc_all.data_ptr()
@@ -629,6 +649,88 @@ def sweep(cm, torch, dev, args):
                       "gpu_beats_cpu_from_host_slices_from_n": cross, "all_results_match_cpu": all_ok, "sweep": rows}), flush=True)
     if not all_ok:
         raise SystemExit("bench.py --sweep: a GPU result differs from the CPU port's")
+
+
+def sweep_distributed(cm, torch, dist, dev, rank, world, args):
+    """The size sweep on N ranks (north_star: "at 1/2/4/8 GPUs"): every size through
+    curdlemsm.distributed.msm_g1_distributed(split="auto") on ALL ranks -- window ranges up to 2^21
+    pairs, point ranges beyond -- the wall time of one synchronous distributed call (barrier, call,
+    MAX over the ranks; median of 9), and on rank 0 the CPU port on the same inputs with the result
+    compared bit for bit.  Rank 0 prints one JSON object with n_gpus = world."""
+    from curdlemsm.distributed import choose_split, msm_g1_distributed
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+    import coracle as co
+    cores = host_cores()
+    native = False
+    if rank == 0:
+        try:
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "native"], check=True, capture_output=True, timeout=120)
+            native = True
+        except Exception:
+            native = False
+    on_gpu = dist.get_backend() == "nccl"
+    r1 = cm.Rand(1)
+    k = limbs_to_int(r1.get_fr()) * R_INV % R_MOD
+    q = limbs_to_int(r1.get_fr()) * R_INV % R_MOD
+    sizes = [1 << e for e in range(10, 21)]
+    if args.sweep_sizes:
+        sizes = [int(x) for x in args.sweep_sizes.split(",")]
+    nmax = max(sizes)
+    d_all = torch.empty((nmax, 12), dtype=torch.int64, device=dev)
+    cm.synth_points_walk_device(k, q, nmax, d_all.data_ptr())
+    sc_all = uniform_scalars(np.random.default_rng(2), nmax)     # the same seed on every rank: replicated inputs
+    d_sc_all = torch.from_numpy(sc_all.view(np.int64)).to(dev)
+    pts_all = d_all.cpu().numpy().view(np.uint64) if rank == 0 else None
+    torch.cuda.synchronize()
+    rows, all_ok = [], True
+    for n in sizes:
+        pp, sp = d_all.data_ptr(), d_sc_all.data_ptr()
+        call = lambda: msm_g1_distributed(pp, sp, n, device=dev if on_gpu else None, split="auto")
+        for _ in range(3):
+            res = call()
+        lat = []
+        for _ in range(9):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = call()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            lat.append(float(t.item()) * 1e3)
+        wall = float(np.median(lat))
+        row = {"n_pairs": n, "logn": int(np.log2(n)), "split": choose_split(n, world), "window_bits": cm.window_bits(n),
+               "num_windows": cm.num_windows(n, 0), "wall_ms": round(wall, 4), "pairs_per_s": round(n / wall * 1e3, 1),
+               "hbm_frac_whole_call": round(BYTES_PER_PAIR * n / (wall * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 6)}
+        if rank == 0:
+            threads = min(cores, 256)
+            best, best_threads = None, threads
+            for th in ([threads] if n >= 4096 else [1, threads]):
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    ref = co.msm_fast(pts_all[:n], sc_all[:n], threads=th, native=native)
+                    dt = time.perf_counter() - t1
+                    if best is None or dt < best:
+                        best, best_threads = dt, th
+            same = bool((res == ref).all())
+            all_ok = all_ok and same
+            row.update({"cpu_port_ms": round(best * 1e3, 4), "cpu_port_pairs_per_s": round(n / best, 1), "cpu_cores": best_threads,
+                        "gpu_over_cpu": round(best * 1e3 / wall, 2), "gpu_matches_cpu": same})
+            print(json.dumps(row), file=sys.stderr, flush=True)
+        rows.append(row)
+    flag = torch.tensor([0.0 if all_ok else 1.0], dtype=torch.float64, device=dev if on_gpu else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    all_ok = float(flag.item()) == 0.0
+    if rank == 0:
+        print(json.dumps({"metric": "BLS12-381 G1 MSM size sweep N=2^10..2^20 (north_star), distributed", "n_gpus": world, "unit": "pairs/s",
+                          "dtype": "u32", "data": "synthetic", "hbm_peak_GBs": HBM_PEAK_GBS, "bytes_per_pair": BYTES_PER_PAIR,
+                          "backend": dist.get_backend(),
+                          "what": "one synchronous msm_g1_distributed(split='auto') per size on every rank: window ranges "
+                                  "(all_gather of 144 B partials) up to 2^21 pairs, point ranges beyond; barrier, call, MAX over ranks",
+                          "cpu_baseline": {"kind": "port", "cores": min(cores, 256),
+                                           "what": f"oracle/cpu_msm_fast.c ({'-march=native' if native else 'portable'}), best of 3 per size, rank 0"},
+                          "all_results_match_cpu": all_ok, "sweep": rows}), flush=True)
+    if not all_ok:
+        raise SystemExit("bench.py --sweep: a distributed GPU result differs from the CPU port's")
 
 
 def cpu_baseline(cm, k, q, n, sc, gpu_result, d_pts):

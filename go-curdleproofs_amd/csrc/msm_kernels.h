@@ -121,6 +121,24 @@ hipError_t launch_combine(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t 
 hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32_t n, void* d_out, hipStream_t stream);
 
 // Element-wise primitive test (curdle_selftest_op); all pointers are device memory.
+// ONE table says what an operation reads and writes per element and how many lanes it takes: the host
+// wrapper sizes its buffers from it, the launcher its grid, the kernel its indexing, and the Python
+// binding asks for it (curdle_selftest_shape) -- an operation missing from any of the four used to
+// fall through to another operation's widths (the r3a abort).
+struct SelftestOp {
+  uint32_t in_words;   // 32-bit words read per element
+  uint32_t out_words;  // ... written per element
+  uint32_t lanes;      // lanes per element: 4 for the lane-distributed (quad) operations
+};
+static constexpr int kSelftestOps = 12;
+static constexpr SelftestOp kSelftestTable[kSelftestOps] = {
+    {24, 12, 1}, {24, 12, 1}, {24, 12, 1}, {24, 12, 1},  // 0..3  Fp mul / add / sub / sqr
+    {16, 8, 1},                                           // 4     Fr Montgomery -> canonical
+    {96, 48, 1}, {96, 48, 1}, {96, 48, 1},                // 5..7  XYZZ madd / add / dbl, one lane
+    {96, 48, 4}, {96, 48, 4}, {96, 48, 4},                // 8..10 add / dbl / small multiple on quads
+    {8, 10, 1},                                           // 11    the GLV split
+};
+// hipErrorInvalidValue for an op outside the table (nothing is launched).
 hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream);
 
 // decode_kernels.hip: n compressed G1 points (48 B each) -> n gnark affine points (24 u32

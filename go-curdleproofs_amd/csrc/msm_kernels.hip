@@ -1466,13 +1466,17 @@ hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32
 // ---------------------------------------------------------------------------
 // All operands and results cross this kernel in gnark form; the operation itself
 // runs in the internal radix-2^28 form the MSM kernels use.
-__global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __restrict__ in, size_t n, u32* __restrict__ out) {
+// The widths come from kSelftestTable (msm_kernels.h) as arguments; a branch whose own layout does
+// not match them returns without touching memory, and so does an unknown op.
+__global__ void __launch_bounds__(kBlock, 2)
+    k_selftest(int op, const u32* __restrict__ in, size_t n, u32* __restrict__ out, u32 in_w, u32 out_w) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (op >= 8 && op <= 10) {  // lane-distributed point operations (quad28.h): four lanes per element
+    if (in_w != 96 || out_w != 48) return;
     i >>= 2;
     if (i >= n) return;  // whole quads leave together
     G1XYZZ ga, gb;
-    const u32* src = in + i * 96;
+    const u32* src = in + i * in_w;
     u32* a32 = reinterpret_cast<u32*>(&ga);
     u32* b32 = reinterpret_cast<u32*>(&gb);
     for (int k = 0; k < 48; k++) {
@@ -1493,26 +1497,26 @@ __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __res
     G1XYZZ o;
     d28::to_gnark(o, pa);
     const u32* o32 = reinterpret_cast<const u32*>(&o);
-    for (int k = 0; k < 48; k++) out[i * 48 + k] = o32[k];
+    for (int k = 0; k < 48; k++) out[i * out_w + k] = o32[k];
     return;
   }
   if (i >= n) return;
   if (op == 11) {  // the GLV split exactly as k_digits runs it
+    if (in_w != 8 || out_w != 10) return;
     Fr k;
-    for (int j = 0; j < 8; j++) k.l[j] = in[i * 8 + j];
+    for (int j = 0; j < 8; j++) k.l[j] = in[i * in_w + j];
     u32 a[4], b[4], sa, sb;
     glv_split(k, a, b, sa, sb);
     for (int j = 0; j < 4; j++) {
-      out[i * 10 + j] = a[j];
-      out[i * 10 + 4 + j] = b[j];
+      out[i * out_w + j] = a[j];
+      out[i * out_w + 4 + j] = b[j];
     }
-    out[i * 10 + 8] = sa;
-    out[i * 10 + 9] = sb;
-    return;
-  }
-  if (op <= 3) {
+    out[i * out_w + 8] = sa;
+    out[i * out_w + 9] = sb;
+  } else if (op >= 0 && op <= 3) {
+    if (in_w != 24 || out_w != 12) return;
     u32 w[24];
-    for (int k = 0; k < 24; k++) w[k] = in[i * 24 + k];
+    for (int k = 0; k < 24; k++) w[k] = in[i * in_w + k];
     F28 a, b, r;
     d28::from_gnark(a, w);
     d28::from_gnark(b, w + 12);
@@ -1522,15 +1526,17 @@ __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __res
     else d28::sqr(r, a);
     u32 o[12];
     d28::to_gnark(o, r);
-    for (int k = 0; k < 12; k++) out[i * 12 + k] = o[k];
+    for (int k = 0; k < 12; k++) out[i * out_w + k] = o[k];
   } else if (op == 4) {
+    if (in_w != 16 || out_w != 8) return;
     Fr a, r;
-    for (int k = 0; k < 8; k++) a.l[k] = in[i * 16 + k];
+    for (int k = 0; k < 8; k++) a.l[k] = in[i * in_w + k];
     f_from_mont<FrParams>(r, a);
-    for (int k = 0; k < 8; k++) out[i * 8 + k] = r.l[k];
-  } else {
+    for (int k = 0; k < 8; k++) out[i * out_w + k] = r.l[k];
+  } else if (op >= 5 && op <= 7) {
+    if (in_w != 96 || out_w != 48) return;
     G1XYZZ ga, gb;
-    const u32* src = in + i * 96;
+    const u32* src = in + i * in_w;
     u32* a32 = reinterpret_cast<u32*>(&ga);
     u32* b32 = reinterpret_cast<u32*>(&gb);
     for (int k = 0; k < 48; k++) {
@@ -1551,13 +1557,17 @@ __global__ void __launch_bounds__(kBlock, 2) k_selftest(int op, const u32* __res
     G1XYZZ o;
     d28::to_gnark(o, acc);
     const u32* o32 = reinterpret_cast<const u32*>(&o);
-    for (int k = 0; k < 48; k++) out[i * 48 + k] = o32[k];
+    for (int k = 0; k < 48; k++) out[i * out_w + k] = o32[k];
   }
 }
 
 hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream) {
-  const size_t lanes = op >= 8 && op <= 10 ? 4 * n : n;
-  hipLaunchKernelGGL(k_selftest, dim3(cdiv(lanes, kBlock)), dim3(kBlock), 0, stream, op, d_in, n, d_out);
+  if (op < 0 || op >= kSelftestOps || !d_in || !d_out) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  const SelftestOp& t = kSelftestTable[op];
+  const size_t lanes = (size_t)t.lanes * n;
+  hipLaunchKernelGGL(k_selftest, dim3(cdiv(lanes, kBlock)), dim3(kBlock), 0, stream, op, d_in, n, d_out, t.in_words,
+                     t.out_words);
   return hipGetLastError();
 }
 

@@ -51,7 +51,7 @@ SYMBOLS = [
     "curdle_acc_new", "curdle_acc_free", "curdle_acc_accumulate_check", "curdle_acc_accumulate_check_deferred",
     "curdle_acc_verify",
     "curdle_acc_get_A_c", "curdle_acc_num_bases", "curdle_acc_export",
-    "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op", "curdle_msm_free_slots",
+    "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op", "curdle_selftest_shape", "curdle_msm_free_slots",
     "curdle_synth_points_walk_device",
     "curdle_crs_generate", "curdle_crs_free", "curdle_crs_size", "curdle_shuffle_permute_commit",
     "curdle_prove", "curdle_verify", "curdle_proof_from_bytes", "curdle_proof_free", "curdle_verify_proof",
@@ -125,6 +125,7 @@ _profile_enable = _sig("curdle_profile_enable", C.c_int, C.c_int)
 _profile_last = _sig("curdle_profile_last", C.c_int, C.POINTER(_Profile))
 _synth_walk = _sig("curdle_synth_points_walk_device", C.c_int, _vp, _vp, C.c_size_t, _vp)
 _selftest_op = _sig("curdle_selftest_op", C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_int)
+_selftest_shape = _sig("curdle_selftest_shape", C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 
 
 _crs_generate = _sig("curdle_crs_generate", _vp, C.c_size_t, _vp)
@@ -434,13 +435,16 @@ def profile_last() -> dict:
     }
 
 
-_SELFTEST_W = {0: (24, 12), 1: (24, 12), 2: (24, 12), 3: (24, 12), 4: (16, 8), 5: (96, 48), 6: (96, 48), 7: (96, 48),
-               8: (96, 48), 9: (96, 48), 10: (96, 48), 11: (8, 10)}
+def selftest_shape(op: int):
+    """(words read, words written) per item of selftest operation `op`: the library's own table."""
+    iw, ow = C.c_uint32(0), C.c_uint32(0)
+    _check(_selftest_shape(op, C.byref(iw), C.byref(ow)))
+    return iw.value, ow.value
 
 
 def selftest_op(op: int, inp: np.ndarray, on_device: bool) -> np.ndarray:
     """inp: uint32[n, in_width] -> uint32[n, out_width] (see curdle_selftest_op)."""
-    iw, ow = _SELFTEST_W[op]
+    iw, ow = selftest_shape(op)
     inp = np.ascontiguousarray(inp, dtype=np.uint32)
     assert inp.ndim == 2 and inp.shape[1] == iw, inp.shape
     out = np.zeros((inp.shape[0], ow), dtype=np.uint32)

@@ -504,6 +504,10 @@ int curdle_synth_points_walk_device(const uint64_t k[4], const uint64_t q[4], si
  * (limbs are passed as uint32 little-endian; 24/16/96/8 in and 12/8/48/10 out per item)
  * on_device = 0 runs the same header code on the host CPU. */
 int curdle_selftest_op(int op, const uint64_t* in, size_t n, uint64_t* out, int on_device);
+/* Words per item operation `op` reads and writes: the ONE table the entry point above, its launcher
+ * and its kernel index (a binding sizes its arrays from this instead of keeping a copy).
+ * CURDLE_EINVAL for an op the library does not have. */
+int curdle_selftest_shape(int op, uint32_t* in_words, uint32_t* out_words);
 
 #ifdef __cplusplus
 }

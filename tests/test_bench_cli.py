@@ -26,3 +26,51 @@ def test_bench_refuses_to_run_without_a_device(cm):
     for line in p.stdout.splitlines():            # and no line that could be read as a measurement
         if line.startswith("{"):
             assert json.loads(line).get("value") is None
+
+
+# ------------------------------------------------------------------------------------------------
+# On the GPU box: everything a multi-GPU run would execute for the first time -- RCCL
+# initialisation with device_id, the pinned PartialExchange, the lagged all_gather of the
+# partials, the accept-bit all_gather of the config-5 leg, the distributed sweep, the CPU baseline
+# on an N > 1 line -- executed ONCE on the one GPU there is: bench.py in a FRESH child process
+# (the launcher env is set before anything touches the GPU) with the nccl backend forced at world
+# size 1 ("the nccl backend has never run, not even at world size 1").
+# ------------------------------------------------------------------------------------------------
+import pytest
+
+
+def _run_forced_dist(extra, timeout=600):
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               CURDLE_DIST_BACKEND="nccl")
+    env.pop("MASTER_PORT", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist"] + extra, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1500:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_the_nccl_path_of_the_bench_runs_at_world_size_one(gpu):
+    line = _run_forced_dist(["--steps", "6", "--warmup", "2", "--logn", "16", "--no-verify"])
+    assert line["n_gpus"] == 1 and line["value"] and line["value"] > 0
+    assert "over nccl" in line["config"]["parallelism"]            # the partials went through RCCL's all_gather
+    assert "exchange" in line["config"]["host_ms_per_step"]
+    cb = line["cpu_baseline"]                                       # attached on the distributed path too
+    assert cb["gpu_matches_cpu"] and cb["gpu_full_size_verified"]
+
+
+@pytest.mark.gpu
+def test_the_accept_bit_exchange_of_config_5_runs_over_nccl(gpu):
+    line = _run_forced_dist(["--mode", "whisk-batch", "--proofs", "96", "--steps", "1", "--warmup", "1"])
+    assert line["accept_bits_exact"] is True and line["value"] and line["value"] > 0
+    assert "over nccl" in line["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_the_distributed_sweep_runs_on_every_rank(gpu):
+    line = _run_forced_dist(["--sweep", "--sweep-sizes", "1024,32768"])
+    assert line["n_gpus"] == 1 and line["backend"] == "nccl" and line["all_results_match_cpu"] is True
+    assert [r["n_pairs"] for r in line["sweep"]] == [1024, 32768]
+    assert all(r["gpu_matches_cpu"] and r["wall_ms"] > 0 for r in line["sweep"])

@@ -3,19 +3,28 @@
 run with devices = {0, 0}: two contexts -- each with its own streams, workspace slots, decode
 contexts, resident copies of the CRS and host thread -- on the one GPU.  Everything below goes
 through the same entry points a Go host would bind (go/curdlemsm/curdlemsm.go)."""
+import os
+import subprocess
+import sys
 import threading
 
 import numpy as np
 import pytest
 
+from conftest import ROOT
 from test_msm_gpu import _walk_expected, rand_scalars
 
 pytestmark = pytest.mark.gpu
 
+# The HIP devices of the two contexts.  {0, 0} on a one-GPU box; "0,1" under the logical-device shim
+# (tools/logical_devices_shim.cpp: one GPU posing as two, every cross-device use of a stream, event
+# or allocation an error) and on a box that really has two.
+DEVS = [int(x) for x in os.environ.get("CURDLE_TEST_DEVICES", "0,0").split(",")]
+
 
 @pytest.fixture(scope="module")
 def two(gpu):
-    gpu.init_devices([0, 0])
+    gpu.init_devices(DEVS)
     assert gpu.device_count() == 2
     yield gpu
     gpu.set_device(0)
@@ -50,7 +59,7 @@ def test_contexts_and_tickets(two, oracle, coracle):
         cm.set_device(2)
     with pytest.raises(cm.CurdleError):
         cm.init_devices([0])                                   # a standing configuration is not silently replaced
-    cm.init_devices([0, 0])                                    # the same list again is fine
+    cm.init_devices(DEVS)                                      # the same list again is fine
     assert cm.get_device() == 0
     assert on_device(cm, 1, cm.get_device) == 1 and cm.get_device() == 0     # the selection is per thread
     k, q = oracle.Rand(3).get_frs(2)
@@ -60,16 +69,17 @@ def test_contexts_and_tickets(two, oracle, coracle):
     exp = coracle.msm_pippenger(pts, sc, threads=4)
     assert (on_device(cm, 1, lambda: cm.msm_g1(pts, sc)) == exp).all()
     # a ticket names its context: submitted on context 1, waited for from a thread on context 0
-    d_p = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
-    d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
-    t1 = on_device(cm, 1, lambda: cm.msm_g1_device_submit(d_p.data_ptr(), d_s.data_ptr(), n))
-    t0 = cm.msm_g1_device_submit(d_p.data_ptr(), d_s.data_ptr(), n)
+    # every context reads inputs resident on ITS device
+    d_p = [torch.from_numpy(pts.view(np.int64)).to(f"cuda:{DEVS[d]}") for d in (0, 1)]
+    d_s = [torch.from_numpy(sc.view(np.int64)).to(f"cuda:{DEVS[d]}") for d in (0, 1)]
+    t1 = on_device(cm, 1, lambda: cm.msm_g1_device_submit(d_p[1].data_ptr(), d_s[1].data_ptr(), n))
+    t0 = cm.msm_g1_device_submit(d_p[0].data_ptr(), d_s[0].data_ptr(), n)
     assert (t1 >> 3) & 0x1F == 1 and (t0 >> 3) & 0x1F == 0
     assert (cm.msm_wait(t1) == exp).all() and (cm.msm_wait(t0) == exp).all()
     with pytest.raises(cm.CurdleError):
         cm.msm_wait(t1)                                        # already waited for
     # every slot of BOTH contexts can be in flight at once
-    tickets = [on_device(cm, d, lambda: [cm.msm_g1_device_submit(d_p.data_ptr(), d_s.data_ptr(), n) for _ in range(cm.MSM_SLOTS)])
+    tickets = [on_device(cm, d, lambda d=d: [cm.msm_g1_device_submit(d_p[d].data_ptr(), d_s[d].data_ptr(), n) for _ in range(cm.MSM_SLOTS)])
                for d in (0, 1)]
     for ts in tickets:
         for t in ts:
@@ -92,7 +102,12 @@ def test_one_msm_over_both_contexts(two, oracle, coracle):
         exp = _walk_expected(oracle, coracle, k, q, sc)
         assert (cm.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == exp).all()
         assert (cm.msm_g1(d_pts.cpu().numpy().view(np.uint64), sc) == exp).all(), n
-        ptrs, sptrs = [d_pts.data_ptr()] * 2, [d_sc.data_ptr()] * 2
+        # the replicated inputs: context 1's copy lives on its own device
+        # (through the host: a peer copy queues device 1's memory on a stream of device 0, which the
+        # logical-device shim counts as a mix-up -- the library itself never does that)
+        d_pts1 = d_pts.cpu().to(f"cuda:{DEVS[1]}") if DEVS[1] != DEVS[0] else d_pts
+        d_sc1 = torch.from_numpy(sc.view(np.int64)).to(f"cuda:{DEVS[1]}") if DEVS[1] != DEVS[0] else d_sc
+        ptrs, sptrs = [d_pts.data_ptr(), d_pts1.data_ptr()], [d_sc.data_ptr(), d_sc1.data_ptr()]
         for split in (cm.SPLIT_AUTO, cm.SPLIT_WINDOWS, cm.SPLIT_POINTS):
             assert (cm.msm_g1_replicated(ptrs, sptrs, n, split) == exp).all(), (n, split)
     with pytest.raises(cm.CurdleError):
@@ -149,3 +164,28 @@ def test_whisk_batch_over_both_contexts(two, oracle):
     expect[40] = False
     assert cm.whisk_is_valid_shuffle_proof_batch(crs, pres, posts, proofs, cm.Rand(1), nthreads=8) == expect
     assert on_device(cm, 1, lambda: cm.whisk_is_valid_shuffle_proof(crs, sets[0][0], sets[0][1], sets[0][2], cm.Rand(2))) is True
+
+
+def test_the_suite_above_with_two_logical_devices(gpu, tmp_path):
+    """devices = {0, 0} cannot see a missing hipSetDevice: both contexts' streams, events and
+    allocations live on the one device whatever thread made them.  So the tests above run once
+    more, in a child process, under tools/logical_devices_shim.cpp: the one GPU reports TWO devices,
+    every stream / event / allocation is tagged with the logical device current at its creation,
+    and a launch, event record or copy that mixes logical devices -- or a big-LDS launch whose
+    opt-in was made on the other device -- fails the call.  The child must pass with no violation
+    and with launches checked on BOTH logical devices ("what is missing" 5)."""
+    if os.environ.get("CURDLE_TEST_DEVICES"):
+        pytest.skip("already the child run")
+    shim = str(tmp_path / "logical_devices_shim.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-Wno-deprecated-declarations", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tools", "logical_devices_shim.cpp"), "-o", shim, "-ldl"])
+    env = dict(os.environ, LD_PRELOAD=shim, CURDLE_TEST_DEVICES="0,1", CURDLE_LOGICAL_DEVICES="2")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_multi_device.py"), "-x", "-q",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    tail = p.stdout[-2500:] + p.stderr[-2500:]
+    assert p.returncode == 0, tail
+    assert "VIOLATION" not in p.stderr, tail
+    import re
+    m = re.search(r"launches checked per device: (\d+) (\d+); .*violations: (\d+)", p.stderr)
+    assert m, tail
+    assert int(m.group(1)) > 100 and int(m.group(2)) > 100 and int(m.group(3)) == 0, m.group(0)
