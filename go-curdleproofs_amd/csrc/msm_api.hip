@@ -100,7 +100,7 @@ struct Slot {
   hipEvent_t ev[CURDLE_PROF_MAX_KERNELS + 1];
   bool ev_made = false;
   // the call in flight
-  bool dbg_sorted = false, dbg_sorted2 = false;
+  struct curdle_dbases* held_bases = nullptr;  // a pipelined MSM over a resident base set keeps its reference until the wait
   bool busy = false;
   bool claimed = false;   // a curdle_msm_wait is finishing this call (a second wait on the ticket is refused)
   uint32_t gen = 0;       // bumped at every acquire: tickets carry it, stale ones are refused
@@ -520,15 +520,11 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
     const bool shapes = k == 1 && min_nbkt >= 4096 && (min_nbkt & 127u) == 0 && p.max_nbkt <= 32768 && p.n <= (1u << 24);
     p.two_level = shapes && forced != 1 && (forced == 2 || p.n >= (1u << 17)) ? 1u : 0u;
   }
-  // One single-block scan launch instead of six: up to 8,192 slots it is also the faster one; up to
-  // 65,536 slots (a two-window partial of the multi-GPU split) it is slower in isolation (0.14 ms:
-  // 64 consecutive slots per thread) but a pipelined caller only pays for launches, not latency.
-  {
-    const uint64_t slots = (uint64_t)k * p.NB;
-    uint64_t pipelined_max = 65536;
-    if (const char* env = getenv("CURDLE_FUSE_SCAN_MAX")) pipelined_max = (uint64_t)atoll(env);
-    p.fuse_scan = slots <= 8192 || (!latency_mode && slots <= pipelined_max) ? 1u : 0u;
-  }
+  // One single-block scan launch instead of six up to 8,192 bucket slots, where it is also the faster
+  // one; beyond that the multi-block form (0.03 ms against 0.14 / 0.26 ms for the 32,768 / 65,536 slots of
+  // an 8-way / 4-way rank of the window split; a pipelined rank step measured the same either way,
+  // profiles/r04_pipeline_phase_costs.txt, so the kernel that is 5-9x faster alone is taken).
+  p.fuse_scan = (uint64_t)k * p.NB <= 8192 ? 1u : 0u;
   return CURDLE_OK;
 }
 
@@ -630,7 +626,10 @@ struct ChunkJoin {
 int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                  int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail,
                  bool latency_mode = true, bool points28_ready = false, size_t sets = 1, bool many = false,
-                 const ChunkJoin* join = nullptr) {
+                 const ChunkJoin* join = nullptr, const void* ext_points28 = nullptr) {
+  // ext_points28: the bases are a resident, pre-converted set (curdle_dbases: two records per base in the internal
+  // form, the first h_off[k] of them) -- d_points is not read, nothing is converted or copied
+  if (ext_points28 && (k != 1 || sets != 1)) return fail(CURDLE_EINVAL, "resident bases take one MSM per call");
   // sets > 1 (curdle_msm_g1_multi): d_points holds `sets` base sets of h_off[k] points each, all
   // multiplied by the SAME scalars: recoded and sorted once, accumulated per set
   const size_t n_pairs = h_off[k];
@@ -667,7 +666,7 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
     if ((rc = ensure(S.ccur, ((size_t)nw * 256 * 2 + 1) * 4))) return rc;  // the bins' cursors, and their packed starts + sentinel
   }
   p.frag_stride = (uint32_t)(nb + nlanes + 1);
-  if ((rc = ensure(S.points28, sets * n * kA28Bytes))) return rc;
+  if (!ext_points28 && (rc = ensure(S.points28, sets * n * kA28Bytes))) return rc;
   if ((rc = ensure(S.frags, sets * (size_t)p.frag_stride * kX28Bytes))) return rc;
   // what leaves the GPU per window: one sum, or the reduce_bits form's nout bit-positioned points
   const size_t wpts = p.reduce_bits ? p.nout : 1;
@@ -699,7 +698,7 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   ws.sorted = (uint32_t*)S.sorted.p;
   ws.tmp = p.two_level ? (uint32_t*)S.tmp.p : nullptr;
   ws.ccur = p.two_level ? (uint32_t*)S.ccur.p : nullptr;
-  ws.points28 = S.points28.p;
+  ws.points28 = ext_points28 ? const_cast<void*>(ext_points28) : S.points28.p;
   ws.frags = S.frags.p;
   ws.partials = S.partials.p;
   ws.winsums28 = S.winsums28.p;
@@ -725,18 +724,10 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   // second stream beside the sort, which never reads a point: 3.53 -> 3.67 ms at 2^20, nothing
   // at 2^17..2^19 -- conversion and sort are both HBM-bound, so side by side they take as long
   // as one after the other, plus two event hops.
-  // EXPERIMENT (not shipped): which phases cost a pipelined caller its step
-  static const int dbg_skip = [] { const char* e = getenv("CURDLE_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
-  static thread_local int dbg_dummy = 0;
-  const bool skip_sort = (dbg_skip & 1) && S.dbg_sorted;
-  S.dbg_sorted = true;
-  (void)dbg_dummy;
-  if (!skip_sort) {
-  if (!points28_ready && !((dbg_skip & 4) && S.dbg_sorted2)) {  // the device accumulator fills S.points28 itself (resident bases: no conversion here)
+  if (!points28_ready && !ext_points28) {  // the device accumulator fills S.points28 itself; a resident base set is converted already
     HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre));
     prof.mark("convert_points");
   }
-  S.dbg_sorted2 = true;
   HIP_TRY(launch_digits(p, ws, d_scalars, pre));
   prof.mark("digits");
   HIP_TRY(launch_hist(p, ws, pre));
@@ -745,7 +736,6 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   prof.mark("scan");
   HIP_TRY(launch_scatter(p, ws, pre));
   prof.mark("scatter");
-  }
   if (stream != pre) {
     HIP_TRY(hipEventRecord(S.pre_done, pre));
     HIP_TRY(hipStreamWaitEvent(stream, S.pre_done, 0));
@@ -761,7 +751,7 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
     stream = tail;
     prof.st = tail;
   }
-  if (!(dbg_skip & 32)) HIP_TRY(launch_merge_large(p, ws, stream));
+  HIP_TRY(launch_merge_large(p, ws, stream));
   prof.mark("merge_large");
   if (join && join->accumulate_only) {
     HIP_TRY(hipEventRecord(S.acc_done, stream));  // the fragments are complete (the last chunk waits for this)
@@ -783,11 +773,10 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
       HIP_TRY(hipStreamWaitEvent(stream, E->acc_done, 0));
     }
   }
-  if (dbg_skip & 2) {
-  } else if (p.reduce_bits) {
-    if (!(dbg_skip & 8)) HIP_TRY(launch_reduce_segments(p, ws, stream, extra.n ? &extra : nullptr));
+  if (p.reduce_bits) {
+    HIP_TRY(launch_reduce_segments(p, ws, stream, extra.n ? &extra : nullptr));
     prof.mark("bucket_reduce");
-    if (!(dbg_skip & 16)) HIP_TRY(launch_reduce_groups(p, ws, stream));
+    HIP_TRY(launch_reduce_groups(p, ws, stream));
     prof.mark("window_sum");
   } else {
     HIP_TRY(launch_bucket_reduce(p, ws, stream, extra.n ? &extra : nullptr));
@@ -918,7 +907,8 @@ constexpr size_t kMaxSlotsPerPass = (size_t)1024 * 4096;
 
 // enqueue + finish of k MSMs on slot S, in passes if the batch is too large for one.
 int run_passes(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
-               int win_begin, int win_end, hipStream_t pre, hipStream_t main, hipStream_t tail, uint64_t* out) {
+               int win_begin, int win_end, hipStream_t pre, hipStream_t main, hipStream_t tail, uint64_t* out,
+               const void* ext_points28 = nullptr) {
   if (k > 1) {
     size_t n_max = 0;
     for (size_t j = 0; j < k; j++) {
@@ -946,14 +936,15 @@ int run_passes(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, co
       return CURDLE_OK;
     }
   }
-  int rc = enqueue_slot(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, pre, main, tail);
+  int rc = enqueue_slot(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, pre, main, tail, true, false, 1, false,
+                        nullptr, ext_points28);
   if (!rc) rc = finish_slot(cx, S, out);
   return rc;
 }
 
 // Synchronous run of k MSMs with inputs on the device.
 int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c, int win_begin,
-               int win_end, uint64_t* out, void* user_stream) {
+               int win_end, uint64_t* out, void* user_stream, const void* ext_points28 = nullptr) {
   Ctx& cx = cur();
   int idx;
   int rc = acquire_slot(cx, true, &idx);
@@ -966,10 +957,10 @@ int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_of
   }
   if (user_stream) {
     rc = run_passes(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, (hipStream_t)user_stream,
-                    (hipStream_t)user_stream, (hipStream_t)user_stream, out);
+                    (hipStream_t)user_stream, (hipStream_t)user_stream, out, ext_points28);
   } else {
     const SyncStreams st = sync_streams(cx, S);
-    rc = run_passes(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, st.pre, st.main, st.tail, out);
+    rc = run_passes(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, st.pre, st.main, st.tail, out, ext_points28);
   }
   if (rc) drain_slot(cx, S);
   release_slot(cx, idx);
@@ -1776,6 +1767,8 @@ extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_s
   return CURDLE_OK;
 }
 
+void dbases_release_handle(struct curdle_dbases* b);  // defined with the resident base sets below
+
 extern "C" int curdle_msm_wait(int ticket, uint64_t out_jac[18]) {
   Ctx* cp = ticket_ctx(ticket);
   if (!cp || ticket_index(ticket) >= kSlots || !out_jac) return fail(CURDLE_EINVAL, "bad ticket or null output");
@@ -1796,7 +1789,10 @@ extern "C" int curdle_msm_wait(int ticket, uint64_t out_jac[18]) {
   }
   int rc = finish_slot(cx, cx.slots[idx], out_jac);
   if (rc) drain_slot(cx, cx.slots[idx]);
+  curdle_dbases* held = cx.slots[idx].held_bases;  // a resident base set the call read from
+  cx.slots[idx].held_bases = nullptr;
   release_slot(cx, idx);
+  if (held) dbases_release_handle(held);
   return rc;
 }
 
@@ -1909,6 +1905,7 @@ struct curdle_dbases {
   std::mutex mu;
   void* d28[kMaxDevices] = {};       // per context: n internal-form points (P and phi(P) each), kA28Bytes apart
   unsigned epoch[kMaxDevices] = {};  // the context generation each copy belongs to
+  int hipdev[kMaxDevices] = {};      // ... and the HIP device it was allocated on (a copy outlives its context: no device reset)
   int users = 0;                     // accumulations in flight that copy from this set
   bool dead = false;                 // curdle_dbases_free came while users > 0: the last user deletes
 };
@@ -1929,12 +1926,9 @@ namespace {
 void dbases_destroy(curdle_dbases* b) {  // nobody else holds b any more
   for (int i = 0; i < kMaxDevices; i++) {
     if (!b->d28[i]) continue;
-    Ctx& cx = g_ctxs[i];
-    std::lock_guard<std::mutex> g(cx.mu);
-    if (cx.inited && b->epoch[i] == cx.epoch) {  // after curdle_shutdown the context's memory is gone with it
-      (void)hipSetDevice(cx.device);
-      (void)hipFree(b->d28[i]);
-    }
+    // curdle_shutdown destroys a context's streams and workspaces, not the device: a copy made under a
+    // closed context is still an allocation of its device and is freed here (review of round 3: it leaked)
+    if (hipSetDevice(b->hipdev[i]) == hipSuccess) (void)hipFree(b->d28[i]);
   }
   delete b;
 }
@@ -1945,25 +1939,40 @@ int dbases_acquire(Ctx& cx, curdle_dbases* b, void** d28) {
   std::lock_guard<std::mutex> gb(b->mu);
   if (b->dead) return fail(CURDLE_EINVAL, "resident bases were freed");
   const int o = cx.ordinal;
-  std::lock_guard<std::mutex> g(cx.mu);
-  int rc = init_default_locked(cx);
-  if (rc) return rc;
-  if (b->d28[o] && b->epoch[o] != cx.epoch) b->d28[o] = nullptr;  // that memory went with the old context
+  unsigned epoch;
+  int device;
+  {  // the context's mutex only to bring it up and read what the copy is tied to: the upload and the
+     // conversion below run under the set's own mutex, on a stream of their own, so that they do not
+     // hold up every slot acquire / release of the context (review of round 3)
+    std::lock_guard<std::mutex> g(cx.mu);
+    int rc = init_default_locked(cx);
+    if (rc) return rc;
+    epoch = cx.epoch;
+    device = cx.device;
+  }
+  if (b->d28[o] && (b->epoch[o] != epoch || b->hipdev[o] != device)) {  // a copy made under a context that was closed since
+    if (hipSetDevice(b->hipdev[o]) == hipSuccess) (void)hipFree(b->d28[o]);
+    b->d28[o] = nullptr;
+  }
   if (!b->d28[o] && b->n) {
-    HIP_TRY(hipSetDevice(cx.device));
+    HIP_TRY(hipSetDevice(device));
     void *dst = nullptr, *tmp = nullptr;
-    hipError_t e = hipMalloc(&dst, 2 * b->n * kA28Bytes);  // P and phi(P) per base (launch_convert_points_raw)
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&dst, 2 * b->n * kA28Bytes);  // P and phi(P) per base (launch_convert_points_raw)
     if (e == hipSuccess) e = hipMalloc(&tmp, b->n * 96);
-    if (e == hipSuccess) e = hipMemcpyAsync(tmp, b->host.data(), b->n * 96, hipMemcpyHostToDevice, cx.util_stream);
-    if (e == hipSuccess) e = launch_convert_points_raw(tmp, (uint32_t)b->n, dst, cx.util_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(cx.util_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp, b->host.data(), b->n * 96, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_convert_points_raw(tmp, (uint32_t)b->n, dst, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (tmp) (void)hipFree(tmp);
+    if (st) (void)hipStreamDestroy(st);
     if (e != hipSuccess) {
       if (dst) (void)hipFree(dst);
       return fail(e == hipErrorOutOfMemory ? CURDLE_ENOMEM : CURDLE_EHIP, "resident bases: %s", hipGetErrorString(e));
     }
     b->d28[o] = dst;
-    b->epoch[o] = cx.epoch;
+    b->epoch[o] = epoch;
+    b->hipdev[o] = device;
   }
   b->users++;
   *d28 = b->d28[o];
@@ -2023,6 +2032,123 @@ extern "C" size_t curdle_dbases_size(const curdle_dbases* b) { return b ? b->n :
 // A handle keeps its points and re-creates its device copies as needed (another context, a
 // context re-initialised after curdle_shutdown): it stays usable until it is freed.
 extern "C" int curdle_dbases_valid(const curdle_dbases* b) { return b ? 1 : 0; }
+
+void dbases_release_handle(curdle_dbases* b) { dbases_release(b); }
+
+// ---------------------------------------------------------------------------
+// The plain MSM over a resident, pre-converted base set: msmaccumulator.Verify's bases are mostly
+// the CRS (/root/reference/crs.go:10-18; msmaccumulator.go:59), which never changes -- and
+// k_convert_points is 0.10 ms and 360 MB of every 2^20 call (0.16 ms of a pipelined step), which every
+// rank of a window split repeats for ALL points.  The set's internal-form records are read in place.
+// ---------------------------------------------------------------------------
+namespace {
+int dbases_msm_args(const curdle_dbases* bases, const void* scalars, size_t n, uint64_t* out_jac) {
+  if (!bases || !out_jac) return fail(CURDLE_EINVAL, "null argument");
+  if (n > bases->n) return fail(CURDLE_EINVAL, "n = %zu exceeds the %zu resident bases", n, bases->n);
+  if (n && !scalars) return fail(CURDLE_EINVAL, "scalars null with n = %zu", n);
+  return CURDLE_OK;
+}
+}  // namespace
+
+extern "C" int curdle_msm_g1_dbases_windows(const curdle_dbases* bases, const void* d_scalars, size_t n, int window_bits,
+                                            int win_begin, int win_end, uint64_t out_jac[18]) {
+  int rc = dbases_msm_args(bases, d_scalars, n, out_jac);
+  if (rc) return rc;
+  if (n == 0) {
+    set_out_infinity(out_jac);
+    return CURDLE_OK;
+  }
+  curdle_dbases* set = const_cast<curdle_dbases*>(bases);
+  void* d28 = nullptr;
+  if ((rc = dbases_acquire(cur(), set, &d28))) return rc;  // this context's copy, made on first use
+  const uint32_t off[2] = {0, (uint32_t)n};
+  rc = run_device(nullptr, d_scalars, off, 1, window_bits, win_begin, win_end, out_jac, nullptr, d28);
+  dbases_release(set);
+  return rc;
+}
+
+extern "C" int curdle_msm_g1_dbases(const curdle_dbases* bases, const void* d_scalars, size_t n, uint64_t out_jac[18]) {
+  return curdle_msm_g1_dbases_windows(bases, d_scalars, n, 0, 0, -1, out_jac);
+}
+
+// ... with the scalars in HOST memory (what msmaccumulator.Verify holds): 32 bytes per pair cross
+// PCIe instead of 128.
+extern "C" int curdle_msm_g1_dbases_host(const curdle_dbases* bases, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
+  int rc = dbases_msm_args(bases, scalars, n, out_jac);
+  if (rc) return rc;
+  if (n == 0) {
+    set_out_infinity(out_jac);
+    return CURDLE_OK;
+  }
+  Ctx& cx = cur();
+  curdle_dbases* set = const_cast<curdle_dbases*>(bases);
+  void* d28 = nullptr;
+  if ((rc = dbases_acquire(cx, set, &d28))) return rc;
+  int idx;
+  rc = acquire_slot(cx, true, &idx);
+  if (rc) {
+    dbases_release(set);
+    return rc;
+  }
+  Slot& S = cx.slots[idx];
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(cx.device));
+    int r;
+    if ((r = ensure(S.scalars, n * 32))) return r;
+    const SyncStreams st = sync_streams(cx, S);
+    HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st.pre));
+    const uint32_t off[2] = {0, (uint32_t)n};
+    return run_passes(cx, S, nullptr, S.scalars.p, off, 1, 0, 0, -1, st.pre, st.main, st.tail, out_jac, d28);
+  };
+  rc = body();
+  if (rc) drain_slot(cx, S);
+  release_slot(cx, idx);
+  dbases_release(set);
+  return rc;
+}
+
+// The pipelined form (curdle_msm_wait finishes it); the set stays referenced until then.
+extern "C" int curdle_msm_g1_dbases_submit(const curdle_dbases* bases, const void* d_scalars, size_t n, int window_bits,
+                                           int win_begin, int win_end, int* ticket) {
+  uint64_t dummy[18];
+  int rc = dbases_msm_args(bases, d_scalars, n, dummy);
+  if (rc) return rc;
+  if (!ticket) return fail(CURDLE_EINVAL, "ticket is null");
+  Ctx& cx = cur();
+  curdle_dbases* set = const_cast<curdle_dbases*>(bases);
+  void* d28 = nullptr;
+  if ((rc = dbases_acquire(cx, set, &d28))) return rc;
+  int idx;
+  rc = acquire_slot(cx, false, &idx);
+  if (rc) {
+    dbases_release(set);
+    return rc;
+  }
+  Slot& S = cx.slots[idx];
+  hipError_t he = hipSetDevice(cx.device);
+  if (he != hipSuccess) {
+    release_slot(cx, idx);
+    dbases_release(set);
+    return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
+  }
+  const uint32_t off[2] = {0, (uint32_t)n};
+  const unsigned seq = cx.submit_count.fetch_add(1, std::memory_order_relaxed);
+  const unsigned turn = seq % (unsigned)cx.main_streams;
+  hipStream_t main = turn == 0 ? cx.main_stream : cx.main_extra[turn - 1];
+  const bool partial = win_begin > 0 || (win_end >= 0 && win_end < curdle_msm_num_windows(n, window_bits));
+  hipStream_t pre = partial && cx.pre_streams == 2 && (seq & 1u) ? cx.pre_stream2 : cx.pre_stream;
+  rc = enqueue_slot(cx, S, nullptr, d_scalars, off, 1, window_bits, win_begin, win_end, pre, main, S.stream,
+                    /*latency_mode=*/false, false, 1, false, nullptr, d28);
+  if (rc) {
+    drain_slot(cx, S);
+    release_slot(cx, idx);
+    dbases_release(set);
+    return rc;
+  }
+  S.held_bases = set;
+  *ticket = make_ticket(cx, idx, S.gen);
+  return CURDLE_OK;
+}
 
 extern "C" int curdle_dacc_begin(const curdle_dbases* crs, const uint64_t* inst_points, size_t n_inst, curdle_dacc** out) {
   Ctx& cx = cur();

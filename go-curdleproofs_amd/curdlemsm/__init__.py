@@ -62,6 +62,7 @@ SYMBOLS = [
     "curdle_g1_scalar_mul_batch",
     "curdle_g1_compress", "curdle_g1_decompress", "curdle_set_last_error", "curdle_fr_inner_product",
     "curdle_dbases_create", "curdle_dbases_free", "curdle_dbases_size", "curdle_dbases_valid",
+    "curdle_msm_g1_dbases", "curdle_msm_g1_dbases_host", "curdle_msm_g1_dbases_windows", "curdle_msm_g1_dbases_submit",
     "curdle_dacc_begin", "curdle_dacc_run", "curdle_dacc_submit", "curdle_dacc_poll", "curdle_dacc_wait", "curdle_dacc_abort",
     "curdle_verify_set_device_acc", "curdle_verify_export_accumulator",
 ]
@@ -124,6 +125,11 @@ _acc_export = _sig("curdle_acc_export", C.c_int, _vp, _vp, _vp)
 _profile_enable = _sig("curdle_profile_enable", C.c_int, C.c_int)
 _profile_last = _sig("curdle_profile_last", C.c_int, C.POINTER(_Profile))
 _synth_walk = _sig("curdle_synth_points_walk_device", C.c_int, _vp, _vp, C.c_size_t, _vp)
+_dbases_create = _sig("curdle_dbases_create", C.c_int, _vp, C.c_size_t, C.POINTER(C.c_void_p))
+_dbases_free = _sig("curdle_dbases_free", None, _vp)
+_msm_dbases_windows = _sig("curdle_msm_g1_dbases_windows", C.c_int, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp)
+_msm_dbases_host = _sig("curdle_msm_g1_dbases_host", C.c_int, _vp, _vp, C.c_size_t, _vp)
+_msm_dbases_submit = _sig("curdle_msm_g1_dbases_submit", C.c_int, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
 _selftest_op = _sig("curdle_selftest_op", C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_int)
 _selftest_shape = _sig("curdle_selftest_shape", C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 
@@ -262,6 +268,45 @@ def msm_g1_device_submit(d_points: int, d_scalars: int, n: int, window_bits: int
     t = C.c_int(-1)
     _check(_msm_submit(d_points, d_scalars, n, window_bits, win_begin, win_end, C.byref(t)))
     return t.value
+
+
+class DBases:
+    """A resident, pre-converted base set (curdle_dbases): the plain MSM over it uploads and converts
+    nothing per call."""
+
+    def __init__(self, points):
+        pts = _as_u64(points, 12)
+        self.n = len(pts)
+        self._h = C.c_void_p()
+        _check(_dbases_create(_ptr(pts), self.n, C.byref(self._h)))
+
+    def free(self):
+        if self._h:
+            _dbases_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def msm(self, d_scalars: int, n: int = None, window_bits: int = 0, win_begin: int = 0, win_end: int = -1) -> np.ndarray:
+        """scalars in device memory; a window range gives the scaled partial."""
+        out = np.zeros(18, dtype=np.uint64)
+        _check(_msm_dbases_windows(self._h, d_scalars, self.n if n is None else n, window_bits, win_begin, win_end, _ptr(out)))
+        return out
+
+    def msm_host(self, scalars) -> np.ndarray:
+        sc = _as_u64(scalars, 4)
+        out = np.zeros(18, dtype=np.uint64)
+        _check(_msm_dbases_host(self._h, _ptr(sc), len(sc), _ptr(out)))
+        return out
+
+    def submit(self, d_scalars: int, n: int = None, window_bits: int = 0, win_begin: int = 0, win_end: int = -1) -> int:
+        t = C.c_int(-1)
+        _check(_msm_dbases_submit(self._h, d_scalars, self.n if n is None else n, window_bits, win_begin, win_end, C.byref(t)))
+        return t.value
 
 
 def msm_wait(ticket: int) -> np.ndarray:

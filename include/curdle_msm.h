@@ -344,9 +344,30 @@ typedef struct curdle_dbases curdle_dbases; /* a base set on the device, in the 
 int curdle_dbases_create(const uint64_t* points /* n x 12, gnark G1Affine */, size_t n, curdle_dbases** out);
 void curdle_dbases_free(curdle_dbases* b);
 size_t curdle_dbases_size(const curdle_dbases* b);
-/* 0 once curdle_shutdown has closed the context the set was made under (its device memory is
- * gone: free the handle and create it again). */
+/* 1 for a live handle: a set keeps its points and re-creates its device copy as needed (another
+ * context, a context re-initialised after curdle_shutdown), so it stays usable until it is freed. */
 int curdle_dbases_valid(const curdle_dbases* b);
+
+/* The plain MSM over a resident base set: out = sum_{i < n} scalars[i] * bases[i] over the FIRST n
+ * points of the set (n <= curdle_dbases_size).  Replaces (*G1Jac).MultiExp where the bases do not
+ * change between calls -- msmaccumulator.Verify's (/root/reference/msmaccumulator/msmaccumulator.go:59)
+ * are mostly the CRS (crs.go:10-18): SURVEY.md section 8(b)'s "explicit, caller-managed device
+ * handle".  Nothing is uploaded or converted per call (the conversion is 0.10 ms and 360 MB of every
+ * 2^20-pair call with gnark-layout inputs); the set's copy on the calling thread's context is made on
+ * first use.  Same preconditions as curdle_msm_g1 (bases in G1).
+ *   _dbases          scalars in DEVICE memory (n x 32 B Montgomery fr.Elements), synchronous
+ *   _dbases_host     scalars in host memory: 32 bytes per pair cross PCIe instead of 128
+ *   _dbases_windows  the partial over windows [win_begin, win_end) (win_end = -1: all), already
+ *                    scaled -- one device's share of a multi-GPU window split whose every device
+ *                    holds the set (curdle_msm_g1_device_windows' counterpart)
+ *   _dbases_submit   the asynchronous form; curdle_msm_wait(ticket) finishes it.  The set stays
+ *                    referenced until then (curdle_dbases_free in between is deferred). */
+int curdle_msm_g1_dbases(const curdle_dbases* bases, const void* d_scalars, size_t n, uint64_t out_jac[18]);
+int curdle_msm_g1_dbases_host(const curdle_dbases* bases, const uint64_t* scalars, size_t n, uint64_t out_jac[18]);
+int curdle_msm_g1_dbases_windows(const curdle_dbases* bases, const void* d_scalars, size_t n, int window_bits,
+                                 int win_begin, int win_end, uint64_t out_jac[18]);
+int curdle_msm_g1_dbases_submit(const curdle_dbases* bases, const void* d_scalars, size_t n, int window_bits,
+                                int win_begin, int win_end, int* ticket);
 
 #define CURDLE_VEC_EXPLICIT 0 /* x_i = tail[i]                                                        */
 #define CURDLE_VEC_CONST 1    /* x_i = scale                                                          */

@@ -517,6 +517,43 @@ def test_partials_of_the_headline_plan_sum_to_the_full_msm(gpu, oracle, coracle)
         assert (gpu.g1_sum(np.stack(parts)) == exp).all(), ("points", world)
 
 
+def test_msm_over_a_resident_base_set(gpu, oracle, coracle):
+    """curdle_msm_g1_dbases*: the plain MSM over a pre-converted, resident base set (SURVEY.md 8b's
+    caller-managed device handle; msmaccumulator.Verify's bases are mostly the CRS).  Against the C
+    oracle: the whole set and a prefix of it, scalars on the device and in host memory, infinity
+    bases in the set, window-range partials summing to the full result, the asynchronous form
+    (several in flight, the set freed while they are: deferred), and at 2^16 + 5 pairs."""
+    import torch
+    from curdlemsm.distributed import window_partition
+    k, q = oracle.Rand(31).get_frs(2)
+    for n in (1, 700, (1 << 16) + 5):
+        pts = coracle.points_walk(k, q, n)
+        if n > 10:
+            pts[3] = 0                                          # (0, 0) = infinity stays infinity in the set
+            pts[n - 1] = 0
+        sc = rand_scalars(np.random.default_rng(31 + n), n, oracle)
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        exp = coracle.msm_pippenger(pts, sc, threads=8)
+        bases = gpu.DBases(pts)
+        assert (bases.msm(d_sc.data_ptr()) == exp).all(), n
+        assert (bases.msm_host(sc) == exp).all(), n
+        m = n // 2
+        assert (bases.msm(d_sc.data_ptr(), n=m) == coracle.msm_pippenger(pts[:m], sc[:m], threads=8)).all(), (n, m)
+        assert (bases.msm_host(sc[:m]) == coracle.msm_pippenger(pts[:m], sc[:m], threads=8)).all(), (n, m)
+        with pytest.raises(gpu.CurdleError):
+            bases.msm(d_sc.data_ptr(), n=n + 1)                 # more pairs than resident bases
+        c = gpu.window_bits(n)
+        W = gpu.num_windows(n, c)
+        for world in (2, 8):
+            parts = [bases.msm(d_sc.data_ptr(), window_bits=c, win_begin=b, win_end=e)
+                     for b, e in (window_partition(W, world, r) for r in range(world))]
+            assert (gpu.g1_sum(np.stack(parts)) == exp).all(), (n, world)
+        tickets = [bases.submit(d_sc.data_ptr()) for _ in range(4)]
+        bases.free()                                            # deferred: four MSMs still read the set
+        for t in tickets:
+            assert (gpu.msm_wait(t) == exp).all(), n
+
+
 # ------------------------------------------------------------------ batch / multi ---
 def test_batch_and_multi_entry_points(gpu, oracle, coracle):
     k, q = oracle.Rand(9).get_frs(2)
