@@ -618,6 +618,9 @@ struct ChunkJoin {
   bool accumulate_only = false;       // an earlier chunk: no reduce, no window sums, no D2H
   std::vector<Slot*> earlier;         // the last chunk: the slots of the chunks before it
   uint32_t seg = 0;                   // buckets per reduce segment, the same for every chunk (0: the plan's rule)
+  // A chunk is enqueued in two steps: its sort needs only its scalars, which cross PCIe first; the
+  // conversion and everything behind it wait for its points.  0: all at once.
+  int phase = 0;                      // 1: recoding + sort only; 2: conversion, accumulation, tail (same slot, same plan)
 };
 
 // Enqueue every GPU phase of k MSMs on the slot's stream (no host synchronisation).
@@ -724,19 +727,34 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   // second stream beside the sort, which never reads a point: 3.53 -> 3.67 ms at 2^20, nothing
   // at 2^17..2^19 -- conversion and sort are both HBM-bound, so side by side they take as long
   // as one after the other, plus two event hops.
-  if (!points28_ready && !ext_points28) {  // the device accumulator fills S.points28 itself; a resident base set is converted already
+  const int phase = join ? join->phase : 0;
+  const bool convert_here = !points28_ready && !ext_points28;  // the device accumulator fills S.points28 itself; a resident base set is converted already
+  if (convert_here && phase == 0) {
     HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre));
     prof.mark("convert_points");
   }
-  HIP_TRY(launch_digits(p, ws, d_scalars, pre));
-  prof.mark("digits");
-  HIP_TRY(launch_hist(p, ws, pre));
-  prof.mark("hist");
-  HIP_TRY(launch_scan(p, ws, pre));
-  prof.mark("scan");
-  HIP_TRY(launch_scatter(p, ws, pre));
-  prof.mark("scatter");
-  if (stream != pre) {
+  if (phase != 2) {
+    HIP_TRY(launch_digits(p, ws, d_scalars, pre));
+    prof.mark("digits");
+    HIP_TRY(launch_hist(p, ws, pre));
+    prof.mark("hist");
+    HIP_TRY(launch_scan(p, ws, pre));
+    prof.mark("scan");
+    HIP_TRY(launch_scatter(p, ws, pre));
+    prof.mark("scatter");
+    if (phase == 1) {  // the sorted list waits in the slot; the second step comes when the points are there
+      HIP_TRY(hipEventRecord(S.pre_done, pre));
+      return CURDLE_OK;
+    }
+  }
+  if (phase == 2) {  // the caller has made `stream` wait for the chunk's points
+    HIP_TRY(hipStreamWaitEvent(stream, S.pre_done, 0));
+    prof.st = stream;
+    if (convert_here) {
+      HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, stream));
+      prof.mark("convert_points");
+    }
+  } else if (stream != pre) {
     HIP_TRY(hipEventRecord(S.pre_done, pre));
     HIP_TRY(hipStreamWaitEvent(stream, S.pre_done, 0));
     prof.st = stream;
@@ -1035,40 +1053,120 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
   const size_t per = (n + nchunks - 1) / nchunks;
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(cx.device));
-    ChunkJoin last;
-    size_t used = 0;
+    // Round 4: ALL scalars cross first (32 bytes of a pair's 128) and every chunk's recoding and sort is
+    // queued behind them at once: they run while the point chunks stream in, so a chunk whose points
+    // have landed goes straight into its conversion and accumulation.  Before, a chunk's sort waited
+    // for scalars that sat behind the previous chunk's points in the copy queue, and every
+    // accumulation started 0.3-0.6 ms after its copy had ended (profiles/r03_host_buffer_chunks.txt).
+    // A pageable copy occupies the calling thread, so the order of the calls below is the timeline.
+    struct Part {
+      Slot* S;
+      size_t lo, m;
+      ChunkJoin join;
+      hipStream_t main;
+    };
+    std::vector<Part> parts;
     for (size_t lo = 0, i = 0; lo < n; lo += per, i++) {
-      const size_t m = n - lo < per ? n - lo : per;
-      Slot& S = cx.slots[slots[i]];
-      used = i + 1;
-      int r;
-      if ((r = ensure(S.points, m * 96))) return r;
-      if ((r = ensure(S.scalars, m * 32))) return r;
+      Part pt;
+      pt.S = &cx.slots[slots[i]];
+      pt.lo = lo;
+      pt.m = n - lo < per ? n - lo : per;
       const unsigned seq = cx.submit_count.fetch_add(1, std::memory_order_relaxed);
       const unsigned turn = seq % (unsigned)cx.main_streams;
-      hipStream_t main = turn == 0 ? cx.main_stream : cx.main_extra[turn - 1];
-      // every chunk's copy on ONE stream, so that the first chunk arrives at the full PCIe rate
-      // instead of sharing it with the ones behind it; the scalars first: the sort needs only them
-      HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars + 4 * lo, m * 32, hipMemcpyHostToDevice, cx.h2d_stream));
-      HIP_TRY(hipMemcpyAsync(S.points.p, points + 12 * lo, m * 96, hipMemcpyHostToDevice, cx.h2d_stream));
-      HIP_TRY(hipEventRecord(S.pre_done, cx.h2d_stream));
-      HIP_TRY(hipStreamWaitEvent(cx.pre_stream, S.pre_done, 0));
-      const uint32_t off[2] = {0, (uint32_t)m};
-      const bool is_last = lo + per >= n;
-      ChunkJoin mine;
+      pt.main = turn == 0 ? cx.main_stream : cx.main_extra[turn - 1];
       // with three or four fragment lists per bucket the reduction's chain is fragments, not
       // running sums: half as many buckets per quad (N = 2^20, four chunks: 5.30 -> 5.02 ms)
-      mine.seg = nchunks >= 3 ? 8 : 0;
-      mine.accumulate_only = !is_last;
-      if (is_last) mine.earlier = last.earlier;
-      // the last chunk's tail is what the caller waits for: the synchronous rule for its segments
-      // (every chunk must take the same rule: the reduction walks all of them with one plan)
-      if ((r = enqueue_slot(cx, S, S.points.p, S.scalars.p, off, 1, c, 0, -1, cx.pre_stream, main, S.stream,
-                            /*latency_mode=*/true, false, 1, false, &mine)))
-        return r;
-      last.earlier.push_back(&S);
+      pt.join.seg = nchunks >= 3 ? 8 : 0;
+      parts.push_back(pt);
     }
-    return finish_slot(cx, cx.slots[slots[used - 1]], out);  // the last chunk's slot holds the window sums
+    int r;
+    for (Part& pt : parts) {
+      if ((r = ensure(pt.S->points, pt.m * 96))) return r;
+      if ((r = ensure(pt.S->scalars, pt.m * 32))) return r;
+    }
+    // The copies are issued by a thread of their own, back to back (a pageable copy occupies the thread
+    // that issues it for its whole duration): first chunk 0 whole -- the GPU starts after a quarter of
+    // the bytes --, then the scalars of all other chunks, whose sorts run beside the first accumulation
+    // and are done long before their points land, then the point chunks.  This thread queues each
+    // step's kernels as soon as the copy it needs has been issued and its event recorded.  With the
+    // copies and the launches on ONE thread the ~0.1 ms of launches per step sat between the copies, and
+    // the GPU idled 0.6 ms between the first and the second accumulation (profiles/r04_host_buffer_call.txt).
+    struct CopyJob {
+      void* dst;
+      const void* src;
+      size_t bytes;
+      hipEvent_t ev;
+    };
+    std::vector<CopyJob> jobs;
+    jobs.push_back({parts[0].S->scalars.p, scalars + 4 * parts[0].lo, parts[0].m * 32, parts[0].S->pre_done});
+    jobs.push_back({parts[0].S->points.p, points + 12 * parts[0].lo, parts[0].m * 96, parts[0].S->acc_done});
+    for (size_t i = 1; i < parts.size(); i++)
+      jobs.push_back({parts[i].S->scalars.p, scalars + 4 * parts[i].lo, parts[i].m * 32, parts[i].S->pre_done});
+    for (size_t i = 1; i < parts.size(); i++)  // (acc_done is re-recorded by the chunk's accumulation: a scratch event until then)
+      jobs.push_back({parts[i].S->points.p, points + 12 * parts[i].lo, parts[i].m * 96, parts[i].S->acc_done});
+    std::mutex cmu;
+    std::condition_variable ccv;
+    size_t issued = 0;
+    hipError_t copy_err = hipSuccess;
+    std::thread copier([&] {
+      hipError_t e = hipSetDevice(cx.device);
+      for (size_t j = 0; j < jobs.size(); j++) {
+        if (e == hipSuccess) e = hipMemcpyAsync(jobs[j].dst, jobs[j].src, jobs[j].bytes, hipMemcpyHostToDevice, cx.h2d_stream);
+        if (e == hipSuccess) e = hipEventRecord(jobs[j].ev, cx.h2d_stream);
+        {
+          std::lock_guard<std::mutex> g(cmu);
+          issued = j + 1;
+          if (e != hipSuccess && copy_err == hipSuccess) copy_err = e;
+        }
+        ccv.notify_all();
+      }
+    });
+    struct Joiner {  // on every way out
+      std::thread& t;
+      ~Joiner() { t.join(); }
+    } joiner{copier};
+    auto wait_copy = [&](size_t j) -> int {  // copy j has been issued and its event recorded
+      std::unique_lock<std::mutex> g(cmu);
+      ccv.wait(g, [&] { return issued > j; });
+      if (copy_err != hipSuccess) return fail(CURDLE_EHIP, "host-buffer chunk copy: %s", hipGetErrorString(copy_err));
+      return CURDLE_OK;
+    };
+    ChunkJoin last;
+    auto enqueue_sort = [&](Part& pt) -> int {  // behind the chunk's scalars
+      HIP_TRY(hipStreamWaitEvent(cx.pre_stream, pt.S->pre_done, 0));
+      const uint32_t off[2] = {0, (uint32_t)pt.m};
+      pt.join.phase = 1;
+      // every chunk takes the synchronous rule for its segments (the reduction walks all of them with one plan)
+      return enqueue_slot(cx, *pt.S, pt.S->points.p, pt.S->scalars.p, off, 1, c, 0, -1, cx.pre_stream, pt.main, pt.S->stream,
+                          /*latency_mode=*/true, false, 1, false, &pt.join);
+    };
+    auto enqueue_accumulate = [&](size_t i) -> int {  // behind the chunk's points
+      Part& pt = parts[i];
+      HIP_TRY(hipStreamWaitEvent(pt.main, pt.S->acc_done, 0));
+      const uint32_t off[2] = {0, (uint32_t)pt.m};
+      const bool is_last = i + 1 == parts.size();
+      pt.join.phase = 2;
+      pt.join.accumulate_only = !is_last;
+      if (is_last) pt.join.earlier = last.earlier;
+      int rr = enqueue_slot(cx, *pt.S, pt.S->points.p, pt.S->scalars.p, off, 1, c, 0, -1, cx.pre_stream, pt.main, pt.S->stream,
+                            /*latency_mode=*/true, false, 1, false, &pt.join);
+      last.earlier.push_back(pt.S);
+      return rr;
+    };
+    const size_t K = parts.size();
+    if ((r = wait_copy(0))) return r;
+    if ((r = enqueue_sort(parts[0]))) return r;
+    if ((r = wait_copy(1))) return r;
+    if ((r = enqueue_accumulate(0))) return r;
+    for (size_t i = 1; i < K; i++) {
+      if ((r = wait_copy(1 + i))) return r;
+      if ((r = enqueue_sort(parts[i]))) return r;
+    }
+    for (size_t i = 1; i < K; i++) {
+      if ((r = wait_copy(K + i))) return r;
+      if ((r = enqueue_accumulate(i))) return r;
+    }
+    return finish_slot(cx, *parts.back().S, out);  // the last chunk's slot holds the window sums
   };
   int rc = body();
   for (int idx : slots) {
