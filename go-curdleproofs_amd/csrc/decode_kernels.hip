@@ -15,16 +15,13 @@
 #include "fp28.h"
 #include "quad28.h"
 #include "msm_kernels.h"
+#include "../host/knobs.h"
 
 namespace curdle {
 // Up to this many lanes the latency-bound kernels of this file run on quads (four lanes per
-// point, quad28.h); beyond it on one lane per point.  CURDLE_QUAD_MAX_LANES overrides (tuning).
+// point, quad28.h); beyond it on one lane per point.  knob QUAD_MAX_LANES overrides (tuning; host/knobs.h).
 static inline uint64_t quad_max_lanes() {
-  static const uint64_t v = [] {
-    const char* e = getenv("CURDLE_QUAD_MAX_LANES");
-    return e ? (uint64_t)atoll(e) : (uint64_t)131072;
-  }();
-  return v;
+  return knobs::is_set(knobs::QUAD_MAX_LANES) ? (uint64_t)knobs::get(knobs::QUAD_MAX_LANES) : (uint64_t)131072;
 }
 
 

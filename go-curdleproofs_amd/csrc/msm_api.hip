@@ -21,6 +21,7 @@
 
 #include "../../include/curdle_msm.h"
 #include "../host/common_rand.h"
+#include "../host/knobs.h"
 #include "../host/msmaccumulator.h"
 #include "host_math.h"
 #include "msm_kernels.h"
@@ -67,20 +68,15 @@ extern "C" int curdle_set_last_error(int code, const char* msg) { return fail(co
 namespace {
 
 static constexpr int kSlots = 8;
-static const size_t kTwoKernelMax = [] {  // one-shot decodings up to this size take the two-kernel form
-  const char* e = getenv("CURDLE_TWO_KERNEL_MAX");
-  return e ? (size_t)atoll(e) : (size_t)32768;
-}();
+// one-shot decodings up to this size take the two-kernel form
+static inline size_t two_kernel_max() { return knobs::is_set(knobs::TWO_KERNEL_MAX) ? (size_t)knobs::get(knobs::TWO_KERNEL_MAX) : (size_t)32768; }
 static constexpr int kMaxDeferred = 4;          // two-step point decodings in flight (see curdle_g1_decompress_begin); with 2, eight threads verifying from bytes ran at 1,500-2,200 /s, with 4 at 2,400-2,500
 // Batches at least this large combine their window sums on the GPU (k_combine: one quad per
 // MSM, 127 doublings, ~0.5 ms however many) instead of one Horner pass per MSM on the host
 // (0.05 ms each for small MSMs).  Measured after the GLV split, k x 128 / 628 pairs: k = 8 0.67
 // (host) against 0.81 ms, k = 12 0.89 against 0.76, k = 16 1.09 against 0.77, k = 24 1.51
 // against 0.77.
-static const size_t kGpuCombineMin = [] {
-  const char* e = getenv("CURDLE_GPU_COMBINE_MIN");
-  return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)12;
-}();
+static inline size_t gpu_combine_min() { return knobs::get(knobs::GPU_COMBINE_MIN) > 0 ? (size_t)knobs::get(knobs::GPU_COMBINE_MIN) : (size_t)12; }
 
 struct Buf {
   void* p = nullptr;
@@ -286,8 +282,8 @@ int init_locked(Ctx& cx, int device) {
   int prio_least = 0, prio_greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   HIP_TRY(hipStreamCreateWithPriority(&cx.main_stream, hipStreamNonBlocking, prio_least));
-  if (const char* ms = getenv("CURDLE_MAIN_STREAMS")) {
-    cx.main_streams = atoi(ms);
+  if (knobs::is_set(knobs::MAIN_STREAMS)) {
+    cx.main_streams = (int)knobs::get(knobs::MAIN_STREAMS);
     if (cx.main_streams < 1 || cx.main_streams > 4) cx.main_streams = 1;
   }
   // Only the streams that will be used: with more streams than hardware queues
@@ -297,12 +293,10 @@ int init_locked(Ctx& cx, int device) {
     HIP_TRY(hipStreamCreateWithPriority(&cx.main_extra[i], hipStreamNonBlocking, prio_least));
   HIP_TRY(hipStreamCreateWithPriority(&cx.pre_stream, hipStreamNonBlocking, prio_least));
   HIP_TRY(hipStreamCreateWithPriority(&cx.pre_stream2, hipStreamNonBlocking, prio_least));
-  if (const char* ps = getenv("CURDLE_PRE_STREAMS")) cx.pre_streams = atoi(ps) == 1 ? 1 : 2;
-  // Tail streams at normal priority by default: on ROCm 7.2 all high-priority streams of a
-  // process appear to share one hardware queue, which serialises the tails of consecutive
-  // MSMs (measured: 0.93 vs 0.84 ms per 2-window partial).  CURDLE_TAIL_PRIO=1 restores it.
-  const char* tp = getenv("CURDLE_TAIL_PRIO");
-  const int tail_prio = (tp && atoi(tp) == 1) ? prio_greatest : prio_least;
+  // Tail streams at normal priority: on ROCm 7.2 all high-priority streams of a process appear to
+  // share one hardware queue, which serialises the tails of consecutive MSMs (measured in round 2:
+  // 0.93 vs 0.84 ms per 2-window partial).
+  const int tail_prio = prio_least;
   // (Confining the tail streams to 32 / 64 / 128 compute units with hipExtStreamCreateWithCUMask --
   // so that the latency-bound bucket reductions, whose waves sit on their SIMDs for 0.3-0.7 ms
   // and leave room for only one accumulate wave beside them, stop taking a wave slot on half the
@@ -324,10 +318,9 @@ int init_locked(Ctx& cx, int device) {
 int init_default_locked(Ctx& cx) { return init_locked(cx, cx.device); }
 
 int choose_window_bits(size_t n, bool many = false) {
-  const char* env = getenv("CURDLE_WINDOW_BITS");
-  if (env) {
-    int c = atoi(env);
-    if (c >= 4 && c <= 16) return c;
+  {
+    const long long c = knobs::get(knobs::WINDOW_BITS);
+    if (c >= 4 && c <= 16) return (int)c;
   }
   // in TERMS of the GLV split, two per pair: that is what a window's buckets hold
   n *= 2;
@@ -368,7 +361,7 @@ int window_widths(int c, uint8_t bits[kMaxWindows]) {
 int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end,
               bool latency_mode, size_t sets = 1, bool many = false, uint32_t seg_override = 0) {
   if (n_total > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n_total);
-  many = many || k * sets >= kGpuCombineMin;  // a pass of a larger batch keeps the batch's rules
+  many = many || k * sets >= gpu_combine_min();  // a pass of a larger batch keeps the batch's rules
   if (c == 0) c = choose_window_bits(n_max, many);
   if (c < 4 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", c);
   memset(&p, 0, sizeof(p));
@@ -427,19 +420,19 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // 1.83 -> 1.52, 0.98 -> 0.88 and 0.61 -> 0.59 ms.
   if (latency_mode) {
     uint64_t lanes = 65536;
-    if (const char* env = getenv("CURDLE_SYNC_LANES")) lanes = (uint64_t)atoll(env);
+    if (knobs::get(knobs::SYNC_LANES) > 0) lanes = (uint64_t)knobs::get(knobs::SYNC_LANES);
     uint32_t seg = 1;
     while (nbk / seg * 4 > lanes && seg < 32) seg *= 2;
     p.seg = nbk / seg * 4 <= lanes ? seg : 16;
   } else {
     uint64_t lanes = 32768;
-    if (const char* env = getenv("CURDLE_PIPE_LANES")) lanes = (uint64_t)atoll(env);
+    if (knobs::get(knobs::PIPE_LANES) > 0) lanes = (uint64_t)knobs::get(knobs::PIPE_LANES);
     uint32_t seg = p.seg;
     while (nbk / seg * 4 > lanes && seg < 64) seg *= 2;
     p.seg = seg;
   }
   if (seg_override) p.seg = seg_override;
-  if (const char* env = getenv("CURDLE_REDUCE_SEG")) p.seg = (uint32_t)atoi(env);
+  if (knobs::get(knobs::REDUCE_SEG) > 0) p.seg = (uint32_t)knobs::get(knobs::REDUCE_SEG);
   if (p.seg < 1) p.seg = 1;
   while (p.seg > min_nbkt || (p.seg & (p.seg - 1))) p.seg >>= 1;
   p.NS = p.NB / p.seg;
@@ -448,10 +441,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // shared-scalar calls keep k_bucket_reduce_quad: their host pass runs once per RESULT, and ~8 more
   // additions per window and result cost the host more than the GPU saves.
   {
-    static const int forced = [] {
-      const char* e = getenv("CURDLE_REDUCE_BITS");
-      return e ? atoi(e) : -1;
-    }();
+    const long long forced = knobs::get(knobs::REDUCE_BITS);
     p.reduce_bits = (forced < 0 ? k * sets == 1 : forced != 0) && !many ? 1u : 0u;
   }
   const uint32_t gmax = p.reduce_bits ? 16u : 64u;  // quads per group: one wave's, or one block's
@@ -472,21 +462,21 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // reduce has to add, and with 2^21..2^22 entries (a window range of the multi-GPU split) half
   // as many lanes take 0.03-0.05 ms off its chain at no cost to the accumulation; at 2^24
   // entries (N = 2^20) it is 1 % of the pipelined step (2.71 -> 2.68 ms)
-  if (!getenv("CURDLE_TWO_ROUNDS")) {
+  {
     const uint64_t one = (entries + 131072 - 1) / 131072;
     if (one <= 128 && one > L) L = one;
   }
-  if (const char* env = getenv("CURDLE_SEG_LEN")) L = (uint64_t)atoi(env);
+  const bool L_forced = knobs::get(knobs::SEG_LEN) > 0;
+  if (L_forced) L = (uint64_t)knobs::get(knobs::SEG_LEN);
   // small MSMs are latency-bound on the lane's chain of L mixed additions: halve it while the
   // launch stays far below one round of the chip (every lane emits at least one fragment,
   // which the bucket reduce has to add, so not below 4)
-  uint64_t Lmin = entries <= 8 * 65536 ? 4 : 8;
-  if (const char* env = getenv("CURDLE_SEG_LEN_MIN")) Lmin = (uint64_t)atoi(env) < 1 ? 1 : (uint64_t)atoi(env);
+  const uint64_t Lmin = entries <= 8 * 65536 ? 4 : 8;
   if (L < Lmin) L = Lmin;
   // ... and long enough that an evenly loaded bucket of the narrowest window is cut into about
   // eight fragments at most: beyond max_small (16) a bucket takes the merge_large detour, which
   // is there for skewed scalars, not for uniform ones (16,384 pairs: 0.81 -> 0.5 ms)
-  if (!getenv("CURDLE_SEG_LEN") && min_nbkt) {
+  if (!L_forced && min_nbkt) {
     const uint64_t load = (n_max + min_nbkt - 1) / min_nbkt;
     if (L < (load + 7) / 8) L = (load + 7) / 8;
   }
@@ -504,7 +494,6 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // (an MSM of a batch is never split below that).
   uint64_t ch = (entries + 511) / 512;
   if (ch < 4096) ch = 4096;
-  if (const char* env = getenv("CURDLE_SORT_CHUNK")) ch = (uint64_t)atoll(env);
   if (ch > n_max) ch = n_max ? n_max : 1;
   p.chunk = (uint32_t)ch;
   p.gpu_combine = many ? 1u : 0u;
@@ -513,10 +502,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // 2^17 terms the extra launches cost more than the stores save.  CURDLE_SCATTER=1 / 2 forces
   // the one-pass / two-pass form where the shapes allow.
   {
-    static const int forced = [] {
-      const char* e = getenv("CURDLE_SCATTER");
-      return e ? atoi(e) : 0;
-    }();
+    const long long forced = knobs::get(knobs::SCATTER);
     const bool shapes = k == 1 && min_nbkt >= 4096 && (min_nbkt & 127u) == 0 && p.max_nbkt <= 32768 && p.n <= (1u << 24);
     p.two_level = shapes && forced != 1 && (forced == 2 || p.n >= (1u << 17)) ? 1u : 0u;
   }
@@ -908,14 +894,7 @@ void drain_slot(Ctx& cx, Slot& S) {
 struct SyncStreams {
   hipStream_t pre, main, tail;
 };
-SyncStreams sync_streams(Ctx& cx, Slot& S) {
-  static const bool three = [] {
-    const char* e = getenv("CURDLE_SYNC_STREAMS");
-    return e && atoi(e) == 3;
-  }();
-  if (three) return {cx.pre_stream, cx.main_stream, S.stream};
-  return {S.stream, S.stream, S.stream};
-}
+SyncStreams sync_streams(Ctx&, Slot& S) { return {S.stream, S.stream, S.stream}; }
 
 // The scans of the bucket slots hold 1,024 blocks of 4,096 slots: a batch with more slots than
 // that (1,024 MSMs of 2,548 pairs; 2,100 of 628) runs in passes of as many whole MSMs as fit,
@@ -937,7 +916,7 @@ int run_passes(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, co
     int rc = make_plan(probe, h_off[k] - h_off[0], k, n_max, c, win_begin, win_end, true);
     if (rc) return rc;
     size_t per_pass = probe.NB ? kMaxSlotsPerPass / probe.NB : k;
-    if (const char* e = getenv("CURDLE_MAX_MSMS_PER_PASS")) per_pass = atoll(e) > 0 ? (size_t)atoll(e) : per_pass;
+    if (knobs::get(knobs::MAX_MSMS_PER_PASS) > 0) per_pass = (size_t)knobs::get(knobs::MAX_MSMS_PER_PASS);
     if (k > per_pass) {
       std::vector<uint32_t> off;
       for (size_t j0 = 0; j0 < k; j0 += per_pass) {
@@ -1025,7 +1004,7 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
   // lists of all of them.  tools/bench_sync_call.py --variants CURDLE_HOST_CHUNKS=...:
   // see profiles/r03_host_buffer_chunks.txt.
   size_t nchunks = n >= ((size_t)1 << 20) ? 4 : 2;
-  if (const char* e = getenv("CURDLE_HOST_CHUNKS")) nchunks = atoi(e) < 1 ? 1 : (size_t)atoi(e);
+  if (knobs::get(knobs::HOST_CHUNKS) > 0) nchunks = (size_t)knobs::get(knobs::HOST_CHUNKS);
   if (nchunks > (size_t)kMaxFragSources) nchunks = kMaxFragSources;
   // every chunk needs a slot until the reduction has read its fragments: take what is free now
   // (never wait for a slot while holding one), at least one
@@ -1192,7 +1171,7 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
   // roots and, beside them, the subgroup test on the twisted model -- two ~0.5 ms chains that
   // overlap (98 points: 1.10 -> 0.63 ms) where the fused kernel below runs them one after the
   // other.  With every decode context taken it falls through to the fused kernel.
-  if (subgroup_check && n <= kTwoKernelMax) {
+  if (subgroup_check && n <= two_kernel_max()) {
     int ticket = -1;
     int rc2 = curdle_g1_decompress_begin(in, n, out_affine, status, &ticket);
     if (rc2 == CURDLE_OK) {
@@ -1268,8 +1247,7 @@ int ensure_dslot_streams(Ctx& cx) {
   // caller's verification (seen as 354 instead of 1,300 Whisk verifications/s from four threads)
   std::lock_guard<std::mutex> g(cx.mu);
   if (cx.dstreams_ready.load(std::memory_order_relaxed)) return CURDLE_OK;
-  const char* dp = getenv("CURDLE_DECODE_PRIO");
-  const int dprio = dp ? (atoi(dp) == 1 ? cx.prio_greatest : atoi(dp) == 2 ? 0 : cx.prio_least) : cx.prio_least;
+  const int dprio = cx.prio_least;
   for (DSlot& x : cx.dslots) {
     if (x.stream) continue;
     hipStream_t a = nullptr, b = nullptr, c = nullptr;
@@ -1653,6 +1631,11 @@ extern "C" int curdle_shutdown(void) {
   return CURDLE_OK;
 }
 
+extern "C" int curdle_plan_override(const char* name, long long value) {
+  if (knobs::set(name, value)) return fail(CURDLE_EINVAL, "no knob named %s", name ? name : "(null)");
+  return CURDLE_OK;
+}
+
 extern "C" int curdle_last_error(char* buf, size_t len) {
   if (!buf || len == 0) return CURDLE_EINVAL;
   snprintf(buf, len, "%s", g_err);
@@ -1689,7 +1672,7 @@ int msm_host_one_device(const uint64_t* points, const uint64_t* scalars, size_t 
     set_out_infinity(out_jac);
     return CURDLE_OK;
   }
-  if (n >= kHostChunkMin && !getenv("CURDLE_HOST_ONE_COPY")) return run_host_chunked(points, scalars, n, out_jac);
+  if (n >= kHostChunkMin && knobs::get(knobs::HOST_CHUNKS) != 1) return run_host_chunked(points, scalars, n, out_jac);
   const uint32_t off[2] = {0, (uint32_t)n};
   return run_host(points, scalars, off, 1, out_jac);
 }
@@ -1748,11 +1731,7 @@ inline void even_range(size_t n, int D, int d, size_t* lo, size_t* hi) {
 // Below this many pairs a host-buffer MSM stays on the calling thread's device: the hand-off to
 // D host threads and D separate small MSMs (each a fixed ~0.3 ms chain) cost more than they save.
 size_t multi_device_min() {
-  static const size_t v = [] {
-    const char* e = getenv("CURDLE_MULTI_DEVICE_MIN");
-    return e ? (size_t)atoll(e) : (size_t)1 << 16;
-  }();
-  return v;
+  return knobs::is_set(knobs::MULTI_DEVICE_MIN) ? (size_t)knobs::get(knobs::MULTI_DEVICE_MIN) : (size_t)1 << 16;
 }
 }  // namespace
 

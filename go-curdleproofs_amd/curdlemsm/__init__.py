@@ -40,7 +40,7 @@ MSM_SLOTS = 8
 
 # Every symbol include/curdle_msm.h declares (tests check they are all exported).
 SYMBOLS = [
-    "curdle_init", "curdle_shutdown", "curdle_last_error", "curdle_device_available",
+    "curdle_init", "curdle_shutdown", "curdle_last_error", "curdle_plan_override", "curdle_device_available",
     "curdle_init_devices", "curdle_device_count", "curdle_set_device", "curdle_get_device", "curdle_msm_g1_replicated",
     "curdle_msm_g1", "curdle_msm_g1_device", "curdle_msm_g1_device_windows",
     "curdle_msm_g1_device_submit", "curdle_msm_wait",
@@ -93,6 +93,7 @@ _get_device = _sig("curdle_get_device", C.c_int)
 _msm_g1_replicated = _sig("curdle_msm_g1_replicated", C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t,
                           C.c_int, _vp)
 _last_error = _sig("curdle_last_error", C.c_int, C.c_char_p, C.c_size_t)
+_plan_override = _sig("curdle_plan_override", C.c_int, C.c_char_p, C.c_longlong)
 _device_available = _sig("curdle_device_available", C.c_int)
 _msm_g1 = _sig("curdle_msm_g1", C.c_int, _vp, _vp, C.c_size_t, _vp)
 _msm_g1_device = _sig("curdle_msm_g1_device", C.c_int, _vp, _vp, C.c_size_t, _vp, _vp)
@@ -189,6 +190,29 @@ def _as_u64(a, cols=None) -> np.ndarray:
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(_vp)
+
+
+def plan_override(name: str, value=None) -> None:
+    """Test / measurement hook: set one of the library's knobs (host/knobs.h; the name with or without
+    CURDLE_), or put it back to "not set" with value None.  The environment is read only once."""
+    _check(_plan_override(name.encode(), -1 if value is None else int(value)))
+
+
+class knobs:
+    """with knobs(WINDOW_BITS=12, SEG_LEN=16): ... -- the knobs are unset again on the way out."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            plan_override(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            plan_override(k, None)
+        return False
 
 
 def init(device: int = 0) -> None:

@@ -233,8 +233,6 @@ void CompressAffineAvx512(const G1Affine* pts, size_t n, uint8_t* out);  // comp
 
 void CompressAffineBatch(const G1Affine* pts, size_t n, uint8_t* out) {
   static const bool ifma = [] {
-    const char* e = getenv("CURDLE_NO_IFMA");  // A/B measurements
-    if (e && *e && *e != '0') return false;
     __builtin_cpu_init();
     return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512ifma") && __builtin_cpu_supports("avx512vl") &&
            __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq");

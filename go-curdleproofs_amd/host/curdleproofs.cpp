@@ -1,6 +1,7 @@
 // Curdleproofs protocol layers around the MSM hot path -- see curdleproofs.h.
 // Each function cites the reference lines it restates (paths relative to
 // /root/reference).  Transcript labels are those of SURVEY.md appendix A.
+#include "knobs.h"
 #include "curdleproofs.h"
 #include "device_accumulator.h"
 #include "verify_batch_impl.h"
@@ -58,10 +59,7 @@ void Accumulate(MsmAccumulator& acc, const Point& C, const std::vector<Scalar>& 
 // every C where the reference does (MultiExp per argument, then AccumulateCheck) --
 // same accept bit, kept for differential testing.
 std::atomic<int>& EagerFlag() {
-  static std::atomic<int> eager([] {
-    const char* e = getenv("CURDLE_VERIFY_EAGER");
-    return (e && *e && *e != '0') ? 1 : 0;
-  }());
+  static std::atomic<int> eager(knobs::get(knobs::VERIFY_EAGER) > 0 ? 1 : 0);
   return eager;
 }
 bool EagerChecks() { return EagerFlag().load(std::memory_order_relaxed) != 0; }
@@ -111,12 +109,9 @@ const G1Affine kZeroPoint = [] {
   return z;
 }();
 
-// CURDLE_PROVER_FOLD_BASES=1: the recursive provers fold their bases every round, in the
-// reference's order of operations (A/B and tests; read at every Prove so a test can flip it).
-bool ProverFoldsBases() {
-  const char* e = getenv("CURDLE_PROVER_FOLD_BASES");
-  return e && *e && *e != '0';
-}
+// Knob PROVER_FOLD_BASES = 1: the recursive provers fold their bases every round, in the
+// reference's order of operations (A/B and tests, which flip it through curdle_plan_override).
+bool ProverFoldsBases() { return knobs::get(knobs::PROVER_FOLD_BASES) > 0; }
 
 }  // namespace
 
@@ -259,11 +254,7 @@ bool PointDecoder::OnDevice() {
   // CURDLE_HOST_DECODE=1 is an explicit request (A/B measurements of the host decoder), not a
   // fallback: without it a batch of kMinDeviceBatch or more records goes to the GPU and the
   // call fails loudly if there is none.
-  static const bool host_only = [] {
-    const char* e = getenv("CURDLE_HOST_DECODE");
-    return e && *e && *e != '0';
-  }();
-  return !host_only;
+  return !(knobs::get(knobs::HOST_DECODE) > 0);
 }
 void PointDecoder::Start() {
   if (started_ || n_ == 0 || !subgroup_ || !OnDevice() || n_ < kMinDeviceBatch) return;
@@ -1359,10 +1350,7 @@ bool VerifyWhileDecoding(VerifyPrelude& pre, const Proof& proof, const CRS& crs,
                          const std::function<void(DecodedInstance&)>& after_decode, common::Rand& rand) {
   if (!CanVerifyWhileDecoding()) throw std::logic_error("VerifyWhileDecoding needs the device accumulator and deferred checks");
   const size_t ell = crs.Gs.size();
-  static const bool trace = [] {  // CURDLE_VERIFY_TRACE=1: where the time goes (stderr)
-    const char* e = getenv("CURDLE_VERIFY_TRACE");
-    return e && *e && *e != '0';
-  }();
+  const bool trace = knobs::get(knobs::VERIFY_TRACE) > 0;  // where the time goes (stderr)
   const auto t0 = std::chrono::steady_clock::now();
   DeviceSink sink(crs);  // records; the accumulation itself starts once the instance is there
   // the whole host part, from the wire bytes, while the GPU takes the square roots
@@ -1424,10 +1412,7 @@ bool VerifyStarted(VerifyPrelude& pre, const Proof& proof, const CRS& crs, const
     // CURDLE_VERIFY_TRACE=1: where one verification's time goes (stderr), for the host-share
     // figure of DESIGN.md: starting the accumulation (instance upload), the host's transcript
     // and challenge algebra, the device part (scalars kernel + MSM + wait)
-    static const bool trace = [] {
-      const char* e = getenv("CURDLE_VERIFY_TRACE");
-      return e && *e && *e != '0';
-    }();
+    const bool trace = knobs::get(knobs::VERIFY_TRACE) > 0;
     const auto t0 = std::chrono::steady_clock::now();
     // The accumulation takes its workspace slot NOW -- the instance points are uploaded and
     // converted while the host hashes -- unless slots are scarce: with more verifying threads

@@ -1,4 +1,5 @@
 // DeviceSink -- see device_accumulator.h.
+#include "knobs.h"
 #include "device_accumulator.h"
 
 #include <stdlib.h>
@@ -18,10 +19,7 @@ alg::MsmError device_error(const char* what, int rc) {
   return alg::MsmError(std::string(what) + ": " + buf + " (rc " + std::to_string(rc) + ")", rc);
 }
 std::atomic<int>& Flag() {
-  static std::atomic<int> on([] {
-    const char* e = getenv("CURDLE_DEVICE_ACC");
-    return (e && *e == '0') ? 0 : 1;
-  }());
+  static std::atomic<int> on(knobs::get(knobs::DEVICE_ACC) == 0 ? 0 : 1);
   return on;
 }
 }  // namespace

@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 
+#include "knobs.h"
 #include "../../include/curdle_msm.h"
 #include "curdleproofs.h"
 #include "device_accumulator.h"
@@ -34,13 +35,7 @@ namespace proto {
 // and every host core idle during the decoding (k = 1,024 Whisk proofs: 17 + 32 ms of 100).
 // Workers call Wait(i) before they touch proof i; proofs are handed out in index order, so
 // chunks are consumed in the order they are produced.
-inline bool BatchTrace() {  // CURDLE_VERIFY_TRACE=1: the batch's chunk / group timeline (stderr)
-  static const bool on = [] {
-    const char* e = getenv("CURDLE_VERIFY_TRACE");
-    return e && *e && *e != '0';
-  }();
-  return on;
-}
+inline bool BatchTrace() { return knobs::get(knobs::VERIFY_TRACE) > 0; }  // the batch's chunk / group timeline (stderr)
 
 class DecodeAhead {
  public:
@@ -131,7 +126,7 @@ class DecodeAhead {
 // verify_batch 58-66 ms at 64 proofs per chunk, 140-180 ms at 128, 68-82 ms undivided; Whisk
 // 63 ms at 64, 97-111 ms undivided.  Two producers (a third takes a core from the workers).
 inline size_t DecodeAheadChunk(size_t k, size_t points_per_proof = 0) {
-  if (const char* e = getenv("CURDLE_BATCH_CHUNK")) return atoi(e) < 1 ? 1 : (size_t)atoi(e);  // tests, tuning
+  if (knobs::get(knobs::BATCH_CHUNK) > 0) return (size_t)knobs::get(knobs::BATCH_CHUNK);  // tests, tuning
   size_t c = k / 4;
   c = c < 16 ? 16 : c > 64 ? 64 : c;
   // ... and at most 32,768 points: up to there a decoding is the pair of concurrent four-lane
@@ -141,12 +136,11 @@ inline size_t DecodeAheadChunk(size_t k, size_t points_per_proof = 0) {
   return c < 16 ? 16 : c;
 }
 inline int DecodeAheadProducers() {
-  if (const char* e = getenv("CURDLE_BATCH_PRODUCERS")) return atoi(e) < 1 ? 1 : atoi(e);
+  if (knobs::get(knobs::BATCH_PRODUCERS) > 0) return (int)knobs::get(knobs::BATCH_PRODUCERS);
   return 2;
 }
 // The caller's thread budget covers the producers: `nthreads` threads in all while they run.
 inline int BatchWorkers(int nthreads) {
-  if (getenv("CURDLE_BATCH_EXTRA_PRODUCERS")) return nthreads;  // A/B: producers on top of the budget
   const int w = nthreads - DecodeAheadProducers();
   return nthreads >= 4 ? (w < 2 ? 2 : w) : nthreads;
 }
@@ -165,7 +159,7 @@ std::vector<int> VerifyBatchCore(const CRS& crs, size_t k, Source& src, common::
   if (nthreads < 1) nthreads = 1;
   if ((size_t)nthreads > k) nthreads = (int)k;
   size_t flush = 32;
-  if (const char* e = getenv("CURDLE_BATCH_GROUP")) flush = (size_t)atoi(e);
+  if (knobs::get(knobs::BATCH_GROUP) > 0) flush = (size_t)knobs::get(knobs::BATCH_GROUP);
   if (flush < 1) flush = 1;
 
   std::atomic<size_t> next(0);

@@ -1,4 +1,5 @@
 // whisk package restatement -- see whisk.h.  Reference: /root/reference/whisk/whisk.go, types.go.
+#include "knobs.h"
 #include "whisk.h"
 
 #include <chrono>
@@ -259,10 +260,7 @@ std::vector<int> IsValidWhiskShuffleProofBatch(const proto::CRS& crs, const std:
       }
     }
   } src(items);
-  static const bool trace = [] {  // CURDLE_VERIFY_TRACE=1: the batch's wall time (stderr)
-    const char* e = getenv("CURDLE_VERIFY_TRACE");
-    return e && *e && *e != '0';
-  }();
+  const bool trace = knobs::get(knobs::VERIFY_TRACE) > 0;  // the batch's wall time (stderr)
   const auto t0 = std::chrono::steady_clock::now();
   const size_t points_per_proof = k ? WHISK_SHUFFLE_PROOF_SIZE / 48 + 4 * items[0].n : 0;  // an upper bound
   const size_t chunk = proto::DecodeAheadChunk(k, points_per_proof);

@@ -88,6 +88,14 @@ int curdle_get_device(void);
 int curdle_shutdown(void);
 /* Copies the calling thread's last error text (NUL-terminated) into buf. */
 int curdle_last_error(char* buf, size_t len);
+
+/* Test / measurement hook: the library's tunables ("knobs", go-curdleproofs_amd/host/knobs.h: window
+ * width, lane and segment lengths, chunk counts, ...) are read ONCE from the environment
+ * (CURDLE_<NAME>), when the library is first used, and never again.  This call changes one
+ * afterwards -- name with or without the CURDLE_ prefix, value < 0 = back to "not set" (the
+ * library's own rule) -- so that a test can walk a knob through its range inside one process.
+ * Not for production callers; CURDLE_EINVAL for a name the table does not have. */
+int curdle_plan_override(const char* name, long long value);
 /* 1 if a HIP device is visible to the library, else 0 (never fails). */
 int curdle_device_available(void);
 

@@ -23,6 +23,7 @@
 
 #include <map>
 
+#include "../../go-curdleproofs_amd/host/knobs.h"
 #include "../../go-curdleproofs_amd/host/curdleproofs.h"
 #include "../../go-curdleproofs_amd/host/device_accumulator.h"
 #include "../../go-curdleproofs_amd/host/whisk.h"
@@ -149,9 +150,9 @@ static int CompressCheck() {
 static int Flow(size_t ell) {
   Instance in = Make(ell, 7);
   {  // the prover that never folds its bases (default) against the reference's order of operations
-    setenv("CURDLE_PROVER_FOLD_BASES", "1", 1);
+    curdle::knobs::set("PROVER_FOLD_BASES", 1);
     Instance ref = Make(ell, 7);
-    unsetenv("CURDLE_PROVER_FOLD_BASES");
+    curdle::knobs::set("PROVER_FOLD_BASES", -1);
     CHECK(ref.proof == in.proof);
   }
   for (int eager = 0; eager < 2; eager++) {
@@ -287,7 +288,7 @@ static int Flow(size_t ell) {
   // host mirror: exact per-proof bits with a bad instance, a truncated and a bit-flipped proof;
   // decoded two proofs per chunk, ahead of the workers
   {
-    setenv("CURDLE_BATCH_CHUNK", "2", 1);
+    curdle::knobs::set("BATCH_CHUNK", 2);
     Instance other = Make(ell, 21, &in.crs);
     std::vector<uint8_t> truncated(in.proof.begin(), in.proof.end() - 5), flipped(in.proof);
     flipped[flipped.size() - 9] ^= 0x20;
@@ -319,7 +320,7 @@ static int Flow(size_t ell) {
       std::vector<proto::BatchItem> good = {items[0], items[1], items[5]};
       CHECK(proto::VerifyBatch(in.crs, good, br2, 3) == (std::vector<int>{1, 1, 1}));
     }
-    unsetenv("CURDLE_BATCH_CHUNK");
+    curdle::knobs::set("BATCH_CHUNK", -1);
     proto::SetDeviceAccumulator(1);
   }
   printf("flow ell=%zu: completeness, round trip, soundness flips, accumulator table, mirror == device accumulator, batch: ok\n", ell);
@@ -453,7 +454,7 @@ static int WhiskFlow() {
       }
       proto::SetDeviceAccumulator(1);
       // the batch form, decoded chunk by chunk ahead of the workers (one proof per chunk here)
-      setenv("CURDLE_BATCH_CHUNK", "1", 1);
+      curdle::knobs::set("BATCH_CHUNK", 1);
       std::vector<whisk::WhiskTracker> swapped(post);
       std::swap(swapped[0], swapped[1]);
       std::vector<uint8_t> garbled(wproof);
@@ -468,7 +469,7 @@ static int WhiskFlow() {
         CHECK(whisk::IsValidWhiskShuffleProofBatch(in.crs, items, br, 3) == (std::vector<int>{1, 0, 0, 1, 1}));
       }
       proto::SetDeviceAccumulator(1);
-      unsetenv("CURDLE_BATCH_CHUNK");
+      curdle::knobs::set("BATCH_CHUNK", -1);
     }
   CHECK(generated);
   printf("whisk flow: shuffle proof accepted, swapped trackers rejected, broken tracker reported, both routes: ok\n");

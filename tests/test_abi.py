@@ -96,6 +96,34 @@ def glv_split(k, R):
     return s * k1, s * k2
 
 
+def test_knobs_are_read_once_and_changed_only_through_the_hook(cm):
+    """The tunables live in one table (host/knobs.h), read from the environment ONCE; afterwards only
+    curdle_plan_override changes them (a dozen getenv calls on every MSM, next to a
+    document that said there were none)."""
+    n = 1 << 20
+    assert cm.window_bits(n) == 16
+    os.environ["CURDLE_WINDOW_BITS"] = "9"              # too late: the table was loaded at the first question
+    try:
+        assert cm.window_bits(n) == 16
+    finally:
+        del os.environ["CURDLE_WINDOW_BITS"]
+    with cm.knobs(WINDOW_BITS=9):
+        assert cm.window_bits(n) == 9 and cm.num_windows(n) == 15
+    assert cm.window_bits(n) == 16
+    cm.plan_override("CURDLE_WINDOW_BITS", 12)          # the prefixed spelling names the same knob
+    assert cm.window_bits(n) == 12
+    cm.plan_override("WINDOW_BITS", None)
+    assert cm.window_bits(n) == 16
+    for bad in ("NO_SUCH_KNOB", "", "CURDLE_TWO_ROUNDS", "CURDLE_SYNC_STREAMS"):   # closed experiments are gone
+        with pytest.raises(cm.CurdleError):
+            cm.plan_override(bad, 1)
+    import subprocess, sys
+    child = ("import sys; sys.path.insert(0, %r); import curdlemsm as cm; print(cm.window_bits(1 << 20))"
+             % os.path.join(ROOT, "go-curdleproofs_amd"))
+    out = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, CURDLE_WINDOW_BITS="11"), capture_output=True, text=True)
+    assert out.stdout.strip() == "11", (out.stdout, out.stderr[-500:])   # at process start the environment does count
+
+
 def test_selftest_operations_share_one_table(cm):
     """curdle_selftest_op's buffer sizes, its launcher's grid and its kernel's indexing come from ONE
     table, which the binding asks for too: an unknown operation is refused before anything is

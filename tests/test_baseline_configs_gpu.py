@@ -198,10 +198,10 @@ def test_batches_beyond_one_pass_of_bucket_slots(gpu, oracle, coracle, k, size):
     assert (gpu.g1_sum(out) == gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n)).all()
     # the same batch forced into many small passes, and from host buffers
     try:
-        os.environ["CURDLE_MAX_MSMS_PER_PASS"] = "300"
+        gpu.plan_override("MAX_MSMS_PER_PASS", 300)
         assert (gpu.msm_g1_batch_device(d_pts.data_ptr(), d_sc.data_ptr(), offs) == out).all()
     finally:
-        os.environ.pop("CURDLE_MAX_MSMS_PER_PASS", None)
+        gpu.plan_override("MAX_MSMS_PER_PASS", None)
     if k == 2100:
         assert (gpu.msm_g1_batch(pts, sc, offs) == out).all()
 

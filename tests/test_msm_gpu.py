@@ -119,13 +119,13 @@ def test_golden_vectors_every_window_size(gpu, golden):
     extra top window, on vectors that exercise carries and exceptional additions."""
     try:
         for c in range(4, 17):
-            os.environ["CURDLE_WINDOW_BITS"] = str(c)
+            gpu.plan_override("WINDOW_BITS", c)
             for name in ("rand0_n16", "rand0_n257", "edge_window_boundaries", "edge_extreme_scalars",
                          "edge_duplicate_bases", "edge_opposite_points", "edge_infinity_bases"):
                 got = gpu.msm_g1(golden[name + "_points"], golden[name + "_scalars"])
                 assert (got == golden[name + "_expected"]).all(), (name, c)
     finally:
-        os.environ.pop("CURDLE_WINDOW_BITS", None)
+        gpu.plan_override("WINDOW_BITS", None)
 
 
 def test_segment_lengths(gpu, golden):
@@ -133,12 +133,12 @@ def test_segment_lengths(gpu, golden):
     bookkeeping at every alignment)."""
     try:
         for L in (4, 5, 8, 9, 13, 32, 128):
-            os.environ["CURDLE_SEG_LEN"] = str(L)
+            gpu.plan_override("SEG_LEN", L)
             for name in ("rand0_n257", "rand0_n1024", "edge_all_equal_scalars", "edge_small_scalars"):
                 got = gpu.msm_g1(golden[name + "_points"], golden[name + "_scalars"])
                 assert (got == golden[name + "_expected"]).all(), (name, L)
     finally:
-        os.environ.pop("CURDLE_SEG_LEN", None)
+        gpu.plan_override("SEG_LEN", None)
 
 
 def test_reduce_segment_lengths(gpu, golden, oracle, coracle):
@@ -152,19 +152,19 @@ def test_reduce_segment_lengths(gpu, golden, oracle, coracle):
     exp = coracle.msm_pippenger(pts, sc, threads=8)
     try:
         for quad in ("1", "4", "32", "64"):
-            os.environ["CURDLE_REDUCE_SEG"] = quad
+            gpu.plan_override("REDUCE_SEG", int(quad))
             for name in ("rand0_n16", "rand0_n257", "rand0_n1024", "edge_duplicate_bases", "edge_opposite_points",
                          "edge_cancels_to_infinity", "edge_all_equal_scalars", "edge_small_scalars",
                          "edge_window_boundaries", "edge_all_infinity"):
                 got = gpu.msm_g1(golden[name + "_points"], golden[name + "_scalars"])
                 assert (got == golden[name + "_expected"]).all(), (name, quad)
             for c in (6, 11, 16):
-                os.environ["CURDLE_WINDOW_BITS"] = str(c)
+                gpu.plan_override("WINDOW_BITS", c)
                 assert (gpu.msm_g1(pts, sc) == exp).all(), (quad, c)
-            os.environ.pop("CURDLE_WINDOW_BITS", None)
+            gpu.plan_override("WINDOW_BITS", None)
     finally:
-        os.environ.pop("CURDLE_REDUCE_SEG", None)
-        os.environ.pop("CURDLE_WINDOW_BITS", None)
+        gpu.plan_override("REDUCE_SEG", None)
+        gpu.plan_override("WINDOW_BITS", None)
 
 
 # ------------------------------------------------------- seeded random vs C oracle ---
@@ -234,15 +234,16 @@ def test_randomised_differential_small_cases(gpu, oracle, coracle):
                 else:
                     sc_int.append(int.from_bytes(rng.bytes(32), "big") % oracle.R)
             sc = np.array([oracle.fr_to_mont_limbs(v) for v in sc_int], dtype=np.uint64)
-            os.environ["CURDLE_WINDOW_BITS"] = str(int(rng.integers(4, 17)))
-            os.environ["CURDLE_SEG_LEN"] = str(int(rng.integers(8, 40)))
-            os.environ["CURDLE_REDUCE_SEG"] = str(1 << (case % 6))
+            c_case, L_case = int(rng.integers(4, 17)), int(rng.integers(8, 40))
+            gpu.plan_override("WINDOW_BITS", c_case)
+            gpu.plan_override("SEG_LEN", L_case)
+            gpu.plan_override("REDUCE_SEG", 1 << (case % 6))
             got = gpu.msm_g1(pts, sc)
             exp = coracle.msm_naive(pts, sc)
-            assert (got == exp).all(), (case, n, os.environ["CURDLE_WINDOW_BITS"], os.environ["CURDLE_SEG_LEN"])
+            assert (got == exp).all(), (case, n, c_case, L_case)
     finally:
-        for v in ("CURDLE_WINDOW_BITS", "CURDLE_SEG_LEN", "CURDLE_REDUCE_SEG"):
-            os.environ.pop(v, None)
+        for v in ("WINDOW_BITS", "SEG_LEN", "REDUCE_SEG"):
+            gpu.plan_override(v, None)
 
 
 # ---------------------------------------------------- full sizes via properties ---
@@ -291,10 +292,10 @@ def test_host_buffers_in_uneven_chunks(gpu, oracle, coracle):
     pts = d_pts.cpu().numpy().view(np.uint64)
     try:
         for chunks in ("3", "5"):
-            os.environ["CURDLE_HOST_CHUNKS"] = chunks
+            gpu.plan_override("HOST_CHUNKS", int(chunks))
             assert (gpu.msm_g1(pts, sc) == exp).all(), chunks
     finally:
-        os.environ.pop("CURDLE_HOST_CHUNKS", None)
+        gpu.plan_override("HOST_CHUNKS", None)
 
 
 def test_scalars_at_the_boundaries_of_the_split(gpu, oracle, coracle):
@@ -590,12 +591,12 @@ def test_batch_and_multi_entry_points(gpu, oracle, coracle):
             s = np.array([oracle.fr_to_mont_limbs(v % oracle.R) for v in fam], dtype=np.uint64)
             for c in (0, 6, 13):
                 if c:
-                    os.environ["CURDLE_WINDOW_BITS"] = str(c)
+                    gpu.plan_override("WINDOW_BITS", c)
                 out = gpu.msm_g1_multi(sets, s)
                 for j in range(3):
                     assert (out[j] == coracle.msm_pippenger(sets[j], s, threads=4)).all(), (name, c, j)
     finally:
-        os.environ.pop("CURDLE_WINDOW_BITS", None)
+        gpu.plan_override("WINDOW_BITS", None)
 
 
 def test_large_batch_runs_in_one_pass(gpu, oracle, coracle):

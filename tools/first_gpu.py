@@ -62,10 +62,10 @@ for n in (0, 1, 2, 3, 16, 64, 257, 300):
 # every window size
 exp64 = o.msm(base_pts[:64], base_sc[:64])
 for c in range(4, 17):
-    os.environ["CURDLE_WINDOW_BITS"] = str(c)
+    cm.plan_override("WINDOW_BITS", c)
     got = o.jac_from_mont_limbs([int(x) for x in cm.msm_g1(P_l[:64], S_l[:64])])
     log(f"msm n=64 c={c}: parity", got == exp64)
-del os.environ["CURDLE_WINDOW_BITS"]
+cm.plan_override("WINDOW_BITS", None)
 # edge: infinity base, zero scalar, scalar r-1, duplicates, all-equal scalars
 pts_e = list(base_pts[:8]) + [None, base_pts[0], base_pts[0], o.neg(base_pts[1])]
 sc_e = list(base_sc[:8]) + [12345, o.R - 1, 0, base_sc[1]]
