@@ -179,7 +179,9 @@ static constexpr int kMaxDevices = CURDLE_MAX_DEVICES;
 Ctx g_ctxs[kMaxDevices];
 std::atomic<int> g_ndev{1};  // configured contexts: [0, g_ndev)
 std::mutex g_cfg_mu;         // configuration (curdle_init_devices / curdle_shutdown)
+std::atomic<int> g_multi_calls{0};  // calls that span the devices' host threads right now
 thread_local int tl_dev = 0;
+thread_local bool tl_selected = false;  // the thread called curdle_set_device: its host-buffer MSMs stay on that device
 // the calling thread's context; a thread whose selection no longer exists (curdle_shutdown since) is on 0
 inline Ctx& cur() { return g_ctxs[tl_dev < g_ndev.load(std::memory_order_acquire) ? tl_dev : 0]; }
 const bool g_ordinals_set = [] {
@@ -199,6 +201,7 @@ struct DevWorker {
   explicit DevWorker(int ordinal) {
     th = std::thread([this, ordinal] {
       tl_dev = ordinal;
+      tl_selected = true;
       for (;;) {
         std::function<void()> job;
         {
@@ -208,7 +211,12 @@ struct DevWorker {
           job = std::move(q.front());
           q.pop_front();
         }
-        job();
+        try {
+          job();
+        } catch (...) {
+          // a job reports through its own record (run_on_devices converts exceptions to a status); nothing
+          // may leave this thread function: an escaped exception is std::terminate for the whole host process
+        }
       }
     });
   }
@@ -277,6 +285,7 @@ int init_locked(Ctx& cx, int device) {
     return fail(CURDLE_ENODEV, "no HIP device visible (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
   if (device < 0 || device >= ndev) return fail(CURDLE_EINVAL, "device %d out of range (%d visible)", device, ndev);
   HIP_TRY(hipSetDevice(device));
+  cx.device = device;  // from here on a failure leaves handles behind: curdle_init_devices tears them down
   HIP_TRY(hipStreamCreateWithFlags(&cx.util_stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&cx.h2d_stream, hipStreamNonBlocking));
   int prio_least = 0, prio_greatest = 0;
@@ -1479,6 +1488,8 @@ extern "C" int curdle_g1_scalar_mul_batch(const uint64_t* points, const uint64_t
 // ---------------------------------------------------------------------------
 namespace {
 // Everything a context owns; the caller holds cx.mu and has checked that nothing is in flight.
+// Every handle is checked for null: a context whose initialisation failed half-way is torn down by
+// the same code (teardown_partial_locked).
 void teardown_locked(Ctx& C) {
   (void)hipSetDevice(C.device);
   for (DSlot& d : C.dslots) {
@@ -1512,7 +1523,7 @@ void teardown_locked(Ctx& C) {
     d.decoded = nullptr;
   }
   for (Slot& S : C.slots) {
-    (void)hipStreamSynchronize(S.stream);
+    if (S.stream) (void)hipStreamSynchronize(S.stream);
     for (int i = 0; Buf* b = S.all_bufs(i); i++) {
       if (b->p) (void)hipFree(b->p);
       b->p = nullptr;
@@ -1529,15 +1540,17 @@ void teardown_locked(Ctx& C) {
     if (S.ev_made)
       for (auto& e : S.ev) (void)hipEventDestroy(e);
     S.ev_made = false;
-    (void)hipStreamDestroy(S.stream);
+    if (S.stream) (void)hipStreamDestroy(S.stream);
     S.stream = nullptr;
-    (void)hipEventDestroy(S.acc_done);
+    if (S.acc_done) (void)hipEventDestroy(S.acc_done);
     S.acc_done = nullptr;
-    (void)hipEventDestroy(S.pre_done);
+    if (S.pre_done) (void)hipEventDestroy(S.pre_done);
     S.pre_done = nullptr;
   }
-  (void)hipStreamSynchronize(C.main_stream);
-  (void)hipStreamDestroy(C.main_stream);
+  if (C.main_stream) {
+    (void)hipStreamSynchronize(C.main_stream);
+    (void)hipStreamDestroy(C.main_stream);
+  }
   C.main_stream = nullptr;
   for (auto& st : C.main_extra) {
     if (!st) continue;
@@ -1545,19 +1558,24 @@ void teardown_locked(Ctx& C) {
     (void)hipStreamDestroy(st);
     st = nullptr;
   }
-  (void)hipStreamSynchronize(C.pre_stream);
-  (void)hipStreamDestroy(C.pre_stream);
-  C.pre_stream = nullptr;
-  (void)hipStreamSynchronize(C.pre_stream2);
-  (void)hipStreamDestroy(C.pre_stream2);
-  C.pre_stream2 = nullptr;
-  (void)hipStreamDestroy(C.util_stream);
+  for (hipStream_t* st : {&C.pre_stream, &C.pre_stream2}) {
+    if (*st) {
+      (void)hipStreamSynchronize(*st);
+      (void)hipStreamDestroy(*st);
+    }
+    *st = nullptr;
+  }
+  if (C.util_stream) (void)hipStreamDestroy(C.util_stream);
   C.util_stream = nullptr;
-  (void)hipStreamDestroy(C.h2d_stream);
+  if (C.h2d_stream) (void)hipStreamDestroy(C.h2d_stream);
   C.h2d_stream = nullptr;
   C.inited = false;
   C.dstreams_ready.store(false, std::memory_order_release);
-  C.epoch++;  // device memory of curdle_dbases handles made under this context is gone with it
+  C.epoch++;  // curdle_dbases copies made under this context are re-made (and the old ones freed) on their next use
+}
+void teardown_partial_locked(Ctx& C) {
+  teardown_locked(C);
+  C.device = 0;
 }
 }  // namespace
 
@@ -1583,11 +1601,32 @@ extern "C" int curdle_init_devices(const int* devices, int n) {
     if (!same) return fail(CURDLE_EINVAL, "already initialised on %d device(s); curdle_shutdown first", have);
     return CURDLE_OK;
   }
+  // all or nothing: a context this call brought up is torn down again when a later one fails (bad id,
+  // stream creation, out of memory) -- left standing it made every retry fail with "already initialised
+  // on device X" until the process ended, and curdle_shutdown, which walks [0, g_ndev), never reached
+  // it (review of round 3).  A context that was up before the call (curdle_init) stays.
+  bool brought_up[kMaxDevices] = {};
   for (int i = 0; i < n; i++) {
     Ctx& cx = g_ctxs[i];
-    std::lock_guard<std::mutex> g(cx.mu);
-    int rc = init_locked(cx, devices[i]);  // context 0 may be up already (curdle_init): same device or CURDLE_EINVAL
-    if (rc) return rc;
+    int rc;
+    {
+      std::lock_guard<std::mutex> g(cx.mu);
+      const bool was = cx.inited;
+      rc = init_locked(cx, devices[i]);  // context 0 may be up already (curdle_init): same device or CURDLE_EINVAL
+      brought_up[i] = !was && cx.inited;
+      if (rc && !was && !cx.inited) brought_up[i] = cx.util_stream != nullptr;  // failed half-way: its streams exist
+    }
+    if (rc) {
+      char keep[256];
+      snprintf(keep, sizeof(keep), "%s", g_err);
+      for (int j = 0; j <= i; j++) {
+        if (!brought_up[j]) continue;
+        Ctx& cj = g_ctxs[j];
+        std::lock_guard<std::mutex> g(cj.mu);
+        teardown_partial_locked(cj);
+      }
+      return fail(rc, "%s", keep);
+    }
   }
   if (n > 1)
     for (int i = 0; i < n; i++)
@@ -1599,9 +1638,15 @@ extern "C" int curdle_init_devices(const int* devices, int n) {
 extern "C" int curdle_device_count(void) { return g_ndev.load(std::memory_order_acquire); }
 
 extern "C" int curdle_set_device(int ordinal) {
+  if (ordinal == -1) {  // no selection: context 0, and large host-buffer MSMs may spread over all devices again
+    tl_dev = 0;
+    tl_selected = false;
+    return CURDLE_OK;
+  }
   if (ordinal < 0 || ordinal >= g_ndev.load(std::memory_order_acquire))
     return fail(CURDLE_EINVAL, "device ordinal %d outside [0, %d)", ordinal, g_ndev.load());
   tl_dev = ordinal;
+  tl_selected = true;
   return CURDLE_OK;
 }
 
@@ -1610,6 +1655,7 @@ extern "C" int curdle_get_device(void) { return cur().ordinal; }
 extern "C" int curdle_shutdown(void) {
   std::lock_guard<std::mutex> cfg(g_cfg_mu);
   const int have = g_ndev.load(std::memory_order_acquire);
+  if (g_multi_calls.load(std::memory_order_acquire) > 0) return fail(CURDLE_EBUSY, "a multi-device call is still in flight");
   for (int i = 0; i < have; i++) {  // all or nothing: first make sure no context has work in flight
     Ctx& C = g_ctxs[i];
     std::lock_guard<std::mutex> g(C.mu);
@@ -1691,14 +1737,36 @@ int run_on_devices(int D, const std::function<int(int, uint64_t*)>& share, uint6
   std::mutex mu;
   std::condition_variable cv;
   int left = D;
-  for (int d = 0; d < D; d++)  // before anything is posted: the jobs below refer to this frame
-    if (!g_ctxs[d].worker) return fail(CURDLE_EINVAL, "context %d has no host thread (curdle_init_devices was not called)", d);
+  // the devices' host threads are read under the configuration mutex and pinned for the duration of the
+  // call: curdle_shutdown meanwhile returns CURDLE_EBUSY instead of deleting them underneath (review of round 3)
+  struct InFlight {
+    bool on = false;
+    ~InFlight() {
+      if (on) g_multi_calls.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  } in_flight;
+  {
+    std::lock_guard<std::mutex> cfg(g_cfg_mu);
+    if (D != g_ndev.load(std::memory_order_acquire)) return fail(CURDLE_EBUSY, "the device configuration changed under the call");
+    for (int d = 0; d < D; d++)  // before anything is posted: the jobs below refer to this frame
+      if (!g_ctxs[d].worker) return fail(CURDLE_EINVAL, "context %d has no host thread (curdle_init_devices was not called)", d);
+    g_multi_calls.fetch_add(1, std::memory_order_acq_rel);
+    in_flight.on = true;
+  }
   for (int d = 0; d < D; d++) {
     DevWorker* w = g_ctxs[d].worker;
     w->post([&, d] {
       Part& p = parts[(size_t)d];
-      p.rc = share(d, p.jac);
-      if (p.rc) snprintf(p.err, sizeof(p.err), "%s", g_err);  // the worker's thread-local text
+      try {
+        p.rc = share(d, p.jac);
+        if (p.rc) snprintf(p.err, sizeof(p.err), "%s", g_err);  // the worker's thread-local text
+      } catch (const std::bad_alloc&) {  // the std::vector allocations of finish_slot / run_passes / run_host_chunked
+        p.rc = CURDLE_ENOMEM;
+        snprintf(p.err, sizeof(p.err), "out of host memory");
+      } catch (const std::exception& e) {
+        p.rc = CURDLE_EHIP;
+        snprintf(p.err, sizeof(p.err), "%s", e.what());
+      }
       std::lock_guard<std::mutex> g(mu);
       if (--left == 0) cv.notify_one();
     });
@@ -1744,7 +1812,7 @@ extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, si
   if (!points || !scalars) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
   const int D = g_ndev.load(std::memory_order_acquire);
-  if (D > 1 && n >= multi_device_min()) {
+  if (D > 1 && n >= multi_device_min() && !tl_selected) {  // a thread that selected a device (a batch shard, OnDevice) keeps its MSM there
     // Several GPUs behind this one call (curdle_init_devices): by POINT RANGES -- from host buffers
     // the copy is most of the call (128 MiB at N = 2^20 over one GPU's PCIe link), and only a point
     // range divides it: every device copies its own n / D pairs over its own link and runs all

@@ -70,20 +70,27 @@ int curdle_init(int device);
  *     made resident lazily on every context that uses it;
  *   - curdle_msm_g1 splits a large host-buffer MSM by POINT RANGES over all contexts (each GPU
  *     copies and runs its own n / D pairs, the host thread of each device drives it, the D
- *     partial sums are added on the host with the code of curdle_g1_sum: no collective);
+ *     partial sums are added on the host with the code of curdle_g1_sum: no collective) --
+ *     unless the calling thread has SELECTED a device with curdle_set_device: a thread pinned
+ *     to a device (a batch shard, curdlemsm.OnDevice) keeps its MSM there;
  *   - curdle_msm_g1_replicated does the same for inputs the caller keeps resident on every
  *     GPU, by Pippenger windows (north_star's partition) or point ranges;
  *   - curdle_verify_batch and curdle_whisk_is_valid_shuffle_proof_batch shard their proofs
  *     over the contexts (BASELINE config 5: replicas, no data-path exchange).
  * n = 1 is curdle_init(devices[0]).  Fails with CURDLE_EINVAL if the library is already
- * initialised on a different list. */
+ * initialised on a different list.  All or nothing: if one entry cannot be brought up (bad id,
+ * out of memory), every context this call created is closed again and a retry starts clean.
+ * The multi-device paths were exercised as two contexts on one GPU and under a logical-device
+ * interposer (tools/logical_devices_shim.cpp), never on two physical GPUs: unmeasured there. */
 #define CURDLE_MAX_DEVICES 16
 int curdle_init_devices(const int* devices, int n);
 int curdle_device_count(void);      /* contexts configured (1 unless curdle_init_devices said more) */
-int curdle_set_device(int ordinal); /* this thread's current context, 0 <= ordinal < curdle_device_count() */
+/* This thread's current context, 0 <= ordinal < curdle_device_count(); -1 = no selection (context
+ * 0, and large host-buffer MSMs may spread over all devices again). */
+int curdle_set_device(int ordinal);
 int curdle_get_device(void);
 /* Closes every context (streams, workspaces, host threads).  CURDLE_EBUSY while an MSM or a point
- * decoding is in flight on a slot.  Like every teardown of a library, it must not run
+ * decoding is in flight on a slot, or a call that spans the devices' host threads is running.  Like every teardown of a library, it must not run
  * concurrently with other entry points: a call that has not taken its slot yet is not seen. */
 int curdle_shutdown(void);
 /* Copies the calling thread's last error text (NUL-terminated) into buf. */

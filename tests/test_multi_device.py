@@ -27,10 +27,32 @@ def two(gpu):
     gpu.init_devices(DEVS)
     assert gpu.device_count() == 2
     yield gpu
-    gpu.set_device(0)
+    gpu.set_device(-1)
     gpu.shutdown()
     gpu.init(0)
     assert gpu.device_count() == 1
+
+
+def test_init_devices_is_all_or_nothing(gpu, oracle, coracle):
+    """A list with a device that cannot be brought up leaves NOTHING behind: the contexts the call
+    had created are closed again, the configuration is what it was, a retry starts clean (review of
+    round 3: contexts [0, i) stayed initialised, unreachable for curdle_shutdown, and every later
+    list failed with "already initialised on device X")."""
+    cm = gpu
+    assert cm.device_count() == 1
+    for bad in ([DEVS[0], 99], [DEVS[0], DEVS[1], 99], [99]):
+        with pytest.raises(cm.CurdleError):
+            cm.init_devices(bad)
+        assert cm.device_count() == 1
+    k, q = oracle.Rand(5).get_frs(2)
+    pts = coracle.points_walk(k, q, 300)
+    sc = rand_scalars(np.random.default_rng(5), 300, oracle)
+    assert (cm.msm_g1(pts, sc) == coracle.msm_pippenger(pts, sc, threads=2)).all()   # context 0 is untouched
+    cm.init_devices(DEVS)                                  # ... and the good list comes up
+    assert cm.device_count() == 2
+    cm.shutdown()
+    cm.init(0)
+    assert cm.device_count() == 1
 
 
 def on_device(cm, ordinal, fn):
@@ -68,6 +90,14 @@ def test_contexts_and_tickets(two, oracle, coracle):
     sc = rand_scalars(np.random.default_rng(3), n, oracle)
     exp = coracle.msm_pippenger(pts, sc, threads=4)
     assert (on_device(cm, 1, lambda: cm.msm_g1(pts, sc)) == exp).all()
+    # a thread that SELECTED a device keeps a large host-buffer MSM there (the calling thread of this
+    # test never selected one: its large calls spread over both, test_one_msm_over_both_contexts)
+    big_n = 1 << 16
+    big_pts = coracle.points_walk(k, q, big_n)
+    big_sc = rand_scalars(np.random.default_rng(33), big_n, oracle)
+    big_exp = coracle.msm_pippenger(big_pts, big_sc, threads=8)
+    assert (on_device(cm, 1, lambda: cm.msm_g1(big_pts, big_sc)) == big_exp).all()
+    assert (cm.msm_g1(big_pts, big_sc) == big_exp).all()
     # a ticket names its context: submitted on context 1, waited for from a thread on context 0
     # every context reads inputs resident on ITS device
     d_p = [torch.from_numpy(pts.view(np.int64)).to(f"cuda:{DEVS[d]}") for d in (0, 1)]
