@@ -156,8 +156,17 @@ __device__ __forceinline__ bool in_subgroup(F28& x, F28& y, u32 (*sh_x)[kBlock],
 // SUB: with the subgroup test behind the square root (one-shot decodings too large for the
 // two-kernel form); without it the kernel is the square-root half of that form and carries none
 // of the point arithmetic's registers.
+// The one-lane builds (batches beyond 32,768 points) at TWO waves per SIMD have 256 registers and spill
+// 20-22 of them to scratch (96 bytes per lane).  Compiled for ONE wave per SIMD (-DCURDLE_LANE_WAVES=1)
+// the allocator takes the accumulation registers too and nothing spills -- measured, round 4
+// (profiles/r04_decode_one_lane.txt): 65,536 points 2.94 ms without spills against
+// 2.97 with, 2^20 points 54.0 against 49.0 ms (subgroup test on), 30.4 against 29.6 (off): the second
+// wave is worth more than the 22 scratch words cost, so the spilling build stays.
+#ifndef CURDLE_LANE_WAVES
+#define CURDLE_LANE_WAVES 2
+#endif
 template <bool QUAD, bool SUB>
-__global__ void __launch_bounds__(kBlock, 2)
+__global__ void __launch_bounds__(kBlock, QUAD ? 2 : CURDLE_LANE_WAVES)
     k_g1_decompress(const uint8_t* __restrict__ in, u32 n, u32* __restrict__ out, uint8_t* __restrict__ status) {
   // x and y wait in LDS (limb-major: conflict-free) while the subgroup test runs: with the
   // two 56-register points of the scalar multiplication live there is no room for them.
@@ -285,7 +294,7 @@ __global__ void __launch_bounds__(kBlock, 2)
 // happen for x < p: the curve has odd order, so no point has y = 0.)
 // Writes sub[i] = 1 (in the subgroup, or not a candidate: malformed / infinity records) or 0.
 template <bool QUAD>
-__global__ void __launch_bounds__(kBlock, 2)
+__global__ void __launch_bounds__(kBlock, QUAD ? 2 : CURDLE_LANE_WAVES)
     k_g1_subgroup_from_x(const uint8_t* __restrict__ in, u32 n, uint8_t* __restrict__ sub) {
   __shared__ u32 sh_x[d28::N][kBlock];
   __shared__ u32 sh_y[d28::N][kBlock];

@@ -346,8 +346,12 @@ int choose_window_bits(size_t n, bool many = false) {
   // terms go through merge_large), so the steps sit well before them.  A large batch of small
   // MSMs is throughput-bound instead (wider windows double its bucket-reduce work) and keeps
   // lg - 2.
-  if (!many && n >= 600) c = n <= 3000 ? 8 : n <= 12000 ? 10 : n <= 160000 ? 11 : n <= 400000 ? 14 : n <= 900000 ? 15 : 16;
-  if (n >= 600 && c < 8 && !many) c = 8;
+  // Round 4, with the bucket reduction that no longer multiplies (its chain is a handful of additions per
+  // level, so wider windows cost less than they did; profiles/r04_window_bits_sweep.txt, pairs -> ms): 10
+  // from 300 pairs (628: 0.346 against 0.354 at 8; 1,268 -- the verifier's MSM -- 0.359 against 0.387;
+  // 2,548: 0.383), 11 from 3,000 (4,096: 0.398 against 0.418 at 10) up to 45,000, 13 up to 100,000
+  // (65,536: 0.666 against 0.711 at 11), 14 up to 200,000, 15 up to 450,000, 16 beyond.
+  if (!many && n >= 600) c = n <= 6000 ? 10 : n <= 90000 ? 11 : n <= 200000 ? 13 : n <= 400000 ? 14 : n <= 900000 ? 15 : 16;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
   return c;
@@ -428,7 +432,9 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // rule before this one left at 4-bucket segments, two rounds of quads for 8 windows --
   // 1.83 -> 1.52, 0.98 -> 0.88 and 0.61 -> 0.59 ms.
   if (latency_mode) {
-    uint64_t lanes = 65536;
+    // (round 4: a whole round, 131,072 lanes, since the reduction lost its per-segment scalar multiple: shorter
+    // segments now cost a quad almost nothing extra -- 131,072 pairs 0.93 -> 0.89 ms, 2^20 3.45 -> 3.41)
+    uint64_t lanes = 131072;
     if (knobs::get(knobs::SYNC_LANES) > 0) lanes = (uint64_t)knobs::get(knobs::SYNC_LANES);
     uint32_t seg = 1;
     while (nbk / seg * 4 > lanes && seg < 32) seg *= 2;
