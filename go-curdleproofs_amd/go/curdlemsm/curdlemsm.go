@@ -106,6 +106,11 @@ var MinGPUPairs = 32
 // gnark's Decoder / SetBytes, which check the subgroup.
 //
 // Inputs below MinGPUPairs stay on gnark's CPU path (cfg: the reference's common.MultiExpConf).
+//
+// If the GPU call fails (no device, out of memory, a HIP error) and FallbackToCPU is set, the
+// result comes from gnark's MultiExp instead and the GPU's error is handed to OnFallback:
+// SURVEY.md section 5's failure row wants a verifier's accept bits to be independent of the
+// GPU's health.  Off by default: a deployment that bought a GPU wants to hear that it is not used.
 func MultiExp(dst *bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Element, cfg ecc.MultiExpConfig) (*bls12381.G1Jac, error) {
 	if len(points) != len(scalars) {
 		return nil, errors.New("len(points) != len(scalars)")
@@ -123,6 +128,107 @@ func MultiExp(dst *bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Elem
 			(*C.uint64_t)(unsafe.Pointer(dst)))
 	})
 	if err != nil {
+		if FallbackToCPU {
+			if OnFallback != nil {
+				OnFallback(err)
+			}
+			return dst.MultiExp(points, scalars, cfg)
+		}
+		return nil, err
+	}
+	return dst, nil
+}
+
+// FallbackToCPU: a failed GPU call is answered by gnark's CPU MultiExp (same result: both compute
+// the group element) instead of an error.  OnFallback, if set, hears the GPU's error each time
+// (log it, count it, page someone).
+var (
+	FallbackToCPU = false
+	OnFallback    func(gpuErr error)
+)
+
+// Split of MultiExpReplicated (CURDLE_SPLIT_* in curdle_msm.h).
+const (
+	SplitAuto    = 0 // the library's rule: windows up to 2^21 pairs, point ranges beyond
+	SplitWindows = 1 // north_star's partition: device d runs Pippenger windows [w_d, w_d+1) over all pairs
+	SplitPoints  = 2 // device d runs all windows over pairs [d n/D, (d+1) n/D)
+)
+
+// MultiExpReplicated is INTEGRATION.md section 3.1's call: ONE MSM over inputs the caller keeps
+// RESIDENT on every configured device (InitDevices), split by Pippenger windows or by point
+// ranges, the D partial sums added on the host (curdle_msm_g1_replicated; BASELINE config 4 from
+// one Go process).  dPoints[d] / dScalars[d] are DEVICE pointers on device d (n x 96 B gnark
+// G1Affine, n x 32 B fr.Element), e.g. from hipMalloc through another binding; they are passed
+// through as integers, never dereferenced by Go.
+func MultiExpReplicated(dst *bls12381.G1Jac, dPoints, dScalars []uintptr, n int, split int) error {
+	d := DeviceCount()
+	if len(dPoints) != d || len(dScalars) != d {
+		return fmt.Errorf("curdlemsm: MultiExpReplicated: %d devices configured, %d / %d pointers given", d, len(dPoints), len(dScalars))
+	}
+	// two C arrays of D device addresses (not Go pointers: nothing to pin)
+	pa := (*[1 << 8]unsafe.Pointer)(C.calloc(C.size_t(2*d), C.size_t(unsafe.Sizeof(uintptr(0)))))
+	if pa == nil {
+		return errors.New("curdlemsm: out of memory")
+	}
+	defer C.free(unsafe.Pointer(pa))
+	for i := 0; i < d; i++ {
+		pa[i] = unsafe.Pointer(dPoints[i])   //nolint:govet // a device address travelling as an integer
+		pa[d+i] = unsafe.Pointer(dScalars[i]) //nolint:govet
+	}
+	return locked(func() C.int {
+		return C.curdle_msm_g1_replicated((*unsafe.Pointer)(unsafe.Pointer(&pa[0])), (*unsafe.Pointer)(unsafe.Pointer(&pa[d])),
+			C.size_t(n), C.int(split), (*C.uint64_t)(unsafe.Pointer(dst)))
+	})
+}
+
+// ResidentBases is a base set converted once and kept on the GPU (curdle_dbases): the CRS of a
+// verifier (crs.go:10-18) -- msmaccumulator.Verify's bases are mostly those.  MultiExp over it
+// uploads 32 bytes per pair (the scalars) instead of 128 and converts nothing.
+type ResidentBases struct{ h *C.curdle_dbases }
+
+// NewResidentBases copies and converts the points now (on the calling thread's device; every other
+// configured device makes its copy the first time it is used there).
+func NewResidentBases(points []bls12381.G1Affine) (*ResidentBases, error) {
+	r := &ResidentBases{}
+	var pp unsafe.Pointer
+	if len(points) > 0 {
+		pp = unsafe.Pointer(&points[0])
+	}
+	if err := locked(func() C.int { return C.curdle_dbases_create((*C.uint64_t)(pp), C.size_t(len(points)), &r.h) }); err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(r, func(r *ResidentBases) { r.Free() })
+	return r, nil
+}
+
+// Free releases the device copies (deferred by the library while an MSM still reads them).
+func (r *ResidentBases) Free() {
+	if r.h != nil {
+		C.curdle_dbases_free(r.h)
+		r.h = nil
+	}
+}
+
+// MultiExp: dst = sum_i scalars[i] * bases[i] over the first len(scalars) bases of the set.  Same
+// fallback rule as MultiExp (the caller passes the bases' host copy for that case, or nil).
+func (r *ResidentBases) MultiExp(dst *bls12381.G1Jac, scalars []fr.Element, hostBases []bls12381.G1Affine, cfg ecc.MultiExpConfig) (*bls12381.G1Jac, error) {
+	if r.h == nil {
+		return nil, errors.New("curdlemsm: resident bases were freed")
+	}
+	var sp unsafe.Pointer
+	if len(scalars) > 0 {
+		sp = unsafe.Pointer(&scalars[0])
+	}
+	err := locked(func() C.int {
+		return C.curdle_msm_g1_dbases_host(r.h, (*C.uint64_t)(sp), C.size_t(len(scalars)), (*C.uint64_t)(unsafe.Pointer(dst)))
+	})
+	if err != nil {
+		if FallbackToCPU && len(hostBases) >= len(scalars) {
+			if OnFallback != nil {
+				OnFallback(err)
+			}
+			return dst.MultiExp(hostBases[:len(scalars)], scalars, cfg)
+		}
 		return nil, err
 	}
 	return dst, nil
