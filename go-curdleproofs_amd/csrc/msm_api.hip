@@ -372,7 +372,7 @@ int window_widths(int c, uint8_t bits[kMaxWindows]) {
 
 // Plan for k MSMs of n_total pairs in all, the largest having n_max pairs.
 int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end,
-              bool latency_mode, size_t sets = 1, bool many = false, uint32_t seg_override = 0) {
+              bool latency_mode, size_t sets = 1, bool many = false, uint32_t seg_override = 0, bool light_host = false) {
   if (n_total > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n_total);
   many = many || k * sets >= gpu_combine_min();  // a pass of a larger batch keeps the batch's rules
   if (c == 0) c = choose_window_bits(n_max, many);
@@ -455,9 +455,19 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // the window leaves the GPU as bit-positioned points for the host's Horner pass.  Batches and
   // shared-scalar calls keep k_bucket_reduce_quad: their host pass runs once per RESULT, and ~8 more
   // additions per window and result cost the host more than the GPU saves.
+  // ... and tiny MSMs too (below 300 pairs the plan has 19-32 windows of 8-64 buckets: five to seven points
+  // per window for the host against a 3-to-6-bit multiple on the GPU -- 8..299 pairs measured 0.01-0.03 ms
+  // slower, and the batch verifiers, which are host-bound, lost a quarter of their throughput to the
+  // longer host passes of their per-proof MSMs: profiles/r04_reduce_bits_small.txt).
+  // Knob REDUCE_BITS: 0 / 1 = never / wherever the shapes allow; 2 = synchronous calls only.
   {
     const long long forced = knobs::get(knobs::REDUCE_BITS);
-    p.reduce_bits = (forced < 0 ? k * sets == 1 : forced != 0) && !many ? 1u : 0u;
+    // (light_host: a queued MSM of a batch verifier -- a host-bound caller with dozens in flight, to whom the
+    // longer host pass costs throughput and the shorter GPU chain buys nothing: 1,024 Whisk proofs 31-36 ms
+    // per batch with k_bucket_reduce_quad, 41-46 with this form)
+    const bool shapes = k * sets == 1 && !many && !light_host;
+    const bool pays = n_total >= 600;  // terms: two per pair
+    p.reduce_bits = shapes && (forced < 0 ? pays : forced == 1 || (forced == 2 && pays && latency_mode)) ? 1u : 0u;
   }
   const uint32_t gmax = p.reduce_bits ? 16u : 64u;  // quads per group: one wave's, or one block's
   p.G = min_nbkt / p.seg < gmax ? min_nbkt / p.seg : gmax;
@@ -630,7 +640,7 @@ struct ChunkJoin {
 int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                  int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail,
                  bool latency_mode = true, bool points28_ready = false, size_t sets = 1, bool many = false,
-                 const ChunkJoin* join = nullptr, const void* ext_points28 = nullptr) {
+                 const ChunkJoin* join = nullptr, const void* ext_points28 = nullptr, bool light_host = false) {
   // ext_points28: the bases are a resident, pre-converted set (curdle_dbases: two records per base in the internal
   // form, the first h_off[k] of them) -- d_points is not read, nothing is converted or copied
   if (ext_points28 && (k != 1 || sets != 1)) return fail(CURDLE_EINVAL, "resident bases take one MSM per call");
@@ -643,7 +653,7 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
     if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
   }
   MsmPlan& p = S.plan;
-  int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets, many, join ? join->seg : 0);
+  int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets, many, join ? join->seg : 0, light_host);
   if (rc) return rc;
   // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
   const size_t n = 2 * n_pairs;
@@ -2092,14 +2102,18 @@ int dbases_acquire(Ctx& cx, curdle_dbases* b, void** d28) {
   const int o = cx.ordinal;
   unsigned epoch;
   int device;
+  hipStream_t st = nullptr;
   {  // the context's mutex only to bring it up and read what the copy is tied to: the upload and the
-     // conversion below run under the set's own mutex, on a stream of their own, so that they do not
-     // hold up every slot acquire / release of the context (review of round 3)
+     // conversion below run under the set's own mutex, so that they do not hold up every slot acquire /
+     // release of the context (review of round 3).  On the context's utility stream: a stream created and
+     // destroyed here cost every later verification 0.25 ms until the next hipFree
+     // (tools/dbg_verify_slowdown.py: 0.85 -> 1.09 ms at ell = 252 after ANY base set had been made).
     std::lock_guard<std::mutex> g(cx.mu);
     int rc = init_default_locked(cx);
     if (rc) return rc;
     epoch = cx.epoch;
     device = cx.device;
+    st = cx.util_stream;
   }
   if (b->d28[o] && (b->epoch[o] != epoch || b->hipdev[o] != device)) {  // a copy made under a context that was closed since
     if (hipSetDevice(b->hipdev[o]) == hipSuccess) (void)hipFree(b->d28[o]);
@@ -2108,15 +2122,12 @@ int dbases_acquire(Ctx& cx, curdle_dbases* b, void** d28) {
   if (!b->d28[o] && b->n) {
     HIP_TRY(hipSetDevice(device));
     void *dst = nullptr, *tmp = nullptr;
-    hipStream_t st = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&dst, 2 * b->n * kA28Bytes);  // P and phi(P) per base (launch_convert_points_raw)
+    hipError_t e = hipMalloc(&dst, 2 * b->n * kA28Bytes);  // P and phi(P) per base (launch_convert_points_raw)
     if (e == hipSuccess) e = hipMalloc(&tmp, b->n * 96);
     if (e == hipSuccess) e = hipMemcpyAsync(tmp, b->host.data(), b->n * 96, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_convert_points_raw(tmp, (uint32_t)b->n, dst, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (tmp) (void)hipFree(tmp);
-    if (st) (void)hipStreamDestroy(st);
     if (e != hipSuccess) {
       if (dst) (void)hipFree(dst);
       return fail(e == hipErrorOutOfMemory ? CURDLE_ENOMEM : CURDLE_EHIP, "resident bases: %s", hipGetErrorString(e));
@@ -2370,9 +2381,21 @@ extern "C" void curdle_dacc_abort(curdle_dacc* acc) {
   dacc_end(acc);
 }
 
+namespace {
+int dacc_submit_impl(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool, size_t pool_len,
+                     const uint64_t* extra_points, const uint64_t* extra_scalars, size_t n_extra, uint64_t* export_scalars,
+                     bool queued);
+}
+// The asynchronous form: what a batch worker queues before it goes on verifying (light on the host, see make_plan).
 extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool,
                                   size_t pool_len, const uint64_t* extra_points, const uint64_t* extra_scalars,
                                   size_t n_extra, uint64_t* export_scalars) {
+  return dacc_submit_impl(acc, checks, n_checks, pool, pool_len, extra_points, extra_scalars, n_extra, export_scalars, true);
+}
+namespace {
+int dacc_submit_impl(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n_checks, const uint64_t* pool, size_t pool_len,
+                     const uint64_t* extra_points, const uint64_t* extra_scalars, size_t n_extra, uint64_t* export_scalars,
+                     bool queued) {
   if (!acc) return fail(CURDLE_EINVAL, "null accumulator");
   if (acc->submitted) return fail(CURDLE_EINVAL, "accumulation already submitted");
   Ctx& cx = *acc->ctx;
@@ -2435,7 +2458,7 @@ extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* che
       HIP_TRY(hipMemcpyAsync(h + bytes, S.scalars.p, n_res * 32, hipMemcpyDeviceToHost, st));
     const uint32_t off[2] = {0, (uint32_t)n};
     if ((r = enqueue_slot(cx, S, nullptr, S.scalars.p, off, 1, 0, 0, -1, st, st, st, /*latency_mode=*/true,
-                          /*points28_ready=*/true)))
+                          /*points28_ready=*/true, 1, false, nullptr, nullptr, /*light_host=*/queued)))
       return r;
     acc->export_off = bytes;
     acc->submitted = true;
@@ -2448,6 +2471,7 @@ extern "C" int curdle_dacc_submit(curdle_dacc* acc, const curdle_dacc_check* che
   }
   return rc;
 }
+}  // namespace
 
 extern "C" int curdle_dacc_poll(curdle_dacc* acc, int* done) {
   if (!acc || !done) return fail(CURDLE_EINVAL, "null argument");
@@ -2499,7 +2523,7 @@ extern "C" int curdle_dacc_run(curdle_dacc* acc, const curdle_dacc_check* checks
     curdle_dacc_abort(acc);
     return fail(CURDLE_EINVAL, "null argument");
   }
-  int rc = curdle_dacc_submit(acc, checks, n_checks, pool, pool_len, extra_points, extra_scalars, n_extra, export_scalars);
+  int rc = dacc_submit_impl(acc, checks, n_checks, pool, pool_len, extra_points, extra_scalars, n_extra, export_scalars, false);
   if (rc) return rc;  // the submission already ended the accumulation
   return curdle_dacc_wait(acc, out_jac);
 }
