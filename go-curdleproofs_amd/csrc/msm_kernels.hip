@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kCoarseThreads)
     k_scatter_coarse(const u32* __restrict__ digits, MsmPlan p, u32* __restrict__ ccur, u32* __restrict__ tmp) {
   __shared__ u32 cnt[kCoarseMax], off[kCoarseMax + 1], gbase[kCoarseMax];
-  extern __shared__ u32 lds_cnt[];  // 80 KiB: the tile's entries sorted by bin, and each entry's bin
+  extern __shared__ u32 lds_cnt[];  // 40 KiB (kCoarseTile * 5 bytes): the tile's entries sorted by bin, and each entry's bin -- below the 64 KiB default, no opt-in needed
   u32* buf = lds_cnt;
   unsigned char* binof = reinterpret_cast<unsigned char*>(lds_cnt + kCoarseTile);
   const u32 tid = threadIdx.x, lw = blockIdx.y;
