@@ -440,9 +440,10 @@ def main():
                         "kernel_span_ms_in_pipeline": span, "valu": valu,
                         "note": "achieved = 128 B x n / the kernel's own duration (HIP events, nothing else in flight); "
                                 "integer-VALU bound (381-bit Montgomery arithmetic), see DESIGN.md.  kernel_ms_alone is "
-                                "the PIPELINED plan's kernels run alone: its bucket reduce takes 64-bucket segments (a "
-                                "quarter round of lanes, a longer chain) because it runs beside the next MSM's "
-                                "accumulation; the synchronous plan behind single_call_ms takes 32 (0.6 ms)"}
+                                "the PIPELINED plan's kernels run alone: its bucket reduce (k_reduce_segments) takes "
+                                "32-bucket segments (a quarter round of lanes, a longer chain) because it runs beside "
+                                "the next MSM's accumulation; the synchronous plan behind single_call_ms takes 8 "
+                                "(0.26-0.30 ms; window_sum = k_reduce_level)"}
         out = {
             "metric": f"BLS12-381 G1 MSM scalar-point pairs/sec at N=2^{args.logn}",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -72,7 +72,9 @@ def test_device_selection_and_multi_device_entry_points_check_their_arguments(cm
         cm.set_device(cm.device_count())
     assert e.value.code == cm.EINVAL
     with pytest.raises(cm.CurdleError):
-        cm.set_device(-1)
+        cm.set_device(-2)
+    cm.set_device(-1)                      # "no selection": context 0, host MSMs may spread over all devices again
+    assert cm.get_device() == 0
     out = np.zeros(18, dtype=np.uint64)
     assert lib.curdle_msm_g1_replicated(None, None, 5, 0, None) == cm.EINVAL          # no output
     assert lib.curdle_msm_g1_replicated(None, None, 5, 3, out.ctypes.data) == cm.EINVAL  # no such split
