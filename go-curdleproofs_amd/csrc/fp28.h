@@ -80,7 +80,23 @@ CURDLE_D28_TABLE(kK8B, 0x4ffd5558u, 0x4f7ffffbu, 0x4ffffdcbu, 0x4fff58a5u, 0x412
                  0x49c2895bu, 0x43ba5c23u, 0x45d66baeu, 0x4d3db216u, 0x434d2589u, 0x4f51cbfbu, 0x000d0084u)
 #undef CURDLE_D28_TABLE
 
+#ifdef CURDLE_MAC_PLAIN
+// Experiment switch (round 4): the column blocks in plain C instead of the generated inline asm --
+// the same v_mad_u64_u32 count, none of the wait states hipcc pads after every asm statement, but
+// ~210 more v_lshl_add_u64 per mixed addition.  profiles/r04_mac_plain_vs_asm.txt has the timing.
+template <int K>
+__device__ __forceinline__ void m28v(u64& acc, const u32* a, const u32* b) {
+#pragma unroll
+  for (int i = 0; i < K; i++) acc += (u64)a[i] * (u64)b[-i];
+}
+template <int K>
+__device__ __forceinline__ void m28s(u64& acc, const u32* a, const u32* b) {
+#pragma unroll
+  for (int i = 0; i < K; i++) acc += (u64)a[i] * (u64)b[-i];
+}
+#else
 #include "mac28_gfx950.inc"
+#endif
 
 struct PTable {
   u32 v[N];
