@@ -94,8 +94,21 @@ __device__ __forceinline__ void m28s(u64& acc, const u32* a, const u32* b) {
 #pragma unroll
   for (int i = 0; i < K; i++) acc += (u64)a[i] * (u64)b[-i];
 }
+template <int K>
+__device__ __forceinline__ void m28vset(u64& acc, const u32* a, const u32* b) {
+  acc = 0;
+  m28v<K>(acc, a, b);
+}
 #else
 #include "mac28_gfx950.inc"
+#ifdef CURDLE_MAC_NO_SET  // A/B: the accumulator zeroed by a move in front of the chain, as before round 4
+#define m28vset m28vset_by_move
+template <int K>
+__device__ __forceinline__ void m28vset_by_move(u64& acc, const u32* a, const u32* b) {
+  acc = 0;
+  m28v<K>(acc, a, b);
+}
+#endif
 #endif
 
 struct PTable {
@@ -115,10 +128,13 @@ __device__ __forceinline__ void mul_inl(F28& r, const F28& a, const F28& b) {
   const PTable P;
   u32 m[N];
   u32 t[N];
-  u64 acc = 0;
+  u64 acc;
   static_for<0, N>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    m28v<k + 1>(acc, &a.l[0], &b.l[k]);
+    if constexpr (k == 0)
+      m28vset<1>(acc, &a.l[0], &b.l[0]);  // the chain's first product sets the accumulator (no v_mov_b64 acc, 0)
+    else
+      m28v<k + 1>(acc, &a.l[0], &b.l[k]);
     if constexpr (k > 0) m28s<k>(acc, &m[0], &P.v[k]);
     m[k] = ((u32)acc * N0) & MASK;
     m28s<1>(acc, &m[k], &P.v[0]);
@@ -143,17 +159,20 @@ __device__ __forceinline__ void sqr_inl(F28& r, const F28& a) {
   const PTable P;
   u32 m[N];
   u32 t[N];
-  u64 acc = 0;
+  u64 acc;
   static_for<0, 2 * N - 1>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     constexpr int lo = k < N ? 0 : k - N + 1;   // smallest i with k - i <= N-1
     constexpr int pairs = (k + 1) / 2 - lo;     // i in [lo, k/2) with i < k - i
     if constexpr (pairs > 0) {
-      u64 cross = 0;
-      m28v<pairs>(cross, &a.l[lo], &a.l[k - lo]);
+      u64 cross;
+      m28vset<pairs>(cross, &a.l[lo], &a.l[k - lo]);
       acc += cross << 1;
     }
-    if constexpr (k % 2 == 0) m28v<1>(acc, &a.l[k / 2], &a.l[k / 2]);
+    if constexpr (k == 0)
+      m28vset<1>(acc, &a.l[0], &a.l[0]);
+    else if constexpr (k % 2 == 0)
+      m28v<1>(acc, &a.l[k / 2], &a.l[k / 2]);
     if constexpr (k < N) {
       if constexpr (k > 0) m28s<k>(acc, &m[0], &P.v[k]);
       m[k] = ((u32)acc * N0) & MASK;
@@ -181,10 +200,13 @@ __device__ __forceinline__ void mul2_inl(F28& r, const F28& a, const F28& b, con
   const PTable P;
   u32 m[N];
   u32 t[N];
-  u64 acc = 0;
+  u64 acc;
   static_for<0, N>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    m28v<k + 1>(acc, &a.l[0], &b.l[k]);
+    if constexpr (k == 0)
+      m28vset<1>(acc, &a.l[0], &b.l[0]);
+    else
+      m28v<k + 1>(acc, &a.l[0], &b.l[k]);
     m28v<k + 1>(acc, &c.l[0], &d.l[k]);
     if constexpr (k > 0) m28s<k>(acc, &m[0], &P.v[k]);
     m[k] = ((u32)acc * N0) & MASK;
