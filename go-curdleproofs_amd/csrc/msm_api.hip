@@ -166,7 +166,6 @@ struct Ctx {
   // per partial the sort is no smaller than for a whole MSM (every rank converts and recodes
   // all n pairs) while the accumulation is 1/world of it, so one in-order sort stream was the
   // bottleneck of the pipeline (8 ranks: 1.06 -> 0.80 ms per step with 5 in flight).
-  // CURDLE_PRE_STREAMS=1 disables.
   hipStream_t pre_stream2 = nullptr;
   int pre_streams = 2;
   Slot slots[kSlots];
@@ -914,8 +913,8 @@ void drain_slot(Ctx& cx, Slot& S) {
 // Streams of a synchronous call.  The caller waits for this very call, so every phase goes to
 // the slot's own stream: no event hops between streams (each costs a cross-queue dependency,
 // ~10 us with 16 hardware queues: 0.58 -> 0.50 ms for a 1,268-pair MSM), and concurrent callers
-// still overlap, each on its slot's stream.  CURDLE_SYNC_STREAMS=3 restores the three-stream
-// layout of the pipelined entry points.
+// still overlap, each on its slot's stream.  (The three-stream layout of the pipelined entry points was
+// measured slower for synchronous calls in round 2; its knob is gone.)
 struct SyncStreams {
   hipStream_t pre, main, tail;
 };
@@ -1261,8 +1260,7 @@ namespace {
 // profiles/r02_verify_from_bytes_queues.txt); since the two chains overlap the test is over when
 // the MSM starts, priorities no longer change one verification's latency (1.14-1.17 ms at ell =
 // 252 in all six combinations of 4 / 16 hardware queues and the three priorities), and with
-// eight threads verifying at once the lowest one measured best.  CURDLE_DECODE_PRIO=1 selects
-// the highest, =2 the default one.
+// eight threads verifying at once the lowest one measured best (the knob that selected the others is gone).
 int ensure_dslot_streams(Ctx& cx) {
   // the flag is set (release) after every stream and event of every decode context was stored, and
   // read (acquire) before any of them is used: no thread sees a half-made context

@@ -37,4 +37,4 @@ for T in (1, 2, 3, 4, 8, 16):
     [t.join() for t in th]
     dt = time.perf_counter() - t0
     out.append(f"{T}: {T*per/dt:.0f}/s")
-print("whisk verifies/s by threads (queues=%s, prio=%s, acc=%s): " % (os.environ["GPU_MAX_HW_QUEUES"], os.environ.get("CURDLE_DECODE_PRIO", "0"), os.environ.get("CURDLE_DEVICE_ACC", "1")) + ", ".join(out), flush=True)
+print("whisk verifies/s by threads (queues=%s, acc=%s): " % (os.environ["GPU_MAX_HW_QUEUES"], os.environ.get("CURDLE_DEVICE_ACC", "1")) + ", ".join(out), flush=True)
