@@ -67,6 +67,12 @@ CURDLE_D28_TABLE(kBeta, 0x2421b59u, 0xbee4867u, 0x1d31002u, 0x4760184u, 0x4cc508
 // 2^384 mod p: mul by it maps internal form back to gnark form
 CURDLE_D28_TABLE(kToExt, 0x002fffdu, 0x0900000u, 0xc000276u, 0x000bc40u, 0x8baebf4u, 0x5753c75u, 0x55f4898u, 0x7052574u,
                  0x7ce5853u, 0x56ec6d7u, 0x71a97a2u, 0xe4935c0u, 0xec3fa80u, 0x0015f65u)
+// 2^388 mod p and 2^390 mod p: the X and Y coordinates of an MSM result leave through these instead of
+// kToExt (the bucket sums live on an isomorphic curve, see from_gnark_iso)
+CURDLE_D28_TABLE(kToExtX16, 0x0345521u, 0x9d00000u, 0xc002aeeu, 0x00cd3f7u, 0xbd93084u, 0x48b5790u, 0xdb70ed3u, 0xa763809u,
+                 0x2d6af76u, 0x96ffe76u, 0xa2538bau, 0x935ff00u, 0x35abc8fu, 0x000d580u)
+CURDLE_D28_TABLE(kToExtY64, 0x0d1ff2eu, 0x7600000u, 0x800ac46u, 0x03379b4u, 0x31c84b8u, 0xe0e8824u, 0x80dd9a7u, 0xb683dcfu,
+                 0x26c26d0u, 0xc4a5eecu, 0x1457663u, 0x804b29fu, 0x9967f3eu, 0x00015deu)
 // K*p in borrow-proof limb form: limbs 0..12 >= 2^28 - 1, limb 13 = top(K*p) - 1,
 // so (a + K - b) is non-negative limb by limb for normalised b < (K-1)p.
 CURDLE_D28_TABLE(kK4, 0x1ffeaaacu, 0x1fbffffeu, 0x1ffffee6u, 0x1fffac53u, 0x18907aaeu, 0x183dac3cu, 0x1d9cc349u,
@@ -400,6 +406,64 @@ __device__ __forceinline__ void canonical_lt2p(F28& a) {
     for (int i = 0; i < N; i++) a.l[i] = d[i];
   }
 }
+// Limb i of p << S, normalised (S < 28).
+template <int S>
+__device__ __forceinline__ u32 kPshl(int i) {
+  const u64 lo = i > 0 ? (u64)kP(i - 1) >> (28 - S) : 0;
+  const u64 v = ((u64)kP(i) << S) | lo;
+  return (u32)(i < N - 1 ? v & MASK : v);
+}
+// a -= 2^S p if a >= 2^S p (a normalised).
+template <int S>
+__device__ __forceinline__ void cond_sub_pshl(F28& a) {
+  u32 d[N];
+  int borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    int t = (int)a.l[i] - (int)kPshl<S>(i) - borrow;
+    borrow = t < 0;
+    d[i] = (u32)t & (i < N - 1 ? MASK : 0xffffffffu);
+  }
+  if (!borrow) {
+#pragma unroll
+    for (int i = 0; i < N; i++) a.l[i] = d[i];
+  }
+}
+// 12 saturated limbs -> 14 limbs of 28 bits of (the integer << S), S <= 4.
+template <int S>
+__device__ __forceinline__ void unpack_shl(F28& r, const u32* w) {
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const int bit = 28 * j - S;
+    u32 v;
+    if (bit < 0) {
+      v = w[0] << (-bit);
+    } else {
+      const int lo = bit >> 5, sh = bit & 31;
+      v = w[lo] >> sh;
+      if (sh > 4 && lo + 1 < 12) v |= w[lo + 1] << (32 - sh);
+    }
+    r.l[j] = v & MASK;
+  }
+}
+// The bases of an MSM WITHOUT a product.  A gnark element x*2^384 read as an internal one is x/2^8 in
+// internal form.  (x, y) -> (x / u^2, y / u^3) maps y^2 = x^3 + 4 onto y^2 = x^3 + 4 / u^6, and the XYZZ
+// formulas for a = 0 (madd, add, dbl) never use the constant term, nor does phi (beta x, y): with u = 4
+// the image of a base is (16 x / 2^8, 4 y / 2^8) = the gnark words shifted left by 4 and 2 bits.  Every
+// bucket, segment and window sum of the MSM kernels lives on that curve; the three places a result leaves
+// (write_point_quad, write_window_sum_quad, k_combine) map it back by the constants kToExtX16 / kToExtY64
+// in the product they spend on the 2^392 -> 2^384 change anyway.  Conditional subtractions bring the
+// shifted values under the bounds madd asks of an affine operand (x, y < 2p).
+__device__ __forceinline__ void from_gnark_iso_x(F28& r, const u32* w) {
+  unpack_shl<4>(r, w);  // < 16p
+  cond_sub_pshl<3>(r);
+  cond_sub_pshl<2>(r);
+  cond_sub_pshl<1>(r);  // < 2p
+}
+__device__ __forceinline__ void from_gnark_iso_y(F28& r, const u32* w) {
+  unpack_shl<2>(r, w);  // < 4p
+  cond_sub_pshl<1>(r);  // < 2p
+}
 // gnark fp.Element (12 x u32, Montgomery 2^384, canonical) -> internal, < 2p.
 __device__ __forceinline__ void from_gnark(F28& r, const u32* w) {
   F28 t, c;
@@ -413,6 +477,17 @@ __device__ __forceinline__ void to_gnark(u32* w, const F28& a) {
   F28 t, c;
 #pragma unroll
   for (int i = 0; i < N; i++) c.l[i] = kToExt(i);
+  mul(t, a, c);
+  canonical_lt2p(t);
+  pack(w, t);
+}
+
+// Coordinate `role` (0 X, 1 Y, 2 ZZ, 3 ZZZ) of an MSM result, from the curve the bases were mapped to
+// (from_gnark_iso) back to gnark form.
+__device__ __forceinline__ void to_gnark_msm(u32* w, const F28& a, u32 role) {
+  F28 t, c;
+#pragma unroll
+  for (int i = 0; i < N; i++) c.l[i] = role == 0 ? kToExtX16(i) : (role == 1 ? kToExtY64(i) : kToExt(i));
   mul(t, a, c);
   canonical_lt2p(t);
   pack(w, t);

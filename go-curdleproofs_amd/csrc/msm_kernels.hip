@@ -557,22 +557,46 @@ __device__ __forceinline__ const A28* a28_at(const A28* base, size_t i) {
   return reinterpret_cast<const A28*>(reinterpret_cast<const char*>(base) + i * kA28Bytes);
 }
 
-__global__ void __launch_bounds__(kBlock, 2)
+// 128 points per block.  Every lane converts one base; the two 128-byte records it produces go through
+// LDS so that the block writes its 32 KiB of output as whole lines, 1 KiB per wave instruction (written
+// straight from the lanes, a store instruction touched 64 lines, 16 bytes of each).  Chunk k of lane t
+// sits at chunk k ^ (t & 15) of the lane's 256 bytes: 4-way bank conflicts on the way in, none on the
+// way out.
+static constexpr int kCvtBlock = 128;
+__global__ void __launch_bounds__(kCvtBlock)
     k_convert_points(const uint4* __restrict__ points, u32 n, A28* __restrict__ out) {
-  u32 i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  u32 w[24];
-  d28::load_words<24>(w, points + (size_t)i * 6);
-  A28 a;
-  d28::from_gnark(a.x, w);
-  d28::from_gnark(a.y, w + 12);
-  d28::store(a28_at(out, 2 * (size_t)i), a);
-  // ... and phi(P) = (beta x, y) as the record behind it (GLV, k_digits); infinity (0, 0) stays (0, 0)
-  F28 beta;
+  __shared__ uint4 stage[kCvtBlock * 16];
+  const u32 tid = threadIdx.x;
+  const u32 base = blockIdx.x * kCvtBlock;
+  const u32 i = base + tid;
+  if (i < n) {
+    u32 w[24];
+    d28::load_words<24>(w, points + (size_t)i * 6);
+    A28 a;
+    d28::from_gnark_iso_x(a.x, w);  // no product: the MSM runs on an isomorphic curve (fp28.h)
+    d28::from_gnark_iso_y(a.y, w + 12);
+    uint4* mine = stage + tid * 16;
+    const u32 sw = tid & 15u;
+    const u32* aw = reinterpret_cast<const u32*>(&a);
 #pragma unroll
-  for (int j = 0; j < d28::N; j++) beta.l[j] = d28::kBeta(j);
-  d28::mul(a.x, a.x, beta);
-  d28::store(a28_at(out, 2 * (size_t)i + 1), a);
+    for (u32 k = 0; k < 7; k++) mine[k ^ sw] = make_uint4(aw[4 * k], aw[4 * k + 1], aw[4 * k + 2], aw[4 * k + 3]);
+    mine[7u ^ sw] = make_uint4(0, 0, 0, 0);
+    // ... and phi(P) = (beta x, y) as the record behind it (GLV, k_digits); infinity (0, 0) stays (0, 0)
+    F28 beta;
+#pragma unroll
+    for (int j = 0; j < d28::N; j++) beta.l[j] = d28::kBeta(j);
+    d28::mul(a.x, a.x, beta);
+#pragma unroll
+    for (u32 k = 0; k < 7; k++) mine[(8u + k) ^ sw] = make_uint4(aw[4 * k], aw[4 * k + 1], aw[4 * k + 2], aw[4 * k + 3]);
+    mine[15u ^ sw] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  const u32 cnt = min((u32)kCvtBlock, n - base) * 16u;  // 16-byte chunks this block owns
+  uint4* dst = reinterpret_cast<uint4*>(a28_at(out, 2 * (size_t)base));
+  for (u32 c = tid; c < cnt; c += kCvtBlock) {
+    const u32 t = c >> 4, k = c & 15u;
+    dst[c] = stage[t * 16 + (k ^ (t & 15u))];
+  }
 }
 
 // Sum of `acc` over aligned groups of G lanes (G a power of two <= 256) of a
@@ -954,7 +978,7 @@ int reduce_bits_position(const MsmPlan& p, int w, uint32_t slot) { return reduce
 // This lane's coordinate of a point, gnark form, to the host's array.
 __device__ __forceinline__ void write_point_quad(const F28& c, G1XYZZ* dst) {
   u32 w12[12];
-  d28::to_gnark(w12, c);
+  d28::to_gnark_msm(w12, c, q28::role());
   u32* d = reinterpret_cast<u32*>(dst) + 12u * q28::role();
 #pragma unroll
   for (int i = 0; i < 12; i++) d[i] = w12[i];
@@ -1117,7 +1141,7 @@ __device__ __forceinline__ void write_window_sum_quad(const F28& c, G1XYZZ* wins
   const u32 nw = p.win_end - p.win_begin;
   if (!p.gpu_combine) {
     u32 w12[12];
-    d28::to_gnark(w12, c);
+    d28::to_gnark_msm(w12, c, q28::role());
     u32* dst = reinterpret_cast<u32*>(&winsums[(size_t)j * nw + lw]) + 12u * q28::role();
 #pragma unroll
     for (int i = 0; i < 12; i++) dst[i] = w12[i];
@@ -1188,7 +1212,7 @@ __global__ void __launch_bounds__(kBlock, 2)
       for (int q = 0; q < dbls; q++) q28::dbl(acc);
   }
   u32 w12[12];
-  d28::to_gnark(w12, acc);  // this lane's coordinate; ZZ = 0 (infinity) stays 0
+  d28::to_gnark_msm(w12, acc, q28::role());  // this lane's coordinate; ZZ = 0 (infinity) stays 0
   u32* dst = reinterpret_cast<u32*>(&results[j]) + 12u * q28::role();
 #pragma unroll
   for (int i = 0; i < 12; i++) dst[i] = w12[i];
@@ -1289,7 +1313,7 @@ hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t 
 
 hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_out28, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_convert_points, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(k_convert_points, dim3(cdiv(n, kCvtBlock)), dim3(kCvtBlock), 0, stream,
                      reinterpret_cast<const uint4*>(d_points), n, reinterpret_cast<A28*>(d_out28));
   return hipGetLastError();
 }
