@@ -509,6 +509,15 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // into more than max_small fragments (they would all take the merge_large detour): grow L
   if (entries / L > ((uint64_t)1 << 22)) L = entries >> 22;
   p.L = (uint32_t)L;
+  // The two waves a SIMD holds of a synchronous call's accumulation take turns at high priority (k_accumulate):
+  // left to the hardware's oldest-first rule one of them ran ahead, finished after 57 % of the kernel and
+  // left the other alone at 0.77 of the pair's rate (wave stamps: profiles/r04_wave_trace.txt; 2^20: kernel
+  // 2.50 -> 2.38 ms, the call 3.18 -> 3.05).  Not for pipelined calls: the next MSM's waves take the freed
+  // slots there, and raised priorities starve the sort and reduce kernels beside them (2.58 -> 2.69 ms per step).
+  {
+    const long long v = knobs::get(knobs::ACC_PRIO);
+    p.acc_prio = v >= 0 ? (uint32_t)(v > 24 ? 24 : v) : (latency_mode && !light_host && entries / L >= 65536 ? 15u : 0u);
+  }
   p.max_small = 16;
   // a bucket with more than max_small fragments holds more than (max_small - 1) * L entries
   uint64_t ml = entries / ((uint64_t)(p.max_small - 1) * p.L) + 1;
@@ -2596,6 +2605,9 @@ extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64
         glv_split(k, d, d + 4, sa, sb);
         d[8] = sa;
         d[9] = sb;
+      } else if (op == 12) {  // into the MSM's curve and back: the identity, both bounds kept
+        memcpy(d, s, 96);
+        d[24] = d[25] = 1;
       } else if (op <= 3) {
         Fp a, b, r;
         memcpy(&a, s, 48);
@@ -2654,6 +2666,12 @@ extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64
   return CURDLE_OK;
 }
 
+#ifdef CURDLE_TRACE_WAVES
+namespace curdle { hipError_t debug_read_wave_trace(unsigned long long* out, size_t words); }
+extern "C" int curdle_debug_wave_trace(uint64_t* out, size_t words) {
+  return curdle::debug_read_wave_trace((unsigned long long*)out, words) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int curdle_selftest_shape(int op, uint32_t* in_words, uint32_t* out_words) {
   if (op < 0 || op >= kSelftestOps || !in_words || !out_words) return fail(CURDLE_EINVAL, "selftest op %d outside [0, %d)", op, kSelftestOps);
   *in_words = kSelftestTable[op].in_words;

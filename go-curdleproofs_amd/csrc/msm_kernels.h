@@ -24,6 +24,7 @@ struct MsmPlan {
   uint32_t sets;       // base sets sharing every scalar vector's recoding and sort (1 but for curdle_msm_g1_multi)
   uint32_t kr;         // results = k * sets; result r = set * k + j
   uint32_t frag_stride;  // fragments reserved per base set
+  uint32_t acc_prio;     // k_accumulate: log2 of the priority time slice in 10 ns ticks, 0 = no turns (knob ACC_PRIO)
   uint32_t n_max;      // pairs of the largest MSM
   int c;               // requested maximum window width
   int W;               // windows of the full decomposition
@@ -130,13 +131,14 @@ struct SelftestOp {
   uint32_t out_words;  // ... written per element
   uint32_t lanes;      // lanes per element: 4 for the lane-distributed (quad) operations
 };
-static constexpr int kSelftestOps = 12;
+static constexpr int kSelftestOps = 13;
 static constexpr SelftestOp kSelftestTable[kSelftestOps] = {
     {24, 12, 1}, {24, 12, 1}, {24, 12, 1}, {24, 12, 1},  // 0..3  Fp mul / add / sub / sqr
     {16, 8, 1},                                           // 4     Fr Montgomery -> canonical
     {96, 48, 1}, {96, 48, 1}, {96, 48, 1},                // 5..7  XYZZ madd / add / dbl, one lane
     {96, 48, 4}, {96, 48, 4}, {96, 48, 4},                // 8..10 add / dbl / small multiple on quads
     {8, 10, 1},                                           // 11    the GLV split
+    {24, 26, 1},                                          // 12    a base into the MSM's curve and back (+ the two bound flags)
 };
 // hipErrorInvalidValue for an op outside the table (nothing is launched).
 hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream);

@@ -638,16 +638,32 @@ __device__ __forceinline__ void group_sum(X28& acc, u32 G, X28* wave_partials /*
 // next bucket the lane stores its running sum as a fragment of the finished
 // bucket and starts again from infinity.  Fragments of one bucket are
 // contiguous: slot = foff[bucket] + (t - start[bucket] / L).
+#ifdef CURDLE_TRACE_WAVES
+// Experiment build only: start / end (100 MHz wall clock) and hardware id of every wave of the LAST accumulate launch.
+__device__ unsigned long long g_wave_trace[4 * 8192];
+hipError_t debug_read_wave_trace(unsigned long long* out, size_t words) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), words * 8 < sizeof(g_wave_trace) ? words * 8 : sizeof(g_wave_trace));
+}
+#endif
 template <int WAVES>
 __global__ void __launch_bounds__(kBlock, WAVES)
     k_accumulate(const A28* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ starts,
-                 const u32* __restrict__ foff, X28* __restrict__ frags, u32 nb, u32 L, u32 set_points, u32 frag_stride) {
+                 const u32* __restrict__ foff, X28* __restrict__ frags, u32 nb, u32 L, u32 set_points, u32 frag_stride,
+                 u32 prio_shift) {
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
   // base set blockIdx.y of a shared-scalar call: its own points and fragments, the one sorted list
   points = a28_at(points, (size_t)blockIdx.y * set_points);
   frags += (size_t)blockIdx.y * frag_stride;
   const u32 total = starts[nb];
   u32 pos = t * L;
+#ifdef CURDLE_TRACE_WAVES
+  const u32 wv = t >> 6;
+  if ((t & 63u) == 0 && wv < 8192u) {
+    g_wave_trace[4 * wv] = wall_clock64();
+    g_wave_trace[4 * wv + 2] = __builtin_amdgcn_s_getreg(63492);
+    g_wave_trace[4 * wv + 3] = __builtin_amdgcn_s_getreg(63508);
+  }
+#endif
   if (pos >= total) return;
   const u32 end = min(pos + L, total);
   // bucket containing `pos`: first index with starts[idx] > pos, minus one
@@ -677,7 +693,14 @@ __global__ void __launch_bounds__(kBlock, WAVES)
   u32 e_next = q[0];
   A28 pt_next;
   d28::load(pt_next, a28_at(points, e_next & 0x7fffffffu));
+  const u32 slot = __builtin_amdgcn_s_getreg(63492) & 1u;  // HW_ID: this wave's slot on its SIMD, low bit
   for (; pos < end; pos++) {
+    if (prio_shift) {
+      if ((((u32)wall_clock64() >> prio_shift) ^ slot) & 1u)
+        __builtin_amdgcn_s_setprio(3);
+      else
+        __builtin_amdgcn_s_setprio(0);
+    }
     const u32 e = e_next;
     A28 pt = pt_next;
     if (++queued == 8) {
@@ -708,6 +731,9 @@ __global__ void __launch_bounds__(kBlock, WAVES)
     d28::madd<true>(acc, pt.x, pt.y);
   }
   d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
+#ifdef CURDLE_TRACE_WAVES
+  if ((t & 63u) == 0 && wv < 8192u) g_wave_trace[4 * wv + 1] = wall_clock64();
+#endif
 }
 
 // One block per queued bucket (more than max_small fragments): tree-sum of the
@@ -1326,7 +1352,7 @@ hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream
   // registers and was slower
   hipLaunchKernelGGL(k_accumulate<2>, dim3(cdiv(nlanes, kBlock), p.sets), dim3(kBlock), 0, stream,
                      reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
-                     reinterpret_cast<X28*>(ws.frags), nb, p.L, p.n, p.frag_stride);
+                     reinterpret_cast<X28*>(ws.frags), nb, p.L, p.n, p.frag_stride, p.acc_prio);
   return hipGetLastError();
 }
 
@@ -1537,6 +1563,28 @@ __global__ void __launch_bounds__(kBlock, 2)
     }
     out[i * out_w + 8] = sa;
     out[i * out_w + 9] = sb;
+  } else if (op == 12) {  // the conversion k_convert_points runs and the exit product of the MSM kernels
+    if (in_w != 24 || out_w != 26) return;
+    u32 w[24];
+    for (int k = 0; k < 24; k++) w[k] = in[i * in_w + k];
+    F28 x, y;
+    d28::from_gnark_iso_x(x, w);
+    d28::from_gnark_iso_y(y, w + 12);
+    u32 o[24];
+    d28::to_gnark_msm(o, x, 0);
+    d28::to_gnark_msm(o + 12, y, 1);
+    for (int k = 0; k < 24; k++) out[i * out_w + k] = o[k];
+    // what madd asks of an affine operand: normalised limbs, value below 2p
+    F28 x2 = x, y2 = y;
+    d28::cond_sub_pshl<1>(x2);
+    d28::cond_sub_pshl<1>(y2);
+    bool same_x = true, same_y = true;
+    for (int k = 0; k < d28::N; k++) {
+      same_x = same_x && x2.l[k] == x.l[k] && x.l[k] <= d28::MASK;
+      same_y = same_y && y2.l[k] == y.l[k] && y.l[k] <= d28::MASK;
+    }
+    out[i * out_w + 24] = same_x;
+    out[i * out_w + 25] = same_y;
   } else if (op >= 0 && op <= 3) {
     if (in_w != 24 || out_w != 12) return;
     u32 w[24];

@@ -37,6 +37,7 @@ enum Id {
   VERIFY_EAGER,       // 1: check points evaluated where the reference does
   VERIFY_TRACE,       // 1: per-phase timings of a verification on stderr
   PROVER_FOLD_BASES,  // 1: the prover folds its bases round by round like the reference
+  ACC_PRIO,           // k_accumulate: the two waves of a SIMD take turns at high priority every 2^v x 10 ns (0: never; unset: 15 for synchronous calls from half a round of lanes)
   COUNT
 };
 // The knob's value, or -1 if it is not set (every knob's valid values are >= 0).

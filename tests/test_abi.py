@@ -130,16 +130,16 @@ def test_selftest_operations_share_one_table(cm):
     """curdle_selftest_op's buffer sizes, its launcher's grid and its kernel's indexing come from ONE
     table, which the binding asks for too: an unknown operation is refused before anything is
     allocated or launched (round 3's r3a abort was an operation known to one of them only)."""
-    shapes = [cm.selftest_shape(op) for op in range(12)]
+    shapes = [cm.selftest_shape(op) for op in range(13)]
     assert shapes[:5] == [(24, 12)] * 4 + [(16, 8)]
-    assert shapes[5:11] == [(96, 48)] * 6 and shapes[11] == (8, 10)
-    for bad in (-1, 12, 99):
+    assert shapes[5:11] == [(96, 48)] * 6 and shapes[11] == (8, 10) and shapes[12] == (24, 26)
+    for bad in (-1, 13, 99):
         with pytest.raises(RuntimeError):
             cm.selftest_shape(bad)
     inp = np.zeros((3, 8), dtype=np.uint32)
     out = np.zeros((3, 10), dtype=np.uint32)
     for on_device in (0, 1):
-        assert cm._selftest_op(12, cm._ptr(inp), 3, cm._ptr(out), on_device) == cm.EINVAL
+        assert cm._selftest_op(13, cm._ptr(inp), 3, cm._ptr(out), on_device) == cm.EINVAL
     # the host build of every operation runs on exactly the table's widths
     for op, (iw, ow) in enumerate(shapes):
         if op in (8, 9, 10):

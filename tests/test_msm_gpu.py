@@ -68,6 +68,29 @@ def test_device_primitives_match_host(gpu, oracle):
             assert xyzz_to_affine(oracle, dev[i]) == xyzz_to_affine(oracle, host[i]), (op, i)
 
 
+def test_bases_enter_the_msm_curve_and_come_back(gpu, oracle):
+    """The MSM kernels run on the image of the curve under (x, y) -> (x / 16, y / 64): a base enters by shifts
+    of its gnark words and conditional subtractions (fp28.h from_gnark_iso_*), a result leaves through 2^388 /
+    2^390 (to_gnark_msm).  Operation 12 runs the two ends on plain field elements: the round trip is the
+    identity and the values in between respect madd's bounds (normalised limbs, below 2p) -- at every boundary
+    of the conditional subtractions (x = k p / 16, y = k p / 4, either side) and on random elements."""
+    P = oracle.P
+    vals = [0, 1, 2, P - 1, P - 2, (P - 1) // 2]
+    for k in range(1, 16):
+        for d in (-2, -1, 0, 1, 2):
+            vals.append((k * P // 16 + d) % P)
+    rng = np.random.default_rng(44)
+    vals += [int.from_bytes(rng.bytes(48), "big") % P for _ in range(4000)]
+    from test_host_mirror import fp32
+    # the words a caller passes are Montgomery forms: every canonical word pattern below p occurs, so the
+    # patterns themselves are what is swept
+    inp = np.array([fp32(v) + fp32(vals[-1 - i]) for i, v in enumerate(vals)], dtype=np.uint32)
+    out = gpu.selftest_op(12, inp, True)
+    assert (out[:, :24] == inp).all()
+    assert (out[:, 24:] == 1).all()
+    assert (out == gpu.selftest_op(12, inp, False)).all()
+
+
 def test_the_split_on_the_device(gpu, oracle):
     """The device build of glv_split (what k_digits runs) on the same 300,000 random and boundary
     scalars as the host build (tests/test_abi.py), against big-integer division, and word for
