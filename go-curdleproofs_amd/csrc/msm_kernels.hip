@@ -53,33 +53,13 @@ __constant__ u32 kPminus2[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabff
                                  0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
 
 // ---------------------------------------------------------------------------
-// Digit recoding.  f(w, mag, neg) is called for w = 0..W-1 in order; windows
+// Digit recoding, for w = 0..W-1 in order: windows
 // below the top are signed (a raw digit above half the window range becomes its
 // negative complement and carries one into the next window), the top window is
 // unsigned.  The scalar is shifted down window by window so every limb index is
 // static (runtime-indexed register arrays would go to scratch).
 // ---------------------------------------------------------------------------
-// The scalar here is one HALF of a GLV split (below): 127 bits in four words.
-template <class F>
-__device__ __forceinline__ void for_each_digit(u32 s0, u32 s1, u32 s2, u32 s3, const MsmPlan& p, F&& f) {
-  u32 carry = 0;
-  for (int w = 0; w < p.W; w++) {
-    const u32 c = p.bits[w];
-    const u32 raw = (s0 & ((1u << c) - 1u)) + carry;
-    s0 = (s0 >> c) | (s1 << (32 - c));
-    s1 = (s1 >> c) | (s2 << (32 - c));
-    s2 = (s2 >> c) | (s3 << (32 - c));
-    s3 >>= c;
-    u32 mag = raw, neg = 0;
-    carry = 0;
-    if (w != p.W - 1 && raw > (1u << (c - 1))) {
-      mag = (1u << c) - raw;
-      neg = 0x80000000u;
-      carry = 1;
-    }
-    f(w, mag, neg);
-  }
-}
+// The scalar here is one HALF of a GLV split (below): 127 bits in four words (the loop is in k_digits).
 
 // GLV: phi(x, y) = (beta x, y) is multiplication by lambda = z^2 - 1 (lambda^2 + lambda + 1 =
 // r), so k P = k1 P + k2 phi(P) with half-length k1, k2: the MSM runs over 2n points with half
@@ -107,14 +87,38 @@ __global__ void __launch_bounds__(kBlock) k_digits(const uint4* __restrict__ sca
   Fr s = load_scalar_canonical(scalars, i);
   u32 a[4], b[4], neg_a, neg_b;
   glv_split(s, a, b, neg_a, neg_b);
-  for_each_digit(a[0], a[1], a[2], a[3], p, [&](int w, u32 mag, u32 neg) {
+  // the two halves' digits of a window leave as ONE 8-byte store: written one half after the other, every
+  // line of `digits` went to memory twice (128 MB for a 64 MB array at N = 2^20, profiles/r04_pmc_summary.txt)
+  u32 ca = 0, cb = 0;
+  for (int w = 0; w < p.W; w++) {
+    const u32 c = p.bits[w];
+    const u32 ra = (a[0] & ((1u << c) - 1u)) + ca, rb = (b[0] & ((1u << c) - 1u)) + cb;
+    a[0] = (a[0] >> c) | (a[1] << (32 - c));
+    a[1] = (a[1] >> c) | (a[2] << (32 - c));
+    a[2] = (a[2] >> c) | (a[3] << (32 - c));
+    a[3] >>= c;
+    b[0] = (b[0] >> c) | (b[1] << (32 - c));
+    b[1] = (b[1] >> c) | (b[2] << (32 - c));
+    b[2] = (b[2] >> c) | (b[3] << (32 - c));
+    b[3] >>= c;
+    u32 ma = ra, na = 0, mb = rb, nb2 = 0;
+    ca = cb = 0;
+    if (w != p.W - 1) {  // windows below the top are signed (header comment above)
+      if (ra > (1u << (c - 1))) {
+        ma = (1u << c) - ra;
+        na = 0x80000000u;
+        ca = 1;
+      }
+      if (rb > (1u << (c - 1))) {
+        mb = (1u << c) - rb;
+        nb2 = 0x80000000u;
+        cb = 1;
+      }
+    }
     if (w >= p.win_begin && w < p.win_end)
-      digits[(size_t)(w - p.win_begin) * p.n + 2 * (size_t)i] = mag ? (mag | (neg ^ neg_a)) : 0u;
-  });
-  for_each_digit(b[0], b[1], b[2], b[3], p, [&](int w, u32 mag, u32 neg) {
-    if (w >= p.win_begin && w < p.win_end)
-      digits[(size_t)(w - p.win_begin) * p.n + 2 * (size_t)i + 1] = mag ? (mag | (neg ^ neg_b)) : 0u;
-  });
+      *reinterpret_cast<uint2*>(&digits[(size_t)(w - p.win_begin) * p.n + 2 * (size_t)i]) =
+          make_uint2(ma ? (ma | (na ^ neg_a)) : 0u, mb ? (mb | (nb2 ^ neg_b)) : 0u);
+  }
 }
 
 // Bucket sort of the pair indices, per-window histogram staged in LDS (at most
