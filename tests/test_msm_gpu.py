@@ -541,6 +541,29 @@ def test_partials_of_the_headline_plan_sum_to_the_full_msm(gpu, oracle, coracle)
         assert (gpu.g1_sum(np.stack(parts)) == exp).all(), ("points", world)
 
 
+def test_priority_turns_of_the_accumulate_waves_do_not_change_results(gpu, oracle, coracle):
+    """A synchronous call from half a round of accumulate lanes lets the two waves of a SIMD take turns at
+    high priority (plan field acc_prio, knob ACC_PRIO: scheduling only).  Same bits with the turns off, at the
+    default and at a slice so short that priorities flip inside every mixed addition -- at 2^18 pairs (a
+    whole round of lanes) against the closed form."""
+    import torch
+    n = 1 << 18
+    k, q = oracle.Rand(5).get_frs(2)
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    sc = rand_scalars(np.random.default_rng(55), n, oracle)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    exp = _walk_expected(oracle, coracle, k, q, sc)
+    try:
+        for v in (None, 0, 1, 6, 15, 24, 40):
+            gpu.plan_override("ACC_PRIO", v)
+            assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == exp).all(), v
+            t = gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n)
+            assert (gpu.msm_wait(t) == exp).all(), v
+    finally:
+        gpu.plan_override("ACC_PRIO", None)
+
+
 def test_msm_over_a_resident_base_set(gpu, oracle, coracle):
     """curdle_msm_g1_dbases*: the plain MSM over a pre-converted, resident base set (SURVEY.md 8b's
     caller-managed device handle; msmaccumulator.Verify's bases are mostly the CRS).  Against the C

@@ -93,6 +93,34 @@ SIMPLE_KERNEL(k_mad_i32_i24, uint32_t, "v_mad_i32_i24 %0, %1, %2, %0")
 SIMPLE_KERNEL(k_mul_f64, double, "v_mul_f64 %0, %1, %0")
 SIMPLE_KERNEL(k_add_f64, double, "v_add_f64 %0, %1, %0")
 
+SIMPLE_KERNEL(k_lshr_b64, uint64_t, "v_lshrrev_b64 %0, 3, %0")
+SIMPLE_KERNEL(k_alignbit, uint32_t, "v_alignbit_b32 %0, %1, %0, 28")
+SIMPLE_KERNEL(k_and_b32, uint32_t, "v_and_b32_e32 %0, %1, %0")
+
+// a multiply-add and ONE other instruction on an independent register, alternating: what the other
+// instruction costs NEXT TO the multiplier (round 4: the accumulation's 880 shifts / masks / q-products)
+#define PAIR_KERNEL(NAME, TYPE2, ASM2)                                                            \
+  __global__ void NAME(uint64_t* out, uint32_t a, uint32_t b, unsigned long long* clk) {          \
+    uint64_t acc[UNROLL];                                                                         \
+    TYPE2 oth[UNROLL];                                                                            \
+    uint32_t x = a + threadIdx.x, y = b + threadIdx.x;                                            \
+    for (int i = 0; i < UNROLL; i++) { acc[i] = i + threadIdx.x; oth[i] = (TYPE2)(i + 3 * threadIdx.x); } \
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
+    for (int it = 0; it < ITERS; it++) {                                                          \
+      _Pragma("unroll") for (int i = 0; i < UNROLL; i++)                                          \
+          asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t" ASM2 : "+v"(acc[i]), "+v"(oth[i]) : "v"(x), "v"(y) : "vcc"); \
+    }                                                                                             \
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
+    uint64_t s = 0;                                                                               \
+    for (int i = 0; i < UNROLL; i++) s += acc[i] + (uint64_t)oth[i];                              \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                               \
+    if (threadIdx.x == 0 && blockIdx.x == 0) *clk = t1 - t0;                                      \
+  }
+PAIR_KERNEL(k_mac_and, uint32_t, "v_and_b32_e32 %1, %2, %1")
+PAIR_KERNEL(k_mac_lshr64, uint64_t, "v_lshrrev_b64 %1, 3, %1")
+PAIR_KERNEL(k_mac_mullo, uint32_t, "v_mul_lo_u32 %1, %2, %1")
+PAIR_KERNEL(k_mac_alignbit, uint32_t, "v_alignbit_b32 %1, %2, %1, 28")
+
 typedef void (*kern_t)(uint64_t*, uint32_t, uint32_t, unsigned long long*);
 
 int main() {
@@ -112,7 +140,10 @@ int main() {
       {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, UNROLL},
       {"v_add_u32", k_add_u32, UNROLL}, {"v_lshl_add_u64", k_lshl_add_u64, UNROLL},
       {"v_fma_f32", k_fma_f32, UNROLL}, {"v_fma_f64", k_fma_f64, UNROLL}, {"v_mul_f64", k_mul_f64, UNROLL},
-      {"v_add_f64", k_add_f64, UNROLL}};
+      {"v_add_f64", k_add_f64, UNROLL},
+      {"v_lshrrev_b64", k_lshr_b64, UNROLL}, {"v_alignbit_b32", k_alignbit, UNROLL}, {"v_and_b32", k_and_b32, UNROLL},
+      {"mad + v_and_b32 (per pair)", k_mac_and, UNROLL}, {"mad + v_lshrrev_b64 (per pair)", k_mac_lshr64, UNROLL},
+      {"mad + v_mul_lo_u32 (per pair)", k_mac_mullo, UNROLL}, {"mad + v_alignbit_b32 (per pair)", k_mac_alignbit, UNROLL}};
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   for (int waves_per_simd : {1, 2, 4}) {
