@@ -514,6 +514,13 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // left the other alone at 0.77 of the pair's rate (wave stamps: profiles/r04_wave_trace.txt; 2^20: kernel
   // 2.50 -> 2.38 ms, the call 3.18 -> 3.05).  Not for pipelined calls: the next MSM's waves take the freed
   // slots there, and raised priorities starve the sort and reduce kernels beside them (2.58 -> 2.69 ms per step).
+  // A pipelined call's reduction runs beside the next MSMs' accumulations, whose waves are older and win the
+  // arbiter: raised to priority 3 its waves give their slots back sooner (2.59-2.61 -> 2.54-2.55 ms per step, four
+  // A/B pairs on two boxes, profiles/r04_wave_priorities.txt; the sort kernels raised as well: half the gain lost)
+  {
+    const long long v = knobs::get(knobs::REDUCE_PRIO);
+    p.reduce_prio = v >= 0 ? (uint32_t)(v > 3 ? 3 : v) : (latency_mode ? 0u : 3u);
+  }
   {
     const long long v = knobs::get(knobs::ACC_PRIO);
     p.acc_prio = v >= 0 ? (uint32_t)(v > 24 ? 24 : v) : (latency_mode && !light_host && entries / L >= 65536 ? 15u : 0u);

@@ -24,6 +24,7 @@ struct MsmPlan {
   uint32_t sets;       // base sets sharing every scalar vector's recoding and sort (1 but for curdle_msm_g1_multi)
   uint32_t kr;         // results = k * sets; result r = set * k + j
   uint32_t frag_stride;  // fragments reserved per base set
+  uint32_t reduce_prio;  // s_setprio of the reduction kernels' waves (knob REDUCE_PRIO; 3 for pipelined calls)
   uint32_t acc_prio;     // k_accumulate: log2 of the priority time slice in 10 ns ticks, 0 = no turns (knob ACC_PRIO)
   uint32_t n_max;      // pairs of the largest MSM
   int c;               // requested maximum window width

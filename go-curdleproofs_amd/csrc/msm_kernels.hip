@@ -47,6 +47,12 @@ using d28::F28;
 using d28::X28;
 
 static constexpr int kBlock = 256;
+// s_setprio takes an immediate
+__device__ __forceinline__ void set_wave_prio(u32 v) {
+  if (v == 1) __builtin_amdgcn_s_setprio(1);
+  else if (v == 2) __builtin_amdgcn_s_setprio(2);
+  else if (v == 3) __builtin_amdgcn_s_setprio(3);
+}
 
 // p - 2 (Fermat inversion exponent), 32-bit words
 __constant__ u32 kPminus2[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
@@ -913,6 +919,7 @@ __device__ __forceinline__ void group_bits_and_sum(F28& S, F28& T, u32 G) {
 // [sum S | total T | X_0 .. X_(lgG-1)].
 __global__ void __launch_bounds__(kBlock, 2)
     k_reduce_segments(FragSources src, X28* __restrict__ groups, MsmPlan p) {
+  set_wave_prio(p.reduce_prio);
   const u32 tid = threadIdx.x;
   const u32 q = blockIdx.x * (kBlock / 4) + (tid >> 2);  // logical lane
   const bool live = q < p.kr * p.NS;
@@ -1037,6 +1044,7 @@ struct ReduceLevel {
 };
 __global__ void __launch_bounds__(kBlock, 2)
     k_reduce_level(const X28* __restrict__ in, X28* __restrict__ out, G1XYZZ* __restrict__ host_out, MsmPlan p, ReduceLevel lv) {
+  set_wave_prio(p.reduce_prio);
   __shared__ F28 sh[4][6][4];
   const u32 lw = blockIdx.x, jr = blockIdx.y / lv.nblk_max, blk = blockIdx.y - jr * lv.nblk_max, z = blockIdx.z;
   const int w = p.win_begin + (int)lw;

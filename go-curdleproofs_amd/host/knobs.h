@@ -38,6 +38,7 @@ enum Id {
   VERIFY_TRACE,       // 1: per-phase timings of a verification on stderr
   PROVER_FOLD_BASES,  // 1: the prover folds its bases round by round like the reference
   ACC_PRIO,           // k_accumulate: the two waves of a SIMD take turns at high priority every 2^v x 10 ns (0: never; unset: 15 for synchronous calls from half a round of lanes)
+  REDUCE_PRIO,        // wave priority (0..3) of k_reduce_segments / k_reduce_level; unset: 3 for pipelined calls, 0 for synchronous ones
   COUNT
 };
 // The knob's value, or -1 if it is not set (every knob's valid values are >= 0).
