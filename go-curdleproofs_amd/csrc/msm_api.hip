@@ -2674,7 +2674,10 @@ extern "C" int curdle_selftest_op(int op, const uint64_t* in64, size_t n, uint64
 }
 
 #ifdef CURDLE_TRACE_WAVES
-namespace curdle { hipError_t debug_read_wave_trace(unsigned long long* out, size_t words); }
+namespace curdle { hipError_t debug_read_wave_trace(unsigned long long* out, size_t words); hipError_t debug_read_wave_clk(unsigned long long* out, size_t words); }
+extern "C" int curdle_debug_wave_clk(uint64_t* out, size_t words) {
+  return curdle::debug_read_wave_clk((unsigned long long*)out, words) == hipSuccess ? 0 : -1;
+}
 extern "C" int curdle_debug_wave_trace(uint64_t* out, size_t words) {
   return curdle::debug_read_wave_trace((unsigned long long*)out, words) == hipSuccess ? 0 : -1;
 }

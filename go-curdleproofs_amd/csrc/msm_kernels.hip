@@ -651,8 +651,12 @@ __device__ __forceinline__ void group_sum(X28& acc, u32 G, X28* wave_partials /*
 #ifdef CURDLE_TRACE_WAVES
 // Experiment build only: start / end (100 MHz wall clock) and hardware id of every wave of the LAST accumulate launch.
 __device__ unsigned long long g_wave_trace[4 * 8192];
+__device__ unsigned long long g_wave_clk[2 * 8192];  // s_memtime (shader clock) at the same two points
 hipError_t debug_read_wave_trace(unsigned long long* out, size_t words) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), words * 8 < sizeof(g_wave_trace) ? words * 8 : sizeof(g_wave_trace));
+}
+hipError_t debug_read_wave_clk(unsigned long long* out, size_t words) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_clk), words * 8 < sizeof(g_wave_clk) ? words * 8 : sizeof(g_wave_clk));
 }
 #endif
 template <int WAVES>
@@ -670,6 +674,7 @@ __global__ void __launch_bounds__(kBlock, WAVES)
   const u32 wv = t >> 6;
   if ((t & 63u) == 0 && wv < 8192u) {
     g_wave_trace[4 * wv] = wall_clock64();
+    g_wave_clk[2 * wv] = __builtin_amdgcn_s_memtime();
     g_wave_trace[4 * wv + 2] = __builtin_amdgcn_s_getreg(63492);
     g_wave_trace[4 * wv + 3] = __builtin_amdgcn_s_getreg(63508);
   }
@@ -742,7 +747,10 @@ __global__ void __launch_bounds__(kBlock, WAVES)
   }
   d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
 #ifdef CURDLE_TRACE_WAVES
-  if ((t & 63u) == 0 && wv < 8192u) g_wave_trace[4 * wv + 1] = wall_clock64();
+  if ((t & 63u) == 0 && wv < 8192u) {
+    g_wave_trace[4 * wv + 1] = wall_clock64();
+    g_wave_clk[2 * wv + 1] = __builtin_amdgcn_s_memtime();
+  }
 #endif
 }
 

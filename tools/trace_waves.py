@@ -38,6 +38,11 @@ def main():
     buf = np.zeros((W, 4), dtype=np.uint64)
     assert fn(buf.ctypes.data, W * 4) == 0
     live = buf[:, 1] > 0
+    clk = np.zeros((W, 2), dtype=np.uint64)
+    fc = cm._lib.curdle_debug_wave_clk
+    fc.argtypes = [C.c_void_p, C.c_size_t]
+    fc.restype = C.c_int
+    assert fc(clk.ctypes.data, W * 2) == 0
     t0 = buf[live, 0].astype(np.int64)
     t1 = buf[live, 1].astype(np.int64)
     hw = buf[live, 2].astype(np.int64)
@@ -51,6 +56,8 @@ def main():
     print("start  us: min %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f" % (s.min(), q(s, 50), q(s, 90), q(s, 99), s.max()))
     print("end    us: min %.1f  p1 %.1f  p10 %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f" % (e.min(), q(e, 1), q(e, 10), q(e, 50), q(e, 90), q(e, 99), e.max()))
     print("length us: min %.1f  p1 %.1f  p10 %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f" % (d.min(), q(d, 1), q(d, 10), q(d, 50), q(d, 90), q(d, 99), d.max()))
+    dc = (clk[live, 1].astype(np.int64) - clk[live, 0].astype(np.int64)) / np.maximum(t1 - t0, 1) * 100.0  # s_memtime ticks per microsecond
+    print("s_memtime ticks per us over a wave's life: min %.1f  p50 %.1f  max %.1f  (the counter s_memtime reads; 100 = it is the same 100 MHz clock)" % (dc.min(), q(dc, 50), dc.max()))
     print("mean length %.1f us = %.3f of the span: the rest of the span is slots standing empty" % (d.mean(), d.mean() / e.max()))
     for x in sorted(set(xcc.tolist())):
         m = xcc == x
