@@ -433,7 +433,10 @@ def main():
                         "mixed_additions_per_launch": madds, "sorted_entries": counts["entries"],
                         "fragments": counts["fragments"], "peak": peak,
                         "achieved": madds * MADS_PER_MADD / (solo[dom] * 1e-3),
-                        "frac": round(madds * MADS_PER_MADD / (solo[dom] * 1e-3) / peak, 4)}
+                        "frac": round(madds * MADS_PER_MADD / (solo[dom] * 1e-3) / peak, 4),
+                        "peak_note": "nominal: 1024 SIMDs x 64 lanes x 2.4 GHz / 4.9 cycles; under this kernel the chip "
+                                     "sustains ~2.05 GHz (s_memtime stamps, profiles/r04_wave_trace.txt), where a "
+                                     "v_mad_u64_u32 is a 4-cycle instruction: the same achieved rate is ~0.90 of that"}
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                         "kernel_ms": solo[dom], "kernel_ms_alone": solo,
