@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Where the accumulation's time goes wave by wave (experiment build only).
 
-Needs a library built with -DCURDLE_TRACE_WAVES (k_accumulate stamps the 100 MHz wall clock at each wave's
-first and last instruction and its hardware id); point CURDLE_MSM_LIB at it:
-    CURDLE_MSM_LIB=build_trace/libcurdlemsm_trace.so python tools/trace_waves.py [logn]
+Needs the experiment build (-DCURDLE_TRACE_WAVES: k_accumulate stamps the 100 MHz wall clock and the shader clock
+at each wave's first and last instruction, and its hardware id); build it and point CURDLE_MSM_LIB at it:
+    make -C go-curdleproofs_amd trace
+    CURDLE_MSM_LIB=$PWD/build_trace/libcurdlemsm_trace.so python tools/trace_waves.py [logn]
 Runs ONE synchronous MSM (nothing else in flight), reads the stamps of its accumulate launch and prints the
 spread of starts, ends and durations, per XCD and per SIMD slot."""
 import ctypes as C
