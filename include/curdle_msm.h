@@ -537,7 +537,12 @@ int curdle_synth_points_walk_device(const uint64_t k[4], const uint64_t q[4], si
  *          the host's scalar multiplication): in: n x 8 words of a CANONICAL scalar k < r,
  *          out: n x (|k1| 4 words | k2 4 words | sign of the k1 term | sign of the k2 term,
  *          0x80000000 = negative), with k = +-|k1| +- k2 * lambda (mod r), both halves < 2^127
- * (limbs are passed as uint32 little-endian; 24/16/96/8 in and 12/8/48/10 out per item)
+ *   op 12: the two ends of the curve change the MSM kernels make (csrc/fp28.h from_gnark_iso_x / _y:
+ *          a base enters as (x / 16, y / 64) by shifts of its gnark words; to_gnark_msm: a result
+ *          leaves through 2^388 / 2^390) on plain field elements: in: n x (Fp | Fp), out: n x
+ *          (Fp | Fp | 1 if the x image is normalised and below 2p | the same for y); the round trip
+ *          is the identity (the host build copies)
+ * (limbs are passed as uint32 little-endian; 24/16/96/8/24 in and 12/8/48/10/26 out per item)
  * on_device = 0 runs the same header code on the host CPU. */
 int curdle_selftest_op(int op, const uint64_t* in, size_t n, uint64_t* out, int on_device);
 /* Words per item operation `op` reads and writes: the ONE table the entry point above, its launcher
