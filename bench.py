@@ -854,6 +854,15 @@ def verify_leg(cm, reps, warmup):
     for i in range(warmup):
         if not cm.verify_proof(crs, proof, Rs, Ss, Ts, Us, M, rands[i]):
             raise SystemExit("bench.py: an honest proof was rejected")
+    # A process' first ~250 verifications run 20 % slower than the ones after them (1.04 against 0.85 ms:
+    # tools/verify_settle_probe.py -- a GPU that has only seen 0.25 ms bursts has not left its idle clocks), which
+    # is what `--mode verify` alone used to time: keep warming until half a second of them has gone by.
+    tw = time.perf_counter()
+    extra = 0
+    while time.perf_counter() - tw < 0.5 and extra < 2000:
+        if not cm.verify_proof(crs, proof, Rs, Ss, Ts, Us, M, cm.Rand(5000 + extra)):
+            raise SystemExit("bench.py: an honest proof was rejected")
+        extra += 1
     t0 = time.perf_counter()
     for i in range(reps):
         if not cm.verify_proof(crs, proof, Rs, Ss, Ts, Us, M, rands[warmup + i]):
