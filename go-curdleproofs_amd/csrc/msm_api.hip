@@ -88,7 +88,7 @@ struct Slot {
   hipEvent_t acc_done = nullptr;
   hipEvent_t pre_done = nullptr;
   Buf points, scalars, offsets, points28, counts, starts, cursor, fragcnt, foff, small, digits, sorted, frags, partials,
-      winsums, winsums28, results, job, tmp, ccur;
+      winsums, winsums28, results, job, tmp, ccur, fold_sums, fold_meta;
   void* h_stage[2] = {nullptr, nullptr};  // pinned staging of the device accumulator (instance points; job)
   size_t h_stage_cap[2] = {0, 0};
   void* h_buf = nullptr;  // pinned: window sums (host combine) or results (GPU combine)
@@ -108,7 +108,8 @@ struct Slot {
 
   Buf* all_bufs(int i) {
     Buf* b[] = {&points, &scalars, &offsets, &points28, &counts, &starts, &cursor, &fragcnt, &foff, &small,
-                &digits, &sorted,  &frags,   &partials, &winsums, &winsums28, &results, &job,      &tmp,    &ccur};
+                &digits, &sorted,  &frags,   &partials, &winsums, &winsums28, &results, &job,      &tmp,    &ccur,
+                &fold_sums, &fold_meta};
     return i < (int)(sizeof(b) / sizeof(b[0])) ? b[i] : nullptr;
   }
 };
@@ -647,6 +648,10 @@ struct ChunkJoin {
   // A chunk is enqueued in two steps: its sort needs only its scalars, which cross PCIe first; the
   // conversion and everything behind it wait for its points.  0: all at once.
   int phase = 0;                      // 1: recoding + sort only; 2: conversion, accumulation, tail (same slot, same plan)
+  // Progressive folding (round 4): an earlier chunk's fragments are added into one running sum per bucket as soon as
+  // its accumulation is done (k_fold_fragments); the last chunk's reduction reads the sums as ONE fragment source.
+  Slot* fold_home = nullptr;          // the slot that owns the sums (the first chunk's); null: the reduction walks every chunk's fragments
+  Slot* fold_prev = nullptr;          // the chunk before this one: its acc_done then means "accumulated AND folded"
 };
 
 // Enqueue every GPU phase of k MSMs on the slot's stream (no host synchronisation).
@@ -798,12 +803,36 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   HIP_TRY(launch_merge_large(p, ws, stream));
   prof.mark("merge_large");
   if (join && join->accumulate_only) {
-    HIP_TRY(hipEventRecord(S.acc_done, stream));  // the fragments are complete (the last chunk waits for this)
+    if (join->fold_home) {
+      Slot& H = *join->fold_home;
+      if (p.k != 1 || sets != 1) return fail(CURDLE_EINVAL, "folding takes one MSM per chunk");
+      if (!join->fold_prev) {
+        int rf;
+        if ((rf = ensure(H.fold_sums, (size_t)p.NB * kX28Bytes))) return rf;
+        if ((rf = ensure(H.fold_meta, 2 * (size_t)p.NB * 4))) return rf;
+      } else {
+        HIP_TRY(hipStreamWaitEvent(stream, join->fold_prev->acc_done, 0));  // the sums so far
+      }
+      HIP_TRY(launch_fold_fragments(p, ws, H.fold_sums.p, H.fold_meta.p, !join->fold_prev, stream));
+      prof.mark("fold");
+    }
+    HIP_TRY(hipEventRecord(S.acc_done, stream));  // the fragments are complete (and folded): the next chunk / the last one waits for this
     return CURDLE_OK;
   }
   FragSources extra;
   memset(&extra, 0, sizeof(extra));
-  if (join) {
+  if (join && join->fold_home && join->fold_prev) {
+    const Slot& H = *join->fold_home;
+    const MsmPlan& q = join->fold_prev->plan;
+    if (q.c != p.c || q.NB != p.NB || q.seg != p.seg || q.k != 1 || p.k != 1 || sets != 1 || q.win_begin != p.win_begin ||
+        q.win_end != p.win_end || H.fold_sums.cap < (size_t)p.NB * kX28Bytes)
+      return fail(CURDLE_EINVAL, "chunks of one MSM must share the plan");
+    extra.frags[0] = H.fold_sums.p;
+    extra.foff[0] = (const uint32_t*)H.fold_meta.p;
+    extra.fragcnt[0] = (const uint32_t*)H.fold_meta.p + p.NB;
+    extra.n = 1;
+    HIP_TRY(hipStreamWaitEvent(stream, join->fold_prev->acc_done, 0));
+  } else if (join) {
     for (Slot* E : join->earlier) {
       if (extra.n >= (uint32_t)kMaxFragSources - 1) return fail(CURDLE_EINVAL, "too many chunks for one reduction");
       const MsmPlan& q = E->plan;
@@ -1045,7 +1074,9 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
   // see profiles/r03_host_buffer_chunks.txt.
   size_t nchunks = n >= ((size_t)1 << 20) ? 4 : 2;
   if (knobs::get(knobs::HOST_CHUNKS) > 0) nchunks = (size_t)knobs::get(knobs::HOST_CHUNKS);
-  if (nchunks > (size_t)kMaxFragSources) nchunks = kMaxFragSources;
+  // (without folding the reduction takes one fragment list per chunk: at most kMaxFragSources)
+  const bool fold_on = knobs::get(knobs::HOST_FOLD) != 0;
+  if (nchunks > (fold_on ? (size_t)kSlots : (size_t)kMaxFragSources)) nchunks = fold_on ? kSlots : kMaxFragSources;
   // every chunk needs a slot until the reduction has read its fragments: take what is free now
   // (never wait for a slot while holding one), at least one
   std::vector<int> slots;
@@ -1151,6 +1182,8 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       return CURDLE_OK;
     };
     ChunkJoin last;
+    // (knob HOST_FOLD=0: the reduction walks every chunk's fragment list, as until round 4)
+    const bool fold = knobs::get(knobs::HOST_FOLD) != 0 && parts.size() >= 2;
     auto enqueue_sort = [&](Part& pt) -> int {  // behind the chunk's scalars
       HIP_TRY(hipStreamWaitEvent(cx.pre_stream, pt.S->pre_done, 0));
       const uint32_t off[2] = {0, (uint32_t)pt.m};
@@ -1166,6 +1199,10 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       const bool is_last = i + 1 == parts.size();
       pt.join.phase = 2;
       pt.join.accumulate_only = !is_last;
+      if (fold) {
+        pt.join.fold_home = parts[0].S;
+        pt.join.fold_prev = i ? parts[i - 1].S : nullptr;
+      }
       if (is_last) pt.join.earlier = last.earlier;
       int rr = enqueue_slot(cx, *pt.S, pt.S->points.p, pt.S->scalars.p, off, 1, c, 0, -1, cx.pre_stream, pt.main, pt.S->stream,
                             /*latency_mode=*/true, false, 1, false, &pt.join);

@@ -920,6 +920,41 @@ __device__ __forceinline__ void group_bits_and_sum(F28& S, F28& T, u32 G) {
   }
 }
 
+// Host-buffer MSMs accumulated in chunks (msm_api.hip run_host_chunked): a chunk's fragments are folded into
+// ONE running sum per bucket as soon as its accumulation is done -- while later chunks are still crossing
+// PCIe or being accumulated -- so that the call's single reduction, which is what remains after the last copy
+// has landed, walks one point per bucket for all the earlier chunks instead of their 1.5 fragments each.
+// One quad per bucket slot; meta[b] = b (the sums' "fragment offset"), meta[nb + b] = 1 once any chunk had a
+// fragment there: the sums are a fragment source like any other (FragSources).
+__global__ void __launch_bounds__(kBlock, 2)
+    k_fold_fragments(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
+                     X28* __restrict__ sums, u32* __restrict__ meta, u32 nb, u32 max_small, u32 first) {
+  // (a 128-register build at priority 3, so that a wave fits beside the next chunk's two accumulate waves, and the same
+  // for the usually empty k_merge_large launch in front of it: measured, no better -- profiles/r04_host_fold.txt)
+  const u32 b = blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2);
+  if (b >= nb) return;  // whole quads leave together
+  u32 m = fragcnt[b];
+  if (m > max_small) m = 1;  // pre-merged by k_merge_large into its first slot
+  const X28* f = frags + foff[b];
+  F28 acc, x;
+  u32 any = m ? 1u : 0u;
+  if (first) {
+    q28::set_inf(acc);
+  } else {
+    q28::load(acc, &sums[b]);
+    any |= meta[nb + b];
+  }
+  for (u32 k = 0; k < m; k++) {
+    q28::load(x, &f[k]);
+    q28::add(acc, x);
+  }
+  q28::store(&sums[b], acc);
+  if (q28::role() == 0) {
+    meta[b] = b;
+    meta[nb + b] = any;
+  }
+}
+
 // One quad per segment of `seg` consecutive buckets, as in k_bucket_reduce_quad: ONE addition per
 // step, the next fragment into the running sum or the running sum into the segment sum.  The
 // fragment a step adds was loaded during the step before it, and a bucket's bookkeeping one bucket
@@ -1415,6 +1450,15 @@ hipError_t launch_reduce_segments(const MsmPlan& p, const MsmWorkspace& ws, hipS
   src.n++;
   hipLaunchKernelGGL(k_reduce_segments, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream, src,
                      reinterpret_cast<X28*>(ws.partials), p);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_fragments(const MsmPlan& p, const MsmWorkspace& ws, void* sums, void* meta, bool first, hipStream_t stream) {
+  if (p.k != 1 || p.sets != 1) return hipErrorInvalidValue;  // one MSM, one base set: the chunks of a host-buffer call
+  const u32 nb = p.NB;
+  hipLaunchKernelGGL(k_fold_fragments, dim3(cdiv(nb, kBlock / 4)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(sums),
+                     reinterpret_cast<u32*>(meta), nb, p.max_small, first ? 1u : 0u);
   return hipGetLastError();
 }
 

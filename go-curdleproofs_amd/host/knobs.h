@@ -39,6 +39,7 @@ enum Id {
   PROVER_FOLD_BASES,  // 1: the prover folds its bases round by round like the reference
   ACC_PRIO,           // k_accumulate: the two waves of a SIMD take turns at high priority every 2^v x 10 ns (0: never; unset: 15 for synchronous calls from half a round of lanes)
   REDUCE_PRIO,        // wave priority (0..3) of k_reduce_segments / k_reduce_level; unset: 3 for pipelined calls, 0 for synchronous ones
+  HOST_FOLD,          // 0: chunked host-buffer MSMs keep every chunk's fragments for the one reduction (no progressive folding)
   COUNT
 };
 // The knob's value, or -1 if it is not set (every knob's valid values are >= 0).

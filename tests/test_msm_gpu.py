@@ -321,6 +321,40 @@ def test_host_buffers_in_uneven_chunks(gpu, oracle, coracle):
         gpu.plan_override("HOST_CHUNKS", None)
 
 
+def test_chunked_host_call_folds_fragments_also_for_skewed_scalars(gpu, oracle, coracle):
+    """The chunks of a host-buffer call fold their fragments into one running sum per bucket as they finish
+    (k_fold_fragments), and the call's one reduction reads the sums beside the last chunk's fragments.  With
+    uniform scalars, with scalars that all fall into a handful of buckets (every chunk takes the k_merge_large
+    detour and the fold reads ONE pre-merged fragment for those buckets), with a
+    chunk whose scalars are all zero (no fragments at all), with folding switched off (HOST_FOLD=0: the
+    reduction walks every chunk's list): the same bits as the device-resident call and the closed form."""
+    import torch
+    n = (1 << 19) + 77
+    k, q = oracle.Rand(3).get_frs(2)
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    pts = d_pts.cpu().numpy().view(np.uint64)
+    rng = np.random.default_rng(77)
+    uniform = rand_scalars(rng, n, oracle)
+    few = np.array([oracle.fr_to_mont_limbs(v) for v in (5, 5 + (1 << 40), oracle.R - 3, 12345678901234567890)], dtype=np.uint64)
+    skewed = few[rng.integers(0, len(few), size=n)]
+    holed = uniform.copy()
+    holed[n // 4: n // 2] = 0                                     # the second of four chunks contributes nothing
+    try:
+        for name, sc in (("uniform", uniform), ("skewed", skewed), ("holed", holed)):
+            d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+            exp = gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
+            if name != "holed":
+                assert (exp == _walk_expected(oracle, coracle, k, q, sc)).all(), name
+            for chunks, fold in ((4, None), (2, None), (6, None), (4, 0)):
+                gpu.plan_override("HOST_CHUNKS", chunks)
+                gpu.plan_override("HOST_FOLD", fold)
+                assert (gpu.msm_g1(pts, sc) == exp).all(), (name, chunks, fold)
+    finally:
+        gpu.plan_override("HOST_CHUNKS", None)
+        gpu.plan_override("HOST_FOLD", None)
+
+
 def test_scalars_at_the_boundaries_of_the_split(gpu, oracle, coracle):
     """k_digits splits every scalar as k = +-(k1 + k2 lambda) with a Barrett division
     (msm_kernels.hip glv_split): the scalars where its branches flip -- around (r - 1) / 2,
