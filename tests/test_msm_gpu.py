@@ -594,8 +594,17 @@ def test_priority_turns_of_the_accumulate_waves_do_not_change_results(gpu, oracl
             assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == exp).all(), v
             t = gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n)
             assert (gpu.msm_wait(t) == exp).all(), v
+        gpu.plan_override("ACC_PRIO", None)
+        # ... and the priority the reduction's waves run at (REDUCE_PRIO: 3 by default in pipelined calls)
+        for v in (0, 1, 2, 3, 9):
+            gpu.plan_override("REDUCE_PRIO", v)
+            tickets = [gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n) for _ in range(3)]
+            for t in tickets:
+                assert (gpu.msm_wait(t) == exp).all(), v
+            assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == exp).all(), v
     finally:
         gpu.plan_override("ACC_PRIO", None)
+        gpu.plan_override("REDUCE_PRIO", None)
 
 
 def test_msm_over_a_resident_base_set(gpu, oracle, coracle):
