@@ -47,6 +47,10 @@ using d28::F28;
 using d28::X28;
 
 static constexpr int kBlock = 256;
+// s_getreg_b32 operands: (size - 1) << 11 | offset << 6 | register id.  HW_ID (4): wave slot 3:0, SIMD 5:4, CU 11:8,
+// SH 12, SE 15:13; XCC_ID (20): the XCD in 3:0.
+static constexpr int kGetregHwId = ((32 - 1) << 11) | 4;
+static constexpr int kGetregXccId = ((32 - 1) << 11) | 20;
 // s_setprio takes an immediate
 __device__ __forceinline__ void set_wave_prio(u32 v) {
   if (v == 1) __builtin_amdgcn_s_setprio(1);
@@ -675,8 +679,8 @@ __global__ void __launch_bounds__(kBlock, WAVES)
   if ((t & 63u) == 0 && wv < 8192u) {
     g_wave_trace[4 * wv] = wall_clock64();
     g_wave_clk[2 * wv] = __builtin_amdgcn_s_memtime();
-    g_wave_trace[4 * wv + 2] = __builtin_amdgcn_s_getreg(63492);
-    g_wave_trace[4 * wv + 3] = __builtin_amdgcn_s_getreg(63508);
+    g_wave_trace[4 * wv + 2] = __builtin_amdgcn_s_getreg(kGetregHwId);
+    g_wave_trace[4 * wv + 3] = __builtin_amdgcn_s_getreg(kGetregXccId);
   }
 #endif
   if (pos >= total) return;
@@ -708,7 +712,7 @@ __global__ void __launch_bounds__(kBlock, WAVES)
   u32 e_next = q[0];
   A28 pt_next;
   d28::load(pt_next, a28_at(points, e_next & 0x7fffffffu));
-  const u32 slot = __builtin_amdgcn_s_getreg(63492) & 1u;  // HW_ID: this wave's slot on its SIMD, low bit
+  const u32 slot = __builtin_amdgcn_s_getreg(kGetregHwId) & 1u;  // this wave's slot on its SIMD, low bit
   for (; pos < end; pos++) {
     if (prio_shift) {
       if ((((u32)wall_clock64() >> prio_shift) ^ slot) & 1u)
