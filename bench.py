@@ -128,6 +128,10 @@ def main():
                     help="diagnostic: the timed steps run curdle_msm_g1_dbases_submit over a resident, pre-converted base "
                          "set instead of gnark-layout points (never the headline `value`: the default run reports this "
                          "figure beside it as config.resident_bases)")
+    ap.add_argument("--bases-unchanged", action="store_true",
+                    help="diagnostic: the timed steps pass CURDLE_MSM_BASES_UNCHANGED (curdle_msm_g1_device_submit_ex): "
+                         "the library converts the resident gnark-layout bases once and keeps its copy -- what a rank of the "
+                         "window split may do with inputs that stay put between calls (never the headline `value`)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: on ONE GPU, run only the share rank 0 of an N-rank job would run "
                          "(no collective); prints the per-rank step time, not a bench line")
@@ -241,7 +245,8 @@ def main():
             tk = bases().submit(sc_ptr, n_mine, window_bits=c_mine, win_begin=wb, win_end=we if args.split == "windows" else -1)
         else:
             tk = cm.msm_g1_device_submit(pts_ptr, sc_ptr, n_mine, window_bits=c_mine, win_begin=wb,
-                                         win_end=we if args.split == "windows" else -1)
+                                         win_end=we if args.split == "windows" else -1,
+                                         flags=cm.MSM_BASES_UNCHANGED if args.bases_unchanged else 0)
         host_t["submit"] += time.perf_counter() - t_
         return tk
 
@@ -392,6 +397,7 @@ def main():
 
     if args.emulate_world > 1:
         print(json.dumps({"emulated_world": args.emulate_world, "split": args.split, "windows": [wb, we],
+                          "bases_unchanged_flag": bool(args.bases_unchanged),
                           "resident_bases": bases_box["on"],
                           "points": [p_lo, p_hi], "ms_per_step_rank0": ms_per_step,
                           "single_call_ms": single_call_ms, "in_flight": depth, "host_ms_per_step": host_ms,

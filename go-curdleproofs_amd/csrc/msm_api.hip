@@ -97,12 +97,15 @@ struct Slot {
   bool ev_made = false;
   // the call in flight
   struct curdle_dbases* held_bases = nullptr;  // a pipelined MSM over a resident base set keeps its reference until the wait
+  int held_cache = -1;                         // ... or over a cached converted copy (Ctx::bcache)
   bool busy = false;
   bool claimed = false;   // a curdle_msm_wait is finishing this call (a second wait on the ticket is refused)
   uint32_t gen = 0;       // bumped at every acquire: tickets carry it, stale ones are refused
   hipStream_t run_stream = nullptr;
   MsmPlan plan;
   bool profiled = false;
+  uint32_t coarse_nw = 0;     // window count the zeroed tail of `ccur` was laid out for
+  bool coarse_dirty = false;  // a call was abandoned between its ensure and its last launch: clear `ccur` again
   int prof_n = 0;
   const char* prof_name[CURDLE_PROF_MAX_KERNELS];
 
@@ -170,7 +173,21 @@ struct Ctx {
   hipStream_t pre_stream2 = nullptr;
   int pre_streams = 2;
   Slot slots[kSlots];
+  // Converted copies of base arrays whose callers promised they do not change (CURDLE_MSM_BASES_UNCHANGED): keyed
+  // by the device pointer and the count, made on first use on util_stream, reused by every later flagged call.
+  struct BaseCache {
+    const void* key = nullptr;
+    size_t n = 0;
+    Buf buf;
+    hipEvent_t ready = nullptr;  // recorded behind the conversion; every user's first stream waits for it
+    int users = 0;               // calls in flight that read the copy
+    uint64_t stamp = 0;          // last use (the least recently used idle entry is replaced)
+  };
+  static constexpr int kBaseCache = 4;
+  BaseCache bcache[kBaseCache];
+  uint64_t bstamp = 0;
   unsigned epoch = 0;  // bumped by curdle_shutdown: resident base sets of a closed context are refused
+  int pending_uploads = 0;  // resident base sets being copied + converted on util_stream right now (outside cx.mu): curdle_shutdown waits for none
   int profile = 0;  // 0 off, 1 every phase, 2 the dominant kernel only
   curdle_profile last = {};
 };
@@ -180,6 +197,7 @@ Ctx g_ctxs[kMaxDevices];
 std::atomic<int> g_ndev{1};  // configured contexts: [0, g_ndev)
 std::mutex g_cfg_mu;         // configuration (curdle_init_devices / curdle_shutdown)
 std::atomic<int> g_multi_calls{0};  // calls that span the devices' host threads right now
+std::atomic<unsigned long long> g_spread_calls{0};  // host-buffer MSMs that were spread over several devices, ever
 thread_local int tl_dev = 0;
 thread_local bool tl_selected = false;  // the thread called curdle_set_device: its host-buffer MSMs stay on that device
 // the calling thread's context; a thread whose selection no longer exists (curdle_shutdown since) is on 0
@@ -285,8 +303,10 @@ int init_locked(Ctx& cx, int device) {
     return fail(CURDLE_ENODEV, "no HIP device visible (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
   if (device < 0 || device >= ndev) return fail(CURDLE_EINVAL, "device %d out of range (%d visible)", device, ndev);
   HIP_TRY(hipSetDevice(device));
-  cx.device = device;  // from here on a failure leaves handles behind: curdle_init_devices tears them down
   HIP_TRY(hipStreamCreateWithFlags(&cx.util_stream, hipStreamNonBlocking));
+  // only now: a failure before the first handle exists leaves the context exactly as it was (review of round 4: with
+  // the id set first, a failed util_stream left cx.device on the failed id and nothing to tear down by)
+  cx.device = device;  // from here on a failure leaves handles behind: curdle_init_devices tears them down
   HIP_TRY(hipStreamCreateWithFlags(&cx.h2d_stream, hipStreamNonBlocking));
   int prio_least = 0, prio_greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
@@ -317,6 +337,7 @@ int init_locked(Ctx& cx, int device) {
     HIP_TRY(hipEventCreateWithFlags(&s.acc_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
   }
+  for (auto& bc : cx.bcache) HIP_TRY(hipEventCreateWithFlags(&bc.ready, hipEventDisableTiming));
   cx.prio_greatest = prio_greatest;
   cx.prio_least = prio_least;
   cx.device = device;
@@ -362,17 +383,20 @@ int choose_window_bits(size_t n, bool many = false) {
 // of n pairs is 2 n terms over W = ceil(127 / c) windows, the 127 bits spread as evenly as
 // possible (the wider windows lowest), the top window unsigned.  For c = 16 that is 7 windows
 // of 16 bits and a 15-bit top window.
+// (Without the split -- CURDLE_MSM_ANY_CURVE_POINT -- the same rule over the 255 bits of the whole scalar.)
 constexpr int kScalarBits = 127;
-int window_widths(int c, uint8_t bits[kMaxWindows]) {
-  const int W = (kScalarBits + c - 1) / c;
-  const int base = kScalarBits / W, extra = kScalarBits % W;
+constexpr int kScalarBitsNoGlv = 255;
+int window_widths(int c, uint8_t bits[kMaxWindows], int scalar_bits = kScalarBits) {
+  const int W = (scalar_bits + c - 1) / c;
+  const int base = scalar_bits / W, extra = scalar_bits % W;
   for (int w = 0; w < W; w++) bits[w] = (uint8_t)(base + (w < extra ? 1 : 0));
   return W;
 }
 
 // Plan for k MSMs of n_total pairs in all, the largest having n_max pairs.
 int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win_begin, int win_end,
-              bool latency_mode, size_t sets = 1, bool many = false, uint32_t seg_override = 0, bool light_host = false) {
+              bool latency_mode, size_t sets = 1, bool many = false, uint32_t seg_override = 0, bool light_host = false,
+              bool glv = true) {
   if (n_total > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n_total);
   many = many || k * sets >= gpu_combine_min();  // a pass of a larger batch keeps the batch's rules
   if (c == 0) c = choose_window_bits(n_max, many);
@@ -387,7 +411,10 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   p.kr = (uint32_t)(k * sets);
   p.n_max = (uint32_t)n_max;
   p.c = c;
-  p.W = window_widths(c, p.bits);
+  p.glv = glv ? 1u : 0u;
+  // (without the split the terms keep their numbering -- 2 i is k P_i, 2 i + 1 never contributes -- so every
+  // kernel behind k_digits is the same code; the opt-out pays for it with a digit array twice the needed size)
+  p.W = window_widths(c, p.bits, glv ? kScalarBits : kScalarBitsNoGlv);
   if (win_end < 0) win_end = p.W;
   if (win_begin < 0 || win_begin > win_end || win_end > p.W)
     return fail(CURDLE_EINVAL, "window range [%d, %d) outside [0, %d)", win_begin, win_end, p.W);
@@ -544,14 +571,23 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // the one-pass / two-pass form where the shapes allow.
   {
     const long long forced = knobs::get(knobs::SCATTER);
-    const bool shapes = k == 1 && min_nbkt >= 4096 && (min_nbkt & 127u) == 0 && p.max_nbkt <= 32768 && p.n <= (1u << 24);
+    const bool shapes = k == 1 && min_nbkt >= 4096 && (min_nbkt & 127u) == 0 && p.max_nbkt <= 32768 && p.n <= (1u << 24) &&
+                        win_end - win_begin <= 20;
     p.two_level = shapes && forced != 1 && (forced == 2 || p.n >= (1u << 17)) ? 1u : 0u;
   }
   // One single-block scan launch instead of six up to 8,192 bucket slots, where it is also the faster
   // one; beyond that the multi-block form (0.03 ms against 0.14 / 0.26 ms for the 32,768 / 65,536 slots of
   // an 8-way / 4-way rank of the window split; a pipelined rank step measured the same either way,
   // profiles/r04_pipeline_phase_costs.txt, so the kernel that is 5-9x faster alone is taken).
-  p.fuse_scan = (uint64_t)k * p.NB <= 8192 ? 1u : 0u;
+  // Round 5: k_scan_one -- one block as well, but the slots read once, coalesced, and the block scans by wave
+  // shuffles -- up to 32,768 slots (knob SCAN: 0 / 1 / 2 = six launches / k_scan_fused / k_scan_one where the sizes allow).
+  {
+    const uint64_t nbs = (uint64_t)k * p.NB;
+    const long long forced = knobs::get(knobs::SCAN);
+    p.fuse_scan = nbs <= 32768 ? 2u : 0u;
+    if (forced == 0) p.fuse_scan = 0;
+    if (forced == 1) p.fuse_scan = nbs <= 8192 ? 1u : 0u;
+  }
   return CURDLE_OK;
 }
 
@@ -657,10 +693,24 @@ struct ChunkJoin {
 // Enqueue every GPU phase of k MSMs on the slot's stream (no host synchronisation).
 // d_points / d_scalars are device pointers holding the pairs of all MSMs back to back
 // and must stay valid until the matching finish_slot(); h_off has k + 1 entries.
+int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
+                      int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail, bool latency_mode,
+                      bool points28_ready, size_t sets, bool many, const ChunkJoin* join, const void* ext_points28,
+                      bool light_host, bool glv);
 int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                  int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail,
                  bool latency_mode = true, bool points28_ready = false, size_t sets = 1, bool many = false,
-                 const ChunkJoin* join = nullptr, const void* ext_points28 = nullptr, bool light_host = false) {
+                 const ChunkJoin* join = nullptr, const void* ext_points28 = nullptr, bool light_host = false,
+                 bool glv = true) {
+  const int rc = enqueue_slot_impl(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, pre, stream, tail, latency_mode,
+                                   points28_ready, sets, many, join, ext_points28, light_host, glv);
+  if (rc == CURDLE_OK) S.coarse_dirty = false;  // every launch of the call is in its queue: k_digits leaves its counters zero
+  return rc;
+}
+int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
+                      int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail, bool latency_mode,
+                      bool points28_ready, size_t sets, bool many, const ChunkJoin* join, const void* ext_points28,
+                      bool light_host, bool glv) {
   // ext_points28: the bases are a resident, pre-converted set (curdle_dbases: two records per base in the internal
   // form, the first h_off[k] of them) -- d_points is not read, nothing is converted or copied
   if (ext_points28 && (k != 1 || sets != 1)) return fail(CURDLE_EINVAL, "resident bases take one MSM per call");
@@ -673,7 +723,7 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
     if (h_off[j + 1] - h_off[j] > n_max) n_max = h_off[j + 1] - h_off[j];
   }
   MsmPlan& p = S.plan;
-  int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets, many, join ? join->seg : 0, light_host);
+  int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets, many, join ? join->seg : 0, light_host, glv);
   if (rc) return rc;
   // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
   const size_t n = 2 * n_pairs;
@@ -697,7 +747,16 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
   if ((rc = ensure(S.sorted, (size_t)nw * n * 4))) return rc;
   if (p.two_level) {
     if ((rc = ensure(S.tmp, (size_t)nw * n * 4))) return rc;
-    if ((rc = ensure(S.ccur, ((size_t)nw * 256 * 2 + 1) * 4))) return rc;  // the bins' cursors, and their packed starts + sentinel
+    // the bins' cursors, their packed starts + sentinel, and the coarse counts + ticket of k_digits, which must be
+    // zero before the call's first launch: the kernel leaves them zero, so they are cleared only when the buffer is
+    // made (or moved), when the window count changes their place, and after a call that failed half-way
+    const void* before = S.ccur.p;
+    if ((rc = ensure(S.ccur, coarse_words(nw) * 4))) return rc;
+    if (S.ccur.p != before || S.coarse_nw != nw || S.coarse_dirty) {
+      HIP_TRY(hipMemsetAsync(S.ccur.p, 0, coarse_words(nw) * 4, pre));
+      S.coarse_nw = nw;
+    }
+    S.coarse_dirty = true;  // until this call's kernels are all enqueued
   }
   p.frag_stride = (uint32_t)(nb + nlanes + 1);
   if (!ext_points28 && (rc = ensure(S.points28, sets * n * kA28Bytes))) return rc;
@@ -974,7 +1033,7 @@ constexpr size_t kMaxSlotsPerPass = (size_t)1024 * 4096;
 // enqueue + finish of k MSMs on slot S, in passes if the batch is too large for one.
 int run_passes(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                int win_begin, int win_end, hipStream_t pre, hipStream_t main, hipStream_t tail, uint64_t* out,
-               const void* ext_points28 = nullptr) {
+               const void* ext_points28 = nullptr, bool glv = true) {
   if (k > 1) {
     size_t n_max = 0;
     for (size_t j = 0; j < k; j++) {
@@ -1003,14 +1062,15 @@ int run_passes(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, co
     }
   }
   int rc = enqueue_slot(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, pre, main, tail, true, false, 1, false,
-                        nullptr, ext_points28);
+                        nullptr, ext_points28, false, glv);
   if (!rc) rc = finish_slot(cx, S, out);
   return rc;
 }
 
 // Synchronous run of k MSMs with inputs on the device.
 int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c, int win_begin,
-               int win_end, uint64_t* out, void* user_stream, const void* ext_points28 = nullptr) {
+               int win_end, uint64_t* out, void* user_stream, const void* ext_points28 = nullptr, bool glv = true,
+               hipEvent_t wait_for = nullptr) {
   Ctx& cx = cur();
   int idx;
   int rc = acquire_slot(cx, true, &idx);
@@ -1022,11 +1082,16 @@ int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_of
     return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
   }
   if (user_stream) {
-    rc = run_passes(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, (hipStream_t)user_stream,
-                    (hipStream_t)user_stream, (hipStream_t)user_stream, out, ext_points28);
+    if (wait_for) he = hipStreamWaitEvent((hipStream_t)user_stream, wait_for, 0);
+    rc = he != hipSuccess ? fail(CURDLE_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(he))
+                          : run_passes(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, (hipStream_t)user_stream,
+                                       (hipStream_t)user_stream, (hipStream_t)user_stream, out, ext_points28, glv);
   } else {
     const SyncStreams st = sync_streams(cx, S);
-    rc = run_passes(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, st.pre, st.main, st.tail, out, ext_points28);
+    if (wait_for) he = hipStreamWaitEvent(st.pre, wait_for, 0);
+    rc = he != hipSuccess ? fail(CURDLE_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(he))
+                          : run_passes(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, st.pre, st.main, st.tail, out,
+                                       ext_points28, glv);
   }
   if (rc) drain_slot(cx, S);
   release_slot(cx, idx);
@@ -1034,7 +1099,7 @@ int run_device(const void* d_points, const void* d_scalars, const uint32_t* h_of
 }
 
 // Synchronous run with inputs in host memory: staged through the slot's own buffers.
-int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_off, size_t k, uint64_t* out) {
+int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_off, size_t k, uint64_t* out, bool glv = true) {
   Ctx& cx = cur();
   int idx;
   int rc = acquire_slot(cx, true, &idx);
@@ -1049,7 +1114,7 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
     const SyncStreams st = sync_streams(cx, S);
     HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, st.pre));
     HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st.pre));
-    return run_passes(cx, S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, st.pre, st.main, st.tail, out);
+    return run_passes(cx, S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, st.pre, st.main, st.tail, out, nullptr, glv);
   };
   rc = body();
   if (rc) drain_slot(cx, S);
@@ -1063,7 +1128,7 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
 // calling thread, not the GPU -- and the partial sums are added on the host.  At N = 2^20 the
 // copy (128 MiB) costs more than the arithmetic.
 constexpr size_t kHostChunkMin = (size_t)1 << 19;  // below this a call is one chunk
-int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out) {
+int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t* out, bool glv = true) {
   Ctx& cx = cur();
   // Round 2 ran every chunk as an MSM of its own and added the results: 6.4 ms in one copy, 5.8
   // in two chunks, 6.5 in four at N = 2^20 on a 29 GB/s link -- two half-size MSMs cost more than
@@ -1190,7 +1255,7 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       pt.join.phase = 1;
       // every chunk takes the synchronous rule for its segments (the reduction walks all of them with one plan)
       return enqueue_slot(cx, *pt.S, pt.S->points.p, pt.S->scalars.p, off, 1, c, 0, -1, cx.pre_stream, pt.main, pt.S->stream,
-                          /*latency_mode=*/true, false, 1, false, &pt.join);
+                          /*latency_mode=*/true, false, 1, false, &pt.join, nullptr, false, glv);
     };
     auto enqueue_accumulate = [&](size_t i) -> int {  // behind the chunk's points
       Part& pt = parts[i];
@@ -1205,7 +1270,7 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       }
       if (is_last) pt.join.earlier = last.earlier;
       int rr = enqueue_slot(cx, *pt.S, pt.S->points.p, pt.S->scalars.p, off, 1, c, 0, -1, cx.pre_stream, pt.main, pt.S->stream,
-                            /*latency_mode=*/true, false, 1, false, &pt.join);
+                            /*latency_mode=*/true, false, 1, false, &pt.join, nullptr, false, glv);
       last.earlier.push_back(pt.S);
       return rr;
     };
@@ -1614,6 +1679,16 @@ void teardown_locked(Ctx& C) {
     if (S.pre_done) (void)hipEventDestroy(S.pre_done);
     S.pre_done = nullptr;
   }
+  for (auto& bc : C.bcache) {
+    if (bc.buf.p) (void)hipFree(bc.buf.p);
+    bc.buf.p = nullptr;
+    bc.buf.cap = 0;
+    if (bc.ready) (void)hipEventDestroy(bc.ready);
+    bc.ready = nullptr;
+    bc.key = nullptr;
+    bc.n = 0;
+    bc.users = 0;
+  }
   if (C.main_stream) {
     (void)hipStreamSynchronize(C.main_stream);
     (void)hipStreamDestroy(C.main_stream);
@@ -1719,24 +1794,35 @@ extern "C" int curdle_set_device(int ordinal) {
 
 extern "C" int curdle_get_device(void) { return cur().ordinal; }
 
+// how many host-buffer MSMs were spread over several devices so far (tests: a thread that cleared its selection spreads again)
+extern "C" unsigned long long curdle_stat_spread_calls(void) { return g_spread_calls.load(std::memory_order_relaxed); }
+
+// -1 when the calling thread has made no selection (its large host-buffer MSMs spread over all devices)
+extern "C" int curdle_get_device_selection(void) { return tl_selected ? cur().ordinal : -1; }
+
 extern "C" int curdle_shutdown(void) {
   std::lock_guard<std::mutex> cfg(g_cfg_mu);
   const int have = g_ndev.load(std::memory_order_acquire);
   if (g_multi_calls.load(std::memory_order_acquire) > 0) return fail(CURDLE_EBUSY, "a multi-device call is still in flight");
-  for (int i = 0; i < have; i++) {  // all or nothing: first make sure no context has work in flight
+  // all or nothing, and nothing may start in between: every context's mutex is held from the check to the end of
+  // the teardown (in ordinal order; no other path holds two of them), so a slot acquire or a resident-bases upload
+  // either is seen here (CURDLE_EBUSY) or finds the context closed afterwards
+  std::vector<std::unique_lock<std::mutex>> held;
+  held.reserve((size_t)have);
+  for (int i = 0; i < have; i++) held.emplace_back(g_ctxs[i].mu);
+  for (int i = 0; i < have; i++) {
     Ctx& C = g_ctxs[i];
-    std::lock_guard<std::mutex> g(C.mu);
     if (!C.inited) continue;
     for (Slot& S : C.slots)
       if (S.busy) return fail(CURDLE_EBUSY, "an MSM is still in flight");
     for (DSlot& d : C.dslots)
       if (d.busy) return fail(CURDLE_EBUSY, "a point decoding is still in flight");
+    if (C.pending_uploads > 0) return fail(CURDLE_EBUSY, "a resident base set is still being uploaded");
   }
   for (int i = 0; i < have; i++) {
     Ctx& C = g_ctxs[i];
-    delete C.worker;  // joins the device's host thread (its queue is empty: nothing is in flight)
+    delete C.worker;  // joins the device's host thread (its queue is empty: nothing is in flight, and posting takes g_cfg_mu)
     C.worker = nullptr;
-    std::lock_guard<std::mutex> g(C.mu);
     if (C.inited) teardown_locked(C);
     C.device = 0;
   }
@@ -1780,14 +1866,14 @@ extern "C" int curdle_msm_num_windows(size_t n, int window_bits) { return curdle
 
 namespace {
 // One MSM from host buffers on the calling thread's context.
-int msm_host_one_device(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
+int msm_host_one_device(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18], bool glv = true) {
   if (n == 0) {
     set_out_infinity(out_jac);
     return CURDLE_OK;
   }
-  if (n >= kHostChunkMin && knobs::get(knobs::HOST_CHUNKS) != 1) return run_host_chunked(points, scalars, n, out_jac);
+  if (n >= kHostChunkMin && knobs::get(knobs::HOST_CHUNKS) != 1) return run_host_chunked(points, scalars, n, out_jac, glv);
   const uint32_t off[2] = {0, (uint32_t)n};
-  return run_host(points, scalars, off, 1, out_jac);
+  return run_host(points, scalars, off, 1, out_jac, glv);
 }
 
 // share(d, out18) runs on the host thread of context d (whose current context is d) for every
@@ -1833,6 +1919,9 @@ int run_on_devices(int D, const std::function<int(int, uint64_t*)>& share, uint6
       } catch (const std::exception& e) {
         p.rc = CURDLE_EHIP;
         snprintf(p.err, sizeof(p.err), "%s", e.what());
+      } catch (...) {  // anything else: the decrement below must run, or the caller waits for ever (review of round 4)
+        p.rc = CURDLE_EHIP;
+        snprintf(p.err, sizeof(p.err), "unknown exception in a device's host thread");
       }
       std::lock_guard<std::mutex> g(mu);
       if (--left == 0) cv.notify_one();
@@ -1870,8 +1959,11 @@ size_t multi_device_min() {
 }
 }  // namespace
 
-extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
+extern "C" int curdle_msm_g1_ex(const uint64_t* points, const uint64_t* scalars, size_t n, unsigned flags, uint64_t out_jac[18]) {
   if (!out_jac) return fail(CURDLE_EINVAL, "out_jac is null");
+  if (flags & ~(unsigned)CURDLE_MSM_ANY_CURVE_POINT)
+    return fail(CURDLE_EINVAL, "flags 0x%x: a host-buffer MSM takes CURDLE_MSM_ANY_CURVE_POINT only", flags);
+  const bool glv = !(flags & CURDLE_MSM_ANY_CURVE_POINT);
   if (n == 0) {
     set_out_infinity(out_jac);
     return CURDLE_OK;
@@ -1884,13 +1976,18 @@ extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, si
     // the copy is most of the call (128 MiB at N = 2^20 over one GPU's PCIe link), and only a point
     // range divides it: every device copies its own n / D pairs over its own link and runs all
     // windows over them (a window range would send all n pairs to every device).
+    g_spread_calls.fetch_add(1, std::memory_order_relaxed);
     return run_on_devices(D, [&](int d, uint64_t* part) {
       size_t lo, hi;
       even_range(n, D, d, &lo, &hi);
-      return msm_host_one_device(points + 12 * lo, scalars + 4 * lo, hi - lo, part);
+      return msm_host_one_device(points + 12 * lo, scalars + 4 * lo, hi - lo, part, glv);
     }, out_jac);
   }
-  return msm_host_one_device(points, scalars, n, out_jac);
+  return msm_host_one_device(points, scalars, n, out_jac, glv);
+}
+
+extern "C" int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
+  return curdle_msm_g1_ex(points, scalars, n, 0, out_jac);
 }
 
 extern "C" int curdle_msm_g1_replicated(const void* const* d_points, const void* const* d_scalars, size_t n, int split,
@@ -1930,13 +2027,94 @@ extern "C" int curdle_msm_g1_replicated(const void* const* d_points, const void*
   }, out_jac);
 }
 
-extern "C" int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, size_t n, int window_bits,
-                                            int win_begin, int win_end, uint64_t out_jac[18], void* stream) {
+namespace {
+// The converted copy of (d_points, n) on this context, made now if there is none.  On success *entry >= 0 names
+// the cache entry (one user reference taken: bases_cache_release gives it back), *d28 its records and *ready the
+// event behind its conversion; *entry = -1 with CURDLE_OK means every entry is in use by calls in flight: the
+// caller converts per call, as without the flag.
+int bases_cache_acquire(Ctx& cx, const void* d_points, size_t n, int* entry, const void** d28, hipEvent_t* ready) {
+  *entry = -1;
+  std::lock_guard<std::mutex> g(cx.mu);
+  int rc = init_default_locked(cx);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(cx.device));
+  int victim = -1;
+  for (int i = 0; i < Ctx::kBaseCache; i++) {
+    Ctx::BaseCache& bc = cx.bcache[i];
+    if (bc.key == d_points && bc.n == n) {
+      bc.users++;
+      bc.stamp = ++cx.bstamp;
+      *entry = i;
+      *d28 = bc.buf.p;
+      *ready = bc.ready;
+      return CURDLE_OK;
+    }
+    if (bc.users == 0 && (victim < 0 || bc.stamp < cx.bcache[victim].stamp)) victim = i;
+  }
+  if (victim < 0) return CURDLE_OK;
+  Ctx::BaseCache& bc = cx.bcache[victim];
+  bc.key = nullptr;
+  // (under the context's mutex: a second caller with the same key must find the entry complete, its event recorded;
+  // the allocation below happens once per base array)
+  if ((rc = ensure(bc.buf, 2 * n * kA28Bytes))) return rc;
+  HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)n, bc.buf.p, cx.util_stream));
+  HIP_TRY(hipEventRecord(bc.ready, cx.util_stream));
+  bc.key = d_points;
+  bc.n = n;
+  bc.users = 1;
+  bc.stamp = ++cx.bstamp;
+  *entry = victim;
+  *d28 = bc.buf.p;
+  *ready = bc.ready;
+  return CURDLE_OK;
+}
+void bases_cache_release(Ctx& cx, int entry) {
+  if (entry < 0) return;
+  std::lock_guard<std::mutex> g(cx.mu);
+  if (cx.bcache[entry].users > 0) cx.bcache[entry].users--;
+}
+int check_flags(unsigned flags) {
+  if (flags & ~(unsigned)(CURDLE_MSM_ANY_CURVE_POINT | CURDLE_MSM_BASES_UNCHANGED)) return fail(CURDLE_EINVAL, "unknown flags 0x%x", flags);
+  return CURDLE_OK;
+}
+}  // namespace
+
+extern "C" int curdle_msm_forget_bases(const void* d_points) {
+  Ctx& cx = cur();
+  std::lock_guard<std::mutex> g(cx.mu);
+  for (auto& bc : cx.bcache)
+    if (bc.key == d_points) bc.key = nullptr;  // calls in flight keep reading the copy; nobody finds it any more
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_msm_g1_device_windows_ex(const void* d_points, const void* d_scalars, size_t n, int window_bits,
+                                               int win_begin, int win_end, unsigned flags, uint64_t out_jac[18], void* stream) {
   if (!out_jac) return fail(CURDLE_EINVAL, "out_jac is null");
+  int rc = check_flags(flags);
+  if (rc) return rc;
   if (n && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
+  const bool glv = !(flags & CURDLE_MSM_ANY_CURVE_POINT);
   const uint32_t off[2] = {0, (uint32_t)n};
-  return run_device(d_points, d_scalars, off, 1, window_bits, win_begin, win_end, out_jac, stream);
+  Ctx& cx = cur();
+  int entry = -1;
+  const void* d28 = nullptr;
+  hipEvent_t ready = nullptr;
+  if ((flags & CURDLE_MSM_BASES_UNCHANGED) && n && (rc = bases_cache_acquire(cx, d_points, n, &entry, &d28, &ready))) return rc;
+  rc = run_device(d_points, d_scalars, off, 1, window_bits, win_begin, win_end, out_jac, stream, entry >= 0 ? d28 : nullptr, glv,
+                  entry >= 0 ? ready : nullptr);
+  bases_cache_release(cx, entry);
+  return rc;
+}
+
+extern "C" int curdle_msm_g1_device_ex(const void* d_points, const void* d_scalars, size_t n, unsigned flags, uint64_t out_jac[18],
+                                       void* stream) {
+  return curdle_msm_g1_device_windows_ex(d_points, d_scalars, n, 0, 0, -1, flags, out_jac, stream);
+}
+
+extern "C" int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, size_t n, int window_bits,
+                                            int win_begin, int win_end, uint64_t out_jac[18], void* stream) {
+  return curdle_msm_g1_device_windows_ex(d_points, d_scalars, n, window_bits, win_begin, win_end, 0, out_jac, stream);
 }
 
 extern "C" int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n, uint64_t out_jac[18],
@@ -1947,14 +2125,17 @@ extern "C" int curdle_msm_g1_device(const void* d_points, const void* d_scalars,
 // Asynchronous pair: submit enqueues all GPU phases of one MSM (or one window range)
 // on a free workspace slot and returns at once; wait blocks for it and finishes on
 // the host.  Up to CURDLE_MSM_SLOTS calls can be in flight.
-extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_scalars, size_t n, int window_bits,
-                                           int win_begin, int win_end, int* ticket) {
+extern "C" int curdle_msm_g1_device_submit_ex(const void* d_points, const void* d_scalars, size_t n, int window_bits,
+                                              int win_begin, int win_end, unsigned flags, int* ticket) {
   Ctx& cx = cur();
   if (!ticket) return fail(CURDLE_EINVAL, "ticket is null");
+  int rc = check_flags(flags);
+  if (rc) return rc;
   if (n && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
+  const bool glv = !(flags & CURDLE_MSM_ANY_CURVE_POINT);
   int idx;
-  int rc = acquire_slot(cx, false, &idx);
+  rc = acquire_slot(cx, false, &idx);
   if (rc) return rc;
   Slot& S = cx.slots[idx];
   hipError_t he = hipSetDevice(cx.device);
@@ -1962,21 +2143,40 @@ extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_s
     release_slot(cx, idx);
     return fail(CURDLE_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
   }
+  int entry = -1;
+  const void* d28 = nullptr;
+  hipEvent_t ready = nullptr;
+  if ((flags & CURDLE_MSM_BASES_UNCHANGED) && n && (rc = bases_cache_acquire(cx, d_points, n, &entry, &d28, &ready))) {
+    release_slot(cx, idx);
+    return rc;
+  }
   const uint32_t off[2] = {0, (uint32_t)n};
   const unsigned seq = cx.submit_count.fetch_add(1, std::memory_order_relaxed);
   const unsigned turn = seq % (unsigned)cx.main_streams;
   hipStream_t main = turn == 0 ? cx.main_stream : cx.main_extra[turn - 1];
-  const bool partial = win_begin > 0 || (win_end >= 0 && win_end < curdle_msm_num_windows(n, window_bits));
+  uint8_t wb[kMaxWindows];
+  const int W = window_widths(window_bits ? window_bits : choose_window_bits(n), wb, glv ? kScalarBits : kScalarBitsNoGlv);
+  const bool partial = win_begin > 0 || (win_end >= 0 && win_end < W);
   hipStream_t pre = partial && cx.pre_streams == 2 && (seq & 1u) ? cx.pre_stream2 : cx.pre_stream;
-  rc = enqueue_slot(cx, S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, pre, main,
-                    S.stream, /*latency_mode=*/false);
+  if (entry >= 0 && (he = hipStreamWaitEvent(main, ready, 0)) != hipSuccess)  // the accumulation is what reads the copy
+    rc = fail(CURDLE_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(he));
+  if (!rc)
+    rc = enqueue_slot(cx, S, d_points, d_scalars, off, 1, window_bits, win_begin, win_end, pre, main, S.stream,
+                      /*latency_mode=*/false, false, 1, false, nullptr, entry >= 0 ? d28 : nullptr, false, glv);
   if (rc) {
     drain_slot(cx, S);
     release_slot(cx, idx);
+    bases_cache_release(cx, entry);
     return rc;
   }
+  S.held_cache = entry;
   *ticket = make_ticket(cx, idx, S.gen);
   return CURDLE_OK;
+}
+
+extern "C" int curdle_msm_g1_device_submit(const void* d_points, const void* d_scalars, size_t n, int window_bits,
+                                           int win_begin, int win_end, int* ticket) {
+  return curdle_msm_g1_device_submit_ex(d_points, d_scalars, n, window_bits, win_begin, win_end, 0, ticket);
 }
 
 void dbases_release_handle(struct curdle_dbases* b);  // defined with the resident base sets below
@@ -2003,8 +2203,11 @@ extern "C" int curdle_msm_wait(int ticket, uint64_t out_jac[18]) {
   if (rc) drain_slot(cx, cx.slots[idx]);
   curdle_dbases* held = cx.slots[idx].held_bases;  // a resident base set the call read from
   cx.slots[idx].held_bases = nullptr;
+  const int cached = cx.slots[idx].held_cache;     // ... or a cached converted copy
+  cx.slots[idx].held_cache = -1;
   release_slot(cx, idx);
   if (held) dbases_release_handle(held);
+  bases_cache_release(cx, cached);
   return rc;
 }
 
@@ -2171,9 +2374,24 @@ int dbases_acquire(Ctx& cx, curdle_dbases* b, void** d28) {
     b->d28[o] = nullptr;
   }
   if (!b->d28[o] && b->n) {
-    HIP_TRY(hipSetDevice(device));
+    // the upload runs outside cx.mu on the context's utility stream: counted as in flight, so that a
+    // concurrent curdle_shutdown answers CURDLE_EBUSY instead of destroying the stream under the copy
+    // (review of round 4), and published only if the context is still the one the copy was made under
+    {
+      std::lock_guard<std::mutex> g(cx.mu);
+      if (!cx.inited || cx.epoch != epoch) return fail(CURDLE_EBUSY, "the context was shut down under a resident-bases upload");
+      cx.pending_uploads++;
+    }
+    struct Pending {
+      Ctx& c;
+      ~Pending() {
+        std::lock_guard<std::mutex> g(c.mu);
+        c.pending_uploads--;
+      }
+    } pending{cx};
+    hipError_t e = hipSetDevice(device);
     void *dst = nullptr, *tmp = nullptr;
-    hipError_t e = hipMalloc(&dst, 2 * b->n * kA28Bytes);  // P and phi(P) per base (launch_convert_points_raw)
+    if (e == hipSuccess) e = hipMalloc(&dst, 2 * b->n * kA28Bytes);  // P and phi(P) per base (launch_convert_points_raw)
     if (e == hipSuccess) e = hipMalloc(&tmp, b->n * 96);
     if (e == hipSuccess) e = hipMemcpyAsync(tmp, b->host.data(), b->n * 96, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_convert_points_raw(tmp, (uint32_t)b->n, dst, st);

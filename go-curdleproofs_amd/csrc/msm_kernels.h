@@ -41,7 +41,8 @@ struct MsmPlan {
   uint32_t max_large;  // capacity of the large-bucket queue
   uint32_t chunk;      // pairs per sort block
   uint32_t gpu_combine;  // 1: window sums combined on the GPU (large batches), 0: on the host
-  uint32_t fuse_scan;    // 1: the bucket-slot scans run as one single-block launch
+  uint32_t fuse_scan;    // the bucket-slot scans: 0 six launches (multi-block), 1 k_scan_fused (small calls), 2 k_scan_one (one block, up to 65,536 slots)
+  uint32_t glv;          // 1: scalars split with the endomorphism (bases must be in G1); 0: 255-bit scalars whole, any curve point
   uint32_t two_level;    // 1: the scatter runs in two passes (coarse bins, then buckets): single large MSMs
   // The bucket reduction without a scalar multiple (single MSMs; k_reduce_segments / k_reduce_groups):
   // a window's sum_b (b + 1) B_b leaves the GPU as `nout` points with bit positions, which the host's
@@ -75,7 +76,7 @@ struct MsmWorkspace {
   uint32_t* digits;   // [nw][n]   |digit| | sign<<31, window-major
   uint32_t* sorted;   // [nw * n]  pair index | sign<<31, grouped by bucket
   uint32_t* tmp;      // [nw * n]  two-level scatter: entries grouped by coarse bin (null otherwise)
-  uint32_t* ccur;     // [2 * nw * 256 + 1] two-level scatter: the bins' cursors, then their packed starts
+  uint32_t* ccur;     // [coarse_words(nw)] two-level sort: the bins' cursors, their packed starts, the coarse counts and k_digits' ticket
   void* points28;     // [n]       input points in internal form (d28::A28, 112 B)
   void* frags;        // [nb + lanes + 1]  d28::X28 (224 B)
   void* partials;     // [k * NS / G]      d28::X28, one per group of G bucket-reduce lanes
@@ -95,6 +96,11 @@ struct FragSources {
   const uint32_t* fragcnt[kMaxFragSources];  // [nb]
   uint32_t n;
 };
+
+// Words of MsmWorkspace::ccur for nw windows, and the offset from which it must be ZERO before a call's first
+// launch (the coarse counts and the ticket; the kernels leave them zero again).
+size_t coarse_words(uint32_t nw);
+size_t coarse_zero_offset_words(uint32_t nw);
 
 // Every launcher enqueues on `stream` and returns the launch status.
 // n gnark affine points -> internal form at d_out28 (kA28Bytes apart), outside a plan: the device accumulator

@@ -62,6 +62,15 @@ __device__ __forceinline__ void set_wave_prio(u32 v) {
 __constant__ u32 kPminus2[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
                                  0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
 
+// the two-level sort of single large MSMs (further down): bins of 2^kFineBits buckets
+static constexpr int kFineBits = 7;
+static constexpr u32 kFineMask = (1u << kFineBits) - 1u;
+static constexpr int kCoarseMax = 256;          // bins per window: 32,768 buckets / 128
+static constexpr int kCoarseThreads = 512;
+static constexpr int kCoarseTile = 8192;        // terms per block of the first pass: 32-entry (one line) runs per bin on average
+static constexpr int kFineTile = 2048;          // positions per block of the second pass
+static constexpr int kFineCap = 1024;           // LDS counters of the second pass (bucket slots per sweep)
+
 // ---------------------------------------------------------------------------
 // Digit recoding, for w = 0..W-1 in order: windows
 // below the top are signed (a raw digit above half the window range becomes its
@@ -87,47 +96,160 @@ __device__ __forceinline__ Fr load_scalar_canonical(const uint4* scalars, u32 i)
 
 // Phase 1: recode every scalar once.  digits[lw][i] = |d| | sign << 31 (0 = no
 // contribution), window-major so the sort passes below read them coalesced.
-__global__ void __launch_bounds__(kBlock) k_digits(const uint4* __restrict__ scalars, MsmPlan p,
-                                                   u32* __restrict__ digits, u32* __restrict__ counts, u32 nb) {
-  u32 i = blockIdx.x * kBlock + threadIdx.x;
-  // the histogram's counters start from zero: cleared here, one launch before k_hist adds into
+//
+// GLV = false (MsmPlan::glv == 0, CURDLE_MSM_ANY_CURVE_POINT): no endomorphism -- the 255-bit scalar is
+// recoded whole over W = ceil(255 / c) windows as term 2 i, term 2 i + 1 (the phi(P) record) never
+// contributes.  The result is then k P for EVERY point of the curve, in the subgroup or not.
+//
+// COARSE = true (MsmPlan::two_level: single large MSMs): the same launch also counts the terms per COARSE
+// bin (128 buckets) of every window in LDS; k_coarse_scan (one block) turns the counts into the bins' first
+// positions (ccur: the coarse scatter's cursors; cstart: the same packed over the windows in slot order,
+// with the total behind them, for the fine passes).  Round 5: the sort of such an MSM used
+// to begin with a 32,768-counter LDS histogram per block and ~1.9 M global atomics per window (k_hist:
+// 0.052 ms for ONE window of N = 2^20) and a scan of all bucket slots BEFORE anything could be placed; now the
+// coarse partition needs only these <= 256 counters per window, and the buckets are counted afterwards on
+// the bin-grouped array, where a tile of 2,048 entries touches <= 128 counters (k_scatter_fine<true>).
+static constexpr int kCoarseWinMax = 20;  // windows of a two-level plan: c >= 13, so <= 10 with the split, <= 20 without
+// Blocks publish their coarse counts into one of kCoarseReps copies of the counters (blockIdx mod kCoarseReps): 4,096
+// blocks adding into ONE copy took 0.35 ms at N = 2^20 -- 4,096 atomics on each of 256 addresses, one after the other
+// (gpurun_out/r5d) -- and the launch is capped at kDigitsCoarseMaxBlocks blocks, each walking several tiles of scalars.
+static constexpr int kCoarseReps = 16;
+struct CoarseOut {
+  u32* ccount;  // [kCoarseReps][nw * 256] zero when k_digits starts; k_coarse_scan leaves them zero again
+  u32* ccur;    // [nw * 256]
+  u32* cstart;  // [bins + 1]
+};
+// The coarse build runs 1,024-thread blocks, at most one per compute unit: what a block publishes at its end is
+// nw x 256 global atomics however few scalars it walked, and the chip completes ~50 G of them per second
+// (1,024 blocks of 256 threads: +0.03-0.04 ms on the launch at N = 2^20, gpurun_out/r5f).
+static constexpr int kDigitsCoarseBlock = 1024;
+static constexpr int kDigitsCoarseMaxBlocks = 256;
+template <bool GLV, bool COARSE>
+__global__ void __launch_bounds__(COARSE ? kDigitsCoarseBlock : kBlock) k_digits(const uint4* __restrict__ scalars, MsmPlan p,
+                                                   u32* __restrict__ digits, u32* __restrict__ counts, u32 nb, CoarseOut co) {
+  constexpr u32 kBlock = COARSE ? kDigitsCoarseBlock : curdle::kBlock;  // this kernel's block size
+  __shared__ u32 cc[COARSE ? kCoarseWinMax * 256 : 1];
+  const u32 tid = threadIdx.x;
+  const u32 nw = (u32)(p.win_end - p.win_begin);
+  // the histogram's counters start from zero: cleared here, one launch before the first kernel adds into
   // them, instead of by a memset node of their own
-  for (u32 b = i; b < nb; b += gridDim.x * kBlock) counts[b] = 0;
-  if (i >= p.n / 2) return;  // p.n counts the split's terms: entry 2 i is k1 P_i, entry 2 i + 1 is k2 phi(P_i)
-  Fr s = load_scalar_canonical(scalars, i);
-  u32 a[4], b[4], neg_a, neg_b;
-  glv_split(s, a, b, neg_a, neg_b);
-  // the two halves' digits of a window leave as ONE 8-byte store: written one half after the other, every
-  // line of `digits` went to memory twice (128 MB for a 64 MB array at N = 2^20, profiles/r04_pmc_summary.txt)
-  u32 ca = 0, cb = 0;
-  for (int w = 0; w < p.W; w++) {
-    const u32 c = p.bits[w];
-    const u32 ra = (a[0] & ((1u << c) - 1u)) + ca, rb = (b[0] & ((1u << c) - 1u)) + cb;
-    a[0] = (a[0] >> c) | (a[1] << (32 - c));
-    a[1] = (a[1] >> c) | (a[2] << (32 - c));
-    a[2] = (a[2] >> c) | (a[3] << (32 - c));
-    a[3] >>= c;
-    b[0] = (b[0] >> c) | (b[1] << (32 - c));
-    b[1] = (b[1] >> c) | (b[2] << (32 - c));
-    b[2] = (b[2] >> c) | (b[3] << (32 - c));
-    b[3] >>= c;
-    u32 ma = ra, na = 0, mb = rb, nb2 = 0;
-    ca = cb = 0;
-    if (w != p.W - 1) {  // windows below the top are signed (header comment above)
-      if (ra > (1u << (c - 1))) {
-        ma = (1u << c) - ra;
-        na = 0x80000000u;
-        ca = 1;
+  for (u32 b = blockIdx.x * kBlock + tid; b < nb; b += gridDim.x * kBlock) counts[b] = 0;
+  if constexpr (COARSE) {
+    for (u32 x = tid; x < nw * 256u; x += kBlock) cc[x] = 0;
+    __syncthreads();
+  }
+  // p.n counts the split's terms: entry 2 i is k1 P_i, entry 2 i + 1 is k2 phi(P_i)
+  for (u32 i = blockIdx.x * kBlock + tid; i < p.n / 2; i += gridDim.x * kBlock) {
+    Fr s = load_scalar_canonical(scalars, i);
+    constexpr int NA = GLV ? 4 : 8;
+    u32 a[NA], b[4], neg_a = 0, neg_b = 0;
+    if constexpr (GLV) {
+      glv_split(s, a, b, neg_a, neg_b);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) a[j] = s.l[j];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = 0;
+    }
+    // the two halves' digits of a window leave as ONE 8-byte store: written one half after the other, every
+    // line of `digits` went to memory twice (128 MB for a 64 MB array at N = 2^20, profiles/r04_pmc_summary.txt)
+    u32 ca = 0, cb = 0;
+    for (int w = 0; w < p.W; w++) {
+      const u32 c = p.bits[w];
+      const u32 ra = (a[0] & ((1u << c) - 1u)) + ca, rb = (b[0] & ((1u << c) - 1u)) + cb;
+#pragma unroll
+      for (int j = 0; j + 1 < NA; j++) a[j] = (a[j] >> c) | (a[j + 1] << (32 - c));
+      a[NA - 1] >>= c;
+      if constexpr (GLV) {
+        b[0] = (b[0] >> c) | (b[1] << (32 - c));
+        b[1] = (b[1] >> c) | (b[2] << (32 - c));
+        b[2] = (b[2] >> c) | (b[3] << (32 - c));
+        b[3] >>= c;
       }
-      if (rb > (1u << (c - 1))) {
-        mb = (1u << c) - rb;
-        nb2 = 0x80000000u;
-        cb = 1;
+      u32 ma = ra, na = 0, mb = rb, nb2 = 0;
+      ca = cb = 0;
+      if (w != p.W - 1) {  // windows below the top are signed (header comment above)
+        if (ra > (1u << (c - 1))) {
+          ma = (1u << c) - ra;
+          na = 0x80000000u;
+          ca = 1;
+        }
+        if (rb > (1u << (c - 1))) {
+          mb = (1u << c) - rb;
+          nb2 = 0x80000000u;
+          cb = 1;
+        }
+      }
+      if (w >= p.win_begin && w < p.win_end) {
+        const u32 lw = (u32)(w - p.win_begin);
+        *reinterpret_cast<uint2*>(&digits[(size_t)lw * p.n + 2 * (size_t)i]) =
+            make_uint2(ma ? (ma | (na ^ neg_a)) : 0u, mb ? (mb | (nb2 ^ neg_b)) : 0u);
+        if constexpr (COARSE) {
+          if (ma) atomicAdd(&cc[lw * 256u + ((ma - 1u) >> kFineBits)], 1u);
+          if (mb) atomicAdd(&cc[lw * 256u + ((mb - 1u) >> kFineBits)], 1u);
+        }
       }
     }
-    if (w >= p.win_begin && w < p.win_end)
-      *reinterpret_cast<uint2*>(&digits[(size_t)(w - p.win_begin) * p.n + 2 * (size_t)i]) =
-          make_uint2(ma ? (ma | (na ^ neg_a)) : 0u, mb ? (mb | (nb2 ^ neg_b)) : 0u);
+  }
+  if constexpr (COARSE) {
+    __syncthreads();
+    u32* mine = co.ccount + (size_t)(blockIdx.x % kCoarseReps) * nw * 256u;
+    for (u32 x = tid; x < nw * 256u; x += kBlock) {
+      const u32 v = cc[x];
+      if (v) atomicAdd(&mine[x], v);
+    }
+  }
+}
+
+// The coarse counts -> the bins' first positions: one block.  (Round 5's first build let the LAST block of k_digits do
+// this, found by a ticket every block incremented: 1,024 atomics on one address took 0.08 ms -- same-address device
+// atomics complete one after the other, ~80 ns each on this chip (gpurun_out/r5e) -- a launch of its own is ~7 us.)
+__global__ void __launch_bounds__(kBlock) k_coarse_scan(MsmPlan p, CoarseOut co) {
+  __shared__ u32 cc[kCoarseWinMax * 256];
+  __shared__ u32 sh_scan[kBlock];
+  const u32 tid = threadIdx.x;
+  const u32 nw = (u32)(p.win_end - p.win_begin);
+  const u32 tot = nw * 256u;
+  // the counts are summed over the copies and left zero for the next call
+  for (u32 x = tid; x < tot; x += kBlock) {
+    u32 v = 0;
+#pragma unroll
+    for (int r = 0; r < kCoarseReps; r++) {
+      u32* at = &co.ccount[(size_t)r * tot + x];
+      v += *at;
+      *at = 0;
+    }
+    cc[x] = v;
+  }
+  __syncthreads();
+  // exclusive prefix over the windows' bins in slot order (a window's unused bins hold zero): thread t
+  // takes per = ceil(tot / 256) consecutive entries
+  const u32 per = (tot + kBlock - 1) / kBlock;
+  const u32 lo = min(tid * per, tot), hi = min(lo + per, tot);
+  u32 sum = 0;
+  for (u32 x = lo; x < hi; x++) sum += cc[x];
+  sh_scan[tid] = sum;
+  __syncthreads();
+  for (u32 off = 1; off < (u32)kBlock; off <<= 1) {
+    const u32 t = tid >= off ? sh_scan[tid - off] : 0u;
+    __syncthreads();
+    sh_scan[tid] += t;
+    __syncthreads();
+  }
+  u32 run = sh_scan[tid] - sum;
+  const u32 total = sh_scan[kBlock - 1];
+  for (u32 x = lo; x < hi; x++) {
+    const u32 lw = x >> 8, bin = x & 255u;
+    const u32 w = (u32)p.win_begin + lw;
+    const u32 nbins = p.nbkt[w] >> kFineBits;
+    if (bin < nbins) {
+      co.ccur[x] = run;
+      u32 first = 0;
+      for (u32 y = (u32)p.win_begin; y < w; y++) first += p.nbkt[y] >> kFineBits;
+      co.cstart[first + bin] = run;
+      if (lw == nw - 1 && bin == nbins - 1) co.cstart[first + nbins] = total;  // the sentinel: every entry lies below it
+    }
+    run += cc[x];
   }
 }
 
@@ -211,34 +333,10 @@ __global__ void __launch_bounds__(kSortThreads) k_scatter(const u32* __restrict_
 // kilobytes its own bins cover, which the L2 merges into whole lines.
 // An entry of the intermediate array: term index (24 bits) | fine bucket (7 bits) << 24 | sign << 31.
 // ---------------------------------------------------------------------------
-static constexpr int kFineBits = 7;
-static constexpr u32 kFineMask = (1u << kFineBits) - 1u;
-static constexpr int kCoarseMax = 256;          // bins per window: 32,768 buckets / 128
-static constexpr int kCoarseThreads = 512;
-static constexpr int kCoarseTile = 8192;        // terms per block of the first pass: 32-entry (one line) runs per bin on average
-static constexpr int kFineTile = 2048;          // positions per block of the second pass
-static constexpr int kFineCap = 1024;           // LDS counters of the second pass (bucket slots per sweep)
 
-// coarse cursors: ccur[lw * kCoarseMax + bin] = global position of the bin's first entry (advanced by
-// the first pass), and the same positions packed over all windows in slot order, with the total
-// behind them, for the second pass: cstart[binbase(lw) + bin]
-__global__ void __launch_bounds__(kBlock)
-    k_coarse_init(const u32* __restrict__ starts, MsmPlan p, u32* __restrict__ ccur, u32* __restrict__ cstart, u32 nb) {
-  const u32 t = blockIdx.x * kBlock + threadIdx.x;
-  const u32 nw = p.win_end - p.win_begin;
-  if (t >= nw * kCoarseMax) return;
-  const u32 lw = t / kCoarseMax, bin = t - lw * kCoarseMax;
-  const u32 w = p.win_begin + lw;
-  const u32 nbins = p.nbkt[w] >> kFineBits;
-  if (bin >= nbins) return;
-  const u32 v = starts[p.base[w] + (bin << kFineBits)];
-  ccur[t] = v;
-  u32 first = 0;
-  for (u32 x = p.win_begin; x < w; x++) first += p.nbkt[x] >> kFineBits;
-  cstart[first + bin] = v;
-  if (lw == nw - 1 && bin == nbins - 1) cstart[first + nbins] = starts[nb];  // the sentinel: every entry lies below it
-}
-
+// coarse cursors (written by the last block of k_digits<.., true>): ccur[lw * kCoarseMax + bin] = global position
+// of the bin's first entry (advanced by the first pass), and the same positions packed over all windows
+// in slot order, with the total behind them, for the fine passes: cstart[binbase(lw) + bin]
 __global__ void __launch_bounds__(kCoarseThreads)
     k_scatter_coarse(const u32* __restrict__ digits, MsmPlan p, u32* __restrict__ ccur, u32* __restrict__ tmp) {
   __shared__ u32 cnt[kCoarseMax], off[kCoarseMax + 1], gbase[kCoarseMax];
@@ -305,8 +403,13 @@ __global__ void __launch_bounds__(kCoarseThreads)
 // their latency -- with 1,024 threads and 8,192 positions per block the launch took 0.10 ms at
 // N = 2^20, however the inside was arranged (entries kept in registers, bin tables in LDS, output
 // staged in LDS for contiguous stores: 0.099-0.152 ms).
+// COUNT = true is the same walk as a counting pass (round 5): the tile's entries per bucket slot, published with
+// one global atomic per touched slot -- at most 128 per bin the tile covers, where the LDS histogram over the
+// unsorted digits (k_hist) needed one per (block, non-empty bucket): 1.9 M per window at N = 2^20, now 0.13 M.
+// `cursor` is then the array of bucket sizes (zeroed by k_digits), `sorted` is not touched.
 static constexpr int kFineThreads = 256;
 static constexpr int kFineBinsCached = 64;
+template <bool COUNT>
 __global__ void __launch_bounds__(kFineThreads)
     k_scatter_fine(const u32* __restrict__ tmp, MsmPlan p, const u32* __restrict__ cstart, u32 nbins, u32* __restrict__ cursor,
                    u32* __restrict__ sorted) {
@@ -386,6 +489,14 @@ __global__ void __launch_bounds__(kFineThreads)
     for (int j = 0; j < PER; j++)
       if (slot[j] >= s0 && slot[j] < s1) rank[j] = atomicAdd(&cnt[slot[j] - s0], 1u);
     __syncthreads();
+    if constexpr (COUNT) {
+      for (u32 k = tid; k < S; k += kFineThreads) {
+        const u32 v = cnt[k];
+        if (v) atomicAdd(&cursor[s0 + k], v);
+      }
+      __syncthreads();
+      continue;
+    }
     constexpr int CPT = kFineCap / kFineThreads;  // consecutive counters per thread
     u32 c[CPT], sum = 0;
 #pragma unroll
@@ -558,6 +669,126 @@ __global__ void __launch_bounds__(kScanThreads)
     run += cnt;
   }
   if (tid == 0) foff[nb] = ftotal;
+}
+
+// The same in one single-block launch for up to 65,536 slots, with the slots read ONCE, coalesced (16 bytes per
+// lane), and the two block scans by wave shuffles (round 5).  k_scan_fused above gives every thread 8..64
+// consecutive slots and reads them twice, four bytes at a time and a line apart between neighbouring lanes:
+// 0.14 ms for the 32,768 slots of one window of the multi-GPU split, against 0.036 ms for the six launches of
+// the multi-block form -- this one takes a tile of 4,096 slots per step, two steps' loads in flight.
+static constexpr u32 kScanOneMax = 32768;
+static constexpr int kScanOnePer = kScanOneMax / kScanThreads;  // 32 consecutive slots per thread at most
+// floor(x / L) for x < 2^32 by one 64 x 64 -> high-64 product with M = floor((2^64 - 1) / L) + 1 (exact: the error term
+// x / 2^64 is far below 1 / L).  A hardware-less 32-bit division is ~40 instructions, and one block walks every slot.
+__device__ __forceinline__ u32 div_by(u32 x, u32 m_lo, u32 m_hi) {
+  return (u32)(((u64)__umulhi(x, m_lo) + (u64)x * m_hi) >> 32);
+}
+__device__ __forceinline__ u32 block_exclusive_scan_shfl(u32 v, u32* sh /* [16] */, u32& total) {
+  const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  u32 inc = v;
+#pragma unroll
+  for (u32 off = 1; off < 64; off <<= 1) {
+    const u32 t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();  // sh may still be read from the previous call
+  if (lane == 63) sh[wv] = inc;
+  __syncthreads();
+  u32 before = 0, all = 0;
+#pragma unroll
+  for (u32 k = 0; k < kScanThreads / 64; k++) {
+    const u32 t = sh[k];
+    if (k < wv) before += t;
+    all += t;
+  }
+  total = all;
+  return before + inc - v;
+}
+// Thread t owns slots [t per, (t + 1) per), per a multiple of 4: every load is issued before anything is
+// added (k_scan_fused walks its slots one dependent 4-byte load after the other, twice), two block scans in all.
+__global__ void __launch_bounds__(kScanThreads)
+    k_scan_one(const u32* __restrict__ counts, u32 nb, u32* __restrict__ starts, u32* __restrict__ cursor,
+               u32* __restrict__ fragcnt, u32* __restrict__ foff, u32* __restrict__ large, u32* __restrict__ nlarge, u32 L,
+               u32 max_small, u32 max_large, u32 m_lo, u32 m_hi) {
+  __shared__ u32 sh[kScanThreads / 64];
+  __shared__ u32 sh_nl;
+  const u32 tid = threadIdx.x;
+  if (tid == 0) sh_nl = 0;
+  const u32 per = (((nb + kScanThreads - 1) / kScanThreads) + 3u) & ~3u;  // <= kScanOnePer (checked by the launcher)
+  const u32 lo = tid * per;
+  const bool vec = (nb & 3u) == 0;  // then every group of four slots is whole and 16-byte aligned
+  u32 v[kScanOnePer], f[kScanOnePer];
+#pragma unroll
+  for (int g = 0; g < kScanOnePer / 4; g++) {
+    const u32 at = lo + 4 * g;
+    if (4u * g < per && at < nb) {
+      if (vec) {
+        const uint4 q = *reinterpret_cast<const uint4*>(counts + at);
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[4 * g + k] = at + k < nb ? counts[at + k] : 0u;
+      }
+    } else {
+      v[4 * g] = v[4 * g + 1] = v[4 * g + 2] = v[4 * g + 3] = 0;
+    }
+  }
+  u32 sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanOnePer; k++) sum += v[k];
+  u32 total, ftotal;
+  const u32 first = block_exclusive_scan_shfl(sum, sh, total);
+  // fragments per slot from the slot's start: lanes (start + cnt - 1) / L - start / L + 1; the end of one slot is
+  // the start of the next, so one division per slot and one for the inclusive end
+  u32 run = first, fsum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanOnePer; k++) {
+    const u32 cnt = v[k];
+    f[k] = cnt ? (div_by(run + cnt - 1, m_lo, m_hi) - div_by(run, m_lo, m_hi) + 1u) : 0u;
+    fsum += f[k];
+    run += cnt;
+  }
+  u32 frun = block_exclusive_scan_shfl(fsum, sh, ftotal);
+  run = first;
+#pragma unroll
+  for (int g = 0; g < kScanOnePer / 4; g++) {
+    const u32 at = lo + 4 * g;
+    u32 st[4], fo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      st[k] = run;
+      fo[k] = frun;
+      run += v[4 * g + k];
+      frun += f[4 * g + k];
+      if (f[4 * g + k] > max_small) {
+        const u32 q = atomicAdd(&sh_nl, 1u);
+        if (q < max_large) large[q] = at + k;
+      }
+    }
+    if (4u * g < per && at < nb) {
+      if (vec) {
+        *reinterpret_cast<uint4*>(starts + at) = make_uint4(st[0], st[1], st[2], st[3]);
+        *reinterpret_cast<uint4*>(cursor + at) = make_uint4(st[0], st[1], st[2], st[3]);
+        *reinterpret_cast<uint4*>(fragcnt + at) = make_uint4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+        *reinterpret_cast<uint4*>(foff + at) = make_uint4(fo[0], fo[1], fo[2], fo[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (at + k < nb) {
+            starts[at + k] = st[k];
+            cursor[at + k] = st[k];
+            fragcnt[at + k] = f[4 * g + k];
+            foff[at + k] = fo[k];
+          }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    starts[nb] = total;
+    foff[nb] = ftotal;
+    *nlarge = sh_nl;
+  }
 }
 
 // Phase 0: gnark points (R = 2^384, saturated limbs) -> internal form (fp28.h),
@@ -1327,16 +1558,70 @@ static hipError_t sort_lds_optin() {
   return e;
 }
 
+// Layout of ws.ccur (two-level plans): [nw * 256] coarse cursors | [nw * 256 + 1] packed bin starts + sentinel |
+// [nw * 256] coarse counts | [1] ticket.  The last two must be zero when k_digits starts and are zero again when
+// it ends (msm_api.hip clears them when the buffer is made and after a failed call).
+static inline CoarseOut coarse_out(const MsmPlan& p, const MsmWorkspace& ws) {
+  const size_t nw = (size_t)(p.win_end - p.win_begin);
+  CoarseOut co;
+  co.ccur = ws.ccur;
+  co.cstart = ws.ccur + nw * kCoarseMax;
+  co.ccount = ws.ccur + 2 * nw * kCoarseMax + 1;
+  return co;
+}
+size_t coarse_words(uint32_t nw) { return (2 + (size_t)kCoarseReps) * nw * kCoarseMax + 1; }
+size_t coarse_zero_offset_words(uint32_t nw) { return 2 * (size_t)nw * kCoarseMax + 1; }
+
+// operand shapes the two passes assume (checked on the host): one MSM, every window a whole number of
+// bins and at most kCoarseMax of them, term indices that fit 24 bits
+static hipError_t two_level_shapes(const MsmPlan& p, const MsmWorkspace& ws) {
+  const u32 nw = p.win_end - p.win_begin;
+  if (p.k != 1 || p.n > (1u << 24) || !ws.tmp || !ws.ccur || nw > (u32)kCoarseWinMax) return hipErrorInvalidValue;
+  for (int w = p.win_begin; w < p.win_end; w++)
+    if ((p.nbkt[w] & kFineMask) || (p.nbkt[w] >> kFineBits) > (u32)kCoarseMax) return hipErrorInvalidValue;
+  return hipSuccess;
+}
+
 hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream) {
-  hipLaunchKernelGGL(k_digits, dim3(cdiv(p.n / 2, kBlock)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const uint4*>(d_scalars), p, ws.digits, ws.counts, p.k * p.NB);
+  const u32 bs = p.two_level ? (u32)kDigitsCoarseBlock : (u32)kBlock;
+  const u32 blocks = cdiv(p.n / 2, bs);
+  const dim3 grid(p.two_level && blocks > (u32)kDigitsCoarseMaxBlocks ? (u32)kDigitsCoarseMaxBlocks : blocks), block(bs);
+  const uint4* sc = reinterpret_cast<const uint4*>(d_scalars);
+  CoarseOut co = {nullptr, nullptr, nullptr};
+  if (p.two_level) {
+    hipError_t e = two_level_shapes(p, ws);
+    if (e != hipSuccess) return e;
+    co = coarse_out(p, ws);
+    if (p.glv)
+      hipLaunchKernelGGL((k_digits<true, true>), grid, block, 0, stream, sc, p, ws.digits, ws.counts, p.k * p.NB, co);
+    else
+      hipLaunchKernelGGL((k_digits<false, true>), grid, block, 0, stream, sc, p, ws.digits, ws.counts, p.k * p.NB, co);
+    hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(kBlock), 0, stream, p, co);
+  } else if (p.glv) {
+    hipLaunchKernelGGL((k_digits<true, false>), grid, block, 0, stream, sc, p, ws.digits, ws.counts, p.k * p.NB, co);
+  } else {
+    hipLaunchKernelGGL((k_digits<false, false>), grid, block, 0, stream, sc, p, ws.digits, ws.counts, p.k * p.NB, co);
+  }
   return hipGetLastError();
 }
 
+// Bucket sizes.  Two-level plans: the coarse partition (k_scatter_coarse, from the bins' positions k_digits left)
+// and a counting walk over the bin-grouped array; everything else: the LDS histogram over the digits.
 hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   hipError_t e = sort_lds_optin();
   if (e != hipSuccess) return e;
   const u32 nw = p.win_end - p.win_begin;
+  if (p.two_level) {
+    if ((e = two_level_shapes(p, ws)) != hipSuccess) return e;
+    u32 nbins = 0;
+    for (int w = p.win_begin; w < p.win_end; w++) nbins += p.nbkt[w] >> kFineBits;
+    const CoarseOut co = coarse_out(p, ws);
+    hipLaunchKernelGGL(k_scatter_coarse, dim3(cdiv(p.n, kCoarseTile), nw), dim3(kCoarseThreads), kCoarseTile * 5, stream,
+                       ws.digits, p, co.ccur, ws.tmp);
+    hipLaunchKernelGGL(k_scatter_fine<true>, dim3(cdiv((u64)nw * p.n, kFineTile)), dim3(kFineThreads), 0, stream, ws.tmp, p,
+                       co.cstart, nbins, ws.counts, ws.sorted);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_hist, dim3(cdiv(p.n_max, p.chunk), nw, p.k), dim3(kSortThreads), p.max_nbkt * 4, stream,
                      ws.digits, p, ws.offsets, ws.counts);
   return hipGetLastError();
@@ -1352,7 +1637,13 @@ static hipError_t scan_u32(const u32* in, u32 len, u32* out, u32* blocksum, hipS
 
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nb = p.k * p.NB;
-  if (p.fuse_scan && nb <= kScanFusedMax) {
+  if (p.fuse_scan == 2 && nb <= kScanOneMax && p.L >= 2) {
+    const u64 magic = ~(u64)0 / p.L + 1;  // div_by: floor(x / L) for 32-bit x
+    hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(kScanThreads), 0, stream, ws.counts, nb, ws.starts, ws.cursor,
+                       ws.fragcnt, ws.foff, ws.large, ws.nlarge, p.L, p.max_small, p.max_large, (u32)magic, (u32)(magic >> 32));
+    return hipGetLastError();
+  }
+  if (p.fuse_scan == 1 && nb <= kScanFusedMax) {
     hipLaunchKernelGGL(k_scan_fused, dim3(1), dim3(kScanThreads), 0, stream, ws.counts, nb, ws.starts, ws.cursor,
                        ws.fragcnt, ws.foff, ws.large, ws.nlarge, p.L, p.max_small, p.max_large);
     return hipGetLastError();
@@ -1374,21 +1665,12 @@ hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t 
   hipError_t e = sort_lds_optin();
   if (e != hipSuccess) return e;
   const u32 nw = p.win_end - p.win_begin;
-  if (p.two_level) {
-    // operand shapes the two passes assume (checked here, on the host): one MSM, every window a
-    // whole number of bins and at most kCoarseMax of them, term indices that fit 24 bits
-    if (p.k != 1 || p.n > (1u << 24) || !ws.tmp || !ws.ccur) return hipErrorInvalidValue;
-    for (int w = p.win_begin; w < p.win_end; w++)
-      if ((p.nbkt[w] & kFineMask) || (p.nbkt[w] >> kFineBits) > (u32)kCoarseMax) return hipErrorInvalidValue;
+  if (p.two_level) {  // the entries are grouped by bin already (launch_hist): bins -> buckets
+    if ((e = two_level_shapes(p, ws)) != hipSuccess) return e;
     u32 nbins = 0;
     for (int w = p.win_begin; w < p.win_end; w++) nbins += p.nbkt[w] >> kFineBits;
-    u32* cstart = ws.ccur + (size_t)nw * kCoarseMax;  // [nbins + 1], behind the cursors
-    hipLaunchKernelGGL(k_coarse_init, dim3(cdiv((u64)nw * kCoarseMax, kBlock)), dim3(kBlock), 0, stream, ws.starts, p, ws.ccur,
-                       cstart, p.k * p.NB);
-    hipLaunchKernelGGL(k_scatter_coarse, dim3(cdiv(p.n, kCoarseTile), nw), dim3(kCoarseThreads), kCoarseTile * 5, stream,
-                       ws.digits, p, ws.ccur, ws.tmp);
-    hipLaunchKernelGGL(k_scatter_fine, dim3(cdiv((u64)nw * p.n, kFineTile)), dim3(kFineThreads), 0, stream, ws.tmp, p, cstart,
-                       nbins, ws.cursor, ws.sorted);
+    hipLaunchKernelGGL(k_scatter_fine<false>, dim3(cdiv((u64)nw * p.n, kFineTile)), dim3(kFineThreads), 0, stream, ws.tmp, p,
+                       coarse_out(p, ws).cstart, nbins, ws.cursor, ws.sorted);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_scatter, dim3(cdiv(p.n_max, p.chunk), nw, p.k), dim3(kSortThreads), p.max_nbkt * 4, stream,

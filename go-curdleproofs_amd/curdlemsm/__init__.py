@@ -41,7 +41,10 @@ MSM_SLOTS = 8
 # Every symbol include/curdle_msm.h declares (tests check they are all exported).
 SYMBOLS = [
     "curdle_init", "curdle_shutdown", "curdle_last_error", "curdle_plan_override", "curdle_device_available",
-    "curdle_init_devices", "curdle_device_count", "curdle_set_device", "curdle_get_device", "curdle_msm_g1_replicated",
+    "curdle_init_devices", "curdle_device_count", "curdle_set_device", "curdle_get_device", "curdle_get_device_selection", "curdle_stat_spread_calls",
+    "curdle_msm_g1_replicated",
+    "curdle_msm_g1_ex", "curdle_msm_g1_device_ex", "curdle_msm_g1_device_windows_ex", "curdle_msm_g1_device_submit_ex",
+    "curdle_msm_forget_bases",
     "curdle_msm_g1", "curdle_msm_g1_device", "curdle_msm_g1_device_windows",
     "curdle_msm_g1_device_submit", "curdle_msm_wait",
     "curdle_msm_window_bits", "curdle_msm_num_windows", "curdle_msm_window_widths", "curdle_g1_sum",
@@ -90,6 +93,13 @@ _init_devices = _sig("curdle_init_devices", C.c_int, C.POINTER(C.c_int), C.c_int
 _device_count = _sig("curdle_device_count", C.c_int)
 _set_device = _sig("curdle_set_device", C.c_int, C.c_int)
 _get_device = _sig("curdle_get_device", C.c_int)
+_get_device_selection = _sig("curdle_get_device_selection", C.c_int)
+_msm_g1_ex = _sig("curdle_msm_g1_ex", C.c_int, _vp, _vp, C.c_size_t, C.c_uint, _vp)
+_msm_g1_device_windows_ex = _sig("curdle_msm_g1_device_windows_ex", C.c_int, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                 C.c_uint, _vp, _vp)
+_msm_submit_ex = _sig("curdle_msm_g1_device_submit_ex", C.c_int, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_uint,
+                      C.POINTER(C.c_int))
+_msm_forget_bases = _sig("curdle_msm_forget_bases", C.c_int, _vp)
 _msm_g1_replicated = _sig("curdle_msm_g1_replicated", C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t,
                           C.c_int, _vp)
 _last_error = _sig("curdle_last_error", C.c_int, C.c_char_p, C.c_size_t)
@@ -243,6 +253,19 @@ def get_device() -> int:
     return int(_get_device())
 
 
+def get_device_selection() -> int:
+    """The ordinal this thread selected with set_device, or -1 if it has made no selection."""
+    return int(_get_device_selection())
+
+
+def stat_spread_calls() -> int:
+    return int(_stat_spread_calls())
+
+
+# flags of the *_ex entry points (include/curdle_msm.h)
+MSM_ANY_CURVE_POINT, MSM_BASES_UNCHANGED = 1, 2
+
+
 SPLIT_AUTO, SPLIT_WINDOWS, SPLIT_POINTS = 0, 1, 2
 
 
@@ -263,8 +286,9 @@ def device_available() -> bool:
     return bool(_device_available())
 
 
-def msm_g1(points, scalars) -> np.ndarray:
-    """(*G1Jac).MultiExp on host arrays: points uint64[n,12], scalars uint64[n,4] -> uint64[18]."""
+def msm_g1(points, scalars, flags: int = 0) -> np.ndarray:
+    """(*G1Jac).MultiExp on host arrays: points uint64[n,12], scalars uint64[n,4] -> uint64[18].
+    flags: MSM_ANY_CURVE_POINT = no endomorphism, gnark's result for bases outside the subgroup too."""
     points = _as_u64(points, 12)
     scalars = _as_u64(scalars, 4)
     n = points.shape[0] if points.size else 0
@@ -273,25 +297,41 @@ def msm_g1(points, scalars) -> np.ndarray:
         # gnark MultiExp: "len(points) != len(scalars)"
         raise CurdleError(EINVAL, "len(points) != len(scalars)")
     out = np.zeros(18, dtype=np.uint64)
-    _check(_msm_g1(_ptr(points), _ptr(scalars), n, _ptr(out)))
+    if flags:
+        _check(_msm_g1_ex(_ptr(points), _ptr(scalars), n, int(flags), _ptr(out)))
+    else:
+        _check(_msm_g1(_ptr(points), _ptr(scalars), n, _ptr(out)))
     return out
 
 
 def msm_g1_device(d_points: int, d_scalars: int, n: int, stream: int = 0, window_bits: int = 0,
-                  win_begin: int = 0, win_end: int = -1) -> np.ndarray:
-    """MSM on device-resident inputs (raw device pointers, e.g. torch_tensor.data_ptr())."""
+                  win_begin: int = 0, win_end: int = -1, flags: int = 0) -> np.ndarray:
+    """MSM on device-resident inputs (raw device pointers, e.g. torch_tensor.data_ptr()).
+    flags: MSM_ANY_CURVE_POINT, MSM_BASES_UNCHANGED (the library keeps its converted copy of d_points)."""
     out = np.zeros(18, dtype=np.uint64)
-    _check(_msm_g1_device_windows(d_points, d_scalars, n, window_bits, win_begin, win_end, _ptr(out),
-                                  stream or None))
+    if flags:
+        _check(_msm_g1_device_windows_ex(d_points, d_scalars, n, window_bits, win_begin, win_end, int(flags), _ptr(out),
+                                         stream or None))
+    else:
+        _check(_msm_g1_device_windows(d_points, d_scalars, n, window_bits, win_begin, win_end, _ptr(out),
+                                      stream or None))
     return out
 
 
 def msm_g1_device_submit(d_points: int, d_scalars: int, n: int, window_bits: int = 0, win_begin: int = 0,
-                         win_end: int = -1) -> int:
+                         win_end: int = -1, flags: int = 0) -> int:
     """Enqueue one MSM (or window range) and return a ticket; see msm_wait()."""
     t = C.c_int(-1)
-    _check(_msm_submit(d_points, d_scalars, n, window_bits, win_begin, win_end, C.byref(t)))
+    if flags:
+        _check(_msm_submit_ex(d_points, d_scalars, n, window_bits, win_begin, win_end, int(flags), C.byref(t)))
+    else:
+        _check(_msm_submit(d_points, d_scalars, n, window_bits, win_begin, win_end, C.byref(t)))
     return t.value
+
+
+def msm_forget_bases(d_points: int) -> None:
+    """Drops the converted copy a MSM_BASES_UNCHANGED call left for d_points."""
+    _check(_msm_forget_bases(d_points))
 
 
 class DBases:

@@ -14,7 +14,19 @@ package curdlemsm
 #cgo CFLAGS: -I${SRCDIR}/../../../include
 #cgo LDFLAGS: -L${SRCDIR}/../.. -lcurdlemsm -Wl,-rpath,${SRCDIR}/../..
 #include <stdlib.h>
+#include <stdint.h>
 #include "curdle_msm.h"
+
+// Device addresses travel from Go as integers (uintptr_t), never as unsafe.Pointer: they are not Go
+// pointers, and `unsafe.Pointer(uintptr)` is what `go vet` (unsafeptr) rejects.  The arrays themselves are
+// Go slices of integers -- pointer-free memory, which cgo may pass for the duration of a call.
+static int curdle_go_replicated(const uintptr_t* d_points, const uintptr_t* d_scalars, size_t n, int split, uint64_t* out) {
+	return curdle_msm_g1_replicated((const void* const*)d_points, (const void* const*)d_scalars, n, split, out);
+}
+static int curdle_go_device_ex(uintptr_t d_points, uintptr_t d_scalars, size_t n, unsigned flags, uint64_t* out) {
+	return curdle_msm_g1_device_ex((const void*)d_points, (const void*)d_scalars, n, flags, out, NULL);
+}
+static int curdle_go_forget_bases(uintptr_t d_points) { return curdle_msm_forget_bases((const void*)d_points); }
 */
 import "C"
 
@@ -72,11 +84,13 @@ func DeviceCount() int { return int(C.curdle_device_count()) }
 
 // OnDevice runs f with the calling OS thread's current context set to `ordinal` (the
 // library's selection is per OS thread, like hipSetDevice, so the goroutine is locked to its
-// thread for the duration and the previous selection is restored).
+// thread for the duration and the previous selection is restored -- "no selection" (-1) included: Go reuses OS
+// threads, and a thread left selected on device 0 would keep every later MultiExp that lands on it from
+// spreading over the devices; curdle_get_device() cannot tell "selected 0" from "selected nothing").
 func OnDevice(ordinal int, f func() error) error {
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
-	prev := C.curdle_get_device()
+	prev := C.curdle_get_device_selection()
 	if rc := C.curdle_set_device(C.int(ordinal)); rc != 0 {
 		return fmt.Errorf("curdlemsm: no device %d (rc=%d)", ordinal, int(rc))
 	}
@@ -112,6 +126,25 @@ var MinGPUPairs = 32
 // SURVEY.md section 5's failure row wants a verifier's accept bits to be independent of the
 // GPU's health.  Off by default: a deployment that bought a GPU wants to hear that it is not used.
 func MultiExp(dst *bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Element, cfg ecc.MultiExpConfig) (*bls12381.G1Jac, error) {
+	return MultiExpFlags(dst, points, scalars, cfg, DefaultFlags)
+}
+
+// Flags of MultiExpFlags (CURDLE_MSM_* in curdle_msm.h).
+const (
+	// AnyCurvePoint: no endomorphism -- gnark's own contract: the result is k*P for every point of the
+	// curve, in the prime-order subgroup or not (twice the windows; about 1.3x the time of a large MSM).
+	AnyCurvePoint = 1
+	// BasesUnchanged (device inputs only): the library keeps its converted copy of the base array.
+	BasesUnchanged = 2
+)
+
+// DefaultFlags is what MultiExp passes.  A deployment whose callers hand curdleproof.Verify bases that
+// did NOT come out of gnark's subgroup-checking decoders sets it to AnyCurvePoint and gets gnark's
+// result for every input gnark accepts.
+var DefaultFlags uint = 0
+
+// MultiExpFlags is MultiExp with the options of curdle_msm_g1_ex.
+func MultiExpFlags(dst *bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Element, cfg ecc.MultiExpConfig, flags uint) (*bls12381.G1Jac, error) {
 	if len(points) != len(scalars) {
 		return nil, errors.New("len(points) != len(scalars)")
 	}
@@ -124,7 +157,7 @@ func MultiExp(dst *bls12381.G1Jac, points []bls12381.G1Affine, scalars []fr.Elem
 		sp = unsafe.Pointer(&scalars[0])
 	}
 	err := locked(func() C.int {
-		return C.curdle_msm_g1((*C.uint64_t)(pp), (*C.uint64_t)(sp), C.size_t(len(points)),
+		return C.curdle_msm_g1_ex((*C.uint64_t)(pp), (*C.uint64_t)(sp), C.size_t(len(points)), C.uint(flags),
 			(*C.uint64_t)(unsafe.Pointer(dst)))
 	})
 	if err != nil {
@@ -165,20 +198,29 @@ func MultiExpReplicated(dst *bls12381.G1Jac, dPoints, dScalars []uintptr, n int,
 	if len(dPoints) != d || len(dScalars) != d {
 		return fmt.Errorf("curdlemsm: MultiExpReplicated: %d devices configured, %d / %d pointers given", d, len(dPoints), len(dScalars))
 	}
-	// two C arrays of D device addresses (not Go pointers: nothing to pin)
-	pa := (*[1 << 8]unsafe.Pointer)(C.calloc(C.size_t(2*d), C.size_t(unsafe.Sizeof(uintptr(0)))))
-	if pa == nil {
-		return errors.New("curdlemsm: out of memory")
+	if d == 0 {
+		return errors.New("curdlemsm: MultiExpReplicated: no device configured")
 	}
-	defer C.free(unsafe.Pointer(pa))
-	for i := 0; i < d; i++ {
-		pa[i] = unsafe.Pointer(dPoints[i])   //nolint:govet // a device address travelling as an integer
-		pa[d+i] = unsafe.Pointer(dScalars[i]) //nolint:govet
-	}
+	// []uintptr is pointer-free Go memory: cgo may pass it for the duration of the call, whatever d is
 	return locked(func() C.int {
-		return C.curdle_msm_g1_replicated((*unsafe.Pointer)(unsafe.Pointer(&pa[0])), (*unsafe.Pointer)(unsafe.Pointer(&pa[d])),
+		return C.curdle_go_replicated((*C.uintptr_t)(unsafe.Pointer(&dPoints[0])), (*C.uintptr_t)(unsafe.Pointer(&dScalars[0])),
 			C.size_t(n), C.int(split), (*C.uint64_t)(unsafe.Pointer(dst)))
 	})
+}
+
+// MultiExpDevice is one MSM over inputs resident on the calling thread's device (device addresses as
+// integers), with the flags above: BasesUnchanged makes the library keep its converted copy of dPoints
+// (ForgetBases drops it before the memory is freed or rewritten).
+func MultiExpDevice(dst *bls12381.G1Jac, dPoints, dScalars uintptr, n int, flags uint) error {
+	return locked(func() C.int {
+		return C.curdle_go_device_ex(C.uintptr_t(dPoints), C.uintptr_t(dScalars), C.size_t(n), C.uint(flags),
+			(*C.uint64_t)(unsafe.Pointer(dst)))
+	})
+}
+
+// ForgetBases: see MultiExpDevice.
+func ForgetBases(dPoints uintptr) error {
+	return locked(func() C.int { return C.curdle_go_forget_bases(C.uintptr_t(dPoints)) })
 }
 
 // ResidentBases is a base set converted once and kept on the GPU (curdle_dbases): the CRS of a
@@ -259,11 +301,12 @@ func MultiExpShared(dst []bls12381.G1Jac, sets [][]bls12381.G1Affine, scalars []
 	// The C side takes an array of base-set pointers.  It lives in C memory, zeroed (calloc), and
 	// the Go slices it points to are pinned for the duration of the call (runtime.Pinner,
 	// Go >= 1.21): storing unpinned Go pointers in C memory is what the cgo rules forbid.
-	arr := (*[1 << 20]*C.uint64_t)(C.calloc(C.size_t(len(sets)), C.size_t(unsafe.Sizeof(uintptr(0)))))
-	if arr == nil {
+	mem := C.calloc(C.size_t(len(sets)), C.size_t(unsafe.Sizeof(uintptr(0))))
+	if mem == nil {
 		return errors.New("curdlemsm: out of memory")
 	}
-	defer C.free(unsafe.Pointer(arr))
+	defer C.free(mem)
+	arr := unsafe.Slice((**C.uint64_t)(mem), len(sets)) // no fixed-size array type: any number of sets
 	var pin runtime.Pinner
 	defer pin.Unpin()
 	for i, s := range sets {
@@ -271,7 +314,7 @@ func MultiExpShared(dst []bls12381.G1Jac, sets [][]bls12381.G1Affine, scalars []
 		arr[i] = (*C.uint64_t)(unsafe.Pointer(&s[0]))
 	}
 	return locked(func() C.int {
-		return C.curdle_msm_g1_multi((**C.uint64_t)(unsafe.Pointer(arr)), C.size_t(len(sets)),
+		return C.curdle_msm_g1_multi((**C.uint64_t)(mem), C.size_t(len(sets)),
 			(*C.uint64_t)(unsafe.Pointer(&scalars[0])), C.size_t(len(scalars)), (*C.uint64_t)(unsafe.Pointer(&dst[0])))
 	})
 }

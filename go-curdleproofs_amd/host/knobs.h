@@ -18,10 +18,10 @@ enum Id {
   WINDOW_BITS,        // maximum window width c of every plan (4..16); unset: the size table
   SEG_LEN,            // sorted positions per accumulate lane
   REDUCE_SEG,         // buckets per bucket-reduce segment (power of two)
-  SYNC_LANES,         // lanes the reduce of a synchronous call is sized for (default 65,536)
+  SYNC_LANES,         // lanes the reduce of a synchronous call is sized for (default 131,072)
   PIPE_LANES,         // ... of a pipelined call (default 32,768)
   SCATTER,            // 1: one-pass scatter, 2: two-pass wherever the shapes allow; unset: by size
-  REDUCE_BITS,        // 0: k_bucket_reduce_quad everywhere, 1: the bit-sum reduction everywhere; unset: single MSMs
+  REDUCE_BITS,        // 0: k_bucket_reduce_quad everywhere, 1: the bit-sum reduction wherever the shapes allow, 2: in synchronous calls only; unset: single MSMs from 300 pairs
   HOST_CHUNKS,        // chunks of a host-buffer MSM from 2^19 pairs (1..4)
   MAX_MSMS_PER_PASS,  // MSMs per pass of a batch beyond the bucket-slot limit
   MULTI_DEVICE_MIN,   // pairs from which curdle_msm_g1 spreads over the configured devices
@@ -39,6 +39,7 @@ enum Id {
   PROVER_FOLD_BASES,  // 1: the prover folds its bases round by round like the reference
   ACC_PRIO,           // k_accumulate: the two waves of a SIMD take turns at high priority every 2^v x 10 ns (0: never; unset: 15 for synchronous calls from half a round of lanes)
   REDUCE_PRIO,        // wave priority (0..3) of k_reduce_segments / k_reduce_level; unset: 3 for pipelined calls, 0 for synchronous ones
+  SCAN,               // the bucket-slot scans: 0 six launches, 1 k_scan_fused up to 8,192 slots, 2 k_scan_one up to 32,768; unset: 2
   HOST_FOLD,          // 0: chunked host-buffer MSMs keep every chunk's fragments for the one reduction (no progressive folding)
   COUNT
 };

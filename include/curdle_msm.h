@@ -89,6 +89,12 @@ int curdle_device_count(void);      /* contexts configured (1 unless curdle_init
  * 0, and large host-buffer MSMs may spread over all devices again). */
 int curdle_set_device(int ordinal);
 int curdle_get_device(void);
+/* The calling thread's SELECTION: the ordinal it passed to curdle_set_device, or -1 if it has made none (or
+ * cleared it with -1).  What a binding that selects a device temporarily restores afterwards
+ * (curdlemsm.OnDevice): restoring curdle_get_device()'s 0 would leave the thread pinned to device 0. */
+int curdle_get_device_selection(void);
+/* Diagnostics: host-buffer MSMs (curdle_msm_g1) that were spread over several devices since the library was loaded. */
+unsigned long long curdle_stat_spread_calls(void);
 /* Closes every context (streams, workspaces, host threads).  CURDLE_EBUSY while an MSM or a point
  * decoding is in flight on a slot, or a call that spans the devices' host threads is running.  Like every teardown of a library, it must not run
  * concurrently with other entry points: a call that has not taken its slot yet is not seen. */
@@ -130,11 +136,36 @@ int curdle_device_available(void);
 int curdle_msm_g1(const uint64_t* points, const uint64_t* scalars, size_t n,
                   uint64_t out_jac[CURDLE_G1_JAC_U64]);
 
+/* The same call with options (flags = 0 is curdle_msm_g1).
+ *
+ * CURDLE_MSM_ANY_CURVE_POINT -- the opt-out from the precondition above: gnark's contract.  The scalars are
+ *   NOT split with the endomorphism; each is recoded whole (255 bits, twice the windows), so the result is
+ *   k P for every point P of the curve y^2 = x^3 + 4, in the prime-order subgroup or not -- what
+ *   (*G1Jac).MultiExp (go.mod:6) returns for such input.  Costs about twice the bucket reduction and a digit
+ *   array of twice the needed size; the additions are the same.  For callers that take bases from outside
+ *   without a subgroup check (curdleproof.Verify takes []G1Affine from its caller, curdleproof.go:199-207).
+ * CURDLE_MSM_BASES_UNCHANGED (device-input entry points only) -- the caller promises that the n points at
+ *   d_points have not changed since the previous call that named the same (d_points, n) with this flag on this
+ *   context: the library keeps its converted copy of them (one per pointer and count, at most four per context,
+ *   the least recently used idle one is replaced; 256 bytes per point) and converts nothing on later calls.
+ *   This is the "explicit, caller-managed" form of caching SURVEY.md section 8b allows: without the flag nothing
+ *   is ever cached by pointer (the prover mutates its bases in place between calls).  A rank of the multi-GPU
+ *   window split passes the same resident bases on every call; msmaccumulator.Verify's bases are mostly the CRS.
+ *   curdle_msm_forget_bases(d_points) drops the copy (before the memory is freed or rewritten). */
+#define CURDLE_MSM_ANY_CURVE_POINT 1u
+#define CURDLE_MSM_BASES_UNCHANGED 2u
+int curdle_msm_g1_ex(const uint64_t* points, const uint64_t* scalars, size_t n, unsigned flags,
+                     uint64_t out_jac[CURDLE_G1_JAC_U64]);
+
 /* Same MSM with inputs already resident in device memory (HIP device
  * pointers, same layouts).  `stream` is a hipStream_t or NULL for the
  * library's own stream.  This is what bench.py times. */
 int curdle_msm_g1_device(const void* d_points, const void* d_scalars, size_t n,
                          uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
+/* ... with the flags of curdle_msm_g1_ex (both apply to device inputs). */
+int curdle_msm_g1_device_ex(const void* d_points, const void* d_scalars, size_t n, unsigned flags,
+                            uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
+int curdle_msm_forget_bases(const void* d_points);
 
 /* The same MSM over inputs the caller keeps resident on EVERY configured context:
  * d_points[i] / d_scalars[i] are device pointers on context i's GPU, each holding all n pairs
@@ -156,6 +187,8 @@ int curdle_msm_g1_replicated(const void* const* d_points, const void* const* d_s
  * fails with CURDLE_EBUSY when every slot is in flight. */
 int curdle_msm_g1_device_submit(const void* d_points, const void* d_scalars, size_t n,
                                 int window_bits, int win_begin, int win_end, int* ticket);
+int curdle_msm_g1_device_submit_ex(const void* d_points, const void* d_scalars, size_t n,
+                                   int window_bits, int win_begin, int win_end, unsigned flags, int* ticket);
 int curdle_msm_wait(int ticket, uint64_t out_jac[CURDLE_G1_JAC_U64]);
 /* How many of the CURDLE_MSM_SLOTS workspace slots are free right now (a hint: other threads
  * take and release slots concurrently).  A caller that would hold a slot across host work of
@@ -173,6 +206,9 @@ int curdle_msm_free_slots(void);
 int curdle_msm_g1_device_windows(const void* d_points, const void* d_scalars, size_t n,
                                  int window_bits, int win_begin, int win_end,
                                  uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
+int curdle_msm_g1_device_windows_ex(const void* d_points, const void* d_scalars, size_t n,
+                                    int window_bits, int win_begin, int win_end, unsigned flags,
+                                    uint64_t out_jac[CURDLE_G1_JAC_U64], void* stream);
 int curdle_msm_window_bits(size_t n);              /* the library's choice of c for n   */
 int curdle_msm_num_windows(size_t n, int window_bits); /* W = ceil(127 / c) for that choice */
 /* Widths of the W windows for (n, window_bits), lowest window first (sum = 127: the

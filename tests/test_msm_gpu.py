@@ -888,3 +888,166 @@ def test_batched_scalar_multiplication(gpu, oracle):
         assert (lhs == rhs).all(), hex(K)
         assert oracle.affine_from_mont_limbs([int(v) for v in out[big - 1]]) == oracle.scalar_mul(
             K, oracle.affine_from_mont_limbs([int(v) for v in pts[big - 1]])), hex(K)
+
+
+def _off_subgroup_point(oracle):
+    """A point of y^2 = x^3 + 4 over F_p that is NOT in the prime-order subgroup."""
+    p, R = oracle.P, oracle.R
+    x = 6
+    while True:
+        rhs = (x * x * x + 4) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p == rhs and oracle.scalar_mul(R, (x, y)) is not None:
+            return (x, y)
+        x += 1
+
+
+def test_any_curve_point_flag_is_gnarks_contract(gpu, oracle, coracle):
+    """CURDLE_MSM_ANY_CURVE_POINT: no endomorphism, the scalar recoded whole over twice
+    the windows -- the result is k P for EVERY point of the curve, which is what gnark's MultiExp returns
+    (go.mod:6; SURVEY.md a6 states no subgroup condition).  (1) the off-subgroup point of the test above,
+    where the default path returns k1 P + k2 (beta x, y): with the flag, oracle.scalar_mul(k, P) exactly;
+    (2) mixed MSMs -- bases in G1, outside it, infinity, duplicates -- of every plan family (tiny, the
+    verifier's size, one-pass and two-pass scatter) against the textbook sum; (3) on G1 inputs the flag must
+    not change a bit, at 2^17 + 77 pairs with skewed scalar sets and over window partials."""
+    import torch
+    R = oracle.R
+    P = _off_subgroup_point(oracle)
+    for k in (1, 5, (1 << 127) + 12345, 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % R, R - 2, R - 1):
+        pts = np.array([oracle.affine_to_mont_limbs(P)], dtype=np.uint64)
+        sc = np.array([oracle.fr_to_mont_limbs(k)], dtype=np.uint64)
+        got = gpu.msm_g1(pts, sc, flags=gpu.MSM_ANY_CURVE_POINT)
+        assert [int(v) for v in got] == oracle.jac_to_mont_limbs(oracle.scalar_mul(k, P)), hex(k)
+    # mixed bases: multiples of P (outside G1 unless the multiplier kills the cofactor part), G1 points, infinity
+    rng = np.random.default_rng(55)
+    walk_k, walk_q = oracle.Rand(1).get_frs(2)
+    g1 = coracle.points_walk(walk_k, walk_q, 4096)
+    offs = [oracle.scalar_mul(m, P) for m in (1, 2, 3, 5, 7, 11)]
+    off_limbs = np.array([oracle.affine_to_mont_limbs(t) for t in offs], dtype=np.uint64)
+    for n in (2, 9, 70, 700, 2548, 4096):
+        pts = g1[:n].copy()
+        where = rng.choice(n, size=max(1, n // 7), replace=False)
+        pts[where] = off_limbs[rng.integers(0, len(offs), len(where))]
+        pts[rng.integers(0, n)] = 0                                   # an infinity base
+        sc = rand_scalars(rng, n, oracle)
+        sc[rng.integers(0, n)] = np.array(oracle.fr_to_mont_limbs(R - 1), dtype=np.uint64)
+        exp = coracle.msm_naive(pts, sc) if n <= 700 else coracle.msm_pippenger(pts, sc, threads=4)
+        got = gpu.msm_g1(pts, sc, flags=gpu.MSM_ANY_CURVE_POINT)
+        assert (got == exp).all(), n
+        d_p = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
+        d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        assert (gpu.msm_g1_device(d_p.data_ptr(), d_s.data_ptr(), n, flags=gpu.MSM_ANY_CURVE_POINT) == exp).all(), n
+        if n == 700:
+            assert not (gpu.msm_g1(pts, sc) == exp).all()             # the default path is NOT gnark's there
+    # on G1 the flag changes nothing: two-pass scatter size, skewed scalars, window partials
+    n = (1 << 17) + 77
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(walk_k, walk_q, n, d_pts.data_ptr())
+    uniform = rand_scalars(rng, n, oracle)
+    fams = {"uniform": uniform,
+            "all_equal": np.tile(np.array(oracle.fr_to_mont_limbs(123456789123456789123456789), dtype=np.uint64), (n, 1)),
+            "small": np.array([oracle.fr_to_mont_limbs(i % 300) for i in range(n)], dtype=np.uint64)}
+    for name, sc in fams.items():
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        exp = _walk_expected(oracle, coracle, walk_k, walk_q, sc)
+        for c in (0, 13, 16):
+            got = gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c, flags=gpu.MSM_ANY_CURVE_POINT)
+            assert (got == exp).all(), (name, c)
+    d_sc = torch.from_numpy(uniform.view(np.int64)).to("cuda:0")
+    exp = _walk_expected(oracle, coracle, walk_k, walk_q, uniform)
+    W = (255 + 15) // 16
+    parts = [gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=16, win_begin=w, win_end=min(w + 3, W),
+                               flags=gpu.MSM_ANY_CURVE_POINT) for w in range(0, W, 3)]
+    assert (gpu.g1_sum(np.stack(parts)) == exp).all()
+    # host buffers in chunks (2^19 pairs and more) take the flag too
+    n = 1 << 19
+    d_big = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(walk_k, walk_q, n, d_big.data_ptr())
+    sc = rand_scalars(rng, n, oracle)
+    got = gpu.msm_g1(d_big.cpu().numpy().view(np.uint64), sc, flags=gpu.MSM_ANY_CURVE_POINT)
+    assert (got == _walk_expected(oracle, coracle, walk_k, walk_q, sc)).all()
+    with pytest.raises(gpu.CurdleError):
+        gpu.msm_g1(g1[:4], rand_scalars(rng, 4, oracle), flags=gpu.MSM_BASES_UNCHANGED)   # host buffers are never cached
+    with pytest.raises(gpu.CurdleError):
+        gpu.msm_g1(g1[:4], rand_scalars(rng, 4, oracle), flags=64)
+
+
+def test_bases_unchanged_flag_keeps_a_converted_copy(gpu, oracle, coracle):
+    """CURDLE_MSM_BASES_UNCHANGED: the caller's promise lets the library keep its converted copy of a device
+    base array -- keyed by pointer and count, never without the flag (what a rank of the
+    window split does with its resident bases).  Results are those of the unflagged call: whole MSM, prefix
+    of the array (its own entry), window partials, six pipelined calls, more base arrays than entries (the idle
+    one is replaced), a forgotten array whose memory was rewritten."""
+    import torch
+    F = gpu.MSM_BASES_UNCHANGED
+    k, q = oracle.Rand(1).get_frs(2)
+    n = (1 << 17) + 5
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    rng = np.random.default_rng(77)
+    for rep in range(3):                                              # first call converts, the others reuse
+        sc = rand_scalars(rng, n, oracle)
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        exp = _walk_expected(oracle, coracle, k, q, sc)
+        assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, flags=F) == exp).all(), rep
+    m = 3000                                                          # a prefix is another (pointer, count)
+    assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), m, flags=F) == _walk_expected(oracle, coracle, k, q, sc[:m])).all()
+    W = gpu.num_windows(n, 16)
+    parts = [gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=16, win_begin=w, win_end=w + 1, flags=F)
+             for w in range(W)]
+    assert (gpu.g1_sum(np.stack(parts)) == exp).all()
+    tickets = [gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n, 16, w % W, w % W + 1, flags=F) for w in range(6)]
+    for w, t in enumerate(tickets):
+        assert (gpu.msm_wait(t) == parts[w % W]).all(), w
+    both = gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, flags=F | gpu.MSM_ANY_CURVE_POINT)
+    assert (both == exp).all()
+    # more arrays than cache entries
+    others = []
+    for j in range(6):
+        kj, qj = oracle.Rand(20 + j).get_frs(2)
+        t = torch.empty((2000, 12), dtype=torch.int64, device="cuda:0")
+        gpu.synth_points_walk_device(kj, qj, 2000, t.data_ptr())
+        others.append((kj, qj, t))
+    s2 = rand_scalars(rng, 2000, oracle)
+    d_s2 = torch.from_numpy(s2.view(np.int64)).to("cuda:0")
+    for rnd in range(2):
+        for kj, qj, t in others:
+            assert (gpu.msm_g1_device(t.data_ptr(), d_s2.data_ptr(), 2000, flags=F) == _walk_expected(oracle, coracle, kj, qj, s2)).all()
+    # rewritten memory: forget first, then the new contents count
+    kj, qj, t = others[-1]
+    gpu.msm_forget_bases(t.data_ptr())
+    k9, q9 = oracle.Rand(99).get_frs(2)
+    gpu.synth_points_walk_device(k9, q9, 2000, t.data_ptr())
+    torch.cuda.synchronize()
+    assert (gpu.msm_g1_device(t.data_ptr(), d_s2.data_ptr(), 2000, flags=F) == _walk_expected(oracle, coracle, k9, q9, s2)).all()
+    gpu.msm_forget_bases(d_pts.data_ptr())
+
+
+def test_bucket_slot_scans_agree(gpu, oracle, coracle):
+    """The three builds of the bucket-slot scan (knob SCAN: six launches, k_scan_fused, round 5's k_scan_one:
+    one block, slots read once, wave-shuffle block scans) give the same MSM at sizes on both sides of their
+    limits (8,192 / 65,536 slots) and for a batch."""
+    import torch
+    k, q = oracle.Rand(1).get_frs(2)
+    nmax = 1 << 17
+    d_pts = torch.empty((nmax, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, nmax, d_pts.data_ptr())
+    sc = rand_scalars(np.random.default_rng(8), nmax, oracle)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    try:
+        for n, c in ((9, 0), (300, 0), (1268, 0), (4096, 0), (40000, 11), (65536, 0), (nmax, 14), (nmax, 16)):
+            exp = _walk_expected(oracle, coracle, k, q, sc[:n])
+            for mode in (0, 1, 2, -1):
+                gpu.plan_override("SCAN", mode)
+                assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c) == exp).all(), (n, c, mode)
+        pts = d_pts[:6000].cpu().numpy().view(np.uint64)
+        offs = [0, 100, 100, 2600, 6000]
+        ref = None
+        for mode in (0, 1, 2, -1):
+            gpu.plan_override("SCAN", mode)
+            got = gpu.msm_g1_batch(pts, sc[:6000], offs)
+            ref = got if ref is None else ref
+            assert (got == ref).all(), mode
+        assert (ref[3] == coracle.msm_pippenger(pts[2600:6000], sc[2600:6000], threads=4)).all()
+    finally:
+        gpu.plan_override("SCAN", -1)

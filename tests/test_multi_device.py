@@ -116,6 +116,44 @@ def test_contexts_and_tickets(two, oracle, coracle):
             assert (cm.msm_wait(t) == exp).all()
 
 
+def test_a_thread_that_clears_its_selection_spreads_again(two, oracle, coracle):
+    """curdle_set_device(ordinal >= 0) pins a thread's host-buffer MSMs to that device; -1 clears the
+    selection and large calls spread over all devices again (review of round 4: tools/bench_multi_device.py
+    measured "all devices" from a pinned thread, and curdlemsm.OnDevice restored 0 instead of "none", which
+    left a recycled OS thread pinned for good).  curdle_get_device_selection is what OnDevice restores."""
+    cm = two
+    k, q = oracle.Rand(3).get_frs(2)
+    n = 1 << 16
+    pts = coracle.points_walk(k, q, n)
+    sc = rand_scalars(np.random.default_rng(34), n, oracle)
+    exp = coracle.msm_pippenger(pts, sc, threads=8)
+
+    def script():
+        seen = []
+        assert cm.get_device_selection() == -1                      # a fresh thread has none
+        c0 = cm.stat_spread_calls()
+        assert (cm.msm_g1(pts, sc) == exp).all()
+        seen.append(cm.stat_spread_calls() - c0)                    # spread
+        cm.set_device(1)
+        assert cm.get_device_selection() == 1 and cm.get_device() == 1
+        c0 = cm.stat_spread_calls()
+        assert (cm.msm_g1(pts, sc) == exp).all()
+        seen.append(cm.stat_spread_calls() - c0)                    # pinned: not spread
+        prev = -1                                                   # what OnDevice saved before it selected
+        cm.set_device(prev)
+        assert cm.get_device_selection() == -1 and cm.get_device() == 0
+        c0 = cm.stat_spread_calls()
+        assert (cm.msm_g1(pts, sc) == exp).all()
+        seen.append(cm.stat_spread_calls() - c0)                    # spread again
+        return seen
+
+    box = {}
+    t = threading.Thread(target=lambda: box.update(v=script()))
+    t.start()
+    t.join()
+    assert box.get("v") == [1, 0, 1], box
+
+
 def test_one_msm_over_both_contexts(two, oracle, coracle):
     """curdle_msm_g1 (host buffers: point ranges, one host thread per device) and
     curdle_msm_g1_replicated (resident inputs: Pippenger windows or point ranges) against the

@@ -67,7 +67,13 @@ def main():
         out[f"replicated_{name}_speedup"] = round(one_ms / med, 3)
         out["results_equal"] = out["results_equal"] and bool((r == ref).all())
     pts_h = d_pts[0].cpu().numpy().view(np.uint64)
+    # no selection on this thread: a thread that called set_device(i >= 0) keeps its host-buffer MSMs on that ONE
+    # device, and this figure is "all devices" (review of round 4: it was measured from a thread pinned to device 0)
+    cm.set_device(-1)
+    spread0 = cm.stat_spread_calls()
     r, med, best = timed(lambda: cm.msm_g1(pts_h, sc), reps=5)
+    out["host_slices_spread_over_devices"] = bool(cm.stat_spread_calls() > spread0) or D == 1
+    cm.set_device(0)
     out["host_slices_all_devices_ms"] = round(med, 4)
     out["results_equal"] = out["results_equal"] and bool((r == ref).all())
     # config 5: one batch call, sharded over the devices

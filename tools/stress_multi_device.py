@@ -94,6 +94,6 @@ for tk, n in tickets:                                        # whatever is still
 if errors:
     print("FAILED:", errors[:3])
     sys.exit(1)
-cm.set_device(0)
+cm.set_device(-1)                                           # no selection left on this thread
 cm.shutdown()
 print(f"stress_multi_device: {sum(counts)} operations from {nthreads} threads over 2 contexts in {budget:.0f} s, all results exact; per thread {counts}")
