@@ -795,7 +795,12 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   ws.frags = S.frags.p;
   ws.partials = S.partials.p;
   ws.winsums28 = S.winsums28.p;
-  ws.winsums = (G1XYZZ*)S.winsums.p;
+  // Round 5: what the host's Horner pass reads leaves the GPU by the kernels' own stores into the slot's pinned buffer
+  // (device-visible like all pinned memory here) -- a hundred points or so, 16 bytes per store -- instead of through a
+  // device array and a copy command behind the last kernel (~10 us of every synchronous call; knob DIRECT_RESULTS=0: the copy).
+  const size_t win_bytes = kr * (size_t)nw * wpts * sizeof(G1XYZZ);
+  const bool direct = !p.gpu_combine && win_bytes <= ((size_t)256 << 10) && knobs::get(knobs::DIRECT_RESULTS) != 0;
+  ws.winsums = direct ? (G1XYZZ*)S.h_buf : (G1XYZZ*)S.winsums.p;
   ws.results = (G1XYZZ*)S.results.p;
 
   // the offsets are staged in pinned memory (tail of h_buf) so the copy is truly asynchronous
@@ -819,12 +824,18 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   // as one after the other, plus two event hops.
   const int phase = join ? join->phase : 0;
   const bool convert_here = !points28_ready && !ext_points28;  // the device accumulator fills S.points28 itself; a resident base set is converted already
-  if (convert_here && phase == 0) {
+  // small calls: conversion and recoding in one launch (the host's launches bound the call until the accumulation
+  // starts; knob FRONT=0: two launches)
+  const bool front = convert_here && phase == 0 && !p.two_level && sets * n_pairs <= 16384 && knobs::get(knobs::FRONT) != 0;
+  if (convert_here && phase == 0 && !front) {
     HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre));
     prof.mark("convert_points");
   }
   if (phase != 2) {
-    HIP_TRY(launch_digits(p, ws, d_scalars, pre));
+    if (front)
+      HIP_TRY(launch_front(p, ws, d_points, (uint32_t)(sets * n_pairs), d_scalars, pre));
+    else
+      HIP_TRY(launch_digits(p, ws, d_scalars, pre));
     prof.mark("digits");
     HIP_TRY(launch_hist(p, ws, pre));
     prof.mark("hist");
@@ -920,8 +931,8 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
     HIP_TRY(launch_combine(p, ws, stream));
     prof.mark("combine");
     HIP_TRY(hipMemcpyAsync(S.h_buf, ws.results, kr * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
-  } else {
-    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.winsums, kr * (size_t)nw * wpts * sizeof(G1XYZZ), hipMemcpyDeviceToHost, stream));
+  } else if (!direct) {
+    HIP_TRY(hipMemcpyAsync(S.h_buf, ws.winsums, win_bytes, hipMemcpyDeviceToHost, stream));
   }
   return CURDLE_OK;
 }

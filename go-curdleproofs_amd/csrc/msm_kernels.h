@@ -109,6 +109,9 @@ hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_o
 // chunked host-buffer calls: this chunk's fragments into the per-bucket running sums (sums: NB points, meta: 2 * NB words)
 hipError_t launch_fold_fragments(const MsmPlan& p, const MsmWorkspace& ws, void* sums, void* meta, bool first, hipStream_t stream);
 hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);
+// conversion of npts points into ws.points28 and the recoding in ONE launch (small calls; not for two-level plans)
+hipError_t launch_front(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, uint32_t npts, const void* d_scalars,
+                        hipStream_t stream);
 hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);

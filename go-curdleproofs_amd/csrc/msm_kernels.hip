@@ -124,22 +124,23 @@ struct CoarseOut {
 // (1,024 blocks of 256 threads: +0.03-0.04 ms on the launch at N = 2^20, gpurun_out/r5f).
 static constexpr int kDigitsCoarseBlock = 1024;
 static constexpr int kDigitsCoarseMaxBlocks = 256;
+// (block `bid` of `nblocks`: the body also runs as the second role of k_front below)
 template <bool GLV, bool COARSE>
-__global__ void __launch_bounds__(COARSE ? kDigitsCoarseBlock : kBlock) k_digits(const uint4* __restrict__ scalars, MsmPlan p,
-                                                   u32* __restrict__ digits, u32* __restrict__ counts, u32 nb, CoarseOut co) {
-  constexpr u32 kBlock = COARSE ? kDigitsCoarseBlock : curdle::kBlock;  // this kernel's block size
+__device__ __forceinline__ void digits_body(const uint4* __restrict__ scalars, const MsmPlan& p, u32* __restrict__ digits,
+                                            u32* __restrict__ counts, u32 nb, const CoarseOut& co, const u32 bid, const u32 nblocks) {
+  constexpr u32 kBlock = COARSE ? kDigitsCoarseBlock : curdle::kBlock;  // the block size of the kernels that run this body
   __shared__ u32 cc[COARSE ? kCoarseWinMax * 256 : 1];
   const u32 tid = threadIdx.x;
   const u32 nw = (u32)(p.win_end - p.win_begin);
   // the histogram's counters start from zero: cleared here, one launch before the first kernel adds into
   // them, instead of by a memset node of their own
-  for (u32 b = blockIdx.x * kBlock + tid; b < nb; b += gridDim.x * kBlock) counts[b] = 0;
+  for (u32 b = bid * kBlock + tid; b < nb; b += nblocks * kBlock) counts[b] = 0;
   if constexpr (COARSE) {
     for (u32 x = tid; x < nw * 256u; x += kBlock) cc[x] = 0;
     __syncthreads();
   }
   // p.n counts the split's terms: entry 2 i is k1 P_i, entry 2 i + 1 is k2 phi(P_i)
-  for (u32 i = blockIdx.x * kBlock + tid; i < p.n / 2; i += gridDim.x * kBlock) {
+  for (u32 i = bid * kBlock + tid; i < p.n / 2; i += nblocks * kBlock) {
     Fr s = load_scalar_canonical(scalars, i);
     constexpr int NA = GLV ? 4 : 8;
     u32 a[NA], b[4], neg_a = 0, neg_b = 0;
@@ -193,12 +194,17 @@ __global__ void __launch_bounds__(COARSE ? kDigitsCoarseBlock : kBlock) k_digits
   }
   if constexpr (COARSE) {
     __syncthreads();
-    u32* mine = co.ccount + (size_t)(blockIdx.x % kCoarseReps) * nw * 256u;
+    u32* mine = co.ccount + (size_t)(bid % kCoarseReps) * nw * 256u;
     for (u32 x = tid; x < nw * 256u; x += kBlock) {
       const u32 v = cc[x];
       if (v) atomicAdd(&mine[x], v);
     }
   }
+}
+template <bool GLV, bool COARSE>
+__global__ void __launch_bounds__(COARSE ? kDigitsCoarseBlock : kBlock) k_digits(const uint4* __restrict__ scalars, MsmPlan p,
+                                                   u32* __restrict__ digits, u32* __restrict__ counts, u32 nb, CoarseOut co) {
+  digits_body<GLV, COARSE>(scalars, p, digits, counts, nb, co, blockIdx.x, gridDim.x);
 }
 
 // The coarse counts -> the bins' first positions: one block.  (Round 5's first build let the LAST block of k_digits do
@@ -808,13 +814,13 @@ __device__ __forceinline__ const A28* a28_at(const A28* base, size_t i) {
 // sits at chunk k ^ (t & 15) of the lane's 256 bytes: 4-way bank conflicts on the way in, none on the
 // way out.
 static constexpr int kCvtBlock = 128;
-__global__ void __launch_bounds__(kCvtBlock)
-    k_convert_points(const uint4* __restrict__ points, u32 n, A28* __restrict__ out) {
+// (block `bid`; threads beyond kCvtBlock of a larger block only keep the barrier company: k_front)
+__device__ __forceinline__ void convert_body(const uint4* __restrict__ points, u32 n, A28* __restrict__ out, const u32 bid) {
   __shared__ uint4 stage[kCvtBlock * 16];
   const u32 tid = threadIdx.x;
-  const u32 base = blockIdx.x * kCvtBlock;
+  const u32 base = bid * kCvtBlock;
   const u32 i = base + tid;
-  if (i < n) {
+  if (tid < (u32)kCvtBlock && i < n) {
     u32 w[24];
     d28::load_words<24>(w, points + (size_t)i * 6);
     A28 a;
@@ -838,10 +844,30 @@ __global__ void __launch_bounds__(kCvtBlock)
   __syncthreads();
   const u32 cnt = min((u32)kCvtBlock, n - base) * 16u;  // 16-byte chunks this block owns
   uint4* dst = reinterpret_cast<uint4*>(a28_at(out, 2 * (size_t)base));
-  for (u32 c = tid; c < cnt; c += kCvtBlock) {
+  for (u32 c = tid; c < cnt; c += blockDim.x) {
     const u32 t = c >> 4, k = c & 15u;
     dst[c] = stage[t * 16 + (k ^ (t & 15u))];
   }
+}
+__global__ void __launch_bounds__(kCvtBlock)
+    k_convert_points(const uint4* __restrict__ points, u32 n, A28* __restrict__ out) {
+  convert_body(points, n, out, blockIdx.x);
+}
+
+// Conversion and recoding of a SMALL call in one launch: they read different inputs and nothing of each other,
+// and a small synchronous call is bound by the host's launches until the accumulation starts (nine launches at
+// ~8 us each against ~5 us kernels: rocprofv3 timeline of a 1,268-pair call, gpurun_out/r5i).  Blocks [0, nconv)
+// convert 128 points each, the rest recode.
+template <bool GLV>
+__global__ void __launch_bounds__(kBlock)
+    k_front(const uint4* __restrict__ points, u32 npts, A28* __restrict__ out28, u32 nconv, const uint4* __restrict__ scalars,
+            MsmPlan p, u32* __restrict__ digits, u32* __restrict__ counts, u32 nb) {
+  if (blockIdx.x < nconv) {  // block-uniform
+    convert_body(points, npts, out28, blockIdx.x);
+    return;
+  }
+  const CoarseOut none = {nullptr, nullptr, nullptr};
+  digits_body<GLV, false>(scalars, p, digits, counts, nb, none, blockIdx.x - nconv, gridDim.x - nconv);
 }
 
 // Sum of `acc` over aligned groups of G lanes (G a power of two <= 256) of a
@@ -1294,9 +1320,10 @@ int reduce_bits_position(const MsmPlan& p, int w, uint32_t slot) { return reduce
 __device__ __forceinline__ void write_point_quad(const F28& c, G1XYZZ* dst) {
   u32 w12[12];
   d28::to_gnark_msm(w12, c, q28::role());
-  u32* d = reinterpret_cast<u32*>(dst) + 12u * q28::role();
+  // three 16-byte stores: the array may be the host's pinned buffer, where every store instruction is a write over PCIe
+  uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<u32*>(dst) + 12u * q28::role());
 #pragma unroll
-  for (int i = 0; i < 12; i++) d[i] = w12[i];
+  for (int i = 0; i < 3; i++) d[i] = make_uint4(w12[4 * i], w12[4 * i + 1], w12[4 * i + 2], w12[4 * i + 3]);
 }
 
 // One LEVEL above k_reduce_segments: up to 128 consecutive groups of a window -> one group, the same
@@ -1458,9 +1485,9 @@ __device__ __forceinline__ void write_window_sum_quad(const F28& c, G1XYZZ* wins
   if (!p.gpu_combine) {
     u32 w12[12];
     d28::to_gnark_msm(w12, c, q28::role());
-    u32* dst = reinterpret_cast<u32*>(&winsums[(size_t)j * nw + lw]) + 12u * q28::role();
+    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<u32*>(&winsums[(size_t)j * nw + lw]) + 12u * q28::role());
 #pragma unroll
-    for (int i = 0; i < 12; i++) dst[i] = w12[i];
+    for (int i = 0; i < 3; i++) dst[i] = make_uint4(w12[4 * i], w12[4 * i + 1], w12[4 * i + 2], w12[4 * i + 3]);
   } else {
     q28::store(&winsums28[(size_t)j * nw + lw], c);
   }
@@ -1678,6 +1705,21 @@ hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t 
   return hipGetLastError();
 }
 
+hipError_t launch_front(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, uint32_t npts, const void* d_scalars,
+                        hipStream_t stream) {
+  if (p.two_level || npts == 0) return hipErrorInvalidValue;
+  const u32 nconv = cdiv(npts, kCvtBlock), ndig = cdiv(p.n / 2, kBlock);
+  const uint4* pts = reinterpret_cast<const uint4*>(d_points);
+  const uint4* sc = reinterpret_cast<const uint4*>(d_scalars);
+  if (p.glv)
+    hipLaunchKernelGGL(k_front<true>, dim3(nconv + ndig), dim3(kBlock), 0, stream, pts, npts, reinterpret_cast<A28*>(ws.points28),
+                       nconv, sc, p, ws.digits, ws.counts, p.k * p.NB);
+  else
+    hipLaunchKernelGGL(k_front<false>, dim3(nconv + ndig), dim3(kBlock), 0, stream, pts, npts, reinterpret_cast<A28*>(ws.points28),
+                       nconv, sc, p, ws.digits, ws.counts, p.k * p.NB);
+  return hipGetLastError();
+}
+
 hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_out28, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_convert_points, dim3(cdiv(n, kCvtBlock)), dim3(kCvtBlock), 0, stream,
@@ -1698,7 +1740,9 @@ hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream
 }
 
 hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  hipLaunchKernelGGL(k_merge_large, dim3(p.max_large < 1024u ? p.max_large : 1024u, p.sets), dim3(kBlock), 0, stream,
+  // (at most 256 blocks: the launch is almost always empty -- uniform scalars queue nothing -- and every block of it is four
+  // 222-register waves that have to find room beside the next accumulation before they can read the empty queue and leave)
+  hipLaunchKernelGGL(k_merge_large, dim3(p.max_large < 256u ? p.max_large : 256u, p.sets), dim3(kBlock), 0, stream,
                      ws.large, ws.nlarge, ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.frags), p.max_large, p.frag_stride);
   return hipGetLastError();
 }

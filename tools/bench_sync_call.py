@@ -3,7 +3,7 @@
 on host buffers: what the Go drop-in makes) under alternative settings of the library's plan
 knobs, one child process per setting (the knobs are read once per process); every child's
 result must equal the first setting's.
-Usage: python tools/bench_sync_call.py [--variants "A=1;B=2,C=3;..."] [logn ...]
+Usage: python tools/bench_sync_call.py [--variants "A=1;B=2,C=3;..."] [logn | n=<pairs> ...]
 (default variants: the library's defaults, the one-pass scatter, host buffers in one copy)"""
 import json
 import os
@@ -14,7 +14,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(logn):
+def child(arg):
     sys.path.insert(0, os.path.join(ROOT, "go-curdleproofs_amd"))
     sys.path.insert(0, ROOT)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -23,7 +23,8 @@ def child(logn):
     import curdlemsm as cm
     from bench import uniform_scalars
     cm.init(0)
-    n = 1 << logn
+    n = int(arg[2:]) if arg.startswith("n=") else 1 << int(arg)
+    logn = n.bit_length() - 1
     d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
     cm.synth_points_walk_device(12345, 6789, n, d_pts.data_ptr())
     sc = uniform_scalars(np.random.default_rng(2), n)
@@ -33,7 +34,7 @@ def child(logn):
     for _ in range(3):
         res = cm.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
     lat = []
-    for _ in range(15):
+    for _ in range(15 if n >= (1 << 15) else 60):
         torch.cuda.synchronize()
         t = time.perf_counter()
         cm.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
@@ -48,7 +49,7 @@ def child(logn):
             hl.append((time.perf_counter() - t) * 1e3)
         assert (r2 == res).all()
         host = float(np.median(hl[1:]))
-    print(json.dumps({"logn": logn, "variant": os.environ.get("CURDLE_BENCH_VARIANT", ""),
+    print(json.dumps({"n": n, "logn": logn, "variant": os.environ.get("CURDLE_BENCH_VARIANT", ""),
                       "median_ms": round(float(np.median(lat)), 4), "min_ms": round(min(lat), 4),
                       "host_buffers_ms": host and round(host, 4),
                       "result": [int(v) for v in res[:2]]}))
@@ -56,12 +57,12 @@ def child(logn):
 
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
-        return child(int(sys.argv[2]))
+        return child(sys.argv[2])
     args = sys.argv[1:]
     variants = "DEFAULTS=1;CURDLE_SCATTER=1;CURDLE_HOST_CHUNKS=1"
     if args and args[0] == "--variants":
         variants, args = args[1], args[2:]
-    logns = [int(a) for a in args] or [20, 18, 16]
+    logns = args or ["20", "18", "16"]
     for logn in logns:
         ref = None
         for v in variants.split(";"):
