@@ -550,6 +550,18 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
     p.reduce_prio = v >= 0 ? (uint32_t)(v > 3 ? 3 : v) : (latency_mode ? 0u : 3u);
   }
   {
+    // The sort kernels (and the conversion) of a PIPELINED call at priority 3 (round 5): beside the two accumulate
+    // waves of a neighbouring call -- older, and never short of an instruction -- a young wave gets what is left, and
+    // k_digits took 0.2-0.3 ms there against 0.03 alone; raised, they are through before they have cost the accumulation
+    // anything that shows.  One rank of the 8-way window split 0.466-0.470 -> 0.424-0.426 ms with kept bases and 0.54 ->
+    // 0.485 on gnark-layout inputs, a 4-way rank 0.74 -> 0.69 / 0.84 -> 0.75, the whole MSM 2.598 -> 2.555 ms per step
+    // (two A/B rounds on one box, gpurun_out/r5r; round 4 had measured the raised sort TOGETHER with the raised
+    // reduction slower than the reduction alone -- with the lighter sort of this round it is the other way round).
+    // Synchronous calls have the chip to themselves; chunked host-buffer calls do not move (4.45-4.57 ms either way).
+    const long long v = knobs::get(knobs::AUX_PRIO);
+    p.aux_prio = v >= 0 ? (uint32_t)(v > 3 ? 3 : v) : (!latency_mode ? 3u : 0u);
+  }
+  {
     const long long v = knobs::get(knobs::ACC_PRIO);
     p.acc_prio = v >= 0 ? (uint32_t)(v > 24 ? 24 : v) : (latency_mode && !light_host && entries / L >= 65536 ? 15u : 0u);
   }
@@ -725,6 +737,9 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   MsmPlan& p = S.plan;
   int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets, many, join ? join->seg : 0, light_host, glv);
   if (rc) return rc;
+  // k_scan_one is 16 waves of 121 registers: a block of it needs four SIMDs of one compute unit EMPTY, so beside another
+  // call's accumulation it waits for accumulate waves to end.  Only calls that have the chip to themselves take it.
+  if (p.fuse_scan == 2 && (join || !latency_mode) && knobs::get(knobs::SCAN) != 2) p.fuse_scan = 0;
   // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
   const size_t n = 2 * n_pairs;
   const size_t kr = k * sets;
@@ -828,7 +843,7 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   // starts; knob FRONT=0: two launches)
   const bool front = convert_here && phase == 0 && !p.two_level && sets * n_pairs <= 16384 && knobs::get(knobs::FRONT) != 0;
   if (convert_here && phase == 0 && !front) {
-    HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre));
+    HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre, p.aux_prio));
     prof.mark("convert_points");
   }
   if (phase != 2) {
@@ -1148,7 +1163,17 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
   // fragments while the next one is copied, and the last chunk's reduction folds in the fragment
   // lists of all of them.  tools/bench_sync_call.py --variants CURDLE_HOST_CHUNKS=...:
   // see profiles/r03_host_buffer_chunks.txt.
-  size_t nchunks = n >= ((size_t)1 << 20) ? 4 : 2;
+  // Round 5: GRADED chunks, pairs and points interleaved.  The GPU cannot start before the first chunk has landed
+  // (0.69 ms of a 4.5 ms call with four equal chunks) and, once it runs, it is the slower side of the pipeline (four
+  // quarter accumulations 2.9 ms against 2.4 ms of copies): so the first two chunks are half-size -- the GPU starts
+  // after an eighth of the bytes -- and every chunk's scalars cross right before its points, so that no accumulation
+  // waits for points queued behind other chunks' scalars (the gap 1.43-1.78 ms in profiles/r04_host_fold.txt).
+  // Knob HOST_GRADED=0: equal chunks, all scalars first, as in round 4.
+  // (HOST_GRADED: 1 = graded sizes + interleaved copies, 2 = equal sizes + interleaved copies; unset / 0 = round 4's scheme)
+  const long long graded_knob = knobs::get(knobs::HOST_GRADED);
+  const bool graded = graded_knob == 1;
+  const bool interleave = graded_knob == 1 || graded_knob == 2;
+  size_t nchunks = n >= ((size_t)1 << 20) ? (graded ? 5 : 4) : (graded ? 3 : 2);
   if (knobs::get(knobs::HOST_CHUNKS) > 0) nchunks = (size_t)knobs::get(knobs::HOST_CHUNKS);
   // (without folding the reduction takes one fragment list per chunk: at most kMaxFragSources)
   const bool fold_on = knobs::get(knobs::HOST_FOLD) != 0;
@@ -1176,15 +1201,24 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
     nchunks = slots.size();
   }
   const int c = choose_window_bits(n);
-  const size_t per = (n + nchunks - 1) / nchunks;
+  // chunk sizes: equal, or (graded, three chunks and more) the first two one unit and the others two units each
+  std::vector<size_t> bounds(nchunks + 1, n);
+  bounds[0] = 0;
+  if (graded && nchunks >= 3) {
+    const size_t unit = (n + 2 * (nchunks - 1) - 1) / (2 * (nchunks - 1));
+    size_t at = 0;
+    for (size_t i = 0; i < nchunks; i++) {
+      at += i < 2 ? unit : 2 * unit;
+      bounds[i + 1] = at < n ? at : n;
+    }
+  } else {
+    const size_t per = (n + nchunks - 1) / nchunks;
+    for (size_t i = 1; i < nchunks; i++) bounds[i] = i * per < n ? i * per : n;
+  }
+  bounds[nchunks] = n;
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(cx.device));
-    // Round 4: ALL scalars cross first (32 bytes of a pair's 128) and every chunk's recoding and sort is
-    // queued behind them at once: they run while the point chunks stream in, so a chunk whose points
-    // have landed goes straight into its conversion and accumulation.  Before, a chunk's sort waited
-    // for scalars that sat behind the previous chunk's points in the copy queue, and every
-    // accumulation started 0.3-0.6 ms after its copy had ended (profiles/r03_host_buffer_chunks.txt).
-    // A pageable copy occupies the calling thread, so the order of the calls below is the timeline.
+    // A pageable copy occupies the thread that issues it, so the order of the copies below is the timeline.
     struct Part {
       Slot* S;
       size_t lo, m;
@@ -1192,11 +1226,12 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       hipStream_t main;
     };
     std::vector<Part> parts;
-    for (size_t lo = 0, i = 0; lo < n; lo += per, i++) {
+    for (size_t i = 0; i < nchunks; i++) {
+      if (bounds[i + 1] <= bounds[i]) continue;  // (tiny n under a forced chunk count)
       Part pt;
-      pt.S = &cx.slots[slots[i]];
-      pt.lo = lo;
-      pt.m = n - lo < per ? n - lo : per;
+      pt.S = &cx.slots[slots[parts.size()]];
+      pt.lo = bounds[i];
+      pt.m = bounds[i + 1] - bounds[i];
       const unsigned seq = cx.submit_count.fetch_add(1, std::memory_order_relaxed);
       const unsigned turn = seq % (unsigned)cx.main_streams;
       pt.main = turn == 0 ? cx.main_stream : cx.main_extra[turn - 1];
@@ -1224,12 +1259,26 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       hipEvent_t ev;
     };
     std::vector<CopyJob> jobs;
-    jobs.push_back({parts[0].S->scalars.p, scalars + 4 * parts[0].lo, parts[0].m * 32, parts[0].S->pre_done});
-    jobs.push_back({parts[0].S->points.p, points + 12 * parts[0].lo, parts[0].m * 96, parts[0].S->acc_done});
-    for (size_t i = 1; i < parts.size(); i++)
+    std::vector<size_t> job_s(parts.size()), job_p(parts.size());  // which job carries chunk i's scalars / points
+    auto add_s = [&](size_t i) {
+      job_s[i] = jobs.size();
       jobs.push_back({parts[i].S->scalars.p, scalars + 4 * parts[i].lo, parts[i].m * 32, parts[i].S->pre_done});
-    for (size_t i = 1; i < parts.size(); i++)  // (acc_done is re-recorded by the chunk's accumulation: a scratch event until then)
+    };
+    auto add_p = [&](size_t i) {  // (acc_done is re-recorded by the chunk's accumulation: a scratch event until then)
+      job_p[i] = jobs.size();
       jobs.push_back({parts[i].S->points.p, points + 12 * parts[i].lo, parts[i].m * 96, parts[i].S->acc_done});
+    };
+    if (interleave) {
+      for (size_t i = 0; i < parts.size(); i++) {
+        add_s(i);
+        add_p(i);
+      }
+    } else {  // round 4's order: chunk 0 whole, then every other chunk's scalars, then their points
+      add_s(0);
+      add_p(0);
+      for (size_t i = 1; i < parts.size(); i++) add_s(i);
+      for (size_t i = 1; i < parts.size(); i++) add_p(i);
+    }
     std::mutex cmu;
     std::condition_variable ccv;
     size_t issued = 0;
@@ -1285,19 +1334,18 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       last.earlier.push_back(pt.S);
       return rr;
     };
+    // every step's kernels are queued as soon as the copy they need has been issued: in the order of the jobs
     const size_t K = parts.size();
-    if ((r = wait_copy(0))) return r;
-    if ((r = enqueue_sort(parts[0]))) return r;
-    if ((r = wait_copy(1))) return r;
-    if ((r = enqueue_accumulate(0))) return r;
-    for (size_t i = 1; i < K; i++) {
-      if ((r = wait_copy(1 + i))) return r;
-      if ((r = enqueue_sort(parts[i]))) return r;
-    }
-    for (size_t i = 1; i < K; i++) {
-      if ((r = wait_copy(K + i))) return r;
-      if ((r = enqueue_accumulate(i))) return r;
-    }
+    for (size_t j = 0; j < jobs.size(); j++)
+      for (size_t i = 0; i < K; i++) {
+        if (job_s[i] == j) {
+          if ((r = wait_copy(j))) return r;
+          if ((r = enqueue_sort(parts[i]))) return r;
+        } else if (job_p[i] == j) {
+          if ((r = wait_copy(j))) return r;
+          if ((r = enqueue_accumulate(i))) return r;
+        }
+      }
     return finish_slot(cx, *parts.back().S, out);  // the last chunk's slot holds the window sums
   };
   int rc = body();

@@ -25,6 +25,7 @@ struct MsmPlan {
   uint32_t kr;         // results = k * sets; result r = set * k + j
   uint32_t frag_stride;  // fragments reserved per base set
   uint32_t reduce_prio;  // s_setprio of the reduction kernels' waves (knob REDUCE_PRIO; 3 for pipelined calls)
+  uint32_t aux_prio;     // s_setprio of the sort kernels' and the fold's waves (knob AUX_PRIO; experiment, 0 by default)
   uint32_t acc_prio;     // k_accumulate: log2 of the priority time slice in 10 ns ticks, 0 = no turns (knob ACC_PRIO)
   uint32_t n_max;      // pairs of the largest MSM
   int c;               // requested maximum window width
@@ -105,7 +106,7 @@ size_t coarse_zero_offset_words(uint32_t nw);
 // Every launcher enqueues on `stream` and returns the launch status.
 // n gnark affine points -> internal form at d_out28 (kA28Bytes apart), outside a plan: the device accumulator
 // converts its resident base sets once and per-verification points as they arrive.
-hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_out28, hipStream_t stream);
+hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_out28, hipStream_t stream, uint32_t prio = 0);
 // chunked host-buffer calls: this chunk's fragments into the per-bucket running sums (sums: NB points, meta: 2 * NB words)
 hipError_t launch_fold_fragments(const MsmPlan& p, const MsmWorkspace& ws, void* sums, void* meta, bool first, hipStream_t stream);
 hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d_scalars, hipStream_t stream);

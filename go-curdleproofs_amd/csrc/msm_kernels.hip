@@ -119,17 +119,21 @@ struct CoarseOut {
   u32* ccur;    // [nw * 256]
   u32* cstart;  // [bins + 1]
 };
-// The coarse build runs 1,024-thread blocks, at most one per compute unit: what a block publishes at its end is
-// nw x 256 global atomics however few scalars it walked, and the chip completes ~50 G of them per second
-// (1,024 blocks of 256 threads: +0.03-0.04 ms on the launch at N = 2^20, gpurun_out/r5f).
-static constexpr int kDigitsCoarseBlock = 1024;
-static constexpr int kDigitsCoarseMaxBlocks = 256;
+// The coarse build runs few, large blocks: what a block publishes at its end is nw x 256 global atomics however few
+// scalars it walked, and the chip completes ~50 G of them per second (1,024 blocks of 256 threads: +0.03-0.04 ms on
+// the launch at N = 2^20, gpurun_out/r5f).  512 threads, not 1,024: at 40 registers two waves per SIMD fit beside
+// the two 180-register waves of a neighbouring call's accumulation (512 - 360 = 152), four do not -- a block that
+// cannot be placed waits for accumulate waves to END, and the launch took 0.2-0.4 ms in a chunked host-buffer
+// call (rocprofv3 timeline, gpurun_out/r5m).
+static constexpr int kDigitsCoarseBlock = 512;
+static constexpr int kDigitsCoarseMaxBlocks = 512;
 // (block `bid` of `nblocks`: the body also runs as the second role of k_front below)
 template <bool GLV, bool COARSE>
 __device__ __forceinline__ void digits_body(const uint4* __restrict__ scalars, const MsmPlan& p, u32* __restrict__ digits,
                                             u32* __restrict__ counts, u32 nb, const CoarseOut& co, const u32 bid, const u32 nblocks) {
   constexpr u32 kBlock = COARSE ? kDigitsCoarseBlock : curdle::kBlock;  // the block size of the kernels that run this body
   __shared__ u32 cc[COARSE ? kCoarseWinMax * 256 : 1];
+  set_wave_prio(p.aux_prio);
   const u32 tid = threadIdx.x;
   const u32 nw = (u32)(p.win_end - p.win_begin);
   // the histogram's counters start from zero: cleared here, one launch before the first kernel adds into
@@ -346,6 +350,7 @@ __global__ void __launch_bounds__(kSortThreads) k_scatter(const u32* __restrict_
 __global__ void __launch_bounds__(kCoarseThreads)
     k_scatter_coarse(const u32* __restrict__ digits, MsmPlan p, u32* __restrict__ ccur, u32* __restrict__ tmp) {
   __shared__ u32 cnt[kCoarseMax], off[kCoarseMax + 1], gbase[kCoarseMax];
+  set_wave_prio(p.aux_prio);
   extern __shared__ u32 lds_cnt[];  // 40 KiB (kCoarseTile * 5 bytes): the tile's entries sorted by bin, and each entry's bin -- below the 64 KiB default, no opt-in needed
   u32* buf = lds_cnt;
   unsigned char* binof = reinterpret_cast<unsigned char*>(lds_cnt + kCoarseTile);
@@ -425,6 +430,7 @@ __global__ void __launch_bounds__(kFineThreads)
   __shared__ u32 scan_sh[kFineThreads];
   __shared__ u32 lb[kFineBinsCached + 1], ls[kFineBinsCached + 1];  // the tile's bins: first position, first slot
   __shared__ u32 sh_bin[2];
+  set_wave_prio(p.aux_prio);
   const u32 tid = threadIdx.x;
   const u32 total = cstart[nbins];
   const u32 a = blockIdx.x * kFineTile;
@@ -850,7 +856,8 @@ __device__ __forceinline__ void convert_body(const uint4* __restrict__ points, u
   }
 }
 __global__ void __launch_bounds__(kCvtBlock)
-    k_convert_points(const uint4* __restrict__ points, u32 n, A28* __restrict__ out) {
+    k_convert_points(const uint4* __restrict__ points, u32 n, A28* __restrict__ out, u32 prio) {
+  set_wave_prio(prio);
   convert_body(points, n, out, blockIdx.x);
 }
 
@@ -1189,7 +1196,8 @@ __device__ __forceinline__ void group_bits_and_sum(F28& S, F28& T, u32 G) {
 // fragment there: the sums are a fragment source like any other (FragSources).
 __global__ void __launch_bounds__(kBlock, 2)
     k_fold_fragments(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
-                     X28* __restrict__ sums, u32* __restrict__ meta, u32 nb, u32 max_small, u32 first) {
+                     X28* __restrict__ sums, u32* __restrict__ meta, u32 nb, u32 max_small, u32 first, u32 prio) {
+  set_wave_prio(prio);
   // (a 128-register build at priority 3, so that a wave fits beside the next chunk's two accumulate waves, and the same
   // for the usually empty k_merge_large launch in front of it: measured, no better -- profiles/r04_host_fold.txt)
   const u32 b = blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2);
@@ -1720,10 +1728,10 @@ hipError_t launch_front(const MsmPlan& p, const MsmWorkspace& ws, const void* d_
   return hipGetLastError();
 }
 
-hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_out28, hipStream_t stream) {
+hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_out28, hipStream_t stream, uint32_t prio) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_convert_points, dim3(cdiv(n, kCvtBlock)), dim3(kCvtBlock), 0, stream,
-                     reinterpret_cast<const uint4*>(d_points), n, reinterpret_cast<A28*>(d_out28));
+                     reinterpret_cast<const uint4*>(d_points), n, reinterpret_cast<A28*>(d_out28), prio);
   return hipGetLastError();
 }
 
@@ -1788,7 +1796,7 @@ hipError_t launch_fold_fragments(const MsmPlan& p, const MsmWorkspace& ws, void*
   const u32 nb = p.NB;
   hipLaunchKernelGGL(k_fold_fragments, dim3(cdiv(nb, kBlock / 4)), dim3(kBlock), 0, stream,
                      reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(sums),
-                     reinterpret_cast<u32*>(meta), nb, p.max_small, first ? 1u : 0u);
+                     reinterpret_cast<u32*>(meta), nb, p.max_small, first ? 1u : 0u, p.aux_prio);
   return hipGetLastError();
 }
 

@@ -94,6 +94,7 @@ _device_count = _sig("curdle_device_count", C.c_int)
 _set_device = _sig("curdle_set_device", C.c_int, C.c_int)
 _get_device = _sig("curdle_get_device", C.c_int)
 _get_device_selection = _sig("curdle_get_device_selection", C.c_int)
+_stat_spread_calls = _sig("curdle_stat_spread_calls", C.c_ulonglong)
 _msm_g1_ex = _sig("curdle_msm_g1_ex", C.c_int, _vp, _vp, C.c_size_t, C.c_uint, _vp)
 _msm_g1_device_windows_ex = _sig("curdle_msm_g1_device_windows_ex", C.c_int, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                  C.c_uint, _vp, _vp)

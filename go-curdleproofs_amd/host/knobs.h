@@ -39,9 +39,11 @@ enum Id {
   PROVER_FOLD_BASES,  // 1: the prover folds its bases round by round like the reference
   ACC_PRIO,           // k_accumulate: the two waves of a SIMD take turns at high priority every 2^v x 10 ns (0: never; unset: 15 for synchronous calls from half a round of lanes)
   REDUCE_PRIO,        // wave priority (0..3) of k_reduce_segments / k_reduce_level; unset: 3 for pipelined calls, 0 for synchronous ones
+  AUX_PRIO,           // wave priority (0..3) of the sort kernels, the conversion and the chunk fold; unset: 3 for pipelined calls, 0 for synchronous ones
   SCAN,               // the bucket-slot scans: 0 six launches, 1 k_scan_fused up to 8,192 slots, 2 k_scan_one up to 32,768; unset: 2
   FRONT,              // 0: small calls convert and recode in two launches instead of one (k_front)
   DIRECT_RESULTS,     // 0: window sums cross to the host by a copy command instead of the kernels' own stores into pinned memory
+  HOST_GRADED,        // 0: host-buffer MSMs in equal chunks with all scalars copied first (round 4) instead of graded chunks, scalars and points interleaved
   HOST_FOLD,          // 0: chunked host-buffer MSMs keep every chunk's fragments for the one reduction (no progressive folding)
   COUNT
 };
