@@ -498,6 +498,9 @@ def main():
             # barrier below -- seconds, far inside the collective's timeout
             out["cpu_baseline"] = cpu_baseline(cm, k, q, n, sc, result, d_pts)
             ok = out["cpu_baseline"]["gpu_matches_cpu"] and out["cpu_baseline"]["gpu_full_size_verified"]
+            if world == 1 and args.logn == 20 and not args.emulate_world:
+                out["sweep"] = compact_sweep(cm, torch, d_pts, sc, d_sc)
+                ok = ok and all(r_["gpu_matches_cpu"] for r_ in out["sweep"])
         if not ok:
             out["value"] = None   # a wrong result has no throughput
     # BASELINE config 5 beside the headline at every N (replicas: every rank verifies its share of
@@ -801,6 +804,57 @@ def sweep_distributed(cm, torch, dist, dev, rank, world, args):
                           "all_results_match_cpu": all_ok, "sweep": rows}), flush=True)
     if not all_ok:
         raise SystemExit("bench.py --sweep: a distributed GPU result differs from the CPU port's")
+
+
+def compact_sweep(cm, torch, d_pts, sc, d_sc):
+    """north_star's size table inside the DEFAULT line (the table existed only as a
+    builder-run artifact): N = 2^10, 2^12, .., 2^20 on prefixes of the headline's resident inputs -- the wall
+    time of one synchronous curdle_msm_g1_device call (median of 7, no phase events), pairs/s, the dominant
+    kernel's HBM fraction (128 B x N / the accumulation's own duration / 8 TB/s) and multiply-issue fraction
+    from a separate profiled pass, and the CPU port on the same inputs (all granted cores; one run below 2^18,
+    best of two from there), its result compared bit for bit.  About two seconds in all."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+    import coracle as co
+    cores = host_cores()
+    threads = min(cores, 256)
+    native = os.path.exists(os.path.join(ROOT, "oracle", "libcurdle_cpufast_native.so"))   # cpu_baseline() built it, if it can be built here
+    pts = d_pts.cpu().numpy().view(np.uint64)
+    peak_mads = 1024 * 64 * 2.4e9 / 4.9
+    pp, sp = d_pts.data_ptr(), d_sc.data_ptr()
+    rows = []
+    for logn in range(10, 21, 2):
+        n = 1 << logn
+        cm.profile_enable(0)
+        for _ in range(3):
+            res = cm.msm_g1_device(pp, sp, n)
+        lat = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cm.msm_g1_device(pp, sp, n)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        wall = float(np.median(lat))
+        cm.profile_enable(1)
+        acc, counts = [], {}
+        for _ in range(3):
+            cm.msm_g1_device(pp, sp, n)
+            pr = cm.profile_last()
+            acc.append(pr["kernels"].get("accumulate", 0.0))
+            counts = {"entries": pr["entries"], "fragments": pr["fragments"]}
+        cm.profile_enable(0)
+        acc_ms = float(np.mean(acc))
+        best = None
+        for _ in range(1 if logn < 18 else 2):
+            t1 = time.perf_counter()
+            ref = co.msm_fast(pts[:n], sc[:n], threads=threads if n >= 4096 else 1, native=native)
+            dt = time.perf_counter() - t1
+            best = dt if best is None else min(best, dt)
+        rows.append({"logn": logn, "wall_ms": round(wall, 4), "pairs_per_s": round(n / wall * 1e3, 1),
+                     "hbm_frac": round(BYTES_PER_PAIR * n / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if acc_ms else None,
+                     "valu_frac": (round((counts["entries"] - counts["fragments"]) * MADS_PER_MADD / (acc_ms * 1e-3) / peak_mads, 4)
+                                   if acc_ms and counts.get("entries") else None),
+                     "cpu_port_pairs_per_s": round(n / best, 1), "gpu_matches_cpu": bool((res == ref).all())})
+    return rows
 
 
 def cpu_baseline(cm, k, q, n, sc, gpu_result, d_pts):

@@ -515,7 +515,9 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // as many lanes take 0.03-0.05 ms off its chain at no cost to the accumulation; at 2^24
   // entries (N = 2^20) it is 1 % of the pipelined step (2.71 -> 2.68 ms)
   {
-    const uint64_t one = (entries + 131072 - 1) / 131072;
+    // (knob ROUND_LANES: the lanes of that round; unset: 131,072)
+    const uint64_t round_lanes = knobs::get(knobs::ROUND_LANES) > 0 ? (uint64_t)knobs::get(knobs::ROUND_LANES) : 131072;
+    const uint64_t one = (entries + round_lanes - 1) / round_lanes;
     if (one <= 128 && one > L) L = one;
   }
   const bool L_forced = knobs::get(knobs::SEG_LEN) > 0;

@@ -10,7 +10,7 @@ namespace curdle {
 namespace knobs {
 namespace {
 const char* const kNames[COUNT] = {
-    "WINDOW_BITS", "SEG_LEN",        "REDUCE_SEG",      "SYNC_LANES",     "PIPE_LANES",      "SCATTER",
+    "WINDOW_BITS", "SEG_LEN", "ROUND_LANES", "REDUCE_SEG",      "SYNC_LANES",     "PIPE_LANES",      "SCATTER",
     "REDUCE_BITS", "HOST_CHUNKS",    "MAX_MSMS_PER_PASS", "MULTI_DEVICE_MIN", "MAIN_STREAMS", "TWO_KERNEL_MAX",
     "GPU_COMBINE_MIN", "QUAD_MAX_LANES", "BATCH_CHUNK",  "BATCH_PRODUCERS", "BATCH_GROUP",     "DEVICE_ACC",
     "HOST_DECODE", "VERIFY_EAGER",   "VERIFY_TRACE",    "PROVER_FOLD_BASES", "ACC_PRIO", "REDUCE_PRIO", "AUX_PRIO", "SCAN", "FRONT", "DIRECT_RESULTS", "HOST_GRADED", "HOST_FOLD"};

@@ -17,6 +17,7 @@ namespace knobs {
 enum Id {
   WINDOW_BITS,        // maximum window width c of every plan (4..16); unset: the size table
   SEG_LEN,            // sorted positions per accumulate lane
+  ROUND_LANES,        // lanes of the one round a mid-size accumulation is cut into (unset: 131,072 = two waves on every SIMD)
   REDUCE_SEG,         // buckets per bucket-reduce segment (power of two)
   SYNC_LANES,         // lanes the reduce of a synchronous call is sized for (default 131,072)
   PIPE_LANES,         // ... of a pipelined call (default 32,768)
