@@ -43,10 +43,11 @@ timeout -k 10 300 python3 $R/bench.py --mode whisk-batch --steps 5 --warmup 1 > 
 timeout -k 10 300 python3 $R/bench.py --mode verify --steps 200 --warmup 20 > $O/verify_line.json 2> /dev/null
 rm -f $O/multi_gpu_emulation.jsonl
 for w in 2 4 8; do timeout -k 10 200 python3 $R/bench.py --emulate-world $w --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl; done
+for w in 2 4 8; do timeout -k 10 200 python3 $R/bench.py --emulate-world $w --bases-unchanged --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl; done
 for w in 2 4 8; do timeout -k 10 200 python3 $R/bench.py --emulate-world $w --resident-bases --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl; done
 timeout -k 10 200 python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl
 for lg in 22 24; do timeout -k 10 300 python3 $R/bench.py --logn $lg --steps 10 --warmup 2 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 > $O/bench_2p$lg.json; done
-timeout -k 10 400 python3 $R/tools/bench_sync_call.py 20 19 18 16 > $O/sync_call.jsonl 2> /dev/null
+timeout -k 10 400 python3 $R/tools/bench_sync_call.py --variants "DEFAULTS=1" 20 19 18 17 16 14 n=4096 n=1268 n=308 > $O/sync_call.jsonl 2> /dev/null
 timeout -k 10 120 python3 $R/tools/bench_h2d.py > $O/h2d.txt 2>&1
 timeout -k 10 120 $R/tools/ubench_affine > $O/batched_affine.txt 2>&1
 timeout -k 10 400 python3 $R/tools/bench_configs.py 2> $O/configs.err > $O/configs.json
