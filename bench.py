@@ -821,8 +821,14 @@ def compact_sweep(cm, torch, d_pts, sc, d_sc):
     pts = d_pts.cpu().numpy().view(np.uint64)
     peak_mads = 1024 * 64 * 2.4e9 / 4.9
     pp, sp = d_pts.data_ptr(), d_sc.data_ptr()
-    rows = []
-    for logn in range(10, 21, 2):
+    # the GPU columns of all sizes first, behind a quarter second of warm-up (the CPU port between two sizes would leave the
+    # GPU idle for up to half a second, and a GPU that has idled runs its next calls at lower clocks), then the CPU column
+    cm.profile_enable(0)
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < 0.25:
+        cm.msm_g1_device(pp, sp, 1 << 18)
+    gpu = {}
+    for logn in range(20, 9, -2):
         n = 1 << logn
         cm.profile_enable(0)
         for _ in range(3):
@@ -833,7 +839,6 @@ def compact_sweep(cm, torch, d_pts, sc, d_sc):
             t1 = time.perf_counter()
             cm.msm_g1_device(pp, sp, n)
             lat.append((time.perf_counter() - t1) * 1e3)
-        wall = float(np.median(lat))
         cm.profile_enable(1)
         acc, counts = [], {}
         for _ in range(3):
@@ -842,7 +847,11 @@ def compact_sweep(cm, torch, d_pts, sc, d_sc):
             acc.append(pr["kernels"].get("accumulate", 0.0))
             counts = {"entries": pr["entries"], "fragments": pr["fragments"]}
         cm.profile_enable(0)
-        acc_ms = float(np.mean(acc))
+        gpu[logn] = (res, float(np.median(lat)), float(np.mean(acc)), counts)
+    rows = []
+    for logn in range(10, 21, 2):
+        n = 1 << logn
+        res, wall, acc_ms, counts = gpu[logn]
         best = None
         for _ in range(1 if logn < 18 else 2):
             t1 = time.perf_counter()

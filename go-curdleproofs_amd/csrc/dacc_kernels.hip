@@ -28,9 +28,28 @@ __device__ __forceinline__ Fr load_fr(const uint4* pool, u32 off) {
   return r;
 }
 
+// Round 5: the pool (the checks' Fr constants: weights, alphas, gammas, q, explicit tails) and the check descriptions are
+// staged in LDS once per block when they fit (a verification at ell = 252: ~1,000 elements).  Every lane used to read them
+// from global memory inside its loops -- a dozen dependent loads per check and slot, the same addresses in every lane --
+// and the kernel took 0.050 ms of a 0.83 ms verification (rocprofv3 timeline, gpurun_out/r5w).
+static constexpr u32 kDaccLdsBytes = 60 * 1024;
+template <bool LDS>
 __global__ void __launch_bounds__(kBlock)
-    k_dacc_scalars(const curdle_dacc_check* __restrict__ checks, u32 n_checks, const uint4* __restrict__ pool, u32 n_crs,
-                   u32 n_inst, uint4* __restrict__ out) {
+    k_dacc_scalars(const curdle_dacc_check* __restrict__ checks_g, u32 n_checks, const uint4* __restrict__ pool_g, u32 pool_len,
+                   u32 n_crs, u32 n_inst, uint4* __restrict__ out) {
+  extern __shared__ uint4 lds_stage[];
+  const uint4* pool = pool_g;
+  const curdle_dacc_check* checks = checks_g;
+  if constexpr (LDS) {
+    const u32 pool_q = 2 * pool_len;                                             // uint4 per pool
+    const u32 chk_q = (n_checks * (u32)sizeof(curdle_dacc_check) + 15u) / 16u;   // the host pads the array to 32 bytes
+    for (u32 i = threadIdx.x; i < pool_q; i += kBlock) lds_stage[i] = pool_g[i];
+    const uint4* cg = reinterpret_cast<const uint4*>(checks_g);
+    for (u32 i = threadIdx.x; i < chk_q; i += kBlock) lds_stage[pool_q + i] = cg[i];
+    __syncthreads();
+    pool = lds_stage;
+    checks = reinterpret_cast<const curdle_dacc_check*>(lds_stage + pool_q);
+  }
   const u32 slot = blockIdx.x * kBlock + threadIdx.x;
   if (slot >= n_crs + n_inst) return;
   const u32 set = slot < n_crs ? CURDLE_SET_CRS : CURDLE_SET_INST;
@@ -74,13 +93,18 @@ __global__ void __launch_bounds__(kBlock)
   out[2 * (size_t)slot + 1] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
 }
 
-hipError_t launch_dacc_scalars(const void* d_checks, uint32_t n_checks, const void* d_pool, uint32_t n_crs, uint32_t n_inst,
-                               void* d_out, hipStream_t stream) {
+hipError_t launch_dacc_scalars(const void* d_checks, uint32_t n_checks, const void* d_pool, uint32_t pool_len, uint32_t n_crs,
+                               uint32_t n_inst, void* d_out, hipStream_t stream) {
   const uint32_t n = n_crs + n_inst;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_dacc_scalars, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const curdle_dacc_check*>(d_checks), n_checks, reinterpret_cast<const uint4*>(d_pool),
-                     n_crs, n_inst, reinterpret_cast<uint4*>(d_out));
+  const size_t need = (size_t)pool_len * 32 + ((size_t)n_checks * sizeof(curdle_dacc_check) + 15) / 16 * 16;
+  const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+  if (need <= kDaccLdsBytes)
+    hipLaunchKernelGGL(k_dacc_scalars<true>, grid, block, need, stream, reinterpret_cast<const curdle_dacc_check*>(d_checks), n_checks,
+                       reinterpret_cast<const uint4*>(d_pool), pool_len, n_crs, n_inst, reinterpret_cast<uint4*>(d_out));
+  else
+    hipLaunchKernelGGL(k_dacc_scalars<false>, grid, block, 0, stream, reinterpret_cast<const curdle_dacc_check*>(d_checks), n_checks,
+                       reinterpret_cast<const uint4*>(d_pool), pool_len, n_crs, n_inst, reinterpret_cast<uint4*>(d_out));
   return hipGetLastError();
 }
 

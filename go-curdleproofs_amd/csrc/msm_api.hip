@@ -2783,7 +2783,7 @@ int dacc_submit_impl(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n
       HIP_TRY(launch_convert_points_raw(dj + o_xp, (uint32_t)n_extra, (char*)S.points28.p + 2 * n_res * kA28Bytes, st));
       HIP_TRY(hipMemcpyAsync((char*)S.scalars.p + n_res * 32, dj + o_xs, n_extra * 32, hipMemcpyDeviceToDevice, st));
     }
-    HIP_TRY(launch_dacc_scalars(dj, (uint32_t)n_checks, dj + o_pool, (uint32_t)n_crs, (uint32_t)n_inst, S.scalars.p, st));
+    HIP_TRY(launch_dacc_scalars(dj, (uint32_t)n_checks, dj + o_pool, (uint32_t)pool_len, (uint32_t)n_crs, (uint32_t)n_inst, S.scalars.p, st));
     if (export_scalars && n_res)
       HIP_TRY(hipMemcpyAsync(h + bytes, S.scalars.p, n_res * 32, hipMemcpyDeviceToHost, st));
     const uint32_t off[2] = {0, (uint32_t)n};

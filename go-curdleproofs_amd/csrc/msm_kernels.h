@@ -170,8 +170,8 @@ hipError_t launch_g1_subgroup_from_bytes(const uint8_t* in, uint32_t n, uint8_t*
 // (ZZ = 0 for infinity); points / addends gnark affine (addends may be null), scalars
 // Montgomery fr.Elements.
 // dacc_kernels.hip: the slot scalars of the device accumulator (checks: curdle_dacc_check[], pool: fr.Elements).
-hipError_t launch_dacc_scalars(const void* d_checks, uint32_t n_checks, const void* d_pool, uint32_t n_crs, uint32_t n_inst,
-                               void* d_out, hipStream_t stream);
+hipError_t launch_dacc_scalars(const void* d_checks, uint32_t n_checks, const void* d_pool, uint32_t pool_len, uint32_t n_crs,
+                               uint32_t n_inst, void* d_out, hipStream_t stream);
 
 hipError_t launch_scalar_mul_batch(const void* points, const void* scalars, int shared_scalar, const void* addends,
                                    uint32_t n, void* out_xyzz, hipStream_t stream);
