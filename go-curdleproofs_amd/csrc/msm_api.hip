@@ -710,21 +710,21 @@ struct ChunkJoin {
 int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                       int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail, bool latency_mode,
                       bool points28_ready, size_t sets, bool many, const ChunkJoin* join, const void* ext_points28,
-                      bool light_host, bool glv);
+                      bool light_host, bool glv, const DaccFront* dfront);
 int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                  int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail,
                  bool latency_mode = true, bool points28_ready = false, size_t sets = 1, bool many = false,
                  const ChunkJoin* join = nullptr, const void* ext_points28 = nullptr, bool light_host = false,
-                 bool glv = true) {
+                 bool glv = true, const DaccFront* dfront = nullptr) {
   const int rc = enqueue_slot_impl(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, pre, stream, tail, latency_mode,
-                                   points28_ready, sets, many, join, ext_points28, light_host, glv);
+                                   points28_ready, sets, many, join, ext_points28, light_host, glv, dfront);
   if (rc == CURDLE_OK) S.coarse_dirty = false;  // every launch of the call is in its queue: k_digits leaves its counters zero
   return rc;
 }
 int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
                       int win_begin, int win_end, hipStream_t pre, hipStream_t stream, hipStream_t tail, bool latency_mode,
                       bool points28_ready, size_t sets, bool many, const ChunkJoin* join, const void* ext_points28,
-                      bool light_host, bool glv) {
+                      bool light_host, bool glv, const DaccFront* dfront) {
   // ext_points28: the bases are a resident, pre-converted set (curdle_dbases: two records per base in the internal
   // form, the first h_off[k] of them) -- d_points is not read, nothing is converted or copied
   if (ext_points28 && (k != 1 || sets != 1)) return fail(CURDLE_EINVAL, "resident bases take one MSM per call");
@@ -739,6 +739,7 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   MsmPlan& p = S.plan;
   int rc = make_plan(p, n_pairs, k, n_max, c, win_begin, win_end, latency_mode, sets, many, join ? join->seg : 0, light_host, glv);
   if (rc) return rc;
+  if (dfront && (p.two_level || k != 1 || sets != 1)) return fail(CURDLE_EINVAL, "internal: the fused accumulator front takes one small MSM");
   // k_scan_one is 16 waves of 121 registers: a block of it needs four SIMDs of one compute unit EMPTY, so beside another
   // call's accumulation it waits for accumulate waves to end.  Only calls that have the chip to themselves take it.
   if (p.fuse_scan == 2 && (join || !latency_mode) && knobs::get(knobs::SCAN) != 2) p.fuse_scan = 0;
@@ -851,6 +852,8 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   if (phase != 2) {
     if (front)
       HIP_TRY(launch_front(p, ws, d_points, (uint32_t)(sets * n_pairs), d_scalars, pre));
+    else if (dfront)  // the device accumulator's job: loose bases, slot scalars and recoding in one launch
+      HIP_TRY(launch_dacc_front(p, ws, *dfront, pre));
     else
       HIP_TRY(launch_digits(p, ws, d_scalars, pre));
     prof.mark("digits");
@@ -2779,17 +2782,36 @@ int dacc_submit_impl(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n
     hipStream_t st = S.stream;
     HIP_TRY(hipMemcpyAsync(S.job.p, h, bytes, hipMemcpyHostToDevice, st));
     char* dj = (char*)S.job.p;
-    if (n_extra) {
-      HIP_TRY(launch_convert_points_raw(dj + o_xp, (uint32_t)n_extra, (char*)S.points28.p + 2 * n_res * kA28Bytes, st));
-      HIP_TRY(hipMemcpyAsync((char*)S.scalars.p + n_res * 32, dj + o_xs, n_extra * 32, hipMemcpyDeviceToDevice, st));
+    // Small jobs (a verification's 1,268 + loose pairs; always below the two-level plans): the loose bases' conversion,
+    // the slot scalars and the recoding in ONE launch (k_dacc_front) instead of four operations on the stream -- the
+    // front of a verification is bound by the host's launches.  Knob FRONT=0: the separate launches.
+    const bool fused = n <= 16384 && knobs::get(knobs::FRONT) != 0;
+    if (!fused) {
+      if (n_extra) {
+        HIP_TRY(launch_convert_points_raw(dj + o_xp, (uint32_t)n_extra, (char*)S.points28.p + 2 * n_res * kA28Bytes, st));
+        HIP_TRY(hipMemcpyAsync((char*)S.scalars.p + n_res * 32, dj + o_xs, n_extra * 32, hipMemcpyDeviceToDevice, st));
+      }
+      HIP_TRY(launch_dacc_scalars(dj, (uint32_t)n_checks, dj + o_pool, (uint32_t)pool_len, (uint32_t)n_crs, (uint32_t)n_inst, S.scalars.p, st));
+      if (export_scalars && n_res)
+        HIP_TRY(hipMemcpyAsync(h + bytes, S.scalars.p, n_res * 32, hipMemcpyDeviceToHost, st));
     }
-    HIP_TRY(launch_dacc_scalars(dj, (uint32_t)n_checks, dj + o_pool, (uint32_t)pool_len, (uint32_t)n_crs, (uint32_t)n_inst, S.scalars.p, st));
-    if (export_scalars && n_res)
-      HIP_TRY(hipMemcpyAsync(h + bytes, S.scalars.p, n_res * 32, hipMemcpyDeviceToHost, st));
+    DaccFront df;
+    df.d_checks = dj;
+    df.d_pool = dj + o_pool;
+    df.d_extra_points = dj + o_xp;
+    df.d_extra_scalars = dj + o_xs;
+    df.d_scalars_out = export_scalars ? S.scalars.p : nullptr;
+    df.n_checks = (uint32_t)n_checks;
+    df.pool_len = (uint32_t)pool_len;
+    df.n_crs = (uint32_t)n_crs;
+    df.n_inst = (uint32_t)n_inst;
+    df.n_extra = (uint32_t)n_extra;
     const uint32_t off[2] = {0, (uint32_t)n};
     if ((r = enqueue_slot(cx, S, nullptr, S.scalars.p, off, 1, 0, 0, -1, st, st, st, /*latency_mode=*/true,
-                          /*points28_ready=*/true, 1, false, nullptr, nullptr, /*light_host=*/queued)))
+                          /*points28_ready=*/true, 1, false, nullptr, nullptr, /*light_host=*/queued, true, fused ? &df : nullptr)))
       return r;
+    if (fused && export_scalars && n_res)  // (tests: behind the whole call on the stream, read at the wait)
+      HIP_TRY(hipMemcpyAsync(h + bytes, S.scalars.p, n_res * 32, hipMemcpyDeviceToHost, st));
     acc->export_off = bytes;
     acc->submitted = true;
     return CURDLE_OK;

@@ -103,6 +103,17 @@ struct FragSources {
 size_t coarse_words(uint32_t nw);
 size_t coarse_zero_offset_words(uint32_t nw);
 
+// The device accumulator's job as the fused front of a small call sees it (launch_dacc_front): device pointers into the
+// uploaded job (checks | pool | loose points | loose scalars) and the counts.
+struct DaccFront {
+  const void* d_checks;
+  const void* d_pool;
+  const void* d_extra_points;
+  const void* d_extra_scalars;
+  void* d_scalars_out;  // [n_crs + n_inst + n_extra] fr.Elements, or null
+  uint32_t n_checks, pool_len, n_crs, n_inst, n_extra;
+};
+
 // Every launcher enqueues on `stream` and returns the launch status.
 // n gnark affine points -> internal form at d_out28 (kA28Bytes apart), outside a plan: the device accumulator
 // converts its resident base sets once and per-verification points as they arrive.
@@ -113,6 +124,8 @@ hipError_t launch_digits(const MsmPlan& p, const MsmWorkspace& ws, const void* d
 // conversion of npts points into ws.points28 and the recoding in ONE launch (small calls; not for two-level plans)
 hipError_t launch_front(const MsmPlan& p, const MsmWorkspace& ws, const void* d_points, uint32_t npts, const void* d_scalars,
                         hipStream_t stream);
+// loose-base conversion + slot scalars + recoding in ONE launch (small device-accumulator calls; not two-level plans)
+hipError_t launch_dacc_front(const MsmPlan& p, const MsmWorkspace& ws, const DaccFront& f, hipStream_t stream);
 hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);

@@ -39,6 +39,7 @@
 
 #include "fp28.h"
 #include "quad28.h"
+#include "dacc_eval.h"
 
 namespace curdle {
 
@@ -127,6 +128,60 @@ struct CoarseOut {
 // call (rocprofv3 timeline, gpurun_out/r5m).
 static constexpr int kDigitsCoarseBlock = 512;
 static constexpr int kDigitsCoarseMaxBlocks = 512;
+// One scalar (canonical integer, below r) -> the digits of pair i in every window of the call's range.
+template <bool GLV, bool COARSE>
+__device__ __forceinline__ void recode_scalar(const Fr& s, const u32 i, const MsmPlan& p, u32* __restrict__ digits, u32* cc) {
+  constexpr int NA = GLV ? 4 : 8;
+  u32 a[NA], b[4], neg_a = 0, neg_b = 0;
+  if constexpr (GLV) {
+    glv_split(s, a, b, neg_a, neg_b);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = s.l[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[j] = 0;
+  }
+  // the two halves' digits of a window leave as ONE 8-byte store: written one half after the other, every
+  // line of `digits` went to memory twice (128 MB for a 64 MB array at N = 2^20, profiles/r04_pmc_summary.txt)
+  u32 ca = 0, cb = 0;
+  for (int w = 0; w < p.W; w++) {
+    const u32 c = p.bits[w];
+    const u32 ra = (a[0] & ((1u << c) - 1u)) + ca, rb = (b[0] & ((1u << c) - 1u)) + cb;
+#pragma unroll
+    for (int j = 0; j + 1 < NA; j++) a[j] = (a[j] >> c) | (a[j + 1] << (32 - c));
+    a[NA - 1] >>= c;
+    if constexpr (GLV) {
+      b[0] = (b[0] >> c) | (b[1] << (32 - c));
+      b[1] = (b[1] >> c) | (b[2] << (32 - c));
+      b[2] = (b[2] >> c) | (b[3] << (32 - c));
+      b[3] >>= c;
+    }
+    u32 ma = ra, na = 0, mb = rb, nb2 = 0;
+    ca = cb = 0;
+    if (w != p.W - 1) {  // windows below the top are signed (header comment above)
+      if (ra > (1u << (c - 1))) {
+        ma = (1u << c) - ra;
+        na = 0x80000000u;
+        ca = 1;
+      }
+      if (rb > (1u << (c - 1))) {
+        mb = (1u << c) - rb;
+        nb2 = 0x80000000u;
+        cb = 1;
+      }
+    }
+    if (w >= p.win_begin && w < p.win_end) {
+      const u32 lw = (u32)(w - p.win_begin);
+      *reinterpret_cast<uint2*>(&digits[(size_t)lw * p.n + 2 * (size_t)i]) =
+          make_uint2(ma ? (ma | (na ^ neg_a)) : 0u, mb ? (mb | (nb2 ^ neg_b)) : 0u);
+      if constexpr (COARSE) {
+        if (ma) atomicAdd(&cc[lw * 256u + ((ma - 1u) >> kFineBits)], 1u);
+        if (mb) atomicAdd(&cc[lw * 256u + ((mb - 1u) >> kFineBits)], 1u);
+      }
+    }
+  }
+}
+
 // (block `bid` of `nblocks`: the body also runs as the second role of k_front below)
 template <bool GLV, bool COARSE>
 __device__ __forceinline__ void digits_body(const uint4* __restrict__ scalars, const MsmPlan& p, u32* __restrict__ digits,
@@ -145,56 +200,8 @@ __device__ __forceinline__ void digits_body(const uint4* __restrict__ scalars, c
   }
   // p.n counts the split's terms: entry 2 i is k1 P_i, entry 2 i + 1 is k2 phi(P_i)
   for (u32 i = bid * kBlock + tid; i < p.n / 2; i += nblocks * kBlock) {
-    Fr s = load_scalar_canonical(scalars, i);
-    constexpr int NA = GLV ? 4 : 8;
-    u32 a[NA], b[4], neg_a = 0, neg_b = 0;
-    if constexpr (GLV) {
-      glv_split(s, a, b, neg_a, neg_b);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; j++) a[j] = s.l[j];
-#pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = 0;
-    }
-    // the two halves' digits of a window leave as ONE 8-byte store: written one half after the other, every
-    // line of `digits` went to memory twice (128 MB for a 64 MB array at N = 2^20, profiles/r04_pmc_summary.txt)
-    u32 ca = 0, cb = 0;
-    for (int w = 0; w < p.W; w++) {
-      const u32 c = p.bits[w];
-      const u32 ra = (a[0] & ((1u << c) - 1u)) + ca, rb = (b[0] & ((1u << c) - 1u)) + cb;
-#pragma unroll
-      for (int j = 0; j + 1 < NA; j++) a[j] = (a[j] >> c) | (a[j + 1] << (32 - c));
-      a[NA - 1] >>= c;
-      if constexpr (GLV) {
-        b[0] = (b[0] >> c) | (b[1] << (32 - c));
-        b[1] = (b[1] >> c) | (b[2] << (32 - c));
-        b[2] = (b[2] >> c) | (b[3] << (32 - c));
-        b[3] >>= c;
-      }
-      u32 ma = ra, na = 0, mb = rb, nb2 = 0;
-      ca = cb = 0;
-      if (w != p.W - 1) {  // windows below the top are signed (header comment above)
-        if (ra > (1u << (c - 1))) {
-          ma = (1u << c) - ra;
-          na = 0x80000000u;
-          ca = 1;
-        }
-        if (rb > (1u << (c - 1))) {
-          mb = (1u << c) - rb;
-          nb2 = 0x80000000u;
-          cb = 1;
-        }
-      }
-      if (w >= p.win_begin && w < p.win_end) {
-        const u32 lw = (u32)(w - p.win_begin);
-        *reinterpret_cast<uint2*>(&digits[(size_t)lw * p.n + 2 * (size_t)i]) =
-            make_uint2(ma ? (ma | (na ^ neg_a)) : 0u, mb ? (mb | (nb2 ^ neg_b)) : 0u);
-        if constexpr (COARSE) {
-          if (ma) atomicAdd(&cc[lw * 256u + ((ma - 1u) >> kFineBits)], 1u);
-          if (mb) atomicAdd(&cc[lw * 256u + ((mb - 1u) >> kFineBits)], 1u);
-        }
-      }
-    }
+    const Fr s = load_scalar_canonical(scalars, i);
+    recode_scalar<GLV, COARSE>(s, i, p, digits, cc);
   }
   if constexpr (COARSE) {
     __syncthreads();
@@ -875,6 +882,49 @@ __global__ void __launch_bounds__(kBlock)
   }
   const CoarseOut none = {nullptr, nullptr, nullptr};
   digits_body<GLV, false>(scalars, p, digits, counts, nb, none, blockIdx.x - nconv, gridDim.x - nconv);
+}
+
+// The device accumulator's front of a SMALL call in one launch (round 5): the conversion of the loose bases, the slot
+// scalars (dacc_eval.h) and their recoding -- four operations on the stream until now (k_convert_points, a device-to-
+// device copy of the loose scalars, k_dacc_scalars, k_digits), each a launch the host pays ~8 us for while the GPU
+// waits (the front of a verification is bound by the host's launches: rocprofv3 timeline, gpurun_out/r5w).  Blocks
+// [0, nconv) convert 128 loose points each into the records behind the resident ones; the others take 256 pairs each:
+// pair i < n_res is a resident slot, whose scalar is evaluated here; the pairs behind them are the loose bases with their
+// scalars from the job.  The scalars are written out as well when the caller wants them (tests; scalars_out).
+struct DaccFrontArgs {
+  const curdle_dacc_check* checks;
+  const uint4* pool;
+  const uint4* extra_points;   // n_extra gnark points
+  const uint4* extra_scalars;  // n_extra fr.Elements (Montgomery)
+  uint4* scalars_out;          // [n_res + n_extra] or null
+  A28* extra_out28;            // where the loose bases' records go (2 per point)
+  u32 n_checks, pool_len, n_crs, n_inst, n_extra, nconv, staged;
+};
+template <bool GLV>
+__global__ void __launch_bounds__(kBlock)
+    k_dacc_front(DaccFrontArgs a, MsmPlan p, u32* __restrict__ digits, u32* __restrict__ counts, u32 nb) {
+  extern __shared__ uint4 lds_stage[];
+  if (blockIdx.x < a.nconv) {  // block-uniform
+    convert_body(a.extra_points, a.n_extra, a.extra_out28, blockIdx.x);
+    return;
+  }
+  const u32 bid = blockIdx.x - a.nconv, nblocks = gridDim.x - a.nconv;
+  const u32 tid = threadIdx.x;
+  for (u32 b = bid * kBlock + tid; b < nb; b += nblocks * kBlock) counts[b] = 0;  // as k_digits does
+  const dacc::View vw = dacc::setup(lds_stage, a.checks, a.n_checks, a.pool, a.pool_len, a.staged != 0, tid, kBlock);
+  const u32 n_res = a.n_crs + a.n_inst;
+  const u32 i = bid * kBlock + tid;
+  if (i >= p.n / 2) return;
+  Fr m;  // the pair's scalar, Montgomery form
+  if (i < n_res)
+    m = dacc::eval_slot(vw, i, a.n_crs);
+  else
+    m = dacc::load_fr(a.extra_scalars, i - n_res);
+  if (a.scalars_out) dacc::store_fr(a.scalars_out, i, m);
+  Fr s;
+  f_from_mont<FrParams>(s, m);
+  u32 none = 0;
+  recode_scalar<GLV, false>(s, i, p, digits, &none);
 }
 
 // Sum of `acc` over aligned groups of G lanes (G a power of two <= 256) of a
@@ -1725,6 +1775,49 @@ hipError_t launch_front(const MsmPlan& p, const MsmWorkspace& ws, const void* d_
   else
     hipLaunchKernelGGL(k_front<false>, dim3(nconv + ndig), dim3(kBlock), 0, stream, pts, npts, reinterpret_cast<A28*>(ws.points28),
                        nconv, sc, p, ws.digits, ws.counts, p.k * p.NB);
+  return hipGetLastError();
+}
+
+static constexpr u32 kDaccFrontLds = 120 * 1024;
+static hipError_t dacc_front_optin() {
+  static std::atomic<uint32_t> done{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint32_t bit = 1u << (dev & 31);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dacc_front<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaccFrontLds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dacc_front<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaccFrontLds);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+
+hipError_t launch_dacc_front(const MsmPlan& p, const MsmWorkspace& ws, const DaccFront& f, hipStream_t stream) {
+  // operand shapes: one MSM of n_crs + n_inst + n_extra pairs, not a two-level plan (its recoding also counts coarse bins)
+  if (p.two_level || p.k != 1 || p.sets != 1 || p.n / 2 != f.n_crs + f.n_inst + f.n_extra) return hipErrorInvalidValue;
+  hipError_t e = dacc_front_optin();
+  if (e != hipSuccess) return e;
+  DaccFrontArgs a;
+  a.checks = reinterpret_cast<const curdle_dacc_check*>(f.d_checks);
+  a.pool = reinterpret_cast<const uint4*>(f.d_pool);
+  a.extra_points = reinterpret_cast<const uint4*>(f.d_extra_points);
+  a.extra_scalars = reinterpret_cast<const uint4*>(f.d_extra_scalars);
+  a.scalars_out = reinterpret_cast<uint4*>(f.d_scalars_out);
+  a.extra_out28 = reinterpret_cast<A28*>(reinterpret_cast<char*>(ws.points28) + 2 * (size_t)(f.n_crs + f.n_inst) * kA28Bytes);
+  a.n_checks = f.n_checks;
+  a.pool_len = f.pool_len;
+  a.n_crs = f.n_crs;
+  a.n_inst = f.n_inst;
+  a.n_extra = f.n_extra;
+  a.nconv = cdiv(f.n_extra, kCvtBlock);
+  const size_t need = dacc::lds_bytes(f.pool_len, f.n_checks, kDaccFrontLds - 36 * 1024);  // beside convert_body's 32 KiB stage
+  a.staged = need ? 1u : 0u;
+  const u32 ndig = cdiv(p.n / 2, kBlock);
+  if (p.glv)
+    hipLaunchKernelGGL(k_dacc_front<true>, dim3(a.nconv + ndig), dim3(kBlock), need, stream, a, p, ws.digits, ws.counts, p.k * p.NB);
+  else
+    hipLaunchKernelGGL(k_dacc_front<false>, dim3(a.nconv + ndig), dim3(kBlock), need, stream, a, p, ws.digits, ws.counts, p.k * p.NB);
   return hipGetLastError();
 }
 
