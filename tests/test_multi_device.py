@@ -154,6 +154,28 @@ def test_a_thread_that_clears_its_selection_spreads_again(two, oracle, coracle):
     assert box.get("v") == [1, 0, 1], box
 
 
+def test_flagged_calls_keep_one_converted_copy_per_context(two, oracle, coracle):
+    """CURDLE_MSM_BASES_UNCHANGED and CURDLE_MSM_ANY_CURVE_POINT on a context other than 0: the converted copy of
+    a base array belongs to the context the call runs on (its own cache, its own device's memory)."""
+    import torch
+    cm = two
+    k, q = oracle.Rand(3).get_frs(2)
+    n = 5000
+    pts = coracle.points_walk(k, q, n)
+    exp = []
+    scs = [rand_scalars(np.random.default_rng(40 + j), n, oracle) for j in range(3)]
+    for sc in scs:
+        exp.append(coracle.msm_pippenger(pts, sc, threads=4))
+    for d in (1, 0):
+        d_p = torch.from_numpy(pts.view(np.int64)).to(f"cuda:{DEVS[d]}")
+        for j, sc in enumerate(scs):
+            d_s = torch.from_numpy(sc.view(np.int64)).to(f"cuda:{DEVS[d]}")
+            flags = cm.MSM_BASES_UNCHANGED | (cm.MSM_ANY_CURVE_POINT if j == 2 else 0)
+            got = on_device(cm, d, lambda: cm.msm_g1_device(d_p.data_ptr(), d_s.data_ptr(), n, flags=flags))
+            assert (got == exp[j]).all(), (d, j)
+        on_device(cm, d, lambda: cm.msm_forget_bases(d_p.data_ptr()))
+
+
 def test_one_msm_over_both_contexts(two, oracle, coracle):
     """curdle_msm_g1 (host buffers: point ranges, one host thread per device) and
     curdle_msm_g1_replicated (resident inputs: Pippenger windows or point ranges) against the
