@@ -1206,10 +1206,27 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
     nchunks = slots.size();
   }
   const int c = choose_window_bits(n);
-  // chunk sizes: equal, or (graded, three chunks and more) the first two one unit and the others two units each
+  // chunk sizes: equal, or (graded, three chunks and more) the first two one unit and the others two units each, or
+  // (knob HOST_PATTERN: decimal digits, one per chunk, in eighths of n -- 3311 = 3/8, 3/8, 1/8, 1/8) as said
   std::vector<size_t> bounds(nchunks + 1, n);
   bounds[0] = 0;
-  if (graded && nchunks >= 3) {
+  const long long pattern = knobs::get(knobs::HOST_PATTERN);
+  if (pattern > 0) {
+    std::vector<int> dig;
+    for (long long v = pattern; v > 0; v /= 10) dig.insert(dig.begin(), (int)(v % 10));
+    int sum = 0;
+    for (int d : dig) sum += d;
+    if (sum == 8 && dig.size() == nchunks) {
+      size_t at = 0;
+      for (size_t i = 0; i < nchunks; i++) {
+        at += (n * (size_t)dig[i] + 7) / 8;
+        bounds[i + 1] = at < n ? at : n;
+      }
+    } else {
+      const size_t per = (n + nchunks - 1) / nchunks;
+      for (size_t i = 1; i < nchunks; i++) bounds[i] = i * per < n ? i * per : n;
+    }
+  } else if (graded && nchunks >= 3) {
     const size_t unit = (n + 2 * (nchunks - 1) - 1) / (2 * (nchunks - 1));
     size_t at = 0;
     for (size_t i = 0; i < nchunks; i++) {

@@ -45,6 +45,7 @@ enum Id {
   FRONT,              // 0: small calls convert and recode in two launches instead of one (k_front)
   DIRECT_RESULTS,     // 0: window sums cross to the host by a copy command instead of the kernels' own stores into pinned memory
   HOST_GRADED,        // 0: host-buffer MSMs in equal chunks with all scalars copied first (round 4) instead of graded chunks, scalars and points interleaved
+  HOST_PATTERN,       // chunk sizes of a host-buffer MSM in eighths, one decimal digit per chunk (3311); needs HOST_CHUNKS = the digit count
   HOST_FOLD,          // 0: chunked host-buffer MSMs keep every chunk's fragments for the one reduction (no progressive folding)
   COUNT
 };
