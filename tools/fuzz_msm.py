@@ -75,9 +75,28 @@ while time.time() < t_end:
     pts[inf] = 0
     sc = scalars(n)
     want = co.msm_pippenger(pts, sc, threads=16)
-    mode = int(rng.integers(0, 3))
+    mode = int(rng.integers(0, 5))
     if mode == 0:
-        got = cm.msm_g1(pts, sc)
+        got = cm.msm_g1(pts, sc, flags=cm.MSM_ANY_CURVE_POINT if rng.integers(0, 3) == 0 else 0)   # round 5: the opt-out from the endomorphism too
+    elif mode == 3:                                                             # round 5: flagged device calls (kept converted bases, no endomorphism)
+        import torch
+        d_p = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
+        d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        flags = int(rng.integers(1, 4))
+        got = cm.msm_g1_device(d_p.data_ptr(), d_s.data_ptr(), n, flags=flags)
+        again = cm.msm_g1_device(d_p.data_ptr(), d_s.data_ptr(), n, flags=flags)   # the second call reads the kept copy
+        if flags & cm.MSM_BASES_UNCHANGED:
+            cm.msm_forget_bases(d_p.data_ptr())
+        if not (again == got).all():
+            got = again
+    elif mode == 4:                                                             # round 5: the pipelined form, three in flight, flags mixed
+        import torch
+        d_p = torch.from_numpy(pts.view(np.int64)).to("cuda:0")
+        d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        tk = [cm.msm_g1_device_submit(d_p.data_ptr(), d_s.data_ptr(), n, flags=int(f)) for f in rng.integers(0, 4, size=3)]
+        res = [cm.msm_wait(t) for t in tk]
+        cm.msm_forget_bases(d_p.data_ptr())
+        got = res[0] if all((r == res[0]).all() for r in res) else res[int(np.argmax([not (r == want).all() for r in res]))]
     elif mode == 1:                                                             # split into a batch of pieces
         cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=3)]))
         parts = cm.msm_g1_batch(pts, sc, np.array(cuts, dtype=np.uint64))
