@@ -372,7 +372,9 @@ int choose_window_bits(size_t n, bool many = false) {
   // from 300 pairs (628: 0.346 against 0.354 at 8; 1,268 -- the verifier's MSM -- 0.359 against 0.387;
   // 2,548: 0.383), 11 from 3,000 (4,096: 0.398 against 0.418 at 10) up to 45,000, 13 up to 100,000
   // (65,536: 0.666 against 0.711 at 11), 14 up to 200,000, 15 up to 450,000, 16 beyond.
-  if (!many && n >= 600) c = n <= 6000 ? 10 : n <= 90000 ? 11 : n <= 200000 ? 13 : n <= 400000 ? 14 : n <= 900000 ? 15 : 16;
+  // Round 5, on the unprofiled call (profiles/r05_window_bits_sweep.txt): the table holds -- 2^14 / 2^15: 11; 2^16: 13 or 14; 2^17: 14; 2^18: 15 --
+  // except that 11 starts paying from ~2,000 pairs (2,548: 0.290 against 0.296 ms at 10; 1,268: 0.279 against 0.270, so the verifier's stays at 10).
+  if (!many && n >= 600) c = n <= 4000 ? 10 : n <= 90000 ? 11 : n <= 200000 ? 13 : n <= 400000 ? 14 : n <= 900000 ? 15 : 16;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
   return c;

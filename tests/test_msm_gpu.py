@@ -428,7 +428,7 @@ def test_sizes_at_the_steps_of_the_plan_tables(gpu, oracle, coracle):
     rules of n (make_plan, choose_window_bits): both sides of every step, synchronous and
     pipelined, against the closed form -- prefixes of one walk, so one set of inputs serves."""
     import torch
-    sizes = [299, 300, 3000, 3001, 45000, 45001, 65536, 100000, 100001, 200001, 450001]
+    sizes = [299, 300, 2000, 2001, 3000, 3001, 45000, 45001, 65536, 100000, 100001, 200001, 450001]
     nmax = max(sizes)
     k, q = oracle.Rand(1).get_frs(2)
     d_pts = torch.empty((nmax, 12), dtype=torch.int64, device="cuda:0")
