@@ -12,7 +12,7 @@ from conftest import ROOT
 def test_bench_help_lists_the_modes():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0
-    for word in ("--gpus", "--steps", "--warmup", "--sweep", "whisk-batch", "verify", "--emulate-world"):
+    for word in ("--gpus", "--steps", "--warmup", "--sweep", "whisk-batch", "verify", "--emulate-world", "--bases-unchanged"):
         assert word in p.stdout, word
 
 
@@ -74,3 +74,20 @@ def test_the_distributed_sweep_runs_on_every_rank(gpu):
     assert line["n_gpus"] == 1 and line["backend"] == "nccl" and line["all_results_match_cpu"] is True
     assert [r["n_pairs"] for r in line["sweep"]] == [1024, 32768]
     assert all(r["gpu_matches_cpu"] and r["wall_ms"] > 0 for r in line["sweep"])
+
+
+@pytest.mark.gpu
+def test_the_default_line_carries_the_size_table(gpu):
+    """north_star's N = 2^10 .. 2^20 table is part of the line the driver records -- wall time,
+    pairs/s, the dominant kernel's HBM and multiply-issue fractions, the CPU port on the same inputs, bit-compared."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-verify"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["value"] and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["gpu_matches_cpu"]
+    rows = line["sweep"]
+    assert [r["logn"] for r in rows] == [10, 12, 14, 16, 18, 20]
+    for r in rows:
+        assert r["gpu_matches_cpu"] is True and r["wall_ms"] > 0 and r["cpu_port_pairs_per_s"] > 0
+        assert 0 < r["hbm_frac"] < 0.02 and 0 < r["valu_frac"] < 1.0
+    assert rows[-1]["pairs_per_s"] > rows[0]["pairs_per_s"]
