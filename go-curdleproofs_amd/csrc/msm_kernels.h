@@ -77,7 +77,7 @@ struct MsmWorkspace {
   uint32_t* digits;   // [nw][n]   |digit| | sign<<31, window-major
   uint32_t* sorted;   // [nw * n]  pair index | sign<<31, grouped by bucket
   uint32_t* tmp;      // [nw * n]  two-level scatter: entries grouped by coarse bin (null otherwise)
-  uint32_t* ccur;     // [coarse_words(nw)] two-level sort: the bins' cursors, their packed starts, the coarse counts and k_digits' ticket
+  uint32_t* ccur;     // [coarse_words(nw)] two-level sort: the bins' cursors, their packed starts, and the copies of the coarse counts
   void* points28;     // [n]       input points in internal form (d28::A28, 112 B)
   void* frags;        // [nb + lanes + 1]  d28::X28 (224 B)
   void* partials;     // [k * NS / G]      d28::X28, one per group of G bucket-reduce lanes
@@ -98,10 +98,9 @@ struct FragSources {
   uint32_t n;
 };
 
-// Words of MsmWorkspace::ccur for nw windows, and the offset from which it must be ZERO before a call's first
-// launch (the coarse counts and the ticket; the kernels leave them zero again).
+// Words of MsmWorkspace::ccur for nw windows.  Its tail (the coarse counts) must be ZERO before a call's first launch;
+// the kernels leave it zero again (msm_api.hip clears the buffer when it is made and after a failed call).
 size_t coarse_words(uint32_t nw);
-size_t coarse_zero_offset_words(uint32_t nw);
 
 // The device accumulator's job as the fused front of a small call sees it (launch_dacc_front): device pointers into the
 // uploaded job (checks | pool | loose points | loose scalars) and the counts.

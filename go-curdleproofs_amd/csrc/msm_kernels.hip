@@ -13,8 +13,10 @@
 //               slots, then of the per-bucket fragment counts
 //   scatter     term indices grouped by (window, bucket).  One pass (LDS histogram again, one
 //               returning atomic per (block, bucket) reserves the range) for batches and small
-//               MSMs; two passes for single large MSMs: by coarse bin of 128 buckets, written as
-//               contiguous runs, then by bucket inside the bins
+//               MSMs.  Single large MSMs sort COARSE-FIRST (round 5): the recoding also counts the
+//               terms per coarse bin of 128 buckets, the terms are written grouped by bin as
+//               contiguous runs, the buckets are counted on that array (a tile of 2,048 entries
+//               touches <= 128 counters), scanned, and the entries placed inside their bins
 //   accumulate  one lane per L consecutive sorted positions: gathers the internal affine
 //               points (112 B in one 128-byte line each), sums them with XYZZ mixed additions
 //               and emits one fragment per bucket it touches, so the work per lane is the same
@@ -1644,7 +1646,7 @@ static hipError_t sort_lds_optin() {
 }
 
 // Layout of ws.ccur (two-level plans): [nw * 256] coarse cursors | [nw * 256 + 1] packed bin starts + sentinel |
-// [nw * 256] coarse counts | [1] ticket.  The last two must be zero when k_digits starts and are zero again when
+// [kCoarseReps][nw * 256] coarse counts.  The counts must be zero when k_digits starts and are zero again when
 // it ends (msm_api.hip clears them when the buffer is made and after a failed call).
 static inline CoarseOut coarse_out(const MsmPlan& p, const MsmWorkspace& ws) {
   const size_t nw = (size_t)(p.win_end - p.win_begin);
@@ -1655,7 +1657,6 @@ static inline CoarseOut coarse_out(const MsmPlan& p, const MsmWorkspace& ws) {
   return co;
 }
 size_t coarse_words(uint32_t nw) { return (2 + (size_t)kCoarseReps) * nw * kCoarseMax + 1; }
-size_t coarse_zero_offset_words(uint32_t nw) { return 2 * (size_t)nw * kCoarseMax + 1; }
 
 // operand shapes the two passes assume (checked on the host): one MSM, every window a whole number of
 // bins and at most kCoarseMax of them, term indices that fit 24 bits
