@@ -49,12 +49,19 @@ def worker(t):
     try:
         while time.time() < stop and not errors:
             cm.set_device(int(rng.integers(0, 2)))
-            op = int(rng.integers(0, 6))
+            op = int(rng.integers(0, 8))
             n = sizes[int(rng.integers(0, len(sizes)))]
             if op == 0:
                 assert (cm.msm_g1(pts[n], scs[n]) == exp[n]).all(), ("host", n)
             elif op == 1:
                 assert (cm.msm_g1_device(d_p[n].data_ptr(), d_s[n].data_ptr(), n) == exp[n]).all(), ("device", n)
+            elif op == 6:                                      # round 5: flagged calls from every thread (kept converted copies, no endomorphism)
+                fl = int(rng.integers(1, 4))
+                assert (cm.msm_g1_device(d_p[n].data_ptr(), d_s[n].data_ptr(), n, flags=fl) == exp[n]).all(), ("flags", n, fl)
+                if rng.integers(0, 8) == 0:
+                    cm.msm_forget_bases(d_p[n].data_ptr())     # while other threads may be reading the copy
+            elif op == 7:
+                assert (cm.msm_g1(pts[n], scs[n], flags=cm.MSM_ANY_CURVE_POINT) == exp[n]).all(), ("host any-curve", n)
             elif op == 2:
                 # at most four tickets outstanding in all: a ticket holds a workspace slot until it is
                 # waited for, and the synchronous calls of the other threads BLOCK for a slot -- sixteen
