@@ -8,7 +8,7 @@
 //	BenchmarkMultiExp/gpu/N=2^k   the same inputs through the cgo shim (host buffers, so the
 //	                              PCIe copy is inside the timed region: compare with bench.py's
 //	                              device-resident figure knowingly)
-//	BenchmarkParity               dst.Equal() between the two for every N, plus the sizes the
+//	TestParity                    dst.Equal() between the two for every N, plus the sizes the
 //	                              protocol meets (6..9, 60..2548): the bit-exactness check
 //	                              against the REAL reference arithmetic that this repository's
 //	                              tests cannot make (parity is pinned on an in-house oracle)
@@ -35,6 +35,7 @@ import (
 
 	"github.com/consensys/gnark-crypto/ecc"
 	bls12381 "github.com/consensys/gnark-crypto/ecc/bls12-381"
+	"github.com/consensys/gnark-crypto/ecc/bls12-381/fp"
 	"github.com/consensys/gnark-crypto/ecc/bls12-381/fr"
 
 	"curdlemsm-bench/curdlemsm"
@@ -124,6 +125,58 @@ func TestParity(t *testing.T) {
 		}
 		if !cpu.Equal(&gpu) {
 			t.Fatalf("n = %d: GPU MultiExp differs from gnark-crypto", n)
+		}
+	}
+}
+
+// offSubgroupPoint returns a point of y^2 = x^3 + 4 that is NOT in the prime-order subgroup (the cofactor of G1 is not 1:
+// most x with a square right-hand side give one).  gnark's MultiExp is defined for it; the library's default path is not
+// (it splits scalars with the endomorphism): curdlemsm.AnyCurvePoint is the opt-out.
+func offSubgroupPoint() bls12381.G1Affine {
+	var x, y, rhs, four fp.Element
+	four.SetUint64(4)
+	for v := uint64(6); ; v++ {
+		x.SetUint64(v)
+		rhs.Square(&x).Mul(&rhs, &x).Add(&rhs, &four)
+		if y.Sqrt(&rhs) == nil {
+			continue
+		}
+		p := bls12381.G1Affine{X: x, Y: y}
+		if p.IsOnCurve() && !p.IsInSubgroup() {
+			return p
+		}
+	}
+}
+
+// TestParityAnyCurvePoint: with curdlemsm.AnyCurvePoint the GPU result equals gnark's for bases outside the subgroup too
+// (mixed with subgroup points and the infinity base), and for subgroup-only inputs it equals the default path's.
+func TestParityAnyCurvePoint(t *testing.T) {
+	if err := curdlemsm.Init(0); err != nil {
+		t.Skipf("no MI355X: %v", err)
+	}
+	cfg := ecc.MultiExpConfig{NbTasks: runtime.NumCPU()}
+	curdlemsm.MinGPUPairs = 0
+	off := offSubgroupPoint()
+	for _, n := range []int{1, 2, 9, 70, 700, 2548, 1 << 12, (1 << 17) + 77} {
+		points, scalars := inputs(n)
+		for i := 0; i < n; i += 7 {
+			var j bls12381.G1Jac
+			j.FromAffine(&off)
+			j.ScalarMultiplication(&j, big.NewInt(int64(1+i%11)))
+			points[i].FromJacobian(&j)
+		}
+		if n > 4 {
+			points[3] = bls12381.G1Affine{}
+		}
+		var cpu, gpu bls12381.G1Jac
+		if _, err := cpu.MultiExp(points, scalars, cfg); err != nil {
+			t.Fatal(err)
+		}
+		if _, err := curdlemsm.MultiExpFlags(&gpu, points, scalars, cfg, curdlemsm.AnyCurvePoint); err != nil {
+			t.Fatal(err)
+		}
+		if !cpu.Equal(&gpu) {
+			t.Fatalf("n = %d: GPU MultiExp with AnyCurvePoint differs from gnark-crypto on bases outside the subgroup", n)
 		}
 	}
 }
