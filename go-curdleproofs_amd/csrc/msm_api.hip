@@ -104,6 +104,10 @@ struct Slot {
   hipStream_t run_stream = nullptr;
   MsmPlan plan;
   bool profiled = false;
+  Buf chain;                  // k_scan_chain's words and ticket counter (zero when made, never cleared again)
+  uint32_t* h_err = nullptr;  // pinned word a kernel raises when a wait inside it gave up (finish_slot reads it)
+  uint32_t scan_epoch = 0;    // epoch of the slot's last k_scan_chain launch (30 bits, never 0)
+  uint32_t scan_base = 0;     // tickets the slot's launches have taken so far
   uint32_t coarse_nw = 0;     // window count the zeroed tail of `ccur` was laid out for
   bool coarse_dirty = false;  // a call was abandoned between its ensure and its last launch: clear `ccur` again
   int prof_n = 0;
@@ -112,7 +116,7 @@ struct Slot {
   Buf* all_bufs(int i) {
     Buf* b[] = {&points, &scalars, &offsets, &points28, &counts, &starts, &cursor, &fragcnt, &foff, &small,
                 &digits, &sorted,  &frags,   &partials, &winsums, &winsums28, &results, &job,      &tmp,    &ccur,
-                &fold_sums, &fold_meta};
+                &fold_sums, &fold_meta, &chain};
     return i < (int)(sizeof(b) / sizeof(b[0])) ? b[i] : nullptr;
   }
 };
@@ -603,6 +607,13 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
     p.fuse_scan = nbs <= 32768 ? 2u : 0u;
     if (forced == 0) p.fuse_scan = 0;
     if (forced == 1) p.fuse_scan = nbs <= 8192 ? 1u : 0u;
+    // k_scan_chain (round 5): one launch at ANY size, tile sums handed down a chain.  Default wherever k_scan_one does not
+    // apply -- more than 32,768 slots, and (enqueue_slot) every pipelined or chunked call, beside whose neighbours k_scan_one's
+    // 16 x 121-register block cannot start: a rank of the 8-way window split 0.428 -> 0.396 ms per step (scan alone 0.037 ->
+    // 0.014), synchronous 2^16 / 2^17 / 2^18 pairs 0.610 / 0.808 / 1.149 -> 0.589 / 0.788 / 1.130 ms (their six launches were
+    // host-bound), whole pipelined MSM 2.533 -> 2.527; equal to k_scan_one where that runs (profiles/r05_scan_chain.txt).
+    // Knob SCAN: 0 / 1 / 2 as before, 3 = the chain everywhere, 4 or unset = this rule.
+    if (forced == 3 || ((forced == 4 || forced < 0) && p.fuse_scan != 2)) p.fuse_scan = 3;
   }
   return CURDLE_OK;
 }
@@ -744,7 +755,7 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   if (dfront && (p.two_level || k != 1 || sets != 1)) return fail(CURDLE_EINVAL, "internal: the fused accumulator front takes one small MSM");
   // k_scan_one is 16 waves of 121 registers: a block of it needs four SIMDs of one compute unit EMPTY, so beside another
   // call's accumulation it waits for accumulate waves to end.  Only calls that have the chip to themselves take it.
-  if (p.fuse_scan == 2 && (join || !latency_mode) && knobs::get(knobs::SCAN) != 2) p.fuse_scan = 0;
+  if (p.fuse_scan == 2 && (join || !latency_mode) && knobs::get(knobs::SCAN) != 2) p.fuse_scan = 3;  // k_scan_chain: four 60-register waves
   // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
   const size_t n = 2 * n_pairs;
   const size_t kr = k * sets;
@@ -822,6 +833,29 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   const bool direct = !p.gpu_combine && win_bytes <= ((size_t)256 << 10) && knobs::get(knobs::DIRECT_RESULTS) != 0;
   ws.winsums = direct ? (G1XYZZ*)S.h_buf : (G1XYZZ*)S.winsums.p;
   ws.results = (G1XYZZ*)S.results.p;
+  ws.chain = nullptr;
+  ws.chain_ticket = nullptr;
+  ws.host_err = nullptr;
+  ws.chain_base = ws.chain_epoch = 0;
+  if (p.fuse_scan == 3) {
+    const void* before = S.chain.p;
+    if ((rc = ensure(S.chain, scan_chain_bytes()))) return rc;
+    if (!S.h_err) {
+      HIP_TRY(hipHostMalloc((void**)&S.h_err, 64, hipHostMallocDefault));
+      *S.h_err = 0;
+    }
+    S.scan_epoch = (S.scan_epoch + 1) & 0x3fffffffu;
+    if (S.chain.p != before || S.scan_epoch == 0) {  // a new buffer, or the epochs have gone round: no word may look current
+      HIP_TRY(hipMemsetAsync(S.chain.p, 0, scan_chain_bytes(), pre));
+      S.scan_base = 0;
+      if (S.scan_epoch == 0) S.scan_epoch = 1;
+    }
+    ws.chain = (unsigned long long*)S.chain.p;
+    ws.chain_ticket = (uint32_t*)((char*)S.chain.p + scan_chain_bytes() - 64);
+    ws.host_err = S.h_err;
+    ws.chain_base = S.scan_base;
+    ws.chain_epoch = S.scan_epoch;
+  }
 
   // the offsets are staged in pinned memory (tail of h_buf) so the copy is truly asynchronous
   uint32_t* h_off_pinned = (uint32_t*)((char*)S.h_buf + host_need - (k + 1) * 4);
@@ -862,6 +896,7 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
     HIP_TRY(launch_hist(p, ws, pre));
     prof.mark("hist");
     HIP_TRY(launch_scan(p, ws, pre));
+    if (ws.chain) S.scan_base += scan_chain_tiles((uint32_t)nb);  // the tickets that launch takes
     prof.mark("scan");
     HIP_TRY(launch_scatter(p, ws, pre));
     prof.mark("scatter");
@@ -970,6 +1005,10 @@ int finish_slot(Ctx& cx, Slot& S, uint64_t* out) {
     return CURDLE_OK;
   }
   HIP_TRY(hipStreamSynchronize(S.run_stream));
+  if (S.h_err && *S.h_err) {
+    *S.h_err = 0;
+    return fail(CURDLE_EHIP, "internal: a wait inside the bucket-slot scan gave up");
+  }
   if (S.profiled) {
     std::lock_guard<std::mutex> g(cx.mu);
     curdle_profile& L = cx.last;
@@ -1744,6 +1783,9 @@ void teardown_locked(Ctx& C) {
       b->p = nullptr;
       b->cap = 0;
     }
+    if (S.h_err) (void)hipHostFree(S.h_err);
+    S.h_err = nullptr;
+    S.scan_epoch = S.scan_base = 0;
     if (S.h_buf) (void)hipHostFree(S.h_buf);
     S.h_buf = nullptr;
     S.h_buf_cap = 0;

@@ -42,7 +42,7 @@ struct MsmPlan {
   uint32_t max_large;  // capacity of the large-bucket queue
   uint32_t chunk;      // pairs per sort block
   uint32_t gpu_combine;  // 1: window sums combined on the GPU (large batches), 0: on the host
-  uint32_t fuse_scan;    // the bucket-slot scans: 0 six launches (multi-block), 1 k_scan_fused (small calls), 2 k_scan_one (one block, up to 65,536 slots)
+  uint32_t fuse_scan;    // the bucket-slot scans: 0 six launches (multi-block), 1 k_scan_fused (small calls), 2 k_scan_one (one block, up to 32,768 slots), 3 k_scan_chain (one launch, any size)
   uint32_t glv;          // 1: scalars split with the endomorphism (bases must be in G1); 0: 255-bit scalars whole, any curve point
   uint32_t two_level;    // 1: the scatter runs in two passes (coarse bins, then buckets): single large MSMs
   // The bucket reduction without a scalar multiple (single MSMs; k_reduce_segments / k_reduce_groups):
@@ -84,7 +84,16 @@ struct MsmWorkspace {
   void* winsums28;    // [k][nw]           d28::X28 (large batches: combined on the GPU)
   G1XYZZ* winsums;    // [k][nw]   gnark-form XYZZ, canonical coordinates (host combine)
   G1XYZZ* results;    // [k]       XYZZ results of a batched call, gnark form (normalised by the host)
+  // k_scan_chain (MsmPlan::fuse_scan == 3): the chain words [2][1024] (zero when allocated, never cleared again), the
+  // ticket counter behind them, the count it stood at before this launch, this launch's epoch (never 0), and a word
+  // of pinned host memory the kernel raises if a wait inside it gave up
+  unsigned long long* chain;
+  uint32_t* chain_ticket;
+  uint32_t* host_err;
+  uint32_t chain_base, chain_epoch;
 };
+uint32_t scan_chain_tiles(uint32_t nb);  // blocks (= tickets) one k_scan_chain launch over nb slots takes
+size_t scan_chain_bytes();               // bytes behind MsmWorkspace::chain (the ticket counter at the end)
 
 // The fragment lists the bucket reduction folds in: one per CHUNK of an MSM whose pairs were
 // accumulated in several pieces over the same plan (host-buffer calls: a piece is accumulated

@@ -812,6 +812,200 @@ __global__ void __launch_bounds__(kScanThreads)
   }
 }
 
+// The same in ONE launch for ANY number of slots (round 5): blocks of 256 threads take tiles of 4,096 slots and hand their
+// sums down a chain -- the single-pass scan with decoupled look-back, twice in one kernel, because a slot's fragment count
+// needs its global start: (1) tile sums of the counts -> starts, (2) tile sums of the fragment counts -> offsets.  What the
+// six launches of the multi-block form cost a synchronous mid-size call is not their GPU time (5 us each) but the host's
+// ~8 us per launch: at 2^16 pairs (40,960 slots, beyond k_scan_one's one block) the scan section of the timeline was
+// launch-bound, 0.10 ms from k_hist's end to k_scatter's start (rocprofv3, gpurun_out/r5_t16).  64 registers, four waves:
+// unlike k_scan_one a block of this fits beside two accumulate waves of a SIMD, so pipelined calls take it too.
+//   chain[c][t] (c = 0: counts, c = 1: fragments; t = tile): epoch << 34 | state << 32 | value, state 1 = the tile's own sum,
+//   2 = the sum of all tiles up to and including t.  The EPOCH (a per-slot launch counter from the host, never 0) makes
+//   words of earlier launches read as "not there yet", so nothing is cleared between calls.  Tiles are taken in TICKET order
+//   (one atomic per block on a counter that only ever grows; the host passes the count it stood at before this launch), so
+//   a block only ever waits for blocks that have started: every wait ends, whatever order the hardware dispatches in.
+//   A wait that does not end after ~2^20 polls all the same (it cannot, by the argument above) gives up: it raises *host_err
+//   (pinned host memory, read by finish_slot) and goes on with a prefix of 0 -- positions stay inside the arrays.
+static constexpr u32 kChainThreads = 256;
+static constexpr int kChainPer = 16;
+static constexpr u32 kChainTile = kChainThreads * kChainPer;
+static constexpr u32 kChainMaxTiles = 1024;  // 4,194,304 slots: what one pass of a batch may hold (msm_api.hip kMaxSlotsPerPass)
+static constexpr u32 kChainSpinLimit = 1u << 20;
+__device__ __forceinline__ u64 chain_word(u32 epoch, u32 state, u32 value) {
+  return ((u64)epoch << 34) | ((u64)state << 32) | (u64)value;
+}
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+  for (u32 off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// Called by the 64 lanes of ONE wave: publishes tile `my`'s sum `agg` and returns the sum of all tiles before it.
+__device__ __forceinline__ u32 chain_lookback(u64* __restrict__ words, u32 my, u32 epoch, u32 agg, u32* __restrict__ host_err) {
+  const u32 lane = threadIdx.x & 63u;
+  if (my == 0) {
+    if (lane == 0) __hip_atomic_store(&words[0], chain_word(epoch, 2u, agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  if (lane == 0) __hip_atomic_store(&words[my], chain_word(epoch, 1u, agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  u32 prefix = 0, spins = 0;
+  int j = (int)my - 1;  // the nearest tile not summed yet
+  while (true) {
+    const int idx = j - (int)lane;
+    // (tiles before the first count as one with prefix 0)
+    const u64 w = idx >= 0 ? __hip_atomic_load(&words[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : chain_word(epoch, 2u, 0u);
+    const u32 state = (u32)(w >> 34) == epoch ? (u32)(w >> 32) & 3u : 0u;
+    const u64 missing = __ballot(state == 0u);
+    const u32 usable = missing ? (u32)__builtin_ctzll(missing) : 64u;  // lanes [0, usable) hold sums
+    const u64 below = usable >= 64u ? ~(u64)0 : (((u64)1 << usable) - 1u);
+    const u64 full = __ballot(state == 2u) & below;
+    if (full) {
+      const u32 stop = (u32)__builtin_ctzll(full);  // the nearest tile that knows its whole prefix
+      prefix += wave_sum_u32(lane <= stop ? (u32)w : 0u);
+      break;
+    }
+    prefix += wave_sum_u32(lane < usable ? (u32)w : 0u);
+    j -= (int)usable;
+    if (usable == 0u) {
+      if (++spins > kChainSpinLimit) {
+        if (lane == 0) *host_err = 1u;
+        prefix = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  if (lane == 0) __hip_atomic_store(&words[my], chain_word(epoch, 2u, prefix + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  return prefix;
+}
+__device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* sh /* [4] */, u32& total) {
+  const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  u32 inc = v;
+#pragma unroll
+  for (u32 off = 1; off < 64; off <<= 1) {
+    const u32 t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();  // sh may still be read from the previous call
+  if (lane == 63) sh[wv] = inc;
+  __syncthreads();
+  u32 before = 0, all = 0;
+#pragma unroll
+  for (u32 k = 0; k < kChainThreads / 64; k++) {
+    const u32 t = sh[k];
+    if (k < wv) before += t;
+    all += t;
+  }
+  total = all;
+  return before + inc - v;
+}
+struct ScanChain {
+  unsigned long long* words;  // [2][kChainMaxTiles]
+  u32* ticket;
+  u32* host_err;
+  u32 ticket_base, epoch, ntiles;
+};
+__global__ void __launch_bounds__(kChainThreads)
+    k_scan_chain(const u32* __restrict__ counts, u32 nb, u32* __restrict__ starts, u32* __restrict__ cursor,
+                 u32* __restrict__ fragcnt, u32* __restrict__ foff, u32* __restrict__ large, u32* __restrict__ nlarge, u32 L,
+                 u32 max_small, u32 max_large, u32 m_lo, u32 m_hi, ScanChain ch, u32 prio) {
+  set_wave_prio(prio);
+  __shared__ u32 sh[kChainThreads / 64];
+  __shared__ u32 sh_my, sh_pre[2];
+  const u32 tid = threadIdx.x;
+  if (tid == 0) sh_my = atomicAdd(ch.ticket, 1u) - ch.ticket_base;
+  __syncthreads();
+  const u32 my = sh_my;
+  if (my >= ch.ntiles) return;  // block-uniform; a launch has exactly ntiles blocks
+  u64* words0 = reinterpret_cast<u64*>(ch.words);
+  u64* words1 = words0 + kChainMaxTiles;
+  const u32 lo = my * kChainTile + tid * kChainPer;
+  const bool vec = (nb & 3u) == 0;
+  u32 v[kChainPer], f[kChainPer];
+#pragma unroll
+  for (int g = 0; g < kChainPer / 4; g++) {
+    const u32 at = lo + 4 * g;
+    if (at < nb) {
+      if (vec) {
+        const uint4 q = *reinterpret_cast<const uint4*>(counts + at);
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[4 * g + k] = at + k < nb ? counts[at + k] : 0u;
+      }
+    } else {
+      v[4 * g] = v[4 * g + 1] = v[4 * g + 2] = v[4 * g + 3] = 0;
+    }
+  }
+  u32 sum = 0;
+#pragma unroll
+  for (int k = 0; k < kChainPer; k++) sum += v[k];
+  u32 agg, fagg;
+  const u32 first = block_exclusive_scan_256(sum, sh, agg);
+  if (tid < 64) {
+    // the first tile clears the queue of large buckets BEFORE it publishes: every other tile appends after its look-backs,
+    // which (transitively) follow that publication
+    if (my == 0 && tid == 0) __hip_atomic_store(nlarge, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 pre = chain_lookback(words0, my, ch.epoch, agg, ch.host_err);
+    if (tid == 0) sh_pre[0] = pre;
+  }
+  __syncthreads();
+  const u32 pre0 = sh_pre[0];
+  u32 run = pre0 + first, fsum = 0;
+#pragma unroll
+  for (int k = 0; k < kChainPer; k++) {
+    const u32 cnt = v[k];
+    f[k] = cnt ? (div_by(run + cnt - 1, m_lo, m_hi) - div_by(run, m_lo, m_hi) + 1u) : 0u;
+    fsum += f[k];
+    run += cnt;
+  }
+  const u32 ffirst = block_exclusive_scan_256(fsum, sh, fagg);
+  if (tid < 64) {
+    const u32 pre = chain_lookback(words1, my, ch.epoch, fagg, ch.host_err);
+    if (tid == 0) sh_pre[1] = pre;
+  }
+  __syncthreads();
+  const u32 pre1 = sh_pre[1];
+  run = pre0 + first;
+  u32 frun = pre1 + ffirst;
+#pragma unroll
+  for (int g = 0; g < kChainPer / 4; g++) {
+    const u32 at = lo + 4 * g;
+    u32 st[4], fo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      st[k] = run;
+      fo[k] = frun;
+      run += v[4 * g + k];
+      frun += f[4 * g + k];
+      if (f[4 * g + k] > max_small) {
+        const u32 q = atomicAdd(nlarge, 1u);
+        if (q < max_large) large[q] = at + k;
+      }
+    }
+    if (at < nb) {
+      if (vec) {
+        *reinterpret_cast<uint4*>(starts + at) = make_uint4(st[0], st[1], st[2], st[3]);
+        *reinterpret_cast<uint4*>(cursor + at) = make_uint4(st[0], st[1], st[2], st[3]);
+        *reinterpret_cast<uint4*>(fragcnt + at) = make_uint4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+        *reinterpret_cast<uint4*>(foff + at) = make_uint4(fo[0], fo[1], fo[2], fo[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (at + k < nb) {
+            starts[at + k] = st[k];
+            cursor[at + k] = st[k];
+            fragcnt[at + k] = f[4 * g + k];
+            foff[at + k] = fo[k];
+          }
+      }
+    }
+  }
+  if (my == ch.ntiles - 1 && tid == 0) {
+    starts[nb] = pre0 + agg;
+    foff[nb] = pre1 + fagg;
+  }
+}
+
 // Phase 0: gnark points (R = 2^384, saturated limbs) -> internal form (fp28.h),
 // once per MSM: one Montgomery product per coordinate.  (0,0) stays (0,0).
 // element i of the internal point array (kA28Bytes apart: one 128-byte line per point, so a
@@ -1721,12 +1915,29 @@ static hipError_t scan_u32(const u32* in, u32 len, u32* out, u32* blocksum, hipS
   return hipGetLastError();
 }
 
+uint32_t scan_chain_tiles(uint32_t nb) { return cdiv(nb, kChainTile); }
+size_t scan_chain_bytes() { return (size_t)2 * kChainMaxTiles * 8 + 64; }  // the words, then the ticket counter
+
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
   const u32 nb = p.k * p.NB;
   if (p.fuse_scan == 2 && nb <= kScanOneMax && p.L >= 2) {
     const u64 magic = ~(u64)0 / p.L + 1;  // div_by: floor(x / L) for 32-bit x
     hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(kScanThreads), 0, stream, ws.counts, nb, ws.starts, ws.cursor,
                        ws.fragcnt, ws.foff, ws.large, ws.nlarge, p.L, p.max_small, p.max_large, (u32)magic, (u32)(magic >> 32));
+    return hipGetLastError();
+  }
+  if (p.fuse_scan == 3 && ws.chain && p.L >= 2 && nb <= kChainMaxTiles * kChainTile) {
+    const u64 magic = ~(u64)0 / p.L + 1;
+    ScanChain ch;
+    ch.words = ws.chain;
+    ch.ticket = ws.chain_ticket;
+    ch.host_err = ws.host_err;
+    ch.ticket_base = ws.chain_base;
+    ch.epoch = ws.chain_epoch;
+    ch.ntiles = scan_chain_tiles(nb);
+    hipLaunchKernelGGL(k_scan_chain, dim3(ch.ntiles), dim3(kChainThreads), 0, stream, ws.counts, nb, ws.starts, ws.cursor,
+                       ws.fragcnt, ws.foff, ws.large, ws.nlarge, p.L, p.max_small, p.max_large, (u32)magic, (u32)(magic >> 32), ch,
+                       p.aux_prio);
     return hipGetLastError();
   }
   if (p.fuse_scan == 1 && nb <= kScanFusedMax) {
