@@ -880,7 +880,8 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   const bool convert_here = !points28_ready && !ext_points28;  // the device accumulator fills S.points28 itself; a resident base set is converted already
   // small calls: conversion and recoding in one launch (the host's launches bound the call until the accumulation
   // starts; knob FRONT=0: two launches)
-  const bool front = convert_here && phase == 0 && !p.two_level && sets * n_pairs <= 16384 && knobs::get(knobs::FRONT) != 0;
+  const size_t front_max = knobs::get(knobs::FRONT) > 1 ? (size_t)knobs::get(knobs::FRONT) : (size_t)16384;  // (FRONT > 1: the limit in pairs)
+  const bool front = convert_here && phase == 0 && !p.two_level && sets * n_pairs <= front_max && knobs::get(knobs::FRONT) != 0;
   if (convert_here && phase == 0 && !front) {
     HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre, p.aux_prio));
     prof.mark("convert_points");

@@ -42,7 +42,7 @@ enum Id {
   REDUCE_PRIO,        // wave priority (0..3) of k_reduce_segments / k_reduce_level; unset: 3 for pipelined calls, 0 for synchronous ones
   AUX_PRIO,           // wave priority (0..3) of the sort kernels, the conversion and the chunk fold; unset: 3 for pipelined calls, 0 for synchronous ones
   SCAN,               // the bucket-slot scans: 0 six launches, 1 k_scan_fused up to 8,192 slots, 2 k_scan_one up to 32,768, 3 k_scan_chain everywhere; unset or 4: k_scan_one for synchronous calls up to 32,768 slots, k_scan_chain otherwise
-  FRONT,              // 0: small calls convert and recode in two launches instead of one (k_front)
+  FRONT,              // 0: small calls convert and recode in two launches instead of one (k_front); > 1: the limit in pairs (unset: 16,384; larger limits measured equal, profiles/r05_small_sort_one_block.txt)
   DIRECT_RESULTS,     // 0: window sums cross to the host by a copy command instead of the kernels' own stores into pinned memory
   HOST_GRADED,        // 0: host-buffer MSMs in equal chunks with all scalars copied first (round 4) instead of graded chunks, scalars and points interleaved
   HOST_PATTERN,       // chunk sizes of a host-buffer MSM in eighths, one decimal digit per chunk (3311); needs HOST_CHUNKS = the digit count
