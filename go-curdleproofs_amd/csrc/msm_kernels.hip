@@ -10,7 +10,8 @@
 //               ceil(127 / c) windows
 //   hist        bucket sizes, per-window histogram staged in LDS
 //   scan        exclusive prefix of the bucket sizes over all (window, bucket)
-//               slots, then of the per-bucket fragment counts
+//               slots, then of the per-bucket fragment counts -- ONE launch: k_scan_one (one block, synchronous
+//               calls up to 32,768 slots) or k_scan_chain (any size: tiles hand their sums down a chain)
 //   scatter     term indices grouped by (window, bucket).  One pass (LDS histogram again, one
 //               returning atomic per (block, bucket) reserves the range) for batches and small
 //               MSMs.  Single large MSMs sort COARSE-FIRST (round 5): the recoding also counts the
