@@ -614,6 +614,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
     // host-bound), whole pipelined MSM 2.533 -> 2.527; equal to k_scan_one where that runs (profiles/r05_scan_chain.txt).
     // Knob SCAN: 0 / 1 / 2 as before, 3 = the chain everywhere, 4 or unset = this rule.
     if (forced == 3 || ((forced == 4 || forced < 0) && p.fuse_scan != 2)) p.fuse_scan = 3;
+    if (p.L < 2 && p.fuse_scan >= 2) p.fuse_scan = 0;  // both one-launch forms divide by L with a multiply (knob SEG_LEN = 1 only)
   }
   return CURDLE_OK;
 }
@@ -755,7 +756,7 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   if (dfront && (p.two_level || k != 1 || sets != 1)) return fail(CURDLE_EINVAL, "internal: the fused accumulator front takes one small MSM");
   // k_scan_one is 16 waves of 121 registers: a block of it needs four SIMDs of one compute unit EMPTY, so beside another
   // call's accumulation it waits for accumulate waves to end.  Only calls that have the chip to themselves take it.
-  if (p.fuse_scan == 2 && (join || !latency_mode) && knobs::get(knobs::SCAN) != 2) p.fuse_scan = 3;  // k_scan_chain: four 60-register waves
+  if (p.fuse_scan == 2 && (join || !latency_mode) && knobs::get(knobs::SCAN) != 2) p.fuse_scan = 3;  // k_scan_chain: four 60-register waves (L >= 2 holds: make_plan)
   // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
   const size_t n = 2 * n_pairs;
   const size_t kr = k * sets;

@@ -1927,7 +1927,9 @@ hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t str
                        ws.fragcnt, ws.foff, ws.large, ws.nlarge, p.L, p.max_small, p.max_large, (u32)magic, (u32)(magic >> 32));
     return hipGetLastError();
   }
-  if (p.fuse_scan == 3 && ws.chain && p.L >= 2 && nb <= kChainMaxTiles * kChainTile) {
+  if (p.fuse_scan == 3) {
+    // (the caller has counted this launch's tickets already: anything that cannot take the chain is an error, not another path)
+    if (!ws.chain || !ws.chain_ticket || !ws.host_err || p.L < 2 || nb > kChainMaxTiles * kChainTile || ws.chain_epoch == 0) return hipErrorInvalidValue;
     const u64 magic = ~(u64)0 / p.L + 1;
     ScanChain ch;
     ch.words = ws.chain;
