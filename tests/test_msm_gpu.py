@@ -1066,6 +1066,16 @@ def test_bucket_slot_scans_agree(gpu, oracle, coracle):
                 ts = [gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n, 0, w, w + 1) for w in range(w0, min(W, w0 + 5))]
                 parts += [gpu.msm_wait(t) for t in ts]
             assert (gpu.g1_sum(np.stack(parts)) == exp).all(), mode
+        # one position per accumulate lane (knob SEG_LEN = 1): the one-launch scans divide by L with a multiply that needs
+        # L >= 2, so the plan goes back to the six launches whatever SCAN asks for
+        gpu.plan_override("SEG_LEN", 1)
+        try:
+            exp = _walk_expected(oracle, coracle, k, q, sc[:3000])
+            for mode in (3, 2, -1):
+                gpu.plan_override("SCAN", mode)
+                assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), 3000) == exp).all(), mode
+        finally:
+            gpu.plan_override("SEG_LEN", -1)
         # every scalar the same: one bucket per window holds all the terms and goes through the queue of large buckets,
         # which the chain's first tile clears and the others append to
         same = np.repeat(sc[:1], 1 << 16, axis=0)
