@@ -1497,55 +1497,65 @@ __global__ void __launch_bounds__(kBlock, 2)
     int u = (int)p.seg - 1;
     u32 s = 0, m = 0, k = 0;
     const X28* f = nullptr;
-    u32 pm = src.fragcnt[0][g0 + u], pf = src.foff[0][g0 + u];  // bucket u of source 0, read ahead
-    auto open = [&]() {
-      u32 fo;
-      if (s == 0) {
-        m = pm;
-        fo = pf;
-        if (u > 0) {
-          pm = src.fragcnt[0][g0 + u - 1];
-          pf = src.foff[0][g0 + u - 1];
-        }
-      } else {
-        m = src.fragcnt[s][g0 + u];
-        fo = src.foff[s][g0 + u];
-      }
-      if (m > p.max_small) m = 1;  // pre-merged by k_merge_large into its first slot
-      f = reinterpret_cast<const X28*>(src.frags[s]) + set_off + fo;
+    // Round 5 (late): NO load of this loop sits under a branch.  The loop used to fetch the next fragment, and the next
+    // bucket's bookkeeping, inside its "take a fragment" / "close the bucket" branches; a load under a branch lands in
+    // registers of its own, and the copy into the loop-carried registers -- placed where the branch ends -- waited for it on
+    // the spot (s_waitcnt vmcnt(0) a dozen instructions behind the global_load: the ISA of round 4's kernel), so every step of
+    // the chain paid a memory round trip on top of its addition: ~9 us per step where the addition is ~5.7.  Now every lane
+    // issues the same loads at the same place in every step -- what the NEXT step needs, or any valid record if it needs
+    // nothing -- and they are copied into the loop's registers after the addition.
+    const X28* const safe = reinterpret_cast<const X28*>(src.frags[0]);  // a valid record for steps with nothing to fetch
+    auto set_bucket = [&](u32 cnt, u32 fo, u32 source) {  // the fragments of bucket u in `source`
+      m = cnt > p.max_small ? 1u : cnt;                   // (beyond max_small: pre-merged by k_merge_large into its first slot)
+      f = reinterpret_cast<const X28*>(src.frags[source]) + set_off + fo;
       k = 0;
     };
-    F28 nxt;
-    q28::set_inf(nxt);
-    auto seek = [&]() {  // the next fragment of bucket u, if any source has one left: its load is issued here
+    auto more_sources = [&]() {  // bucket u's fragments in the next source that has any (chunked host-buffer calls only)
       while (k >= m && s + 1 < src.n) {
         s++;
-        open();
+        set_bucket(src.fragcnt[s][g0 + u], src.foff[s][g0 + u], s);
       }
-      if (k < m) q28::load(nxt, &f[k]);
     };
-    open();
-    seek();
+    set_bucket(src.fragcnt[0][g0 + u], src.foff[0][g0 + u], 0);
+    more_sources();
+    // source 0's bookkeeping of the bucket BELOW the current one, fetched in every step for the step after it
+    u32 cm, cf;
+    {
+      const u32 un = u > 0 ? (u32)u - 1u : 0u;
+      cm = src.fragcnt[0][g0 + un];
+      cf = src.foff[0][g0 + un];
+    }
+    F28 nxt;
+    q28::load(nxt, k < m ? &f[k] : safe);
     while (u >= 0) {
       const bool take = k < m;  // uniform over the quad
-      F28 b = nxt;
+      const F28 b = nxt;
       if (take) {
         k++;
-        seek();
+        more_sources();
       } else {
         u--;
         s = 0;
         if (u >= 0) {
-          open();
-          seek();
+          set_bucket(cm, cf, 0);
+          more_sources();
         }
       }
+      // the next step's fragment and the bookkeeping of the bucket below the (possibly new) current one: issued here by
+      // every lane, consumed one addition later
+      const u32 un = u > 0 ? (u32)u - 1u : 0u;
+      const u32 lm = src.fragcnt[0][g0 + un], lf = src.foff[0][g0 + un];
+      F28 ld;
+      q28::load(ld, (u >= 0 && k < m) ? &f[k] : safe);
       F28 dst, from;
       q28::sel(dst, take, run, acc);
       q28::sel(from, take, b, run);
       q28::add(dst, from);
       q28::sel(run, take, dst, run);
       q28::sel(acc, take, acc, dst);
+      nxt = ld;
+      cm = lm;
+      cf = lf;
     }
   }
   if (p.G > 1) group_bits_and_sum(acc, run, p.G);

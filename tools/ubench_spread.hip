@@ -121,6 +121,53 @@ __device__ __forceinline__ void mul_spread(F28& r, const F28& a, const F28& b, c
   });
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product on ONE lane with TWO column accumulators (round 5, late): fp28.h's product is one dependency chain -- every
+// multiply-add of a column adds into the same 64-bit accumulator, and the columns follow each other through the carry -- so a
+// wave that is alone on its SIMD waits out every multiply-add's latency.  Here the a x b part of column k + 1 is summed into a
+// second accumulator while column k finishes (its m x p part, m_k, the carry): two independent chains the scheduler can
+// interleave.  Plain C (the compiler picks v_mad_u64_u32 and places the instructions itself).  Same result bits.
+__device__ __forceinline__ void mul_ilp(F28& r, const F28& a, const F28& b) {
+  u32 p[N], m[N], t[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) p[i] = d28::kP(i);
+  u64 A = 0, B = (u64)a.l[0] * b.l[0];
+  static_for<0, 2 * N - 1>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    A += B;  // the a x b sum of column k
+    // column k + 1's a x b sum: nothing of it depends on column k
+    u64 Bn = 0;
+    if constexpr (k + 1 <= 2 * N - 2) {
+      constexpr int lo = k + 1 < N ? 0 : k + 1 - N + 1;
+      constexpr int hi = k + 1 < N ? k + 1 : N - 1;
+      static_for<lo, hi + 1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        Bn += (u64)a.l[i] * b.l[k + 1 - i];
+      });
+    }
+    if constexpr (k < N) {
+      static_for<0, k>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        A += (u64)m[i] * p[k - i];
+      });
+      m[k] = ((u32)A * N0) & MASK;
+      A += (u64)m[k] * p[0];
+    } else {
+      constexpr int i0 = k - N + 1;
+      static_for<i0, N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        A += (u64)m[i] * p[k - i];
+      });
+      t[k - N] = (u32)A & MASK;
+    }
+    A >>= 28;
+    B = Bn;
+  });
+  t[N - 1] = (u32)A;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.l[i] = t[i];
+}
+
 static constexpr int kChain = 96;
 
 __device__ __forceinline__ void seed(F28& a, F28& b, u32 id) {
@@ -149,6 +196,20 @@ __global__ void __launch_bounds__(256) k_chain_lane(u32* out, int chains, unsign
   r = a;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < kChain; it++) d28::mul_inl(r, r, b);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((t & 3u) == 0 && id < (u32)chains) finish(out + (size_t)id * N, r);
+  if (t == 0) *clk = t1 - t0;
+}
+
+// one chain per lane, the two-accumulator product
+__global__ void __launch_bounds__(256) k_chain_ilp(u32* out, int chains, unsigned long long* clk) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  const u32 id = t >> 2;
+  F28 a, b, r;
+  seed(a, b, id);
+  r = a;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kChain; it++) mul_ilp(r, r, b);
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((t & 3u) == 0 && id < (u32)chains) finish(out + (size_t)id * N, r);
   if (t == 0) *clk = t1 - t0;
@@ -184,16 +245,20 @@ int main() {
     CHECK(hipMalloc(&d_a, (size_t)chains * N * 4));
     CHECK(hipMalloc(&d_b, (size_t)chains * N * 4));
     CHECK(hipMalloc(&d_clk, 8));
-    double ms[2] = {0, 0};
-    unsigned long long ticks[2] = {0, 0};
-    for (int which = 0; which < 2; which++) {
+    double ms[3] = {0, 0, 0};
+    unsigned long long ticks[3] = {0, 0, 0};
+    u32* d_c;
+    CHECK(hipMalloc(&d_c, (size_t)chains * N * 4));
+    for (int which = 0; which < 3; which++) {
       for (int rep = 0; rep < 4; rep++) {
         CHECK(hipDeviceSynchronize());
         auto t0 = std::chrono::steady_clock::now();
         if (which == 0)
           hipLaunchKernelGGL(k_chain_lane, dim3(blocks), dim3(256), 0, 0, d_a, chains, d_clk);
-        else
+        else if (which == 1)
           hipLaunchKernelGGL(k_chain_spread, dim3(blocks), dim3(256), 0, 0, d_b, chains, d_clk);
+        else
+          hipLaunchKernelGGL(k_chain_ilp, dim3(blocks), dim3(256), 0, 0, d_c, chains, d_clk);
         CHECK(hipDeviceSynchronize());
         auto t1 = std::chrono::steady_clock::now();
         ms[which] = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -205,6 +270,13 @@ int main() {
     CHECK(hipMemcpy(hb.data(), d_b, hb.size() * 4, hipMemcpyDeviceToHost));
     size_t bad = 0;
     for (size_t i = 0; i < ha.size(); i++) bad += ha[i] != hb[i];
+    std::vector<u32> hc((size_t)chains * N);
+    CHECK(hipMemcpy(hc.data(), d_c, hc.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad_c = 0;
+    for (size_t i = 0; i < ha.size(); i++) bad_c += ha[i] != hc[i];
+    printf("%d wave(s) per SIMD: two-accumulator product on one lane %.3f ms = %.2f us per product (ratio to the one-chain product %.2f); results %s (%zu limbs differ)\n",
+           waves_per_simd, ms[2], ms[2] * 1e3 / kChain, ms[0] / ms[2], bad_c ? "DIFFER" : "equal", bad_c);
+    CHECK(hipFree(d_c));
     // s_memtime counts at 100 MHz on this chip's constant clock?  report wall time per product and the shader-clock estimate
     printf("%d wave(s) per SIMD, %d chains of %d dependent products: one lane per product %.3f ms = %.2f us per product; four lanes per product %.3f ms = %.2f us per product; ratio %.2f; results %s (%zu limbs differ)\n",
            waves_per_simd, chains, kChain, ms[0], ms[0] * 1e3 / kChain, ms[1], ms[1] * 1e3 / kChain, ms[0] / ms[1], bad ? "DIFFER" : "equal", bad);
