@@ -224,22 +224,27 @@ __global__ void __launch_bounds__(COARSE ? kDigitsCoarseBlock : kBlock) k_digits
 // The coarse counts -> the bins' first positions: one block.  (Round 5's first build let the LAST block of k_digits do
 // this, found by a ticket every block incremented: 1,024 atomics on one address took 0.08 ms -- same-address device
 // atomics complete one after the other, ~80 ns each on this chip (gpurun_out/r5e) -- a launch of its own is ~7 us.)
+// (late in round 5: at the call's wave priority like the other sort kernels -- beside an accumulation this one block took
+// 0.18 ms of a chunk's sort against 0.02 alone, rocprofv3 timeline gpurun_out/r5_hosttrace2 -- and the copies read and
+// cleared 16 bytes at a time: 32 loads and stores per thread at eight windows instead of 128)
 __global__ void __launch_bounds__(kBlock) k_coarse_scan(MsmPlan p, CoarseOut co) {
   __shared__ u32 cc[kCoarseWinMax * 256];
   __shared__ u32 sh_scan[kBlock];
+  set_wave_prio(p.aux_prio);
   const u32 tid = threadIdx.x;
   const u32 nw = (u32)(p.win_end - p.win_begin);
   const u32 tot = nw * 256u;
   // the counts are summed over the copies and left zero for the next call
-  for (u32 x = tid; x < tot; x += kBlock) {
-    u32 v = 0;
+  for (u32 x4 = tid; x4 < tot / 4u; x4 += kBlock) {
+    uint4 v = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < kCoarseReps; r++) {
-      u32* at = &co.ccount[(size_t)r * tot + x];
-      v += *at;
-      *at = 0;
+      uint4* at = reinterpret_cast<uint4*>(&co.ccount[(size_t)r * tot]) + x4;
+      const uint4 q = *at;
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      *at = make_uint4(0, 0, 0, 0);
     }
-    cc[x] = v;
+    cc[4 * x4] = v.x; cc[4 * x4 + 1] = v.y; cc[4 * x4 + 2] = v.z; cc[4 * x4 + 3] = v.w;
   }
   __syncthreads();
   // exclusive prefix over the windows' bins in slot order (a window's unused bins hold zero): thread t
@@ -1850,15 +1855,16 @@ static hipError_t sort_lds_optin() {
   return e;
 }
 
-// Layout of ws.ccur (two-level plans): [nw * 256] coarse cursors | [nw * 256 + 1] packed bin starts + sentinel |
-// [kCoarseReps][nw * 256] coarse counts.  The counts must be zero when k_digits starts and are zero again when
-// it ends (msm_api.hip clears them when the buffer is made and after a failed call).
+// Layout of ws.ccur (two-level plans): [nw * 256] coarse cursors | [kCoarseReps][nw * 256] coarse counts (16-byte
+// aligned: k_coarse_scan reads them four at a time) | [nw * 256 + 1] packed bin starts + sentinel.  The counts must be
+// zero when k_digits starts and are zero again when it ends (msm_api.hip clears them when the buffer is made and after a
+// failed call).
 static inline CoarseOut coarse_out(const MsmPlan& p, const MsmWorkspace& ws) {
   const size_t nw = (size_t)(p.win_end - p.win_begin);
   CoarseOut co;
   co.ccur = ws.ccur;
-  co.cstart = ws.ccur + nw * kCoarseMax;
-  co.ccount = ws.ccur + 2 * nw * kCoarseMax + 1;
+  co.ccount = ws.ccur + nw * kCoarseMax;
+  co.cstart = ws.ccur + (1 + (size_t)kCoarseReps) * nw * kCoarseMax;
   return co;
 }
 size_t coarse_words(uint32_t nw) { return (2 + (size_t)kCoarseReps) * nw * kCoarseMax + 1; }
