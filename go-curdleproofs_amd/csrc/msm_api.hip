@@ -909,13 +909,16 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
       return CURDLE_OK;
     }
   }
-  if (phase == 2) {  // the caller has made `stream` wait for the chunk's points
+  if (phase == 2) {  // the caller has made `pre` (the chunk's sort stream) and `stream` wait for the chunk's points
+    if (convert_here) {
+      // on the sort stream, beside the accumulation of the chunk before -- on `stream` the four conversions of a 2^20-pair
+      // call sat BETWEEN the accumulations, 0.18 ms of the call's critical path (timeline gpurun_out/r5_hosttrace2)
+      HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre, p.aux_prio));
+      prof.mark("convert_points");
+      HIP_TRY(hipEventRecord(S.pre_done, pre));  // behind the sort's record on the same stream: covers both
+    }
     HIP_TRY(hipStreamWaitEvent(stream, S.pre_done, 0));
     prof.st = stream;
-    if (convert_here) {
-      HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, stream));
-      prof.mark("convert_points");
-    }
   } else if (stream != pre) {
     HIP_TRY(hipEventRecord(S.pre_done, pre));
     HIP_TRY(hipStreamWaitEvent(stream, S.pre_done, 0));
@@ -1397,6 +1400,7 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
     auto enqueue_accumulate = [&](size_t i) -> int {  // behind the chunk's points
       Part& pt = parts[i];
       HIP_TRY(hipStreamWaitEvent(pt.main, pt.S->acc_done, 0));
+      HIP_TRY(hipStreamWaitEvent(sort_stream(pt), pt.S->acc_done, 0));  // the conversion runs there
       const uint32_t off[2] = {0, (uint32_t)pt.m};
       const bool is_last = i + 1 == parts.size();
       pt.join.phase = 2;
