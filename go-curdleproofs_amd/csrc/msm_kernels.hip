@@ -288,6 +288,7 @@ static constexpr int kSortThreads = 1024;
 __global__ void __launch_bounds__(kSortThreads) k_hist(const u32* __restrict__ digits, MsmPlan p,
                                                       const u32* __restrict__ offsets, u32* __restrict__ counts) {
   extern __shared__ u32 lds_cnt[];
+  set_wave_prio(p.aux_prio);
   const u32 lw = blockIdx.y, j = blockIdx.z;
   // a single MSM covers pairs [0, n): no offsets array to wait for
   const u32 i0 = (p.k == 1 ? 0u : offsets[j]) + blockIdx.x * p.chunk;
@@ -316,6 +317,7 @@ __global__ void __launch_bounds__(kSortThreads) k_scatter(const u32* __restrict_
                                                          const u32* __restrict__ offsets, u32* __restrict__ cursor,
                                                          u32* __restrict__ sorted) {
   extern __shared__ u32 lds_cnt[];
+  set_wave_prio(p.aux_prio);
   const u32 lw = blockIdx.y, j = blockIdx.z;
   const u32 i0 = (p.k == 1 ? 0u : offsets[j]) + blockIdx.x * p.chunk;
   const u32 i1 = min(i0 + p.chunk, p.k == 1 ? p.n : offsets[j + 1]);
