@@ -1191,6 +1191,28 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
     if ((r = ensure(S.points, n * 96))) return r;
     if ((r = ensure(S.scalars, n * 32))) return r;
     const SyncStreams st = sync_streams(cx, S);
+    // One mid-size MSM: the scalars cross first and the recoding + sort run while the points are still crossing (on the
+    // context's copy stream; a pageable copy occupies this thread, not the GPU) -- the sort, 0.07-0.15 ms of such a call,
+    // is off the call's critical path for one event hop.  Knob HOST_OVERLAP_MIN: the pair count from which (0 = never).
+    const long long ov = knobs::get(knobs::HOST_OVERLAP_MIN);
+    const size_t overlap_min = ov >= 0 ? (size_t)ov : (size_t)16384;
+    if (k == 1 && overlap_min > 0 && n >= overlap_min) {
+      const uint32_t off[2] = {0, (uint32_t)n};
+      ChunkJoin join;
+      HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st.pre));
+      join.phase = 1;
+      if ((r = enqueue_slot(cx, S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, st.pre, st.main, st.tail, /*latency_mode=*/true, false, 1,
+                            false, &join, nullptr, false, glv)))
+        return r;
+      HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, cx.h2d_stream));
+      HIP_TRY(hipEventRecord(S.acc_done, cx.h2d_stream));  // (a scratch event until the accumulation re-records it)
+      HIP_TRY(hipStreamWaitEvent(st.pre, S.acc_done, 0));
+      join.phase = 2;
+      if ((r = enqueue_slot(cx, S, S.points.p, S.scalars.p, off, 1, 0, 0, -1, st.pre, st.main, st.tail, /*latency_mode=*/true, false, 1,
+                            false, &join, nullptr, false, glv)))
+        return r;
+      return finish_slot(cx, S, out);
+    }
     HIP_TRY(hipMemcpyAsync(S.points.p, points, n * 96, hipMemcpyHostToDevice, st.pre));
     HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st.pre));
     return run_passes(cx, S, S.points.p, S.scalars.p, h_off, k, 0, 0, -1, st.pre, st.main, st.tail, out, nullptr, glv);

@@ -44,6 +44,7 @@ enum Id {
   SCAN,               // the bucket-slot scans: 0 six launches, 1 k_scan_fused up to 8,192 slots, 2 k_scan_one up to 32,768, 3 k_scan_chain everywhere; unset or 4: k_scan_one for synchronous calls up to 32,768 slots, k_scan_chain otherwise
   FRONT,              // 0: small calls convert and recode in two launches instead of one (k_front); > 1: the limit in pairs (unset: 16,384; larger limits measured equal, profiles/r05_small_sort_one_block.txt)
   DIRECT_RESULTS,     // 0: window sums cross to the host by a copy command instead of the kernels' own stores into pinned memory
+  HOST_OVERLAP_MIN,   // pairs from which ONE host-buffer MSM below 2^19 pairs copies its scalars first and sorts while the points cross (0: never; unset: 16,384)
   HOST_SORT_STREAMS,  // 0: chunked host-buffer calls sort all their chunks on the context's one sort stream instead of each on its slot's own (unset: own streams)
   HOST_GRADED,        // host-buffer MSMs: 1 (unset) graded chunks (1/6, 1/6, 1/3, 1/3 from 2^20 pairs; 1/4, 1/4, 1/2 below), every chunk's scalars copied right before its points; 2 equal chunks, the same copy order; 0 equal chunks, all scalars first (round 4)
   HOST_PATTERN,       // chunk sizes of a host-buffer MSM in eighths, one decimal digit per chunk (3311); needs HOST_CHUNKS = the digit count
