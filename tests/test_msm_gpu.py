@@ -1088,3 +1088,39 @@ def test_bucket_slot_scans_agree(gpu, oracle, coracle):
             assert (got == ref).all(), mode
     finally:
         gpu.plan_override("SCAN", -1)
+
+
+def test_concurrent_host_buffer_calls(gpu, oracle, coracle):
+    """Host-buffer MSMs from several threads at once: chunked calls (from 2^19 pairs: three or four chunks, each on its slot's
+    own streams, all copies on the context's one copy stream, up to four slots per call out of eight) beside mid-size calls
+    whose sort runs under their points' copy -- every result equals the resident call's."""
+    import threading
+    import torch
+
+    def prep(n, seed):
+        k, q = oracle.Rand(seed).get_frs(2)
+        d = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+        gpu.synth_points_walk_device(k, q, n, d.data_ptr())
+        pts = d.cpu().numpy().view(np.uint64).copy()
+        sc = rand_scalars(np.random.default_rng(seed), n, oracle)
+        ref = gpu.msm_g1_device(d.data_ptr(), torch.from_numpy(sc.view(np.int64)).to("cuda:0").data_ptr(), n)
+        return pts, sc, ref
+
+    cases = [prep(1 << 19, 31), prep(600001, 32), prep(40000, 33), prep(1 << 17, 34)]
+    bad = []
+
+    def work(t):
+        for it in range(4):
+            pts, sc, ref = cases[(t + it) % len(cases)]
+            if not (gpu.msm_g1(pts, sc) == ref).all():
+                bad.append((t, it))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not bad, bad
+    # and one of them against the oracle
+    pts, sc, ref = cases[2]
+    assert (ref == coracle.msm_pippenger(pts, sc, threads=4)).all()
