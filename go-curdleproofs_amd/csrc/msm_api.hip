@@ -105,6 +105,8 @@ struct Slot {
   MsmPlan plan;
   bool profiled = false;
   Buf chain;                  // k_scan_chain's words and ticket counter (zero when made, never cleared again)
+  bool chain_dirty = false;   // a call failed between taking the chain and its last launch: the host's ticket count may lag the device's -- clear both
+  Buf mdone;                  // k_merge_large's chunk counters, one per queue entry and base set (zero when made; the kernel leaves them zero)
   uint32_t* h_err = nullptr;  // pinned word a kernel raises when a wait inside it gave up (finish_slot reads it)
   uint32_t scan_epoch = 0;    // epoch of the slot's last k_scan_chain launch (30 bits, never 0)
   uint32_t scan_base = 0;     // tickets the slot's launches have taken so far
@@ -116,7 +118,7 @@ struct Slot {
   Buf* all_bufs(int i) {
     Buf* b[] = {&points, &scalars, &offsets, &points28, &counts, &starts, &cursor, &fragcnt, &foff, &small,
                 &digits, &sorted,  &frags,   &partials, &winsums, &winsums28, &results, &job,      &tmp,    &ccur,
-                &fold_sums, &fold_meta, &chain};
+                &fold_sums, &fold_meta, &chain,   &mdone};
     return i < (int)(sizeof(b) / sizeof(b[0])) ? b[i] : nullptr;
   }
 };
@@ -573,7 +575,13 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
     const long long v = knobs::get(knobs::ACC_PRIO);
     p.acc_prio = v >= 0 ? (uint32_t)(v > 24 ? 24 : v) : (latency_mode && !light_host && entries / L >= 65536 ? 15u : 0u);
   }
-  p.max_small = 16;
+  // Buckets with more fragments than this go through k_merge_large first.  Measured as a knob in round 6
+  // (profiles/r06_max_small.txt): 12 / 8 / 6 / 4 cost uniform inputs of 8,192 .. 65,536 pairs up to 0.03 / 0.07 / 0.10 /
+  // 0.29 ms (their narrow windows hold 9-13 fragments per bucket by design, and a wave per such bucket is a poor trade)
+  // and buy back 0.15 ms only where a few dozen buckets hold exactly that many (64 distinct scalar values at 2^12 pairs).
+  // Up to 4,096 pairs 8 costs uniform inputs nothing (same file: 1,268 and 4,096 pairs equal to the microsecond) and takes
+  // 0.15 ms off a call whose occupied buckets hold exactly 9..16 (0.54 -> 0.39 ms at 4,096 pairs).
+  p.max_small = n_total <= 8192 && k * sets == 1 ? 8 : 16;
   // a bucket with more than max_small fragments holds more than (max_small - 1) * L entries
   uint64_t ml = entries / ((uint64_t)(p.max_small - 1) * p.L) + 1;
   p.max_large = (uint32_t)(ml < nbk ? ml : nbk);
@@ -732,7 +740,10 @@ int enqueue_slot(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, 
                  bool glv = true, const DaccFront* dfront = nullptr) {
   const int rc = enqueue_slot_impl(cx, S, d_points, d_scalars, h_off, k, c, win_begin, win_end, pre, stream, tail, latency_mode,
                                    points28_ready, sets, many, join, ext_points28, light_host, glv, dfront);
-  if (rc == CURDLE_OK) S.coarse_dirty = false;  // every launch of the call is in its queue: k_digits leaves its counters zero
+  if (rc == CURDLE_OK) {
+    S.coarse_dirty = false;  // every launch of the call is in its queue: k_digits leaves its counters zero
+    S.chain_dirty = false;   // ... and the host's count of the scan chain's tickets is the device's
+  }
   return rc;
 }
 int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scalars, const uint32_t* h_off, size_t k, int c,
@@ -848,7 +859,10 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
       *S.h_err = 0;
     }
     S.scan_epoch = (S.scan_epoch + 1) & 0x3fffffffu;
-    if (S.chain.p != before || S.scan_epoch == 0) {  // a new buffer, or the epochs have gone round: no word may look current
+    // (chain_dirty, review of round 5: a call that failed after its k_scan_chain was enqueued -- launch_scan returns
+    // hipGetLastError(), which may be an EARLIER launch's error -- left scan_base behind the device's counter, and every
+    // later launch of the slot would have taken tickets beyond its tile count)
+    if (S.chain.p != before || S.scan_epoch == 0 || S.chain_dirty) {  // a new buffer, or the epochs have gone round: no word may look current
       HIP_TRY(hipMemsetAsync(S.chain.p, 0, scan_chain_bytes(), pre));
       S.scan_base = 0;
       if (S.scan_epoch == 0) S.scan_epoch = 1;
@@ -858,6 +872,13 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
     ws.host_err = S.h_err;
     ws.chain_base = S.scan_base;
     ws.chain_epoch = S.scan_epoch;
+    S.chain_dirty = true;  // until this call's kernels are all enqueued (enqueue_slot)
+  }
+  {
+    const void* before = S.mdone.p;
+    if ((rc = ensure(S.mdone, sets * (size_t)p.max_large * 4))) return rc;
+    if (S.mdone.p != before) HIP_TRY(hipMemsetAsync(S.mdone.p, 0, S.mdone.cap, pre));
+    ws.mdone = (uint32_t*)S.mdone.p;
   }
 
   // the offsets are staged in pinned memory (tail of h_buf) so the copy is truly asynchronous
@@ -1449,7 +1470,19 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
           if ((r = enqueue_accumulate(i))) return r;
         }
       }
-    return finish_slot(cx, *parts.back().S, out);  // the last chunk's slot holds the window sums
+    r = finish_slot(cx, *parts.back().S, out);  // the last chunk's slot holds the window sums
+    // every chunk ran a bucket-slot scan of its own on its own slot: a scan that gave up in an EARLIER chunk raised that
+    // slot's word, which finish_slot above does not look at (review of round 5: the call returned a wrong sum with
+    // CURDLE_OK and the stale flag failed the next, unrelated call on that slot).  The last chunk's reduction is behind
+    // all of them, so every word is final here.
+    for (size_t i = 0; i + 1 < K; i++) {
+      Slot& Sp = *parts[i].S;
+      if (Sp.h_err && *Sp.h_err) {
+        *Sp.h_err = 0;
+        if (!r) r = fail(CURDLE_EHIP, "internal: a wait inside the bucket-slot scan of chunk %zu gave up", i);
+      }
+    }
+    return r;
   };
   int rc = body();
   for (int idx : slots) {
@@ -2017,17 +2050,34 @@ extern "C" int curdle_device_available(void) {
 // ---------------------------------------------------------------------------
 extern "C" int curdle_msm_window_bits(size_t n) { return choose_window_bits(n); }
 
-extern "C" int curdle_msm_window_widths(size_t n, int window_bits, int widths[64]) {
-  int c = window_bits ? window_bits : choose_window_bits(n);
-  if (c < 4 || c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", c);
+// The window width a call will run with: the caller's, or the library's choice for n pairs; anything outside
+// [4, 16] is refused HERE, before window_widths() writes kMaxWindows bytes for it (review of round 5: a width of
+// 1..3 has more than 64 windows, a large negative one none at all).
+static int checked_window_bits(size_t n, int window_bits, int* c) {
+  *c = window_bits ? window_bits : choose_window_bits(n);
+  if (*c < 4 || *c > 16) return fail(CURDLE_EINVAL, "window_bits %d outside [4, 16]", *c);
+  return CURDLE_OK;
+}
+
+extern "C" int curdle_msm_window_widths_ex(size_t n, int window_bits, unsigned flags, int widths[64]) {
+  if (flags & ~(unsigned)(CURDLE_MSM_ANY_CURVE_POINT | CURDLE_MSM_BASES_UNCHANGED)) return fail(CURDLE_EINVAL, "unknown flags 0x%x", flags);
+  int c;
+  if (checked_window_bits(n, window_bits, &c)) return CURDLE_EINVAL;
   uint8_t bits[kMaxWindows];
-  int W = window_widths(c, bits);
+  int W = window_widths(c, bits, (flags & CURDLE_MSM_ANY_CURVE_POINT) ? kScalarBitsNoGlv : kScalarBits);
   if (widths)
     for (int w = 0; w < W; w++) widths[w] = bits[w];
   return W;
 }
 
-extern "C" int curdle_msm_num_windows(size_t n, int window_bits) { return curdle_msm_window_widths(n, window_bits, nullptr); }
+extern "C" int curdle_msm_window_widths(size_t n, int window_bits, int widths[64]) {
+  return curdle_msm_window_widths_ex(n, window_bits, 0, widths);
+}
+
+extern "C" int curdle_msm_num_windows(size_t n, int window_bits) { return curdle_msm_window_widths_ex(n, window_bits, 0, nullptr); }
+extern "C" int curdle_msm_num_windows_ex(size_t n, int window_bits, unsigned flags) {
+  return curdle_msm_window_widths_ex(n, window_bits, flags, nullptr);
+}
 
 namespace {
 // One MSM from host buffers on the calling thread's context.
@@ -2299,6 +2349,8 @@ extern "C" int curdle_msm_g1_device_submit_ex(const void* d_points, const void* 
   if (n && (!d_points || !d_scalars)) return fail(CURDLE_EINVAL, "points/scalars null with n = %zu", n);
   if (n > ((size_t)1 << 27)) return fail(CURDLE_EINVAL, "n = %zu exceeds the supported 2^27 pairs", n);
   const bool glv = !(flags & CURDLE_MSM_ANY_CURVE_POINT);
+  int c_checked;  // before a slot or a cache reference is held, and before window_widths() below
+  if ((rc = checked_window_bits(n, window_bits, &c_checked))) return rc;
   int idx;
   rc = acquire_slot(cx, false, &idx);
   if (rc) return rc;
@@ -2320,7 +2372,7 @@ extern "C" int curdle_msm_g1_device_submit_ex(const void* d_points, const void* 
   const unsigned turn = seq % (unsigned)cx.main_streams;
   hipStream_t main = turn == 0 ? cx.main_stream : cx.main_extra[turn - 1];
   uint8_t wb[kMaxWindows];
-  const int W = window_widths(window_bits ? window_bits : choose_window_bits(n), wb, glv ? kScalarBits : kScalarBitsNoGlv);
+  const int W = window_widths(c_checked, wb, glv ? kScalarBits : kScalarBitsNoGlv);
   const bool partial = win_begin > 0 || (win_end >= 0 && win_end < W);
   hipStream_t pre = partial && cx.pre_streams == 2 && (seq & 1u) ? cx.pre_stream2 : cx.pre_stream;
   if (entry >= 0 && (he = hipStreamWaitEvent(main, ready, 0)) != hipSuccess)  // the accumulation is what reads the copy

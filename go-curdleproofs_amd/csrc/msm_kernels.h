@@ -74,6 +74,7 @@ struct MsmWorkspace {
   uint32_t* blocksum; // [1024]    scan scratch
   uint32_t* large;    // [max_large] buckets queued for merge_large
   uint32_t* nlarge;   // [1]
+  uint32_t* mdone;    // [sets][max_large] k_merge_large: finished chunks per queue entry (zero between calls)
   uint32_t* digits;   // [nw][n]   |digit| | sign<<31, window-major
   uint32_t* sorted;   // [nw * n]  pair index | sign<<31, grouped by bucket
   uint32_t* tmp;      // [nw * n]  two-level scatter: entries grouped by coarse bin (null otherwise)

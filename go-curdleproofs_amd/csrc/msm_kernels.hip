@@ -923,7 +923,10 @@ __global__ void __launch_bounds__(kChainThreads)
   if (tid == 0) sh_my = atomicAdd(ch.ticket, 1u) - ch.ticket_base;
   __syncthreads();
   const u32 my = sh_my;
-  if (my >= ch.ntiles) return;  // block-uniform; a launch has exactly ntiles blocks
+  if (my >= ch.ntiles) {  // block-uniform; a launch has exactly ntiles blocks, so this is a host count that lags the device's:
+    if (tid == 0) *ch.host_err = 1u;  // the call must fail, not return sums over unwritten starts (review of round 5)
+    return;
+  }
   u64* words0 = reinterpret_cast<u64*>(ch.words);
   u64* words1 = words0 + kChainMaxTiles;
   const u32 lo = my * kChainTile + tid * kChainPer;
@@ -1254,10 +1257,22 @@ __global__ void __launch_bounds__(kBlock, WAVES)
     if (pos == gend) {
       d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
       d28::set_inf(acc);
-      do {
-        g++;
-        gend = starts[g + 1];
-      } while (gend == pos);
+      g++;
+      gend = starts[g + 1];
+      if (gend == pos) {
+        // An EMPTY bucket.  Uniform scalars leave next to none, skewed ones leave runs of thousands (all-equal scalars: two
+        // occupied buckets per window; a hot window: one) and a lane that walked such a run one dependent load at a time held
+        // its whole wave back -- 32,768 loads at N = 2^20: the launch took 4.0 ms against 2.25 (profiles/r06_adversarial.json).
+        // Bisect for the first slot that starts beyond pos, as at the lane's start.
+        u32 l2 = g + 2, h2 = nb;
+        while (l2 < h2) {
+          const u32 mid = (l2 + h2) >> 1;
+          if (starts[mid] > pos) h2 = mid;
+          else l2 = mid + 1;
+        }
+        g = l2 - 1;
+        gend = starts[l2];
+      }
     }
     if (d28::affine_is_inf(pt)) continue;  // (0,0) = infinity (curdleproof.go:23)
     if (e >> 31) {
@@ -1276,31 +1291,7 @@ __global__ void __launch_bounds__(kBlock, WAVES)
 #endif
 }
 
-// One block per queued bucket (more than max_small fragments): tree-sum of the
-// fragments into the bucket's first fragment slot; the reduce kernels read ONE fragment for
-// such a bucket (fragcnt itself stays as scanned: base sets of a shared-scalar call share it).
-__global__ void __launch_bounds__(kBlock, 2)
-    k_merge_large(const u32* __restrict__ large, const u32* __restrict__ nlarge, const u32* __restrict__ foff,
-                  const u32* __restrict__ fragcnt, X28* __restrict__ frags, u32 max_large, u32 frag_stride) {
-  __shared__ X28 sh[4];
-  const u32 nl = min(*nlarge, max_large);
-  const u32 tid = threadIdx.x;
-  frags += (size_t)blockIdx.y * frag_stride;
-  for (u32 q = blockIdx.x; q < nl; q += gridDim.x) {  // block-uniform trip count
-    const u32 g = large[q];
-    const u32 m = fragcnt[g];
-    X28* f = frags + foff[g];
-    X28 acc, b;
-    d28::set_inf(acc);
-    for (u32 k = tid; k < m; k += kBlock) {
-      d28::load(b, &f[k]);
-      d28::add(acc, b);
-    }
-    group_sum(acc, kBlock, sh);
-    if (tid == 0) d28::store(&f[0], acc);
-    __syncthreads();
-  }
-}
+// (k_merge_large: behind group_sum_quad, below)
 
 // ---------------------------------------------------------------------------
 // The latency-bound kernels (quad28.h): four adjacent lanes own ONE point between them
@@ -1331,6 +1322,129 @@ __device__ __forceinline__ void group_sum_quad(F28& acc, u32 G, F28 (*wave_parti
         b = wave_partials[(tid >> 6) + k][tid & 3u];
         q28::add(acc, b);
       }
+    }
+  }
+}
+
+// Buckets with more than max_small fragments (queued by the scan kernels: skewed scalars -- all-equal ones, a few
+// distinct values, one hot window; uniform scalars queue nothing and every block leaves at once): their fragments
+// are summed into the bucket's FIRST fragment slot, and the reduce kernels read ONE fragment for such a bucket
+// (fragcnt itself stays as scanned: base sets of a shared-scalar call share it).
+// Round 6.  Until now: one block per queued bucket, every thread a chain of m / 256 whole-point additions (14 product
+// steps each) and a 9-level tree behind it -- all-equal scalars at N = 2^20 queue 16 buckets of 8,192 fragments: 64
+// waves on a chip of 1,024 SIMDs for 0.9 ms, a third of the accumulation (profiles/r06_adversarial.json, "before").
+// Now the unit of work is a CHUNK of 16 S consecutive fragments of one bucket, taken by one wave as 16 quads
+// (quad28.h: an addition is 4 product steps): a quad adds S fragments, the wave's 16 sums meet by shuffles, and the
+// chunk's sum replaces the chunk's first fragment.  Chunks of all queued buckets are numbered through (a prefix sum
+// over the queue, redone by every block in LDS: the queue is short) and dealt to the launch's waves round robin, so
+// 16 buckets of 8,192 fragments are 1,024 waves at once.  The wave that finishes a bucket's LAST chunk (a counter per
+// queue entry, left at zero for the next call) adds the chunk sums the same way into slot 0.  S grows with the
+// bucket (2 up to 1,024 fragments, 4 up to 4,096, 8 up to 16,384, 16 beyond) so that the two serial parts stay
+// balanced: a chain of 4 + 4 + 2 + 4 quad additions for 2,048 fragments, 8 + 4 + 4 + 4 for 8,192, instead of
+// 32 + 9 whole ones.
+static constexpr u32 kMergeTile = 1024;  // queue entries per pass over the queue
+__host__ __device__ inline u32 merge_chunk_shift(u32 m) {  // log2 of the chunk a bucket of m fragments is cut into
+  return m <= 1024u ? 5u : m <= 4096u ? 6u : m <= 16384u ? 7u : 8u;
+}
+__global__ void __launch_bounds__(kBlock, 2)
+    k_merge_large(const u32* __restrict__ large, const u32* __restrict__ nlarge, const u32* __restrict__ foff,
+                  const u32* __restrict__ fragcnt, X28* __restrict__ frags, u32* __restrict__ done, u32 max_large,
+                  u32 frag_stride, u32 prio) {
+  __shared__ u32 pre[kMergeTile], gq[kMergeTile], mq[kMergeTile];
+  __shared__ u32 sh_scan[kBlock / 64];
+  const u32 nl = min(*nlarge, max_large);
+  if (nl == 0) return;  // the usual case
+  set_wave_prio(prio);
+  const u32 tid = threadIdx.x;
+  const u32 lane = tid & 63u, qd = lane >> 2;  // quad inside the wave
+  frags += (size_t)blockIdx.y * frag_stride;
+  done += (size_t)blockIdx.y * max_large;
+  const u32 nwaves = gridDim.x * (kBlock / 64), mywave = blockIdx.x * (kBlock / 64) + (tid >> 6);
+  // More chunks than the launch has waves (hundreds of buckets of a hundred fragments each: 64 distinct scalar values)
+  // would go round several times at the small buckets' chunk size: every bucket's chunks are doubled (up to 256
+  // fragments) until one round takes them all -- 5,120 chunks of 32 on 1,024 waves took 0.30 ms, 2,560 of 64 on 3,072 take 0.1.
+  u32 bump = 0;
+  {
+    u32 mine = 0;
+    for (u32 x = tid; x < nl; x += kBlock) {
+      const u32 m = fragcnt[large[x]], sh = merge_chunk_shift(m);
+      mine += (m + (1u << sh) - 1u) >> sh;
+    }
+    u32 total0;
+    (void)block_exclusive_scan_256(mine, sh_scan, total0);
+    while (bump < 3u && (total0 >> bump) > nwaves) bump++;
+  }
+  auto chunk_shift = [&](u32 m) { return min(merge_chunk_shift(m) + bump, 8u); };
+  for (u32 t0 = 0; t0 < nl; t0 += kMergeTile) {  // block-uniform trip count
+    const u32 cnt = min(kMergeTile, nl - t0);
+    __syncthreads();  // the pass before is done with the tables
+    u32 nch[kMergeTile / kBlock], sum = 0;
+#pragma unroll
+    for (u32 k = 0; k < kMergeTile / kBlock; k++) {
+      const u32 idx = tid * (kMergeTile / kBlock) + k;
+      nch[k] = 0;
+      if (idx < cnt) {
+        const u32 g = large[t0 + idx], m = fragcnt[g];
+        gq[idx] = g;
+        mq[idx] = m;
+        const u32 sh = chunk_shift(m);
+        nch[k] = (m + (1u << sh) - 1u) >> sh;
+      }
+      sum += nch[k];
+    }
+    u32 total;
+    u32 ex = block_exclusive_scan_256(sum, sh_scan, total);
+#pragma unroll
+    for (u32 k = 0; k < kMergeTile / kBlock; k++) {
+      pre[tid * (kMergeTile / kBlock) + k] = ex;
+      ex += nch[k];
+    }
+    __syncthreads();
+    for (u32 c = mywave; c < total; c += nwaves) {  // wave-uniform from here on
+      u32 lo = 0, hi = cnt;  // the queue entry of chunk c: the last one whose first chunk is <= c
+      while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (pre[mid] > c) hi = mid;
+        else lo = mid + 1;
+      }
+      const u32 e = lo - 1;
+      const u32 m = mq[e], sh = chunk_shift(m), base = (c - pre[e]) << sh;
+      const u32 nchunks = (m + (1u << sh) - 1u) >> sh;
+      X28* f = frags + foff[gq[e]];
+      const u32 lim = min(1u << sh, m - base);
+      F28 acc, b, nxt;
+      q28::set_inf(acc);
+      u32 i = qd;  // this quad's fragments: base + qd, + 16, ...; the next one is loaded under the addition before it
+      q28::load(nxt, &f[base + (i < lim ? i : 0u)]);
+      while (i < lim) {  // quad-uniform
+        b = nxt;
+        i += 16;
+        q28::load(nxt, &f[base + (i < lim ? i : 0u)]);
+        q28::add(acc, b);
+      }
+      group_sum_quad(acc, 16u, nullptr);  // shuffles only
+      if (qd == 0) q28::store(&f[base], acc);
+      if (nchunks == 1) continue;
+      // the chunk sums of one bucket are written by waves anywhere on the chip: released here, acquired by the wave
+      // that counts the last one (agent scope: the XCDs' L2s are written back / invalidated by the fences)
+      __threadfence();
+      u32 t = 0;
+      if (lane == 0) t = atomicAdd(&done[t0 + e], 1u);
+      t = __shfl(t, 0, 64);
+      if (t != nchunks - 1) continue;
+      __threadfence();
+      q28::set_inf(acc);
+      i = qd;
+      q28::load(nxt, &f[(size_t)(i < nchunks ? i : 0u) << sh]);
+      while (i < nchunks) {
+        b = nxt;
+        i += 16;
+        q28::load(nxt, &f[(size_t)(i < nchunks ? i : 0u) << sh]);
+        q28::add(acc, b);
+      }
+      group_sum_quad(acc, 16u, nullptr);
+      if (qd == 0) q28::store(&f[0], acc);
+      if (lane == 0) done[t0 + e] = 0;  // as the next call expects it
     }
   }
 }
@@ -2074,10 +2188,15 @@ hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream
 }
 
 hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  // (at most 256 blocks: the launch is almost always empty -- uniform scalars queue nothing -- and every block of it is four
-  // 222-register waves that have to find room beside the next accumulation before they can read the empty queue and leave)
-  hipLaunchKernelGGL(k_merge_large, dim3(p.max_large < 256u ? p.max_large : 256u, p.sets), dim3(kBlock), 0, stream,
-                     ws.large, ws.nlarge, ws.foff, ws.fragcnt, reinterpret_cast<X28*>(ws.frags), p.max_large, p.frag_stride);
+  // One wave per chunk of 32 to 256 fragments, at most 768 blocks = three 165-register waves on every SIMD (the launch is
+  // almost always empty -- uniform scalars queue nothing -- and every block of it has to find room beside the next
+  // accumulation before it can read the empty queue and leave); more chunks than waves go round.
+  const u32 nw = p.win_end - p.win_begin;
+  const u64 nlanes = ((u64)nw * p.n + p.L - 1) / p.L;  // fragments <= bucket slots + lanes
+  const u64 chunks = (u64)p.max_large + ((u64)p.k * p.NB + nlanes) / 32u;
+  const u32 blocks = (u32)(chunks / 4u + 1u < 768u ? chunks / 4u + 1u : 768u);
+  hipLaunchKernelGGL(k_merge_large, dim3(blocks, p.sets), dim3(kBlock), 0, stream, ws.large, ws.nlarge, ws.foff, ws.fragcnt,
+                     reinterpret_cast<X28*>(ws.frags), ws.mdone, p.max_large, p.frag_stride, p.reduce_prio);
   return hipGetLastError();
 }
 

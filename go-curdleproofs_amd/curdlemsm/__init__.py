@@ -47,7 +47,8 @@ SYMBOLS = [
     "curdle_msm_forget_bases",
     "curdle_msm_g1", "curdle_msm_g1_device", "curdle_msm_g1_device_windows",
     "curdle_msm_g1_device_submit", "curdle_msm_wait",
-    "curdle_msm_window_bits", "curdle_msm_num_windows", "curdle_msm_window_widths", "curdle_g1_sum",
+    "curdle_msm_window_bits", "curdle_msm_num_windows", "curdle_msm_window_widths", "curdle_msm_num_windows_ex",
+    "curdle_msm_window_widths_ex", "curdle_g1_sum",
     "curdle_msm_g1_batch", "curdle_msm_g1_batch_device", "curdle_msm_g1_multi",
     "curdle_rand_new", "curdle_rand_free", "curdle_rand_get_fr", "curdle_rand_get_g1_affine",
     "curdle_rand_permutation",
@@ -116,6 +117,8 @@ _msm_wait = _sig("curdle_msm_wait", C.c_int, C.c_int, _vp)
 _window_bits = _sig("curdle_msm_window_bits", C.c_int, C.c_size_t)
 _num_windows = _sig("curdle_msm_num_windows", C.c_int, C.c_size_t, C.c_int)
 _window_widths = _sig("curdle_msm_window_widths", C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int))
+_num_windows_ex = _sig("curdle_msm_num_windows_ex", C.c_int, C.c_size_t, C.c_int, C.c_uint)
+_window_widths_ex = _sig("curdle_msm_window_widths_ex", C.c_int, C.c_size_t, C.c_int, C.c_uint, C.POINTER(C.c_int))
 _msm_batch_device = _sig("curdle_msm_g1_batch_device", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp)
 _g1_sum = _sig("curdle_g1_sum", C.c_int, _vp, C.c_size_t, _vp)
 _msm_batch = _sig("curdle_msm_g1_batch", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
@@ -384,17 +387,18 @@ def window_bits(n: int) -> int:
     return _window_bits(n)
 
 
-def num_windows(n: int, c: int = 0) -> int:
-    rc = _num_windows(n, c)
+def num_windows(n: int, c: int = 0, flags: int = 0) -> int:
+    """W of the plan a call with these flags runs: ceil(127 / c), or ceil(255 / c) with MSM_ANY_CURVE_POINT."""
+    rc = _num_windows_ex(n, c, int(flags))
     if rc < 0:
         _check(rc)
     return rc
 
 
-def window_widths(n: int, c: int = 0):
-    """Widths (bits) of the Pippenger windows for (n, c), lowest first; the top one is unsigned."""
+def window_widths(n: int, c: int = 0, flags: int = 0):
+    """Widths (bits) of the Pippenger windows for (n, c, flags), lowest first; the top one is unsigned."""
     buf = (C.c_int * 64)()
-    W = _window_widths(n, c, buf)
+    W = _window_widths_ex(n, c, int(flags), buf)
     if W < 0:
         _check(W)
     return [int(buf[i]) for i in range(W)]

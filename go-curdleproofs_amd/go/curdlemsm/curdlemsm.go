@@ -218,6 +218,18 @@ func MultiExpDevice(dst *bls12381.G1Jac, dPoints, dScalars uintptr, n int, flags
 	})
 }
 
+// NumWindows is the number of Pippenger windows of the plan a call with these (n, windowBits, flags) runs:
+// ceil(127 / c), or ceil(255 / c) with AnyCurvePoint (the whole scalar is recoded) -- the range a caller of the
+// window-range entry points (curdle_msm_g1_device_windows_ex, one rank per GPU) partitions.  windowBits = 0 is the
+// library's choice for n.
+func NumWindows(n int, windowBits int, flags uint) (int, error) {
+	w := int(C.curdle_msm_num_windows_ex(C.size_t(n), C.int(windowBits), C.uint(flags)))
+	if w < 0 {
+		return 0, fmt.Errorf("curdlemsm: window_bits %d outside [4, 16]", windowBits)
+	}
+	return w, nil
+}
+
 // ForgetBases: see MultiExpDevice.
 func ForgetBases(dPoints uintptr) error {
 	return locked(func() C.int { return C.curdle_go_forget_bases(C.uintptr_t(dPoints)) })

@@ -217,6 +217,13 @@ int curdle_msm_num_windows(size_t n, int window_bits); /* W = ceil(127 / c) for 
  * windows but the top one are recoded into signed digits, the top one is unsigned.
  * Returns W. */
 int curdle_msm_window_widths(size_t n, int window_bits, int widths[64]);
+/* The same two for a call that passes `flags` (review of round 5): with CURDLE_MSM_ANY_CURVE_POINT the
+ * plan recodes the whole 255-bit scalar, so it has W = ceil(255 / c) windows whose widths sum to 255,
+ * and the window ranges of *_windows_ex / *_submit_ex are ranges over THOSE windows -- a caller that
+ * partitions [0, curdle_msm_num_windows()) and passes the flag would cover the low half of every
+ * scalar only, with no error.  flags = 0 (or CURDLE_MSM_BASES_UNCHANGED alone) gives the values above. */
+int curdle_msm_num_windows_ex(size_t n, int window_bits, unsigned flags);
+int curdle_msm_window_widths_ex(size_t n, int window_bits, unsigned flags, int widths[64]);
 
 /* out = sum of k Jacobian points (host memory, any representatives).
  * Replaces the chain of G1Jac.AddAssign a caller would do on partials. */

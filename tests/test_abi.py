@@ -163,6 +163,30 @@ def test_window_plan(cm):
     for bad in (3, 17):
         with pytest.raises(cm.CurdleError):
             cm.num_windows(10, bad)
+    # a call that passes CURDLE_MSM_ANY_CURVE_POINT recodes the whole 255-bit scalar: twice the windows, and the window
+    # ranges of *_windows_ex / *_submit_ex are over THOSE (review of round 5)
+    F = cm.MSM_ANY_CURVE_POINT
+    for c in range(4, 17):
+        w = cm.window_widths(10, c, flags=F)
+        assert len(w) == cm.num_windows(10, c, flags=F) == -(-255 // c)
+        assert sum(w) == 255 and max(w) <= c and max(w) - min(w) <= 1
+    assert cm.num_windows(1 << 20, 0, flags=cm.MSM_BASES_UNCHANGED) == cm.num_windows(1 << 20)
+    with pytest.raises(cm.CurdleError):
+        cm.num_windows(10, 8, flags=64)
+
+
+def test_submit_refuses_a_window_width_outside_the_plan_before_it_touches_anything(cm):
+    """Review of round 5: curdle_msm_g1_device_submit_ex computed the window count of (n, window_bits) into a
+    64-entry array BEFORE the width was validated -- window_bits = 1 has 127 windows (255 without the split), a
+    large negative one none (a division by zero).  Now every width outside [4, 16] is CURDLE_EINVAL before a slot,
+    a cache entry or the device is touched (so this runs without a GPU: the pointers are never read)."""
+    fake = 0x1000
+    for flags in (0, cm.MSM_ANY_CURVE_POINT):
+        for bad in (1, 2, 3, -200, -126, 17, 1 << 20):
+            with pytest.raises(cm.CurdleError) as e:
+                cm.msm_g1_device_submit(fake, fake, 64, window_bits=bad, flags=flags)
+            assert e.value.code == cm.EINVAL, (bad, flags)
+            assert "window_bits" in str(e.value)
 
 
 def recode(s, widths):

@@ -238,3 +238,15 @@ def test_plan_tables_have_not_regressed_by_a_factor(gpu, oracle):
         assert ms < ceiling, (m, ms)
     ms = best_of(lambda: gpu.msm_g1(pts, sc), reps=3)
     assert ms < 11.0, ms
+    # ... and the verifier's worst case (samepermutationargument.go:67): every scalar equal, so that every
+    # term of a window lands in one of two buckets.  Until round 6 such a call took 2.4x a uniform one at 2^16 pairs and
+    # 2.6x from host slices at 2^20 (an empty-slot walk in k_accumulate, one block per large bucket in k_merge_large:
+    # profiles/r06_adversarial_before.json); now it is within a tenth of uniform (profiles/r06_adversarial.json).
+    beta = np.tile(sc[7], (n, 1))
+    d_beta = torch.from_numpy(beta.view(np.int64)).to("cuda:0")
+    for m in (1 << 16, 1 << 20):
+        uni = best_of(lambda: gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), m))
+        eq = best_of(lambda: gpu.msm_g1_device(d_pts.data_ptr(), d_beta.data_ptr(), m))
+        assert eq < 1.5 * uni, (m, eq, uni)
+    eq = best_of(lambda: gpu.msm_g1(pts, beta), reps=3)
+    assert eq < 1.5 * ms, (eq, ms)

@@ -519,6 +519,53 @@ def test_two_pass_scatter_with_skewed_scalars(gpu, oracle, coracle):
     assert (got == _walk_expected(oracle, coracle, k, q, sc_dead)).all()
 
 
+def test_merge_of_large_buckets_in_every_form(gpu, oracle, coracle):
+    """k_merge_large (round 6): buckets with more than 16 fragments are summed by waves of 16 quads, a chunk of 32 to
+    256 fragments each, and the wave that counts a bucket's last chunk adds the chunk sums.  Every form of it against
+    the closed form of the known-discrete-log inputs: a queue far longer than one pass over it (1,024 entries) made of
+    one-chunk buckets; buckets of ~1,000, ~4,000, ~8,000 and ~33,000 fragments (the four chunk sizes, the counter, the
+    second stage); the same through the chunked host-buffer path; and three base sets sharing one fragment
+    bookkeeping.  The bucket-slot walk of k_accumulate over thousands of EMPTY slots (all-equal scalars leave two
+    occupied buckets per window) is the other thing these inputs reach."""
+    import torch
+    k, q = oracle.Rand(1).get_frs(2)
+    n = (1 << 19) + 5
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    gpu.synth_points_walk_device(k, q, n, d_pts.data_ptr())
+    rng = np.random.default_rng(66)
+    try:
+        # (a) ~12,000 queued buckets of 30-70 fragments each
+        m = 1 << 15
+        table = rand_scalars(rng, 1024, oracle)
+        sc = table[rng.integers(0, 1024, m)]
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        gpu.plan_override("SEG_LEN", 2)
+        assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), m) == _walk_expected(oracle, coracle, k, q, sc)).all()
+        gpu.plan_override("SEG_LEN", None)
+        # (b) two occupied buckets per window: 2^19 / L fragments each
+        beta = np.array(oracle.fr_to_mont_limbs(oracle.Rand(4).get_fr()), dtype=np.uint64)
+        sc = np.tile(beta, (n, 1))
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        exp = _walk_expected(oracle, coracle, k, q, sc)
+        for L in (None, 16, 128):
+            gpu.plan_override("SEG_LEN", L)
+            assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == exp).all(), L
+        gpu.plan_override("SEG_LEN", None)
+        assert (gpu.msm_g1(d_pts.cpu().numpy().view(np.uint64), sc) == exp).all()          # four chunks, each merged, then folded
+        t = gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n)                   # the pipelined plan
+        assert (gpu.msm_wait(t) == exp).all()
+        m = 1 << 14
+        assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), m) == _walk_expected(oracle, coracle, k, q, sc[:m])).all()
+        # (c) three base sets, one scalar vector, buckets of several chunks
+        m = 40000
+        sets = [coracle.points_walk(k + 5 * j, q, m) for j in range(3)]
+        out = gpu.msm_g1_multi(sets, sc[:m])
+        for j in range(3):
+            assert (out[j] == coracle.msm_pippenger(sets[j], np.ascontiguousarray(sc[:m]), threads=8)).all(), j
+    finally:
+        gpu.plan_override("SEG_LEN", None)
+
+
 # ------------------------------------------------------------- window partition ---
 def test_window_partials_sum_to_full_msm(gpu, oracle, coracle):
     """The multi-GPU split: partials over a partition of the windows, summed, equal
