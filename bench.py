@@ -132,6 +132,10 @@ def main():
                     help="diagnostic: the timed steps pass CURDLE_MSM_BASES_UNCHANGED (curdle_msm_g1_device_submit_ex): "
                          "the library converts the resident gnark-layout bases once and keeps its copy -- what a rank of the "
                          "window split may do with inputs that stay put between calls (never the headline `value`)")
+    ap.add_argument("--convert-per-call", action="store_true",
+                    help="diagnostic: a window-split rank (N > 1 or --emulate-world) converts its gnark-layout bases on EVERY "
+                         "call instead of passing CURDLE_MSM_BASES_UNCHANGED (the default there since round 6: the inputs "
+                         "are resident and unchanged between steps, which is the flag's contract)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: on ONE GPU, run only the share rank 0 of an N-rank job would run "
                          "(no collective); prints the per-rank step time, not a bench line")
@@ -229,6 +233,13 @@ def main():
     pts_ptr = d_pts.data_ptr() + p_lo * 96
     sc_ptr = d_sc.data_ptr() + p_lo * 32
 
+    # A rank of the window split walks ALL n points for its few windows: converting them on every call (0.06 ms of a 0.4 ms
+    # step at 8 ranks) is what the flag's contract saves when the resident inputs stay put -- which they do here, step after
+    # step, exactly as msmaccumulator.Verify's mostly-CRS bases do (msmaccumulator.go:59).  N = 1 keeps per-call conversion as
+    # the headline `value` and reports the kept-bases figure beside it (config.bases_unchanged): the scaling baseline of the
+    # SAME contract.
+    keep_bases = bool(args.bases_unchanged or (parts > 1 and args.split == "windows" and not args.convert_per_call))
+    msm_flags = cm.MSM_BASES_UNCHANGED if keep_bases else 0
     host_t = {"submit": 0.0, "wait": 0.0}
     # the same pairs as a resident, pre-converted base set (curdle_dbases): made lazily, used by the
     # resident-bases figure beside the headline and by --resident-bases
@@ -246,7 +257,7 @@ def main():
         else:
             tk = cm.msm_g1_device_submit(pts_ptr, sc_ptr, n_mine, window_bits=c_mine, win_begin=wb,
                                          win_end=we if args.split == "windows" else -1,
-                                         flags=cm.MSM_BASES_UNCHANGED if args.bases_unchanged else 0)
+                                         flags=msm_flags)
         host_t["submit"] += time.perf_counter() - t_
         return tk
 
@@ -349,11 +360,77 @@ def main():
         barrier()
         t1 = time.perf_counter()
         if args.split == "windows":
-            cm.msm_g1_device(pts_ptr, sc_ptr, n_mine, window_bits=c_mine, win_begin=wb, win_end=we)
+            cm.msm_g1_device(pts_ptr, sc_ptr, n_mine, window_bits=c_mine, win_begin=wb, win_end=we, flags=msm_flags)
         else:
             cm.msm_g1_device(pts_ptr, sc_ptr, n_mine)
         lat.append((time.perf_counter() - t1) * 1e3)
     single_call_ms = float(np.median(lat))
+
+    # What an N > 1 line must say beside `value`: the pipelined figure is a THROUGHPUT (6 window-range
+    # calls in flight per rank, the exchange of step i finished during step i + 1); one synchronous call -- what
+    # msmaccumulator.Verify issues -- scales by latency, which is another number.  So: one whole distributed call
+    # (barrier, every rank's synchronous window-range call, all_gather, sum; MAX over ranks), the exchange alone, and the
+    # SAME contract at one rank (the whole MSM with the flag on this rank's own GPU: the baseline a speed-up is a ratio to).
+    multi = None
+    if dist is not None:
+        from curdlemsm.distributed import msm_g1_distributed
+        on_gpu = dist.get_backend() == "nccl"
+
+        def max_over_ranks(x):
+            t = torch.tensor([x], dtype=torch.float64, device=dev if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        whole, exch = [], []
+        for _ in range(7):
+            barrier()
+            t1 = time.perf_counter()
+            r_d = msm_g1_distributed(d_pts.data_ptr(), d_sc.data_ptr(), n, device=dev if on_gpu else None, c=c,
+                                     split=args.split, flags=msm_flags)
+            whole.append(max_over_ranks((time.perf_counter() - t1) * 1e3))
+        for _ in range(7):
+            barrier()
+            t1 = time.perf_counter()
+            exchange.finish(exchange.start(result if result is not None else np.zeros(18, dtype=np.uint64)))
+            exch.append(max_over_ranks((time.perf_counter() - t1) * 1e3))
+        base_ms = None
+        if args.split == "windows":
+            def run_whole(count):
+                pend = []
+                for _ in range(count):
+                    if len(pend) == 4:
+                        cm.msm_wait(pend.pop(0))
+                    pend.append(cm.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n, flags=msm_flags))
+                last = None
+                while pend:
+                    last = cm.msm_wait(pend.pop(0))
+                return last
+            run_whole(6)
+            barrier()
+            t1 = time.perf_counter()
+            r_w = run_whole(20)
+            torch.cuda.synchronize()
+            base_ms = max_over_ranks((time.perf_counter() - t1) * 1e3 / 20)
+            if result is not None and not (r_w == result).all():
+                raise SystemExit("bench.py: the one-rank baseline and the distributed result differ")
+        if result is not None and not (r_d == result).all():
+            raise SystemExit("bench.py: a synchronous distributed call and the pipelined steps differ")
+        multi = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                 "bases_unchanged": keep_bases,
+                 "rank_step_ms": round(ms_per_step, 4),
+                 "rank_single_call_ms": round(single_call_ms, 4),
+                 "whole_single_call_ms": round(float(np.median(whole)), 4),
+                 "exchange_ms": round(float(np.median(exch)), 4),
+                 "scaling_baseline": None if base_ms is None else {
+                     "what": "the SAME contract at one rank: the whole MSM, 4 in flight, "
+                             + ("CURDLE_MSM_BASES_UNCHANGED" if keep_bases else "bases converted per call")
+                             + ", run by every rank on its own GPU right after the timed region (MAX over ranks)",
+                     "ms_per_step": round(base_ms, 4), "pairs_per_s": round(n / base_ms * 1e3, 1)},
+                 "note": "`value` is pipelined throughput (in_flight window-range calls per rank, the exchange of step i "
+                         "finished during step i + 1); ONE synchronous call scales as whole_single_call_ms against "
+                         "config.single_call.ms_per_call of the N = 1 line.  No scaling curve was measured by the builder "
+                         "(one-GPU leases): the driver computes efficiency from its own runs."}
+        assert multi["rccl_ranks"] == args.gpus == world, (multi["rccl_ranks"], args.gpus, world)
 
     # The same MSM over a RESIDENT, pre-converted base set (curdle_msm_g1_dbases*): what a caller whose bases
     # do not change between calls gets (msmaccumulator.Verify's are mostly the CRS; every rank of a window
@@ -395,9 +472,29 @@ def main():
         finally:
             bases_box["on"] = False
 
+    # ... and with CURDLE_MSM_BASES_UNCHANGED on the SAME gnark-layout device array (the library keeps its converted copy):
+    # the one-rank figure of the contract every rank of an N > 1 window split runs under -- the scaling baseline.
+    kept = None
+    if dist is None and args.logn <= 22 and not args.no_verify and not keep_bases and not args.emulate_world and not args.resident_bases:
+        msm_flags = cm.MSM_BASES_UNCHANGED
+        try:
+            run_steps(depth + 1)
+            barrier()
+            t1 = time.perf_counter()
+            r_k = run_steps(20)
+            barrier()
+            k_ms = (time.perf_counter() - t1) * 1e3 / 20
+            kept = {"entry_points": "curdle_msm_g1_device_submit_ex / _device_ex with CURDLE_MSM_BASES_UNCHANGED (gnark-layout "
+                                    "device bases converted once, the library keeps its copy): the contract of a window-split rank",
+                    "pipelined_ms_per_step": round(k_ms, 4), "pipelined_pairs_per_s": round(n / k_ms * 1e3, 1),
+                    "ok": bool((r_k == result).all())}
+        finally:
+            msm_flags = 0
+            cm.msm_forget_bases(pts_ptr)
+
     if args.emulate_world > 1:
         print(json.dumps({"emulated_world": args.emulate_world, "split": args.split, "windows": [wb, we],
-                          "bases_unchanged_flag": bool(args.bases_unchanged),
+                          "bases_unchanged_flag": keep_bases,
                           "resident_bases": bases_box["on"],
                           "points": [p_lo, p_hi], "ms_per_step_rank0": ms_per_step,
                           "single_call_ms": single_call_ms, "in_flight": depth, "host_ms_per_step": host_ms,
@@ -491,6 +588,13 @@ def main():
             if not resident.pop("ok"):
                 ok = False
             out["config"]["resident_bases"] = resident
+        if kept is not None:
+            if not kept.pop("ok"):
+                ok = False
+            out["config"]["bases_unchanged"] = kept
+        if multi is not None:
+            out["config"]["multi_gpu"] = multi
+            out["config"]["bases_unchanged_flag"] = keep_bases
         if world == 1 and not args.no_verify and args.logn == 20:
             out["verify"] = verify_leg(cm, 200, 20)
         if not args.no_cpu_baseline:

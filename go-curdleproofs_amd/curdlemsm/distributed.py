@@ -85,8 +85,12 @@ def choose_split(n: int, world_size: int) -> str:
 
 def msm_g1_distributed(d_points: int, d_scalars: int, n: int, group=None, device=None, stream: int = 0,
                        c: int = 0, split: str = "windows",
-                       partial_fn: Optional[Callable[[int, int, int], np.ndarray]] = None) -> np.ndarray:
+                       partial_fn: Optional[Callable[[int, int, int], np.ndarray]] = None, flags: int = 0) -> np.ndarray:
     """Full MSM result (uint64[18]) on every rank.
+
+    flags: those of curdle_msm_g1_device_windows_ex -- MSM_BASES_UNCHANGED when the ranks' resident bases stay put
+    between calls (every rank otherwise converts ALL n points again for its few windows), MSM_ANY_CURVE_POINT for
+    gnark's any-point contract (the window range is then taken over the 255-bit plan's windows).
 
     split = "windows": every rank runs its window range over all n pairs (north_star).
     split = "points":  every rank runs all windows over its point range.
@@ -108,15 +112,17 @@ def msm_g1_distributed(d_points: int, d_scalars: int, n: int, group=None, device
         if partial_fn is not None:
             partial = partial_fn(0, begin, end)
         else:
-            partial = msm_g1_device(d_points + 96 * begin, d_scalars + 32 * begin, end - begin, stream=stream)
+            partial = msm_g1_device(d_points + 96 * begin, d_scalars + 32 * begin, end - begin, stream=stream,
+                                    flags=flags & ~2)      # a point range is another base array on every rank: nothing to keep
     else:
         c = c or window_bits(n)
-        W = num_windows(n, c)
+        W = num_windows(n, c, flags)           # ceil(255 / c) windows with MSM_ANY_CURVE_POINT (review of round 5)
         begin, end = window_partition(W, world, rank)
         if partial_fn is not None:
             partial = partial_fn(c, begin, end)
         else:
-            partial = msm_g1_device(d_points, d_scalars, n, stream=stream, window_bits=c, win_begin=begin, win_end=end)
+            partial = msm_g1_device(d_points, d_scalars, n, stream=stream, window_bits=c, win_begin=begin, win_end=end,
+                                    flags=flags)
     allp = gather_partials(np.ascontiguousarray(partial, dtype=np.uint64), group=group, device=device)
     return g1_sum(allp)
 

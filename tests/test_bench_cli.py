@@ -12,7 +12,8 @@ from conftest import ROOT
 def test_bench_help_lists_the_modes():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0
-    for word in ("--gpus", "--steps", "--warmup", "--sweep", "whisk-batch", "verify", "--emulate-world", "--bases-unchanged"):
+    for word in ("--gpus", "--steps", "--warmup", "--sweep", "whisk-batch", "verify", "--emulate-world", "--bases-unchanged",
+                 "--convert-per-call"):
         assert word in p.stdout, word
 
 
@@ -59,6 +60,44 @@ def test_the_nccl_path_of_the_bench_runs_at_world_size_one(gpu):
     assert "exchange" in line["config"]["host_ms_per_step"]
     cb = line["cpu_baseline"]                                       # attached on the distributed path too
     assert cb["gpu_matches_cpu"] and cb["gpu_full_size_verified"]
+    _check_multi_gpu_keys(line, 1, "nccl")
+
+
+def _check_multi_gpu_keys(line, world, backend):
+    """What an N > 1 line says beside `value`: the ranks RCCL saw, the contract (kept bases), the
+    per-rank step, one rank's and the whole call's synchronous latency, the exchange alone, and the same contract at
+    one rank as the baseline a speed-up is a ratio to."""
+    mg = line["config"]["multi_gpu"]
+    assert mg["rccl_ranks"] == world == line["n_gpus"] and mg["backend"] == backend
+    assert mg["bases_unchanged"] is (world > 1) and line["config"]["bases_unchanged_flag"] is (world > 1)
+    for key in ("rank_step_ms", "rank_single_call_ms", "whole_single_call_ms", "exchange_ms"):
+        assert mg[key] > 0, key
+    assert mg["whole_single_call_ms"] >= 0.9 * mg["rank_single_call_ms"]
+    assert mg["scaling_baseline"]["ms_per_step"] > 0 and mg["scaling_baseline"]["pairs_per_s"] > 0
+    assert "unmeasured" in mg["note"] or "No scaling curve" in mg["note"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_gloo_print_the_multi_gpu_keys(gpu):
+    """The N = 2 line, rehearsed with two ranks sharing the one GPU of the lease (gloo: RCCL refuses two ranks on one
+    device; the figures mean nothing, the branches do): the window split passes CURDLE_MSM_BASES_UNCHANGED by default,
+    every rank runs the one-rank baseline of the same contract, rank 0 prints the new keys and the result still
+    matches the CPU port and the closed form."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CURDLE_DIST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+                        "--warmup", "2", "--logn", "16", "--no-verify"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "over gloo" in line["config"]["parallelism"]
+    assert line["cpu_baseline"]["gpu_matches_cpu"] and line["cpu_baseline"]["gpu_full_size_verified"]
+    _check_multi_gpu_keys(line, 2, "gloo")
 
 
 @pytest.mark.gpu
@@ -91,3 +130,13 @@ def test_the_default_line_carries_the_size_table(gpu):
         assert r["gpu_matches_cpu"] is True and r["wall_ms"] > 0 and r["cpu_port_pairs_per_s"] > 0
         assert 0 < r["hbm_frac"] < 0.02 and 0 < r["valu_frac"] < 1.0
     assert rows[-1]["pairs_per_s"] > rows[0]["pairs_per_s"]
+    # the adversarial families are timed in the same line, each result against the closed form
+    adv = line["adversarial"]
+    fams = {(r["family"], r["logn"]) for r in adv["rows"]}
+    for fam in ("uniform", "all_equal", "small_9bit", "infinity_1pct", "distinct_64"):
+        assert {(fam, 12), (fam, 16), (fam, 20)} <= fams, fam
+    assert ("hot_window", 16) in fams
+    assert all(r["ok"] for r in adv["rows"])
+    for r in adv["rows"]:
+        if r["family"] != "uniform" and r["logn"] >= 16:
+            assert r["ratio_sync"] < 1.5 and r["ratio_host_slices"] < 1.5, r      # the bar is 1.25; boxes jitter

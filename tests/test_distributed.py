@@ -60,6 +60,16 @@ def _worker(rank, world, port, n, result_dir):
         # the reserve partition: point ranges, all windows per rank
         res["points"] = msm_g1_distributed(
             0, 0, n, split="points", partial_fn=lambda c, lo, hi: co.msm_pippenger(pts[lo:hi], sc[lo:hi], threads=2))
+        # gnark's any-point contract: the plan recodes the whole 255-bit scalar, so the ranks partition ceil(255 / c)
+        # windows, not ceil(127 / c) (review of round 5: the low half of every scalar only, with no error)
+        from test_abi import recode
+
+        def partial_any(c, begin, end):
+            widths = cm.window_widths(n, c, flags=cm.MSM_ANY_CURVE_POINT)
+            assert sum(widths) == 255
+            ps = [sum(d << sh for d, sh in recode(s, widths)[begin:end]) % o.R for s in sc_int]
+            return co.msm_pippenger(pts, np.array([o.fr_to_mont_limbs(s) for s in ps], dtype=np.uint64), threads=2)
+        res["any"] = msm_g1_distributed(0, 0, n, c=9, partial_fn=partial_any, flags=cm.MSM_ANY_CURVE_POINT)
         full = co.msm_pippenger(pts, sc, threads=2)
         ok = all((res[c] == full).all() for c in res)
         # config 5 replicas: 11 independent "verifications", round-robin, one all_gather of bits
