@@ -726,6 +726,22 @@ struct ChunkJoin {
   Slot* fold_prev = nullptr;          // the chunk before this one: its acc_done then means "accumulated AND folded"
 };
 
+#ifdef CURDLE_EXP_SKIP
+// Experiment build only (tools/exp/phase_costs.sh -> build_alt/, never the product library): phases of a PIPELINED call left
+// out after the slot's first uses, so that what each phase costs the pipeline can be priced (profiles/r06_pipeline_phase_costs.txt).
+// CURDLE_DEBUG_SKIP bits: 1 conversion, 2 sort, 4 merge_large, 8 reduce_segments, 16 reduce_level.  Results are garbage by construction.
+static unsigned exp_skip_mask() {
+  static const unsigned m = [] {
+    const char* e = getenv("CURDLE_DEBUG_SKIP");
+    return e ? (unsigned)atoi(e) : 0u;
+  }();
+  return m;
+}
+#define EXP_SKIP(bit) (exp_skip_mask() & (bit) && S.gen > 12 && !latency_mode)
+#else
+#define EXP_SKIP(bit) false
+#endif
+
 // Enqueue every GPU phase of k MSMs on the slot's stream (no host synchronisation).
 // d_points / d_scalars are device pointers holding the pairs of all MSMs back to back
 // and must stay valid until the matching finish_slot(); h_off has k + 1 entries.
@@ -906,11 +922,11 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   // starts; knob FRONT=0: two launches)
   const size_t front_max = knobs::get(knobs::FRONT) > 1 ? (size_t)knobs::get(knobs::FRONT) : (size_t)16384;  // (FRONT > 1: the limit in pairs)
   const bool front = convert_here && phase == 0 && !p.two_level && sets * n_pairs <= front_max && knobs::get(knobs::FRONT) != 0;
-  if (convert_here && phase == 0 && !front) {
+  if (convert_here && phase == 0 && !front && !EXP_SKIP(1)) {
     HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre, p.aux_prio));
     prof.mark("convert_points");
   }
-  if (phase != 2) {
+  if (phase != 2 && !EXP_SKIP(2)) {
     if (front)
       HIP_TRY(launch_front(p, ws, d_points, (uint32_t)(sets * n_pairs), d_scalars, pre));
     else if (dfront)  // the device accumulator's job: loose bases, slot scalars and recoding in one launch
@@ -955,7 +971,7 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
     stream = tail;
     prof.st = tail;
   }
-  HIP_TRY(launch_merge_large(p, ws, stream));
+  if (!EXP_SKIP(4)) HIP_TRY(launch_merge_large(p, ws, stream, latency_mode && !join));
   prof.mark("merge_large");
   if (join && join->accumulate_only) {
     if (join->fold_home) {
@@ -1002,9 +1018,9 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
     }
   }
   if (p.reduce_bits) {
-    HIP_TRY(launch_reduce_segments(p, ws, stream, extra.n ? &extra : nullptr));
+    if (!EXP_SKIP(8)) HIP_TRY(launch_reduce_segments(p, ws, stream, extra.n ? &extra : nullptr));
     prof.mark("bucket_reduce");
-    HIP_TRY(launch_reduce_groups(p, ws, stream));
+    if (!EXP_SKIP(16)) HIP_TRY(launch_reduce_groups(p, ws, stream));
     prof.mark("window_sum");
   } else {
     HIP_TRY(launch_bucket_reduce(p, ws, stream, extra.n ? &extra : nullptr));

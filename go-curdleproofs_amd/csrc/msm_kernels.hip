@@ -2187,14 +2187,17 @@ hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream
   return hipGetLastError();
 }
 
-hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  // One wave per chunk of 32 to 256 fragments, at most 768 blocks = three 165-register waves on every SIMD (the launch is
-  // almost always empty -- uniform scalars queue nothing -- and every block of it has to find room beside the next
-  // accumulation before it can read the empty queue and leave); more chunks than waves go round.
+hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, bool wide) {
+  // One wave per chunk of 32 to 256 fragments; more chunks than waves go round.  The launch is almost always empty
+  // (uniform scalars queue nothing) and every block of it has to find room beside the next accumulation before it can
+  // read the empty queue and leave: a synchronous call, which has the chip to itself, takes up to 768 blocks = three
+  // 165-register waves on every SIMD; a pipelined one 256 (768 empty blocks cost its step 0.02 ms of 2.53:
+  // profiles/r06_pipeline_phase_costs.txt).
   const u32 nw = p.win_end - p.win_begin;
   const u64 nlanes = ((u64)nw * p.n + p.L - 1) / p.L;  // fragments <= bucket slots + lanes
   const u64 chunks = (u64)p.max_large + ((u64)p.k * p.NB + nlanes) / 32u;
-  const u32 blocks = (u32)(chunks / 4u + 1u < 768u ? chunks / 4u + 1u : 768u);
+  const u32 cap = wide ? 768u : 256u;
+  const u32 blocks = (u32)(chunks / 4u + 1u < cap ? chunks / 4u + 1u : cap);
   hipLaunchKernelGGL(k_merge_large, dim3(blocks, p.sets), dim3(kBlock), 0, stream, ws.large, ws.nlarge, ws.foff, ws.fragcnt,
                      reinterpret_cast<X28*>(ws.frags), ws.mdone, p.max_large, p.frag_stride, p.reduce_prio);
   return hipGetLastError();
