@@ -76,7 +76,7 @@ static constexpr int kMaxDeferred = 4;          // two-step point decodings in f
 // (0.05 ms each for small MSMs).  Measured after the GLV split, k x 128 / 628 pairs: k = 8 0.67
 // (host) against 0.81 ms, k = 12 0.89 against 0.76, k = 16 1.09 against 0.77, k = 24 1.51
 // against 0.77.
-static inline size_t gpu_combine_min() { return knobs::get(knobs::GPU_COMBINE_MIN) > 0 ? (size_t)knobs::get(knobs::GPU_COMBINE_MIN) : (size_t)12; }
+static inline size_t gpu_combine_min() { return 12; }
 
 struct Buf {
   void* p = nullptr;
@@ -469,14 +469,12 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (latency_mode) {
     // (round 4: a whole round, 131,072 lanes, since the reduction lost its per-segment scalar multiple: shorter
     // segments now cost a quad almost nothing extra -- 131,072 pairs 0.93 -> 0.89 ms, 2^20 3.45 -> 3.41)
-    uint64_t lanes = 131072;
-    if (knobs::get(knobs::SYNC_LANES) > 0) lanes = (uint64_t)knobs::get(knobs::SYNC_LANES);
+    const uint64_t lanes = 131072;
     uint32_t seg = 1;
     while (nbk / seg * 4 > lanes && seg < 32) seg *= 2;
     p.seg = nbk / seg * 4 <= lanes ? seg : 16;
   } else {
-    uint64_t lanes = 32768;
-    if (knobs::get(knobs::PIPE_LANES) > 0) lanes = (uint64_t)knobs::get(knobs::PIPE_LANES);
+    const uint64_t lanes = 32768;  // (16,384 / 65,536 / 131,072 measured equal: profiles/r04_pipeline_phase_costs.txt)
     uint32_t seg = p.seg;
     while (nbk / seg * 4 > lanes && seg < 64) seg *= 2;
     p.seg = seg;
@@ -494,15 +492,12 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // per window for the host against a 3-to-6-bit multiple on the GPU -- 8..299 pairs measured 0.01-0.03 ms
   // slower, and the batch verifiers, which are host-bound, lost a quarter of their throughput to the
   // longer host passes of their per-proof MSMs: profiles/r04_reduce_bits_small.txt).
-  // Knob REDUCE_BITS: 0 / 1 = never / wherever the shapes allow; 2 = synchronous calls only.
   {
-    const long long forced = knobs::get(knobs::REDUCE_BITS);
     // (light_host: a queued MSM of a batch verifier -- a host-bound caller with dozens in flight, to whom the
     // longer host pass costs throughput and the shorter GPU chain buys nothing: 1,024 Whisk proofs 31-36 ms
     // per batch with k_bucket_reduce_quad, 41-46 with this form)
     const bool shapes = k * sets == 1 && !many && !light_host;
-    const bool pays = n_total >= 600;  // terms: two per pair
-    p.reduce_bits = shapes && (forced < 0 ? pays : forced == 1 || (forced == 2 && pays && latency_mode)) ? 1u : 0u;
+    p.reduce_bits = shapes && n_total >= 600 ? 1u : 0u;  // terms: two per pair
   }
   const uint32_t gmax = p.reduce_bits ? 16u : 64u;  // quads per group: one wave's, or one block's
   p.G = min_nbkt / p.seg < gmax ? min_nbkt / p.seg : gmax;
@@ -523,8 +518,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // as many lanes take 0.03-0.05 ms off its chain at no cost to the accumulation; at 2^24
   // entries (N = 2^20) it is 1 % of the pipelined step (2.71 -> 2.68 ms)
   {
-    // (knob ROUND_LANES: the lanes of that round; unset: 131,072)
-    const uint64_t round_lanes = knobs::get(knobs::ROUND_LANES) > 0 ? (uint64_t)knobs::get(knobs::ROUND_LANES) : 131072;
+    const uint64_t round_lanes = 131072;  // (0.8 of a round measured no better: profiles/r05_rank_step_knobs.txt)
     const uint64_t one = (entries + round_lanes - 1) / round_lanes;
     if (one <= 128 && one > L) L = one;
   }
@@ -603,26 +597,17 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
                         win_end - win_begin <= 20;
     p.two_level = shapes && forced != 1 && (forced == 2 || p.n >= (1u << 17)) ? 1u : 0u;
   }
-  // One single-block scan launch instead of six up to 8,192 bucket slots, where it is also the faster
-  // one; beyond that the multi-block form (0.03 ms against 0.14 / 0.26 ms for the 32,768 / 65,536 slots of
-  // an 8-way / 4-way rank of the window split; a pipelined rank step measured the same either way,
-  // profiles/r04_pipeline_phase_costs.txt, so the kernel that is 5-9x faster alone is taken).
-  // Round 5: k_scan_one -- one block as well, but the slots read once, coalesced, and the block scans by wave
-  // shuffles -- up to 32,768 slots (knob SCAN: 0 / 1 / 2 = six launches / k_scan_fused / k_scan_one where the sizes allow).
+  // The bucket-slot scans.  k_scan_one -- one block, the slots read once, coalesced, the block scans by wave shuffles --
+  // up to 32,768 slots; k_scan_chain (round 5) -- one launch at ANY size, tile sums handed down a chain -- beyond that
+  // and (enqueue_slot) for every pipelined or chunked call, beside whose neighbours k_scan_one's 16 x 121-register block
+  // cannot start: a rank of the 8-way window split 0.428 -> 0.396 ms per step, synchronous 2^16 / 2^17 / 2^18 pairs 0.610 /
+  // 0.808 / 1.149 -> 0.589 / 0.788 / 1.130 ms (profiles/r05_scan_chain.txt).  The six-launch multi-block form is left for
+  // ONE case: L = 1 (knob SEG_LEN), since both one-launch forms divide by L with a multiply that needs L >= 2.
+  // (Round 6: the knob SCAN and k_scan_fused, the round-2 single-block form, are gone: every comparison is under profiles/.)
   {
     const uint64_t nbs = (uint64_t)k * p.NB;
-    const long long forced = knobs::get(knobs::SCAN);
-    p.fuse_scan = nbs <= 32768 ? 2u : 0u;
-    if (forced == 0) p.fuse_scan = 0;
-    if (forced == 1) p.fuse_scan = nbs <= 8192 ? 1u : 0u;
-    // k_scan_chain (round 5): one launch at ANY size, tile sums handed down a chain.  Default wherever k_scan_one does not
-    // apply -- more than 32,768 slots, and (enqueue_slot) every pipelined or chunked call, beside whose neighbours k_scan_one's
-    // 16 x 121-register block cannot start: a rank of the 8-way window split 0.428 -> 0.396 ms per step (scan alone 0.037 ->
-    // 0.014), synchronous 2^16 / 2^17 / 2^18 pairs 0.610 / 0.808 / 1.149 -> 0.589 / 0.788 / 1.130 ms (their six launches were
-    // host-bound), whole pipelined MSM 2.533 -> 2.527; equal to k_scan_one where that runs (profiles/r05_scan_chain.txt).
-    // Knob SCAN: 0 / 1 / 2 as before, 3 = the chain everywhere, 4 or unset = this rule.
-    if (forced == 3 || ((forced == 4 || forced < 0) && p.fuse_scan != 2)) p.fuse_scan = 3;
-    if (p.L < 2 && p.fuse_scan >= 2) p.fuse_scan = 0;  // both one-launch forms divide by L with a multiply (knob SEG_LEN = 1 only)
+    p.fuse_scan = nbs <= 32768 ? 2u : 3u;
+    if (p.L < 2) p.fuse_scan = 0;
   }
   return CURDLE_OK;
 }
@@ -783,7 +768,7 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   if (dfront && (p.two_level || k != 1 || sets != 1)) return fail(CURDLE_EINVAL, "internal: the fused accumulator front takes one small MSM");
   // k_scan_one is 16 waves of 121 registers: a block of it needs four SIMDs of one compute unit EMPTY, so beside another
   // call's accumulation it waits for accumulate waves to end.  Only calls that have the chip to themselves take it.
-  if (p.fuse_scan == 2 && (join || !latency_mode) && knobs::get(knobs::SCAN) != 2) p.fuse_scan = 3;  // k_scan_chain: four 60-register waves (L >= 2 holds: make_plan)
+  if (p.fuse_scan == 2 && (join || !latency_mode)) p.fuse_scan = 3;  // k_scan_chain: four 60-register waves (L >= 2 holds: make_plan)
   // a chunk of a host-buffer call sorts (and folds) beside the chunks before it: raised like a pipelined call's sort
   if (join && knobs::get(knobs::AUX_PRIO) < 0) p.aux_prio = 3;
   // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
@@ -860,7 +845,7 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   // (device-visible like all pinned memory here) -- a hundred points or so, 16 bytes per store -- instead of through a
   // device array and a copy command behind the last kernel (~10 us of every synchronous call; knob DIRECT_RESULTS=0: the copy).
   const size_t win_bytes = kr * (size_t)nw * wpts * sizeof(G1XYZZ);
-  const bool direct = !p.gpu_combine && win_bytes <= ((size_t)256 << 10) && knobs::get(knobs::DIRECT_RESULTS) != 0;
+  const bool direct = !p.gpu_combine && win_bytes <= ((size_t)256 << 10);
   ws.winsums = direct ? (G1XYZZ*)S.h_buf : (G1XYZZ*)S.winsums.p;
   ws.results = (G1XYZZ*)S.results.p;
   ws.chain = nullptr;
@@ -919,9 +904,9 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   const int phase = join ? join->phase : 0;
   const bool convert_here = !points28_ready && !ext_points28;  // the device accumulator fills S.points28 itself; a resident base set is converted already
   // small calls: conversion and recoding in one launch (the host's launches bound the call until the accumulation
-  // starts; knob FRONT=0: two launches)
-  const size_t front_max = knobs::get(knobs::FRONT) > 1 ? (size_t)knobs::get(knobs::FRONT) : (size_t)16384;  // (FRONT > 1: the limit in pairs)
-  const bool front = convert_here && phase == 0 && !p.two_level && sets * n_pairs <= front_max && knobs::get(knobs::FRONT) != 0;
+  // starts)
+  const size_t front_max = 16384;  // (larger limits measured equal: profiles/r05_small_sort_one_block.txt)
+  const bool front = convert_here && phase == 0 && !p.two_level && sets * n_pairs <= front_max;
   if (convert_here && phase == 0 && !front && !EXP_SKIP(1)) {
     HIP_TRY(launch_convert_points_raw(d_points, (uint32_t)(sets * n_pairs), ws.points28, pre, p.aux_prio));
     prof.mark("convert_points");
@@ -1230,10 +1215,9 @@ int run_host(const uint64_t* points, const uint64_t* scalars, const uint32_t* h_
     const SyncStreams st = sync_streams(cx, S);
     // One mid-size MSM: the scalars cross first and the recoding + sort run while the points are still crossing (on the
     // context's copy stream; a pageable copy occupies this thread, not the GPU) -- the sort, 0.07-0.15 ms of such a call,
-    // is off the call's critical path for one event hop.  Knob HOST_OVERLAP_MIN: the pair count from which (0 = never).
-    const long long ov = knobs::get(knobs::HOST_OVERLAP_MIN);
-    const size_t overlap_min = ov >= 0 ? (size_t)ov : (size_t)16384;
-    if (k == 1 && overlap_min > 0 && n >= overlap_min) {
+    // is off the call's critical path for one event hop.  From 16,384 pairs.
+    const size_t overlap_min = 16384;
+    if (k == 1 && n >= overlap_min) {
       const uint32_t off[2] = {0, (uint32_t)n};
       ChunkJoin join;
       HIP_TRY(hipMemcpyAsync(S.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st.pre));
@@ -1280,17 +1264,14 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
   // quarter accumulations 2.9 ms against 2.4 ms of copies): so the first two chunks are half-size -- the GPU starts
   // after an eighth of the bytes -- and every chunk's scalars cross right before its points, so that no accumulation
   // waits for points queued behind other chunks' scalars (the gap 1.43-1.78 ms in profiles/r04_host_fold.txt).
-  // Knob HOST_GRADED=0: equal chunks, all scalars first, as in round 4.
-  // (HOST_GRADED: 1 = graded sizes + interleaved copies, 2 = equal sizes + interleaved copies; unset / 0 = round 4's scheme)
   // Round 5, late: graded chunks by DEFAULT, together with two things that were missing when they were first measured (and lost
   // to round 4's order): the chunks' sorts raised to wave priority 3 (they run beside the accumulation of the chunk before;
   // enqueue_slot) and every sort on its chunk's own stream instead of all of them in a row on the context's sort stream.
   // N = 2^20: 4.24-4.26 -> 4.03-4.18 ms on one box (four chunks of 1/6, 1/6, 1/3, 1/3), 2^19: 2.63-2.69 -> 2.51-2.53
   // (profiles/r05_host_buffer_call.txt, the last section).
-  const long long graded_knob = knobs::get(knobs::HOST_GRADED) < 0 ? 1 : knobs::get(knobs::HOST_GRADED);
-  const bool graded = graded_knob == 1;
-  const bool interleave = graded_knob == 1 || graded_knob == 2;
-  size_t nchunks = n >= ((size_t)1 << 20) ? 4 : (graded ? 3 : 2);
+  // (Round 6: the knobs HOST_GRADED, HOST_PATTERN and HOST_SORT_STREAMS that walked these choices are gone; equal chunks, round 4's copy
+  // order, other size patterns and the one sort stream are all in profiles/r05_host_buffer_call.txt.)
+  size_t nchunks = n >= ((size_t)1 << 20) ? 4 : 3;
   if (knobs::get(knobs::HOST_CHUNKS) > 0) nchunks = (size_t)knobs::get(knobs::HOST_CHUNKS);
   // (without folding the reduction takes one fragment list per chunk: at most kMaxFragSources)
   const bool fold_on = knobs::get(knobs::HOST_FOLD) != 0;
@@ -1318,27 +1299,10 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
     nchunks = slots.size();
   }
   const int c = choose_window_bits(n);
-  // chunk sizes: equal, or (graded, three chunks and more) the first two one unit and the others two units each, or
-  // (knob HOST_PATTERN: decimal digits, one per chunk, in eighths of n -- 3311 = 3/8, 3/8, 1/8, 1/8) as said
+  // chunk sizes: (three chunks and more) the first two one unit and the others two units each; otherwise equal
   std::vector<size_t> bounds(nchunks + 1, n);
   bounds[0] = 0;
-  const long long pattern = knobs::get(knobs::HOST_PATTERN);
-  if (pattern > 0) {
-    std::vector<int> dig;
-    for (long long v = pattern; v > 0; v /= 10) dig.insert(dig.begin(), (int)(v % 10));
-    int sum = 0;
-    for (int d : dig) sum += d;
-    if (sum == 8 && dig.size() == nchunks) {
-      size_t at = 0;
-      for (size_t i = 0; i < nchunks; i++) {
-        at += (n * (size_t)dig[i] + 7) / 8;
-        bounds[i + 1] = at < n ? at : n;
-      }
-    } else {
-      const size_t per = (n + nchunks - 1) / nchunks;
-      for (size_t i = 1; i < nchunks; i++) bounds[i] = i * per < n ? i * per : n;
-    }
-  } else if (graded && nchunks >= 3) {
+  if (nchunks >= 3) {
     const size_t unit = (n + 2 * (nchunks - 1) - 1) / (2 * (nchunks - 1));
     size_t at = 0;
     for (size_t i = 0; i < nchunks; i++) {
@@ -1402,16 +1366,9 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       job_p[i] = jobs.size();
       jobs.push_back({parts[i].S->points.p, points + 12 * parts[i].lo, parts[i].m * 96, parts[i].S->acc_done});
     };
-    if (interleave) {
-      for (size_t i = 0; i < parts.size(); i++) {
-        add_s(i);
-        add_p(i);
-      }
-    } else {  // round 4's order: chunk 0 whole, then every other chunk's scalars, then their points
-      add_s(0);
-      add_p(0);
-      for (size_t i = 1; i < parts.size(); i++) add_s(i);
-      for (size_t i = 1; i < parts.size(); i++) add_p(i);
+    for (size_t i = 0; i < parts.size(); i++) {  // every chunk's scalars right before its points
+      add_s(i);
+      add_p(i);
     }
     std::mutex cmu;
     std::condition_variable ccv;
@@ -1444,9 +1401,8 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
     // (knob HOST_FOLD=0: the reduction walks every chunk's fragment list, as until round 4)
     const bool fold = knobs::get(knobs::HOST_FOLD) != 0 && parts.size() >= 2;
     // every chunk's sort on its slot's own stream, not all of them one after the other on the context's sort stream: three
-    // sorts in a row beside the accumulations are late (knob HOST_SORT_STREAMS=0: the one stream)
-    const bool own_sort_streams = knobs::get(knobs::HOST_SORT_STREAMS) != 0;
-    auto sort_stream = [&](Part& pt) { return own_sort_streams && &pt != &parts[0] ? pt.S->stream : cx.pre_stream; };
+    // sorts in a row beside the accumulations are late
+    auto sort_stream = [&](Part& pt) { return &pt != &parts[0] ? pt.S->stream : cx.pre_stream; };
     auto enqueue_sort = [&](Part& pt) -> int {  // behind the chunk's scalars
       hipStream_t ps = sort_stream(pt);
       HIP_TRY(hipStreamWaitEvent(ps, pt.S->pre_done, 0));
@@ -2954,7 +2910,7 @@ int dacc_submit_impl(curdle_dacc* acc, const curdle_dacc_check* checks, size_t n
     // Small jobs (a verification's 1,268 + loose pairs; always below the two-level plans): the loose bases' conversion,
     // the slot scalars and the recoding in ONE launch (k_dacc_front) instead of four operations on the stream -- the
     // front of a verification is bound by the host's launches.  Knob FRONT=0: the separate launches.
-    const bool fused = n <= 16384 && knobs::get(knobs::FRONT) != 0;
+    const bool fused = n <= 16384;
     if (!fused) {
       if (n_extra) {
         HIP_TRY(launch_convert_points_raw(dj + o_xp, (uint32_t)n_extra, (char*)S.points28.p + 2 * n_res * kA28Bytes, st));

@@ -42,7 +42,7 @@ struct MsmPlan {
   uint32_t max_large;  // capacity of the large-bucket queue
   uint32_t chunk;      // pairs per sort block
   uint32_t gpu_combine;  // 1: window sums combined on the GPU (large batches), 0: on the host
-  uint32_t fuse_scan;    // the bucket-slot scans: 0 six launches (multi-block), 1 k_scan_fused (small calls), 2 k_scan_one (one block, up to 32,768 slots), 3 k_scan_chain (one launch, any size)
+  uint32_t fuse_scan;    // the bucket-slot scans: 0 six launches (multi-block; L = 1 only), 2 k_scan_one (one block, up to 32,768 slots), 3 k_scan_chain (one launch, any size)
   uint32_t glv;          // 1: scalars split with the endomorphism (bases must be in G1); 0: 255-bit scalars whole, any curve point
   uint32_t two_level;    // 1: the scatter runs in two passes (coarse bins, then buckets): single large MSMs
   // The bucket reduction without a scalar multiple (single MSMs; k_reduce_segments / k_reduce_groups):

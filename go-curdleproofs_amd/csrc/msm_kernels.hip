@@ -653,58 +653,10 @@ __global__ void __launch_bounds__(kBlock) k_fix_foff(u32* __restrict__ foff, con
   }
 }
 
-// All of the above in ONE single-block launch for calls with at most 65,536 bucket slots
-// (small MSMs are launch-latency-bound: six dependent launches were ~30 us of a 0.4 ms call;
-// a two-window partial of the multi-GPU split has 65,536 slots).
-static constexpr u32 kScanFusedMax = 64 * kScanThreads;
-__global__ void __launch_bounds__(kScanThreads)
-    k_scan_fused(const u32* __restrict__ counts, u32 nb, u32* __restrict__ starts, u32* __restrict__ cursor,
-                 u32* __restrict__ fragcnt, u32* __restrict__ foff, u32* __restrict__ large, u32* __restrict__ nlarge, u32 L,
-                 u32 max_small, u32 max_large) {
-  __shared__ u32 sh[kScanThreads];
-  const u32 tid = threadIdx.x;
-  const u32 per = (nb + kScanThreads - 1) / kScanThreads;  // <= 64 consecutive slots per thread
-  const u32 lo = min(tid * per, nb), hi = min(lo + per, nb);
-  if (tid == 0) *nlarge = 0;
-  // the slots are read twice (the second time from L2) rather than kept in registers
-  u32 sum = 0;
-  for (u32 i = lo; i < hi; i++) sum += counts[i];
-  u32 total;
-  const u32 first = block_exclusive_scan_1024(sum, sh, total);
-  u32 run = first, fsum = 0;
-  for (u32 i = lo; i < hi; i++) {
-    const u32 cnt = counts[i];
-    starts[i] = run;
-    cursor[i] = run;
-    const u32 fc = cnt ? ((run + cnt - 1) / L - run / L + 1) : 0u;
-    fragcnt[i] = fc;
-    fsum += fc;
-    run += cnt;
-  }
-  if (tid == 0) starts[nb] = total;
-  __syncthreads();  // sh is reused; nlarge = 0 is visible to the block
-  u32 ftotal;
-  u32 frun = block_exclusive_scan_1024(fsum, sh, ftotal);
-  run = first;
-  for (u32 i = lo; i < hi; i++) {
-    const u32 cnt = counts[i];
-    const u32 fc = cnt ? ((run + cnt - 1) / L - run / L + 1) : 0u;
-    foff[i] = frun;
-    if (fc > max_small) {
-      u32 q = atomicAdd(nlarge, 1u);
-      if (q < max_large) large[q] = i;
-    }
-    frun += fc;
-    run += cnt;
-  }
-  if (tid == 0) foff[nb] = ftotal;
-}
-
-// The same in one single-block launch for up to 65,536 slots, with the slots read ONCE, coalesced (16 bytes per
-// lane), and the two block scans by wave shuffles (round 5).  k_scan_fused above gives every thread 8..64
-// consecutive slots and reads them twice, four bytes at a time and a line apart between neighbouring lanes:
-// 0.14 ms for the 32,768 slots of one window of the multi-GPU split, against 0.036 ms for the six launches of
-// the multi-block form -- this one takes a tile of 4,096 slots per step, two steps' loads in flight.
+// All of the above in ONE single-block launch for up to 32,768 slots, with the slots read ONCE, coalesced (16 bytes per
+// lane), and the two block scans by wave shuffles (round 5): a tile of 4,096 slots per step, two steps' loads in flight.
+// (k_scan_fused, the round-2 single-block form that gave every thread 8..64 consecutive slots and read them twice, four
+// bytes at a time -- 0.14 ms for 32,768 slots against 0.036 for the six launches -- was removed in round 6.)
 static constexpr u32 kScanOneMax = 32768;
 static constexpr int kScanOnePer = kScanOneMax / kScanThreads;  // 32 consecutive slots per thread at most
 // floor(x / L) for x < 2^32 by one 64 x 64 -> high-64 product with M = floor((2^64 - 1) / L) + 1 (exact: the error term
@@ -2073,11 +2025,6 @@ hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t str
     hipLaunchKernelGGL(k_scan_chain, dim3(ch.ntiles), dim3(kChainThreads), 0, stream, ws.counts, nb, ws.starts, ws.cursor,
                        ws.fragcnt, ws.foff, ws.large, ws.nlarge, p.L, p.max_small, p.max_large, (u32)magic, (u32)(magic >> 32), ch,
                        p.aux_prio);
-    return hipGetLastError();
-  }
-  if (p.fuse_scan == 1 && nb <= kScanFusedMax) {
-    hipLaunchKernelGGL(k_scan_fused, dim3(1), dim3(kScanThreads), 0, stream, ws.counts, nb, ws.starts, ws.cursor,
-                       ws.fragcnt, ws.foff, ws.large, ws.nlarge, p.L, p.max_small, p.max_large);
     return hipGetLastError();
   }
   hipError_t e0 = hipMemsetAsync(ws.nlarge, 0, 4, stream);

@@ -10,10 +10,10 @@ namespace curdle {
 namespace knobs {
 namespace {
 const char* const kNames[COUNT] = {
-    "WINDOW_BITS", "SEG_LEN", "ROUND_LANES", "REDUCE_SEG",      "SYNC_LANES",     "PIPE_LANES",      "SCATTER",
-    "REDUCE_BITS", "HOST_CHUNKS",    "MAX_MSMS_PER_PASS", "MULTI_DEVICE_MIN", "MAIN_STREAMS", "TWO_KERNEL_MAX",
-    "GPU_COMBINE_MIN", "QUAD_MAX_LANES", "BATCH_CHUNK",  "BATCH_PRODUCERS", "BATCH_GROUP",     "DEVICE_ACC",
-    "HOST_DECODE", "VERIFY_EAGER",   "VERIFY_TRACE",    "PROVER_FOLD_BASES", "ACC_PRIO", "REDUCE_PRIO", "AUX_PRIO", "SCAN", "FRONT", "DIRECT_RESULTS", "HOST_OVERLAP_MIN", "HOST_SORT_STREAMS", "HOST_GRADED", "HOST_PATTERN", "HOST_FOLD"};
+    "WINDOW_BITS", "SEG_LEN", "REDUCE_SEG", "SCATTER", "HOST_CHUNKS", "MAX_MSMS_PER_PASS",
+    "MULTI_DEVICE_MIN", "MAIN_STREAMS", "TWO_KERNEL_MAX", "QUAD_MAX_LANES", "BATCH_CHUNK", "BATCH_PRODUCERS",
+    "BATCH_GROUP", "DEVICE_ACC", "HOST_DECODE", "VERIFY_EAGER", "VERIFY_TRACE", "PROVER_FOLD_BASES",
+    "ACC_PRIO", "REDUCE_PRIO", "AUX_PRIO", "HOST_FOLD"};
 std::atomic<long long> g_val[COUNT];
 std::once_flag g_once;
 void load() {

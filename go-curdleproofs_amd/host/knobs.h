@@ -9,6 +9,9 @@
 // profiles/): CURDLE_TWO_ROUNDS, CURDLE_TAIL_PRIO, CURDLE_SYNC_STREAMS, CURDLE_PRE_STREAMS,
 // CURDLE_SEG_LEN_MIN, CURDLE_SORT_CHUNK, CURDLE_FUSE_SCAN_MAX, CURDLE_HOST_ONE_COPY (=
 // CURDLE_HOST_CHUNKS=1), CURDLE_DECODE_PRIO, CURDLE_BATCH_EXTRA_PRODUCERS, CURDLE_NO_IFMA.
+// Round 6, the same for the experiments rounds 4 and 5 closed: CURDLE_ROUND_LANES, CURDLE_SYNC_LANES, CURDLE_PIPE_LANES,
+// CURDLE_REDUCE_BITS, CURDLE_GPU_COMBINE_MIN, CURDLE_SCAN (with k_scan_fused), CURDLE_FRONT, CURDLE_DIRECT_RESULTS,
+// CURDLE_HOST_OVERLAP_MIN, CURDLE_HOST_SORT_STREAMS, CURDLE_HOST_GRADED, CURDLE_HOST_PATTERN.
 #pragma once
 #include <stddef.h>
 
@@ -17,18 +20,13 @@ namespace knobs {
 enum Id {
   WINDOW_BITS,        // maximum window width c of every plan (4..16); unset: the size table
   SEG_LEN,            // sorted positions per accumulate lane
-  ROUND_LANES,        // lanes of the one round a mid-size accumulation is cut into (unset: 131,072 = two waves on every SIMD)
   REDUCE_SEG,         // buckets per bucket-reduce segment (power of two)
-  SYNC_LANES,         // lanes the reduce of a synchronous call is sized for (default 131,072)
-  PIPE_LANES,         // ... of a pipelined call (default 32,768)
   SCATTER,            // 1: one-pass scatter, 2: two-pass wherever the shapes allow; unset: by size
-  REDUCE_BITS,        // 0: k_bucket_reduce_quad everywhere, 1: the bit-sum reduction wherever the shapes allow, 2: in synchronous calls only; unset: single MSMs from 300 pairs
   HOST_CHUNKS,        // chunks of a host-buffer MSM from 2^19 pairs (1..4)
   MAX_MSMS_PER_PASS,  // MSMs per pass of a batch beyond the bucket-slot limit
   MULTI_DEVICE_MIN,   // pairs from which curdle_msm_g1 spreads over the configured devices
   MAIN_STREAMS,       // accumulate streams of a context (1..4), read when the context is created
   TWO_KERNEL_MAX,     // one-shot decodings up to this many points take the two-kernel form
-  GPU_COMBINE_MIN,    // batches of at least this many MSMs combine their windows on the GPU
   QUAD_MAX_LANES,     // decode / scalar-multiplication kernels: quads up to this many lanes
   BATCH_CHUNK,        // batch verification: proofs per decode-ahead chunk
   BATCH_PRODUCERS,    // ... decode-ahead producer threads
@@ -41,13 +39,6 @@ enum Id {
   ACC_PRIO,           // k_accumulate: the two waves of a SIMD take turns at high priority every 2^v x 10 ns (0: never; unset: 15 for synchronous calls from half a round of lanes)
   REDUCE_PRIO,        // wave priority (0..3) of k_reduce_segments / k_reduce_level; unset: 3 for pipelined calls, 0 for synchronous ones
   AUX_PRIO,           // wave priority (0..3) of the sort kernels, the conversion and the chunk fold; unset: 3 for pipelined calls, 0 for synchronous ones
-  SCAN,               // the bucket-slot scans: 0 six launches, 1 k_scan_fused up to 8,192 slots, 2 k_scan_one up to 32,768, 3 k_scan_chain everywhere; unset or 4: k_scan_one for synchronous calls up to 32,768 slots, k_scan_chain otherwise
-  FRONT,              // 0: small calls convert and recode in two launches instead of one (k_front); > 1: the limit in pairs (unset: 16,384; larger limits measured equal, profiles/r05_small_sort_one_block.txt)
-  DIRECT_RESULTS,     // 0: window sums cross to the host by a copy command instead of the kernels' own stores into pinned memory
-  HOST_OVERLAP_MIN,   // pairs from which ONE host-buffer MSM below 2^19 pairs copies its scalars first and sorts while the points cross (0: never; unset: 16,384)
-  HOST_SORT_STREAMS,  // 0: chunked host-buffer calls sort all their chunks on the context's one sort stream instead of each on its slot's own (unset: own streams)
-  HOST_GRADED,        // host-buffer MSMs: 1 (unset) graded chunks (1/6, 1/6, 1/3, 1/3 from 2^20 pairs; 1/4, 1/4, 1/2 below), every chunk's scalars copied right before its points; 2 equal chunks, the same copy order; 0 equal chunks, all scalars first (round 4)
-  HOST_PATTERN,       // chunk sizes of a host-buffer MSM in eighths, one decimal digit per chunk (3311); needs HOST_CHUNKS = the digit count
   HOST_FOLD,          // 0: chunked host-buffer MSMs keep every chunk's fragments for the one reduction (no progressive folding)
   COUNT
 };

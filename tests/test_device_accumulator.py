@@ -197,25 +197,17 @@ def test_resident_crs_survives_shutdown_and_reinit(gpu):
     assert gpu.verify(crs, proof, Ss, Rs, Ts, Us, M, gpu.Rand(2)) is False
 
 
-def test_fused_accumulator_front_equals_the_separate_launches(gpu, oracle):
+def test_fused_accumulator_front_at_every_pool_size(gpu, oracle):
     """Round 5: a small device accumulation runs the loose bases' conversion, the slot scalars and the recoding as
-    ONE launch (k_dacc_front); knob FRONT = 0 keeps the four separate operations.  Same exported base -> scalar
-    map, bit for bit, same decisions (honest and swapped instance), with the slot scalars staged through LDS
-    either way; n = 16 has a pool of a few dozen elements, n = 256 the verifier's ~1,000."""
+    ONE launch (k_dacc_front), the slot scalars staged through LDS; accumulations beyond 16,384 bases (the batch
+    verifiers' groups) keep the four separate operations.  (Round 6: the knob that forced the separate form on small
+    ones is gone; the fused form is held against the HOST mirror's map here, the separate one by the batch tests.)
+    n = 16 has a pool of a few dozen elements, n = 256 the verifier's ~1,000."""
     for n in (16, 64, 256):
         crs, Rs, Ss, Ts, Us, M, perm, k, rs_m = setup(gpu, n)
         proof = gpu.Proof(gpu.prove(crs, Rs, Ss, Ts, Us, M, perm, k, rs_m, gpu.Rand(42)))
-        got = {}
-        try:
-            for mode in (0, None):
-                gpu.plan_override("FRONT", mode)
-                pd, sd, ok = gpu.verify_export_accumulator(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(43), device=True)
-                pr, sr, bad = gpu.verify_export_accumulator(crs, proof, Ss, Rs, Ts, Us, M, gpu.Rand(43), device=True)
-                assert ok and not bad, (n, mode)
-                assert gpu.verify_proof(crs, proof, Rs, Ss, Ts, Us, M, gpu.Rand(44)) is True
-                assert gpu.verify_proof(crs, proof, Ss, Rs, Ts, Us, M, gpu.Rand(44)) is False
-                got[mode] = (pd.copy(), sd.copy(), pr.copy(), sr.copy())
-        finally:
-            gpu.plan_override("FRONT", None)
-        for a, b in zip(got[0], got[None]):
-            assert (a == b).all(), n
+        for inst, want in (((Rs, Ss), True), ((Ss, Rs), False)):
+            pm, sm, ok_m = gpu.verify_export_accumulator(crs, proof, inst[0], inst[1], Ts, Us, M, gpu.Rand(43), device=False)
+            pd, sd, ok_d = gpu.verify_export_accumulator(crs, proof, inst[0], inst[1], Ts, Us, M, gpu.Rand(43), device=True)
+            assert ok_m is want and ok_d is want, (n, want)
+            assert as_map(oracle, pm, sm) == as_map(oracle, pd, sd), (n, want)

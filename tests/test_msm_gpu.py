@@ -1070,12 +1070,13 @@ def test_bases_unchanged_flag_keeps_a_converted_copy(gpu, oracle, coracle):
     gpu.msm_forget_bases(d_pts.data_ptr())
 
 
-def test_bucket_slot_scans_agree(gpu, oracle, coracle):
-    """The builds of the bucket-slot scan (knob SCAN: six launches, k_scan_fused, round 5's k_scan_one -- one
-    block, slots read once, wave-shuffle block scans -- and k_scan_chain -- one launch at any size, tile sums handed
-    down a chain; 3 = everywhere, 4 = wherever k_scan_one does not apply) give the same MSM at sizes on both
-    sides of their limits (8,192 / 32,768 slots, one tile / many tiles of the chain), for a batch, for pipelined
-    calls that reuse a slot's chain words under new epochs, and with a bucket that takes the large-bucket queue."""
+def test_bucket_slot_scans_at_every_size(gpu, oracle, coracle):
+    """The builds of the bucket-slot scan -- k_scan_one (one block, slots read once, wave-shuffle block scans: synchronous
+    calls up to 32,768 slots), k_scan_chain (one launch at any size, tile sums handed down a chain: beyond that, and
+    every pipelined or chunked call) and the six-launch multi-block form (L = 1 only) -- each reached the way a caller
+    reaches it, against the closed form: sizes on both sides of 32,768 slots (one tile / many tiles of the chain), a
+    batch, pipelined calls that reuse a slot's chain words under new epochs, window ranges, one position per lane,
+    and a bucket that takes the large-bucket queue.  (Round 6: the knob that forced a build, and k_scan_fused, are gone.)"""
     import torch
     k, q = oracle.Rand(1).get_frs(2)
     nmax = 1 << 17
@@ -1083,58 +1084,44 @@ def test_bucket_slot_scans_agree(gpu, oracle, coracle):
     gpu.synth_points_walk_device(k, q, nmax, d_pts.data_ptr())
     sc = rand_scalars(np.random.default_rng(8), nmax, oracle)
     d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    for n, c in ((9, 0), (300, 0), (1268, 0), (4096, 0), (40000, 11), (65536, 0), (nmax, 14), (nmax, 16)):
+        exp = _walk_expected(oracle, coracle, k, q, sc[:n])
+        assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c) == exp).all(), (n, c)   # k_scan_one or the chain, by slot count
+        assert (gpu.msm_wait(gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c)) == exp).all(), (n, c)   # the chain
+    pts = d_pts[:6000].cpu().numpy().view(np.uint64)
+    offs = [0, 100, 100, 2600, 6000]
+    got = gpu.msm_g1_batch(pts, sc[:6000], offs)
+    for j in (0, 2, 3):
+        assert (got[j] == coracle.msm_pippenger(pts[offs[j]:offs[j + 1]], sc[offs[j]:offs[j + 1]], threads=4)).all(), j
+    # pipelined calls (several in flight, slots and their chain words reused) and window ranges
+    n = 1 << 16
+    exp = _walk_expected(oracle, coracle, k, q, sc[:n])
+    for _ in range(3):
+        ts = [gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n) for _ in range(5)]
+        for t in ts:
+            assert (gpu.msm_wait(t) == exp).all()
+    W = gpu.num_windows(n)
+    parts = []
+    for w0 in range(0, W, 5):   # at most eight calls can be in flight
+        ts = [gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n, 0, w, w + 1) for w in range(w0, min(W, w0 + 5))]
+        parts += [gpu.msm_wait(t) for t in ts]
+    assert (gpu.g1_sum(np.stack(parts)) == exp).all()
+    # one position per accumulate lane (knob SEG_LEN = 1): the one-launch scans divide by L with a multiply that needs
+    # L >= 2, so the plan takes the six launches
+    gpu.plan_override("SEG_LEN", 1)
     try:
-        for n, c in ((9, 0), (300, 0), (1268, 0), (4096, 0), (40000, 11), (65536, 0), (nmax, 14), (nmax, 16)):
-            exp = _walk_expected(oracle, coracle, k, q, sc[:n])
-            for mode in (0, 1, 2, 3, 4, -1):
-                gpu.plan_override("SCAN", mode)
-                assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n, window_bits=c) == exp).all(), (n, c, mode)
-        pts = d_pts[:6000].cpu().numpy().view(np.uint64)
-        offs = [0, 100, 100, 2600, 6000]
-        ref = None
-        for mode in (0, 1, 2, 3, 4, -1):
-            gpu.plan_override("SCAN", mode)
-            got = gpu.msm_g1_batch(pts, sc[:6000], offs)
-            ref = got if ref is None else ref
-            assert (got == ref).all(), mode
-        assert (ref[3] == coracle.msm_pippenger(pts[2600:6000], sc[2600:6000], threads=4)).all()
-        # pipelined calls (several in flight, slots and their chain words reused) and window ranges
-        for mode in (3, 4):
-            gpu.plan_override("SCAN", mode)
-            n = 1 << 16
-            exp = _walk_expected(oracle, coracle, k, q, sc[:n])
-            for _ in range(3):
-                ts = [gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n) for _ in range(5)]
-                for t in ts:
-                    assert (gpu.msm_wait(t) == exp).all(), mode
-            W = gpu.num_windows(n)
-            parts = []
-            for w0 in range(0, W, 5):   # at most eight calls can be in flight
-                ts = [gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), n, 0, w, w + 1) for w in range(w0, min(W, w0 + 5))]
-                parts += [gpu.msm_wait(t) for t in ts]
-            assert (gpu.g1_sum(np.stack(parts)) == exp).all(), mode
-        # one position per accumulate lane (knob SEG_LEN = 1): the one-launch scans divide by L with a multiply that needs
-        # L >= 2, so the plan goes back to the six launches whatever SCAN asks for
-        gpu.plan_override("SEG_LEN", 1)
-        try:
-            exp = _walk_expected(oracle, coracle, k, q, sc[:3000])
-            for mode in (3, 2, -1):
-                gpu.plan_override("SCAN", mode)
-                assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), 3000) == exp).all(), mode
-        finally:
-            gpu.plan_override("SEG_LEN", -1)
-        # every scalar the same: one bucket per window holds all the terms and goes through the queue of large buckets,
-        # which the chain's first tile clears and the others append to
-        same = np.repeat(sc[:1], 1 << 16, axis=0)
-        d_same = torch.from_numpy(same.view(np.int64)).to("cuda:0")
-        ref = None
-        for mode in (0, 3):
-            gpu.plan_override("SCAN", mode)
-            got = gpu.msm_g1_device(d_pts.data_ptr(), d_same.data_ptr(), 1 << 16)
-            ref = got if ref is None else ref
-            assert (got == ref).all(), mode
+        exp = _walk_expected(oracle, coracle, k, q, sc[:3000])
+        assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), 3000) == exp).all()
+        assert (gpu.msm_wait(gpu.msm_g1_device_submit(d_pts.data_ptr(), d_sc.data_ptr(), 3000)) == exp).all()
     finally:
-        gpu.plan_override("SCAN", -1)
+        gpu.plan_override("SEG_LEN", -1)
+    # every scalar the same: one bucket per window holds all the terms and goes through the queue of large buckets,
+    # which the chain's first tile clears and the others append to
+    same = np.repeat(sc[:1], 1 << 16, axis=0)
+    d_same = torch.from_numpy(same.view(np.int64)).to("cuda:0")
+    exp = _walk_expected(oracle, coracle, k, q, same)
+    assert (gpu.msm_g1_device(d_pts.data_ptr(), d_same.data_ptr(), 1 << 16) == exp).all()
+    assert (gpu.msm_wait(gpu.msm_g1_device_submit(d_pts.data_ptr(), d_same.data_ptr(), 1 << 16)) == exp).all()
 
 
 def test_concurrent_host_buffer_calls(gpu, oracle, coracle):
