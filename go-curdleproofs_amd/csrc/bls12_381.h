@@ -1,6 +1,6 @@
 // BLS12-381 base-field / scalar-field / G1 arithmetic on 32-bit limbs.
 //
-// One header, two consumers: the gfx950 kernels (msm_kernels.hip) and the host
+// One header, two consumers: the gfx950 kernels (msm_*_kernels.hip) and the host
 // side of libcurdlemsm.so (window combine, Jacobian normalisation, the
 // msmaccumulator mirror).  It replaces what the reference gets from the
 // un-vendored gnark-crypto v0.11.0 (/root/reference/go.mod:6): fp.Element,

@@ -1,7 +1,7 @@
 // Evaluation of the device accumulator's scalar slots (include/curdle_msm.h "Accumulator on the device";
 // msmaccumulator/msmaccumulator.go:38-43 with the x vectors of innerproductargument.go:223-234 and
 // samemultiscalarargument.go:267-277 described instead of computed on the host).  Shared by k_dacc_scalars
-// (dacc_kernels.hip) and k_dacc_front (msm_kernels.hip: the same evaluation feeding the digit recoding directly).
+// (dacc_kernels.hip) and k_dacc_front (msm_sort_kernels.hip: the same evaluation feeding the digit recoding directly).
 //
 // Round 5: a block first stages the pool (the checks' Fr constants) and the check descriptions in LDS when they fit; every
 // lane used to read them from global memory inside its loops -- a dozen dependent loads per check and slot, the same

@@ -21,7 +21,7 @@
 
 namespace curdle {
 
-// The evaluation itself lives in dacc_eval.h (shared with k_dacc_front, msm_kernels.hip).
+// The evaluation itself lives in dacc_eval.h (shared with k_dacc_front, msm_sort_kernels.hip).
 static constexpr u32 kDaccLdsBudget = 120 * 1024;  // of the CU's 160 KiB (opt-in beyond 64 KiB, per device)
 
 template <bool LDS>

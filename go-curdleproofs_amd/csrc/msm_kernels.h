@@ -1,4 +1,4 @@
-// Host-callable launchers of the gfx950 MSM kernels (msm_kernels.hip).
+// Host-callable launchers of the gfx950 MSM kernels (msm_sort_kernels.hip, msm_accumulate_kernel.hip, msm_reduce_kernels.hip, msm_misc_kernels.hip).
 // Internal to libcurdlemsm.so; the public surface is include/curdle_msm.h.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -63,7 +63,7 @@ struct MsmPlan {
 static constexpr size_t kX28Bytes = 224;
 static constexpr size_t kA28Bytes = 128;  // stride of the internal point array: a 112-byte d28::A28 padded to one 128-byte line
 
-// Device workspace, laid out by msm_api.hip.  nb = k * NB bucket slots.
+// Device workspace, laid out by msm_enqueue.hip.  nb = k * NB bucket slots.
 struct MsmWorkspace {
   const uint32_t* offsets;  // [k + 1]   first pair of each MSM (device)
   uint32_t* counts;   // [nb]      points per bucket
@@ -98,7 +98,7 @@ size_t scan_chain_bytes();               // bytes behind MsmWorkspace::chain (th
 
 // The fragment lists the bucket reduction folds in: one per CHUNK of an MSM whose pairs were
 // accumulated in several pieces over the same plan (host-buffer calls: a piece is accumulated
-// while the next one crosses PCIe; msm_api.hip run_host_chunked) -- the pieces share the bucket
+// while the next one crosses PCIe; msm_host_chunks.hip run_host_chunked) -- the pieces share the bucket
 // slots, so their fragments meet in ONE reduction instead of one reduction per piece.
 static constexpr int kMaxFragSources = 4;
 struct FragSources {
@@ -109,7 +109,7 @@ struct FragSources {
 };
 
 // Words of MsmWorkspace::ccur for nw windows.  Its tail (the coarse counts) must be ZERO before a call's first launch;
-// the kernels leave it zero again (msm_api.hip clears the buffer when it is made and after a failed call).
+// the kernels leave it zero again (msm_enqueue.hip clears the buffer when it is made and after a failed call).
 size_t coarse_words(uint32_t nw);
 
 // The device accumulator's job as the fused front of a small call sees it (launch_dacc_front): device pointers into the

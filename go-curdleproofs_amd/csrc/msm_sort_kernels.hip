@@ -32,39 +32,14 @@
 // by k_combine (one quad per MSM) for batches.
 //
 // This is 381-bit integer arithmetic: no MFMA, no floating point.  Wave size 64.
-#include <hip/hip_runtime.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <atomic>
-
-#include "msm_kernels.h"
-
-#include "fp28.h"
-#include "quad28.h"
+//
+// THIS FILE: the sort -- conversion, recoding, bucket counts, the bucket-slot scans, the scatter -- and its launchers.
+// The accumulation is msm_accumulate_kernel.hip, everything behind it msm_reduce_kernels.hip, the synthetic bases and
+// the self-test msm_misc_kernels.hip (one translation unit until round 6).
+#include "msm_kernels_common.h"
 #include "dacc_eval.h"
 
 namespace curdle {
-
-using d28::A28;
-using d28::F28;
-using d28::X28;
-
-static constexpr int kBlock = 256;
-// s_getreg_b32 operands: (size - 1) << 11 | offset << 6 | register id.  HW_ID (4): wave slot 3:0, SIMD 5:4, CU 11:8,
-// SH 12, SE 15:13; XCC_ID (20): the XCD in 3:0.
-static constexpr int kGetregHwId = ((32 - 1) << 11) | 4;
-static constexpr int kGetregXccId = ((32 - 1) << 11) | 20;
-// s_setprio takes an immediate
-__device__ __forceinline__ void set_wave_prio(u32 v) {
-  if (v == 1) __builtin_amdgcn_s_setprio(1);
-  else if (v == 2) __builtin_amdgcn_s_setprio(2);
-  else if (v == 3) __builtin_amdgcn_s_setprio(3);
-}
-
-// p - 2 (Fermat inversion exponent), 32-bit words
-__constant__ u32 kPminus2[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
-                                 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
 
 // the two-level sort of single large MSMs (further down): bins of 2^kFineBits buckets
 static constexpr int kFineBits = 7;
@@ -789,7 +764,7 @@ __global__ void __launch_bounds__(kScanThreads)
 static constexpr u32 kChainThreads = 256;
 static constexpr int kChainPer = 16;
 static constexpr u32 kChainTile = kChainThreads * kChainPer;
-static constexpr u32 kChainMaxTiles = 1024;  // 4,194,304 slots: what one pass of a batch may hold (msm_api.hip kMaxSlotsPerPass)
+static constexpr u32 kChainMaxTiles = 1024;  // 4,194,304 slots: what one pass of a batch may hold (msm_internal.h kMaxSlotsPerPass)
 static constexpr u32 kChainSpinLimit = 1u << 20;
 __device__ __forceinline__ u64 chain_word(u32 epoch, u32 state, u32 value) {
   return ((u64)epoch << 34) | ((u64)state << 32) | (u64)value;
@@ -836,27 +811,6 @@ __device__ __forceinline__ u32 chain_lookback(u64* __restrict__ words, u32 my, u
   }
   if (lane == 0) __hip_atomic_store(&words[my], chain_word(epoch, 2u, prefix + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   return prefix;
-}
-__device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* sh /* [4] */, u32& total) {
-  const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  u32 inc = v;
-#pragma unroll
-  for (u32 off = 1; off < 64; off <<= 1) {
-    const u32 t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  __syncthreads();  // sh may still be read from the previous call
-  if (lane == 63) sh[wv] = inc;
-  __syncthreads();
-  u32 before = 0, all = 0;
-#pragma unroll
-  for (u32 k = 0; k < kChainThreads / 64; k++) {
-    const u32 t = sh[k];
-    if (k < wv) before += t;
-    all += t;
-  }
-  total = all;
-  return before + inc - v;
 }
 struct ScanChain {
   unsigned long long* words;  // [2][kChainMaxTiles]
@@ -971,15 +925,6 @@ __global__ void __launch_bounds__(kChainThreads)
 
 // Phase 0: gnark points (R = 2^384, saturated limbs) -> internal form (fp28.h),
 // once per MSM: one Montgomery product per coordinate.  (0,0) stays (0,0).
-// element i of the internal point array (kA28Bytes apart: one 128-byte line per point, so a
-// gathered point never straddles two lines)
-__device__ __forceinline__ A28* a28_at(A28* base, size_t i) {
-  return reinterpret_cast<A28*>(reinterpret_cast<char*>(base) + i * kA28Bytes);
-}
-__device__ __forceinline__ const A28* a28_at(const A28* base, size_t i) {
-  return reinterpret_cast<const A28*>(reinterpret_cast<const char*>(base) + i * kA28Bytes);
-}
-
 // 128 points per block.  Every lane converts one base; the two 128-byte records it produces go through
 // LDS so that the block writes its 32 KiB of output as whole lines, 1 KiB per wave instruction (written
 // straight from the lanes, a store instruction touched 64 lines, 16 bytes of each).  Chunk k of lane t
@@ -1086,824 +1031,9 @@ __global__ void __launch_bounds__(kBlock)
   recode_scalar<GLV, false>(s, i, p, digits, &none);
 }
 
-// Sum of `acc` over aligned groups of G lanes (G a power of two <= 256) of a
-// 256-thread block, by wave shuffles; the result is valid in the first lane of each
-// group.  No LDS tile (a 56 KiB one would keep the next MSM's LDS-histogram blocks
-// off the CU while this latency-bound kernel runs): only 4 x 224 B when G = 256.
-__device__ __forceinline__ void shfl_down_x28(X28& dst, const X28& src, u32 off) {
-  const u32* s = reinterpret_cast<const u32*>(&src);
-  u32* d = reinterpret_cast<u32*>(&dst);
-#pragma unroll
-  for (int i = 0; i < 56; i++) d[i] = __shfl_down(s[i], off, 64);
-}
-__device__ __forceinline__ void group_sum(X28& acc, u32 G, X28* wave_partials /* LDS, 4 entries */) {
-  const u32 tid = threadIdx.x;
-  const u32 lane = tid & 63u;
-  const u32 gw = G < 64u ? G : 64u;
-  X28 b;
-  for (u32 off = gw / 2; off > 0; off >>= 1) {
-    shfl_down_x28(b, acc, off);
-    if ((lane & (gw - 1)) >= off) d28::set_inf(b);  // lanes outside the live half contribute nothing
-    d28::add(acc, b);
-  }
-  if (G > 64u) {  // G = 128 or 256: combine the waves' results
-    if (lane == 0) wave_partials[tid >> 6] = acc;
-    __syncthreads();
-    if ((tid & (G - 1)) == 0) {
-      for (u32 k = 1; k < G / 64u; k++) {
-        b = wave_partials[(tid >> 6) + k];
-        d28::add(acc, b);
-      }
-    }
-  }
-}
-
-// Balanced bucket accumulation.  Lane t owns L consecutive positions of the
-// bucket-sorted point list, whatever buckets they belong to, so every lane of
-// every wave does the same number of mixed additions however skewed the scalars
-// are (all-equal scalars, short top window).  When the list moves on to the
-// next bucket the lane stores its running sum as a fragment of the finished
-// bucket and starts again from infinity.  Fragments of one bucket are
-// contiguous: slot = foff[bucket] + (t - start[bucket] / L).
-#ifdef CURDLE_TRACE_WAVES
-// Experiment build only: start / end (100 MHz wall clock) and hardware id of every wave of the LAST accumulate launch.
-__device__ unsigned long long g_wave_trace[4 * 8192];
-__device__ unsigned long long g_wave_clk[2 * 8192];  // s_memtime (shader clock) at the same two points
-hipError_t debug_read_wave_trace(unsigned long long* out, size_t words) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), words * 8 < sizeof(g_wave_trace) ? words * 8 : sizeof(g_wave_trace));
-}
-hipError_t debug_read_wave_clk(unsigned long long* out, size_t words) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_clk), words * 8 < sizeof(g_wave_clk) ? words * 8 : sizeof(g_wave_clk));
-}
-#endif
-template <int WAVES>
-__global__ void __launch_bounds__(kBlock, WAVES)
-    k_accumulate(const A28* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ starts,
-                 const u32* __restrict__ foff, X28* __restrict__ frags, u32 nb, u32 L, u32 set_points, u32 frag_stride,
-                 u32 prio_shift) {
-  const u32 t = blockIdx.x * kBlock + threadIdx.x;
-  // base set blockIdx.y of a shared-scalar call: its own points and fragments, the one sorted list
-  points = a28_at(points, (size_t)blockIdx.y * set_points);
-  frags += (size_t)blockIdx.y * frag_stride;
-  const u32 total = starts[nb];
-  u32 pos = t * L;
-#ifdef CURDLE_TRACE_WAVES
-  const u32 wv = t >> 6;
-  if ((t & 63u) == 0 && wv < 8192u) {
-    g_wave_trace[4 * wv] = wall_clock64();
-    g_wave_clk[2 * wv] = __builtin_amdgcn_s_memtime();
-    g_wave_trace[4 * wv + 2] = __builtin_amdgcn_s_getreg(kGetregHwId);
-    g_wave_trace[4 * wv + 3] = __builtin_amdgcn_s_getreg(kGetregXccId);
-  }
-#endif
-  if (pos >= total) return;
-  const u32 end = min(pos + L, total);
-  // bucket containing `pos`: first index with starts[idx] > pos, minus one
-  u32 lo = 0, hi = nb;
-  while (lo < hi) {
-    u32 mid = (lo + hi) >> 1;
-    if (starts[mid] > pos) hi = mid;
-    else lo = mid + 1;
-  }
-  u32 g = lo - 1;
-  u32 gend = starts[lo];
-  X28 acc;
-  d28::set_inf(acc);
-  // The lane's indices are read eight at a time into a register queue: between two of its
-  // iterations the XCD's other lanes gather megabytes of points through the 4 MiB L2, so a
-  // 4-byte read per iteration fetched a whole 128-byte line of `sorted` from memory every time
-  // (2.1 GB of the launch's 4.3 GB, profiles/r02_fetch_calibration.txt); eight reads issued
-  // back to back share one line fetch.  The gather of position pos + 1 is issued before the
-  // addition of position pos.
-  u32 q[8];
-  auto refill = [&](u32 from) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = from + j < end ? sorted[from + j] : 0u;
-  };
-  refill(pos);
-  u32 queued = 0;
-  u32 e_next = q[0];
-  A28 pt_next;
-  d28::load(pt_next, a28_at(points, e_next & 0x7fffffffu));
-  const u32 slot = __builtin_amdgcn_s_getreg(kGetregHwId) & 1u;  // this wave's slot on its SIMD, low bit
-  for (; pos < end; pos++) {
-    if (prio_shift) {
-      if ((((u32)wall_clock64() >> prio_shift) ^ slot) & 1u)
-        __builtin_amdgcn_s_setprio(3);
-      else
-        __builtin_amdgcn_s_setprio(0);
-    }
-    const u32 e = e_next;
-    A28 pt = pt_next;
-    if (++queued == 8) {
-      refill(pos + 1);
-      queued = 0;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 7; j++) q[j] = q[j + 1];
-    }
-    if (pos + 1 < end) {
-      e_next = q[0];
-      d28::load(pt_next, a28_at(points, e_next & 0x7fffffffu));
-    }
-    if (pos == gend) {
-      d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
-      d28::set_inf(acc);
-      g++;
-      gend = starts[g + 1];
-      if (gend == pos) {
-        // An EMPTY bucket.  Uniform scalars leave next to none, skewed ones leave runs of thousands (all-equal scalars: two
-        // occupied buckets per window; a hot window: one) and a lane that walked such a run one dependent load at a time held
-        // its whole wave back -- 32,768 loads at N = 2^20: the launch took 4.0 ms against 2.25 (profiles/r06_adversarial.json).
-        // Bisect for the first slot that starts beyond pos, as at the lane's start.
-        u32 l2 = g + 2, h2 = nb;
-        while (l2 < h2) {
-          const u32 mid = (l2 + h2) >> 1;
-          if (starts[mid] > pos) h2 = mid;
-          else l2 = mid + 1;
-        }
-        g = l2 - 1;
-        gend = starts[l2];
-      }
-    }
-    if (d28::affine_is_inf(pt)) continue;  // (0,0) = infinity (curdleproof.go:23)
-    if (e >> 31) {
-      F28 z;
-      d28::set_zero(z);
-      d28::sub_raw<4>(pt.y, z, pt.y);  // 4p - y
-    }
-    d28::madd<true>(acc, pt.x, pt.y);
-  }
-  d28::store(&frags[foff[g] + (t - starts[g] / L)], acc);
-#ifdef CURDLE_TRACE_WAVES
-  if ((t & 63u) == 0 && wv < 8192u) {
-    g_wave_trace[4 * wv + 1] = wall_clock64();
-    g_wave_clk[2 * wv + 1] = __builtin_amdgcn_s_memtime();
-  }
-#endif
-}
-
-// (k_merge_large: behind group_sum_quad, below)
-
-// ---------------------------------------------------------------------------
-// The latency-bound kernels (quad28.h): four adjacent lanes own ONE point between them
-// (X | Y | ZZ | ZZZ), so a 256-thread block carries 64 logical lanes ("quads") and a point
-// addition is 4 product steps instead of 14.  (A one-lane-per-segment build of the bucket
-// reduction existed until round 2: 256 VGPRs with 76 spilled, and slower wherever it was
-// measured against quads with the right segment length -- N = 2^20 pipelined 3.09 vs 3.04
-// ms, 1,024 x 628-pair batch 8.09 vs 7.67 ms, profiles/r02_quad_everywhere.txt.)
-// ---------------------------------------------------------------------------
-// Sum over aligned groups of G quads (G a power of two <= 64); valid in the first quad of
-// each group.  wave_partials: LDS, [4 waves][4 coordinates].
-__device__ __forceinline__ void group_sum_quad(F28& acc, u32 G, F28 (*wave_partials)[4]) {
-  const u32 tid = threadIdx.x;
-  const u32 ll = (tid & 63u) >> 2;       // quad inside the wave, 0..15
-  const u32 gw = G < 16u ? G : 16u;
-  F28 b;
-  for (u32 off = gw / 2; off > 0; off >>= 1) {
-    q28::shfl_down(b, acc, off);
-    if ((ll & (gw - 1)) >= off) q28::set_inf(b);  // quads outside the live half contribute nothing
-    q28::add(acc, b);
-  }
-  if (G > 16u) {  // G = 32 or 64: combine the waves' results
-    if ((tid & 63u) < 4u) wave_partials[tid >> 6][tid & 3u] = acc;
-    __syncthreads();
-    const u32 lt = tid >> 2;             // quad inside the block, 0..63
-    if ((lt & (G - 1)) == 0) {           // whole quads take this branch
-      for (u32 k = 1; k < G / 16u; k++) {
-        b = wave_partials[(tid >> 6) + k][tid & 3u];
-        q28::add(acc, b);
-      }
-    }
-  }
-}
-
-// Buckets with more than max_small fragments (queued by the scan kernels: skewed scalars -- all-equal ones, a few
-// distinct values, one hot window; uniform scalars queue nothing and every block leaves at once): their fragments
-// are summed into the bucket's FIRST fragment slot, and the reduce kernels read ONE fragment for such a bucket
-// (fragcnt itself stays as scanned: base sets of a shared-scalar call share it).
-// Round 6.  Until now: one block per queued bucket, every thread a chain of m / 256 whole-point additions (14 product
-// steps each) and a 9-level tree behind it -- all-equal scalars at N = 2^20 queue 16 buckets of 8,192 fragments: 64
-// waves on a chip of 1,024 SIMDs for 0.9 ms, a third of the accumulation (profiles/r06_adversarial.json, "before").
-// Now the unit of work is a CHUNK of 16 S consecutive fragments of one bucket, taken by one wave as 16 quads
-// (quad28.h: an addition is 4 product steps): a quad adds S fragments, the wave's 16 sums meet by shuffles, and the
-// chunk's sum replaces the chunk's first fragment.  Chunks of all queued buckets are numbered through (a prefix sum
-// over the queue, redone by every block in LDS: the queue is short) and dealt to the launch's waves round robin, so
-// 16 buckets of 8,192 fragments are 1,024 waves at once.  The wave that finishes a bucket's LAST chunk (a counter per
-// queue entry, left at zero for the next call) adds the chunk sums the same way into slot 0.  S grows with the
-// bucket (2 up to 1,024 fragments, 4 up to 4,096, 8 up to 16,384, 16 beyond) so that the two serial parts stay
-// balanced: a chain of 4 + 4 + 2 + 4 quad additions for 2,048 fragments, 8 + 4 + 4 + 4 for 8,192, instead of
-// 32 + 9 whole ones.
-static constexpr u32 kMergeTile = 1024;  // queue entries per pass over the queue
-__host__ __device__ inline u32 merge_chunk_shift(u32 m) {  // log2 of the chunk a bucket of m fragments is cut into
-  return m <= 1024u ? 5u : m <= 4096u ? 6u : m <= 16384u ? 7u : 8u;
-}
-__global__ void __launch_bounds__(kBlock, 2)
-    k_merge_large(const u32* __restrict__ large, const u32* __restrict__ nlarge, const u32* __restrict__ foff,
-                  const u32* __restrict__ fragcnt, X28* __restrict__ frags, u32* __restrict__ done, u32 max_large,
-                  u32 frag_stride, u32 prio) {
-  __shared__ u32 pre[kMergeTile], gq[kMergeTile], mq[kMergeTile];
-  __shared__ u32 sh_scan[kBlock / 64];
-  const u32 nl = min(*nlarge, max_large);
-  if (nl == 0) return;  // the usual case
-  set_wave_prio(prio);
-  const u32 tid = threadIdx.x;
-  const u32 lane = tid & 63u, qd = lane >> 2;  // quad inside the wave
-  frags += (size_t)blockIdx.y * frag_stride;
-  done += (size_t)blockIdx.y * max_large;
-  const u32 nwaves = gridDim.x * (kBlock / 64), mywave = blockIdx.x * (kBlock / 64) + (tid >> 6);
-  // More chunks than the launch has waves (hundreds of buckets of a hundred fragments each: 64 distinct scalar values)
-  // would go round several times at the small buckets' chunk size: every bucket's chunks are doubled (up to 256
-  // fragments) until one round takes them all -- 5,120 chunks of 32 on 1,024 waves took 0.30 ms, 2,560 of 64 on 3,072 take 0.1.
-  u32 bump = 0;
-  {
-    u32 mine = 0;
-    for (u32 x = tid; x < nl; x += kBlock) {
-      const u32 m = fragcnt[large[x]], sh = merge_chunk_shift(m);
-      mine += (m + (1u << sh) - 1u) >> sh;
-    }
-    u32 total0;
-    (void)block_exclusive_scan_256(mine, sh_scan, total0);
-    while (bump < 3u && (total0 >> bump) > nwaves) bump++;
-  }
-  auto chunk_shift = [&](u32 m) { return min(merge_chunk_shift(m) + bump, 8u); };
-  for (u32 t0 = 0; t0 < nl; t0 += kMergeTile) {  // block-uniform trip count
-    const u32 cnt = min(kMergeTile, nl - t0);
-    __syncthreads();  // the pass before is done with the tables
-    u32 nch[kMergeTile / kBlock], sum = 0;
-#pragma unroll
-    for (u32 k = 0; k < kMergeTile / kBlock; k++) {
-      const u32 idx = tid * (kMergeTile / kBlock) + k;
-      nch[k] = 0;
-      if (idx < cnt) {
-        const u32 g = large[t0 + idx], m = fragcnt[g];
-        gq[idx] = g;
-        mq[idx] = m;
-        const u32 sh = chunk_shift(m);
-        nch[k] = (m + (1u << sh) - 1u) >> sh;
-      }
-      sum += nch[k];
-    }
-    u32 total;
-    u32 ex = block_exclusive_scan_256(sum, sh_scan, total);
-#pragma unroll
-    for (u32 k = 0; k < kMergeTile / kBlock; k++) {
-      pre[tid * (kMergeTile / kBlock) + k] = ex;
-      ex += nch[k];
-    }
-    __syncthreads();
-    for (u32 c = mywave; c < total; c += nwaves) {  // wave-uniform from here on
-      u32 lo = 0, hi = cnt;  // the queue entry of chunk c: the last one whose first chunk is <= c
-      while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (pre[mid] > c) hi = mid;
-        else lo = mid + 1;
-      }
-      const u32 e = lo - 1;
-      const u32 m = mq[e], sh = chunk_shift(m), base = (c - pre[e]) << sh;
-      const u32 nchunks = (m + (1u << sh) - 1u) >> sh;
-      X28* f = frags + foff[gq[e]];
-      const u32 lim = min(1u << sh, m - base);
-      F28 acc, b, nxt;
-      q28::set_inf(acc);
-      u32 i = qd;  // this quad's fragments: base + qd, + 16, ...; the next one is loaded under the addition before it
-      q28::load(nxt, &f[base + (i < lim ? i : 0u)]);
-      while (i < lim) {  // quad-uniform
-        b = nxt;
-        i += 16;
-        q28::load(nxt, &f[base + (i < lim ? i : 0u)]);
-        q28::add(acc, b);
-      }
-      group_sum_quad(acc, 16u, nullptr);  // shuffles only
-      if (qd == 0) q28::store(&f[base], acc);
-      if (nchunks == 1) continue;
-      // the chunk sums of one bucket are written by waves anywhere on the chip: released here, acquired by the wave
-      // that counts the last one (agent scope: the XCDs' L2s are written back / invalidated by the fences)
-      __threadfence();
-      u32 t = 0;
-      if (lane == 0) t = atomicAdd(&done[t0 + e], 1u);
-      t = __shfl(t, 0, 64);
-      if (t != nchunks - 1) continue;
-      __threadfence();
-      q28::set_inf(acc);
-      i = qd;
-      q28::load(nxt, &f[(size_t)(i < nchunks ? i : 0u) << sh]);
-      while (i < nchunks) {
-        b = nxt;
-        i += 16;
-        q28::load(nxt, &f[(size_t)(i < nchunks ? i : 0u) << sh]);
-        q28::add(acc, b);
-      }
-      group_sum_quad(acc, 16u, nullptr);
-      if (qd == 0) q28::store(&f[0], acc);
-      if (lane == 0) done[t0 + e] = 0;  // as the next call expects it
-    }
-  }
-}
-
-// One quad per segment of `seg` consecutive buckets.  The running-sum recurrence is run as
-// ONE addition per step -- the next fragment of the current bucket into the running sum,
-// or, when the bucket is exhausted, the running sum into the segment sum -- so quads whose
-// buckets have different fragment counts do not wait for each other bucket by bucket, and
-// the kernel has a single copy of the addition in its main loop.
-__global__ void __launch_bounds__(kBlock, 2)
-    k_bucket_reduce_quad(FragSources src, X28* __restrict__ partials, MsmPlan p) {
-  __shared__ F28 sh[4][4];
-  const u32 tid = threadIdx.x;
-  const u32 q = blockIdx.x * (kBlock / 4) + (tid >> 2);  // logical lane
-  const bool live = q < p.kr * p.NS;
-  F28 acc, run, b;
-  q28::set_inf(acc);
-  q28::set_inf(run);
-  if (live) {
-    const u32 jr = q / p.NS;            // result index = set * k + j
-    const u32 r = q - jr * p.NS;
-    const u32 set = jr / p.k, j = jr - set * p.k;
-    const size_t set_off = (size_t)set * p.frag_stride;  // base sets of a shared-scalar call: one source only
-    int w = p.win_begin;
-    while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
-    const u32 lo = (r - p.base[w] / p.seg) * p.seg;
-    const u32 g0 = j * p.NB + p.base[w] + lo;
-    int u = (int)p.seg - 1;
-    // the bucket's fragments: those of source 0, then source 1, ... (one source but for chunked calls)
-    u32 s = 0, m = 0, k = 0;
-    const X28* f = nullptr;
-    auto open = [&]() {
-      m = src.fragcnt[s][g0 + u];
-      if (m > p.max_small) m = 1;  // pre-merged by k_merge_large into its first slot
-      f = reinterpret_cast<const X28*>(src.frags[s]) + set_off + src.foff[s][g0 + u];
-      k = 0;
-    };
-    open();
-    while (u >= 0) {
-      while (k >= m && s + 1 < src.n) {  // this source has nothing (more) for the bucket: the next one
-        s++;
-        open();
-      }
-      const bool take = k < m;  // uniform over the quad
-      if (take) {
-        q28::load(b, &f[k]);
-        k++;
-      }
-      F28 dst, from;
-      q28::sel(dst, take, run, acc);
-      q28::sel(from, take, b, run);
-      q28::add(dst, from);
-      q28::sel(run, take, dst, run);
-      q28::sel(acc, take, acc, dst);
-      if (!take) {
-        u--;
-        s = 0;
-        if (u >= 0) open();
-      }
-    }
-    // lo * (segment total): every quad of the window runs the same number of steps
-    const int top = 31 - __clz((int)(p.nbkt[w] | 1u));
-    q28::mul_small(b, run, lo, top);
-    q28::add(acc, b);
-  }
-  if (p.G > 1) group_sum_quad(acc, p.G, sh);
-  if (((tid >> 2) & (p.G - 1)) == 0 && live) q28::store(&partials[q / p.G], acc);
-}
-
-// ---------------------------------------------------------------------------
-// The bucket reduction WITHOUT a scalar multiple (single MSMs; MsmPlan::reduce_bits).
-//
-// k_bucket_reduce_quad above gives every quad its segment's lo * (segment total) by a 15-bit
-// double-and-add: 105 product steps of the ~290 in a quad's chain at N = 2^20, as much work again
-// as the running sums, and a 6-level tree plus a window-sum launch behind it (0.42 ms
-// for 5 % of the accumulation's additions).  Here nothing is multiplied on the GPU.  With segment
-// totals T_j and segment running sums S_j (j the segment's index inside its window),
-//
-//     sum_b (b + 1) B_b  =  sum_j S_j  +  seg * sum_j j T_j ,      sum_j j T_j = sum_i 2^i X_i ,
-//     X_i = sum of T_j over the j whose bit i is set,
-//
-// and ALL the X_i fall out of ONE butterfly over the T_j at the cost of a plain tree sum: at the level
-// with offset o every quad whose index has bit o clear adds the value of the quad o further up; at
-// the end the quad with index 0 holds the total and the quad with index 2^i holds X_i.  The quads
-// whose bit o is SET are idle in that level, so they carry the plain sum of the S_j towards the
-// group's last quad in the same instruction stream: one addition per level for both trees.
-// A window leaves the GPU as <= 14 points with bit positions (sum S at 0, X_i at log2(seg) + i) and
-// the host's Horner pass over the windows -- 127 doublings it runs anyway -- takes them in like
-// window sums: ~12 additions per window at ~0.3 us each, where the GPU pays ~5 us per dependent
-// addition.  Two launches: segments -> groups of <= 16 quads (one wave, shuffles only), groups ->
-// the window's points (k_reduce_groups).
-// ---------------------------------------------------------------------------
-// S: plain sum over aligned groups of G quads (G a power of two <= 16), result in the group's LAST
-// quad.  T: the butterfly, total in the group's first quad, X_i in the quad with index 2^i.
-__device__ __forceinline__ void group_bits_and_sum(F28& S, F28& T, u32 G) {
-  const u32 idx = ((threadIdx.x & 63u) >> 2) & (G - 1);
-  for (u32 o = 1; o < G; o <<= 1) {
-    F28 up, dn, a, b;
-    q28::shfl_down(up, T, o);
-    q28::shfl_up(dn, S, o);
-    const bool is_t = (idx & o) == 0;
-    const bool is_s = (idx & (2 * o - 1)) == 2 * o - 1;
-    q28::sel(a, is_t, T, S);
-    q28::sel(b, is_t, up, dn);
-    if (!is_t && !is_s) q28::set_inf(b);  // quad-uniform
-    q28::add(a, b);
-    q28::sel(T, is_t, a, T);
-    q28::sel(S, is_t, S, a);
-  }
-}
-
-// Host-buffer MSMs accumulated in chunks (msm_api.hip run_host_chunked): a chunk's fragments are folded into
-// ONE running sum per bucket as soon as its accumulation is done -- while later chunks are still crossing
-// PCIe or being accumulated -- so that the call's single reduction, which is what remains after the last copy
-// has landed, walks one point per bucket for all the earlier chunks instead of their 1.5 fragments each.
-// One quad per bucket slot; meta[b] = b (the sums' "fragment offset"), meta[nb + b] = 1 once any chunk had a
-// fragment there: the sums are a fragment source like any other (FragSources).
-__global__ void __launch_bounds__(kBlock, 2)
-    k_fold_fragments(const X28* __restrict__ frags, const u32* __restrict__ foff, const u32* __restrict__ fragcnt,
-                     X28* __restrict__ sums, u32* __restrict__ meta, u32 nb, u32 max_small, u32 first, u32 prio) {
-  set_wave_prio(prio);
-  // (a 128-register build at priority 3, so that a wave fits beside the next chunk's two accumulate waves, and the same
-  // for the usually empty k_merge_large launch in front of it: measured, no better -- profiles/r04_host_fold.txt)
-  const u32 b = blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2);
-  if (b >= nb) return;  // whole quads leave together
-  u32 m = fragcnt[b];
-  if (m > max_small) m = 1;  // pre-merged by k_merge_large into its first slot
-  const X28* f = frags + foff[b];
-  F28 acc, x;
-  u32 any = m ? 1u : 0u;
-  if (first) {
-    q28::set_inf(acc);
-  } else {
-    q28::load(acc, &sums[b]);
-    any |= meta[nb + b];
-  }
-  for (u32 k = 0; k < m; k++) {
-    q28::load(x, &f[k]);
-    q28::add(acc, x);
-  }
-  q28::store(&sums[b], acc);
-  if (q28::role() == 0) {
-    meta[b] = b;
-    meta[nb + b] = any;
-  }
-}
-
-// One quad per segment of `seg` consecutive buckets, as in k_bucket_reduce_quad: ONE addition per
-// step, the next fragment into the running sum or the running sum into the segment sum.  The
-// fragment a step adds was loaded during the step before it, and a bucket's bookkeeping one bucket
-// ahead (source 0): the loads are off the chain.  Output per group of G quads: 2 + log2(G) points,
-// [sum S | total T | X_0 .. X_(lgG-1)].
-__global__ void __launch_bounds__(kBlock, 2)
-    k_reduce_segments(FragSources src, X28* __restrict__ groups, MsmPlan p) {
-  set_wave_prio(p.reduce_prio);
-  const u32 tid = threadIdx.x;
-  const u32 q = blockIdx.x * (kBlock / 4) + (tid >> 2);  // logical lane
-  const bool live = q < p.kr * p.NS;
-  F28 acc, run;
-  q28::set_inf(acc);
-  q28::set_inf(run);
-  if (live) {
-    const u32 jr = q / p.NS;            // result index = set * k + j
-    const u32 r = q - jr * p.NS;
-    const u32 set = jr / p.k, j = jr - set * p.k;
-    const size_t set_off = (size_t)set * p.frag_stride;
-    int w = p.win_begin;
-    while (r >= (p.base[w] + p.nbkt[w]) / p.seg) w++;
-    const u32 lo = (r - p.base[w] / p.seg) * p.seg;
-    const u32 g0 = j * p.NB + p.base[w] + lo;
-    int u = (int)p.seg - 1;
-    u32 s = 0, m = 0, k = 0;
-    const X28* f = nullptr;
-    // Round 5 (late): NO load of this loop sits under a branch.  The loop used to fetch the next fragment, and the next
-    // bucket's bookkeeping, inside its "take a fragment" / "close the bucket" branches; a load under a branch lands in
-    // registers of its own, and the copy into the loop-carried registers -- placed where the branch ends -- waited for it on
-    // the spot (s_waitcnt vmcnt(0) a dozen instructions behind the global_load: the ISA of round 4's kernel), so every step of
-    // the chain paid a memory round trip on top of its addition: ~9 us per step where the addition is ~5.7.  Now every lane
-    // issues the same loads at the same place in every step -- what the NEXT step needs, or any valid record if it needs
-    // nothing -- and they are copied into the loop's registers after the addition.
-    const X28* const safe = reinterpret_cast<const X28*>(src.frags[0]);  // a valid record for steps with nothing to fetch
-    auto set_bucket = [&](u32 cnt, u32 fo, u32 source) {  // the fragments of bucket u in `source`
-      m = cnt > p.max_small ? 1u : cnt;                   // (beyond max_small: pre-merged by k_merge_large into its first slot)
-      f = reinterpret_cast<const X28*>(src.frags[source]) + set_off + fo;
-      k = 0;
-    };
-    auto more_sources = [&]() {  // bucket u's fragments in the next source that has any (chunked host-buffer calls only)
-      while (k >= m && s + 1 < src.n) {
-        s++;
-        set_bucket(src.fragcnt[s][g0 + u], src.foff[s][g0 + u], s);
-      }
-    };
-    set_bucket(src.fragcnt[0][g0 + u], src.foff[0][g0 + u], 0);
-    more_sources();
-    // source 0's bookkeeping of the bucket BELOW the current one, fetched in every step for the step after it
-    u32 cm, cf;
-    {
-      const u32 un = u > 0 ? (u32)u - 1u : 0u;
-      cm = src.fragcnt[0][g0 + un];
-      cf = src.foff[0][g0 + un];
-    }
-    F28 nxt;
-    q28::load(nxt, k < m ? &f[k] : safe);
-    while (u >= 0) {
-      const bool take = k < m;  // uniform over the quad
-      const F28 b = nxt;
-      if (take) {
-        k++;
-        more_sources();
-      } else {
-        u--;
-        s = 0;
-        if (u >= 0) {
-          set_bucket(cm, cf, 0);
-          more_sources();
-        }
-      }
-      // the next step's fragment and the bookkeeping of the bucket below the (possibly new) current one: issued here by
-      // every lane, consumed one addition later
-      const u32 un = u > 0 ? (u32)u - 1u : 0u;
-      const u32 lm = src.fragcnt[0][g0 + un], lf = src.foff[0][g0 + un];
-      F28 ld;
-      q28::load(ld, (u >= 0 && k < m) ? &f[k] : safe);
-      F28 dst, from;
-      q28::sel(dst, take, run, acc);
-      q28::sel(from, take, b, run);
-      q28::add(dst, from);
-      q28::sel(run, take, dst, run);
-      q28::sel(acc, take, acc, dst);
-      nxt = ld;
-      cm = lm;
-      cf = lf;
-    }
-  }
-  if (p.G > 1) group_bits_and_sum(acc, run, p.G);
-  if (!live) return;  // groups are live or dead as a whole
-  const u32 idx = q & (p.G - 1);
-  X28* out = groups + (size_t)(q / p.G) * (2 + p.lgG);
-  if (idx == p.G - 1) q28::store(&out[0], acc);
-  if (idx == 0)
-    q28::store(&out[1], run);
-  else if ((idx & (idx - 1)) == 0)
-    q28::store(&out[2 + (31 - __clz((int)idx))], run);
-}
-
-// A window's output point `slot`: which bit position it carries, relative to the window's shift;
-// -1 if the window has no such point (msm_kernels.h).  Slot 0 is the sum of the segment sums, slot 1
-// the total of all buckets (bookkeeping of the levels, of no use to the host), slot 2 + i is X_i.
-__host__ __device__ inline int reduce_slot_position(const MsmPlan& p, int w, u32 slot) {
-  if (slot == 0) return 0;
-  if (slot == 1) return -1;
-  u32 lgn = 0;  // log2 of the window's segments
-  while ((p.seg << (lgn + 1)) <= p.nbkt[w]) lgn++;
-  return slot - 2 < lgn ? (int)(p.lg_seg + slot - 2) : -1;
-}
-int reduce_bits_position(const MsmPlan& p, int w, uint32_t slot) { return reduce_slot_position(p, w, slot); }
-
-// This lane's coordinate of a point, gnark form, to the host's array.
-__device__ __forceinline__ void write_point_quad(const F28& c, G1XYZZ* dst) {
-  u32 w12[12];
-  d28::to_gnark_msm(w12, c, q28::role());
-  // three 16-byte stores: the array may be the host's pinned buffer, where every store instruction is a write over PCIe
-  uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<u32*>(dst) + 12u * q28::role());
-#pragma unroll
-  for (int i = 0; i < 3; i++) d[i] = make_uint4(w12[4 * i], w12[4 * i + 1], w12[4 * i + 2], w12[4 * i + 3]);
-}
-
-// One LEVEL above k_reduce_segments: up to 128 consecutive groups of a window -> one group, the same
-// record with log2(128) more bits: [sum S | total A | X_0 .. ].  Block (window lw, result jr and
-// block index, quantity z) of 64 quads; a quad takes TWO consecutive input groups.  z = 0 and z >= 2
-// are plain sums of that slot.  z = 1 weighs the totals A_e by the group index e, as bit sums again:
-// the lowest new bit is the plain sum of the odd groups' totals (it rides on the S side of the dual
-// tree), the pairs' totals go through the butterfly.  One wave reduces its 16 quads by shuffles;
-// the waves' six results (S in the last quad, T in quads 0 1 2 4 8) meet in LDS, where 6 x nwv <= 24
-// quads of waves 0 and 1 reduce them in groups of nwv quads the same way.  Every wave of a block
-// sits on a SIMD of its own (one block of 512 threads per window and quantity took 0.087 ms at
-// N = 2^20 where this takes half: two waves on a SIMD share its multiplier).
-// A window with more than 128 groups takes a second pass (ng_shift = 7: the groups that are left);
-// the last pass writes the host's array (gnark form) instead of records.
-struct ReduceLevel {
-  u32 ng_shift;   // input groups of window w: nbkt[w] / (seg * G) >> ng_shift (at least 1)
-  u32 P_in;       // points per input record
-  u32 P_out;      // points per output record (last pass: nout)
-  u32 nblk_max;   // blocks per window and result in blockIdx.y
-  u32 in_stride;  // input records per result
-  u32 out_stride; // output records per result (not used by the last pass)
-  u32 last;       // 1: write the host's array
-};
-__global__ void __launch_bounds__(kBlock, 2)
-    k_reduce_level(const X28* __restrict__ in, X28* __restrict__ out, G1XYZZ* __restrict__ host_out, MsmPlan p, ReduceLevel lv) {
-  set_wave_prio(p.reduce_prio);
-  __shared__ F28 sh[4][6][4];
-  const u32 lw = blockIdx.x, jr = blockIdx.y / lv.nblk_max, blk = blockIdx.y - jr * lv.nblk_max, z = blockIdx.z;
-  const int w = p.win_begin + (int)lw;
-  const u32 nw = p.win_end - p.win_begin;
-  const u32 per = p.seg * p.G;
-  u32 ng = (p.nbkt[w] / per) >> lv.ng_shift;  // this window's input groups (a power of two)
-  if (ng == 0) ng = 1;
-  const u32 B = ng < 128u ? ng : 128u;         // input groups per block
-  if (blk * B >= ng) return;                   // block-uniform
-  const u32 Qa = B >= 2u ? B / 2u : 1u;        // quads at work
-  const u32 tid = threadIdx.x, q = tid >> 2, wave = tid >> 6, ql = (tid & 63u) >> 2;
-  // records of window w start where the windows before it end: every window's count is shifted alike
-  u32 first_in = 0, first_out = 0;
-  for (int x = p.win_begin; x < w; x++) {
-    u32 g = (p.nbkt[x] / per) >> lv.ng_shift;
-    if (g == 0) g = 1;
-    first_in += g;
-    first_out += g <= 128u ? 1u : g / 128u;
-  }
-  const X28* base = in + ((size_t)jr * lv.in_stride + first_in + (size_t)blk * B) * lv.P_in;
-  X28* orec = out + ((size_t)jr * lv.out_stride + first_out + blk) * lv.P_out;
-  G1XYZZ* hrec = host_out + ((size_t)jr * nw + lw) * lv.P_out;
-  auto emit = [&](const F28& v, u32 slot) {  // the calling quad's point -> slot of the output record
-    if (lv.last)
-      write_point_quad(v, &hrec[slot]);
-    else
-      q28::store(&orec[slot], v);
-  };
-  F28 S, T, b;
-  q28::set_inf(S);
-  q28::set_inf(T);
-  if (B == 1) {  // nothing to reduce: the record moves on (the host's array gets infinity for the total)
-    if (z >= lv.P_in) return;
-    if (q == 0) {
-      q28::load(S, base + z);
-      if (lv.last && z == 1) q28::set_inf(S);
-      emit(S, z);
-    }
-    if (z == 1 && q >= lv.P_in && q < lv.P_out) emit(S, q);  // S is infinity here: q != 0
-    return;
-  }
-  if (q < Qa) {
-    const X28* e = base + (size_t)(2 * q) * lv.P_in + z;
-    if (z != 1) {
-      q28::load(S, e);
-      q28::load(b, e + lv.P_in);
-      q28::add(S, b);
-    } else {
-      q28::load(T, e);
-      q28::load(S, e + lv.P_in);  // the odd group: bit 0 of the group index
-      q28::add(T, S);
-    }
-  }
-  const u32 G1 = Qa < 16u ? Qa : 16u;
-  u32 lg1 = 0;
-  while ((1u << lg1) < G1) lg1++;
-  if (G1 > 1) group_bits_and_sum(S, T, G1);
-  const u32 nwv = Qa > 16u ? Qa / 16u : 1u;  // 1, 2 or 4 waves hold groups
-  u32 lgw = 0;
-  while ((1u << lgw) < nwv) lgw++;
-  // z = 1: the new bits in order: odd groups | quad bits inside a wave | wave bits
-  const u32 bit0 = lv.P_in;
-  if (nwv == 1) {
-    if (wave == 0) {
-      if (ql == G1 - 1) emit(S, z == 1 ? bit0 : z);
-      if (z == 1) {
-        if (ql == 0) {
-          if (lv.last) q28::set_inf(T);
-          emit(T, 1);
-        } else if (ql < G1 && (ql & (ql - 1)) == 0) {
-          emit(T, bit0 + 1 + (31 - __clz((int)ql)));
-        }
-      }
-    }
-  } else {
-    if (wave < nwv) {
-      if (ql == 15) sh[wave][0][tid & 3u] = S;
-      if (ql == 0) sh[wave][1][tid & 3u] = T;
-      if (ql == 1) sh[wave][2][tid & 3u] = T;
-      if (ql == 2) sh[wave][3][tid & 3u] = T;
-      if (ql == 4) sh[wave][4][tid & 3u] = T;
-      if (ql == 8) sh[wave][5][tid & 3u] = T;
-    }
-    __syncthreads();
-    const u32 slot2 = wave * 16u + ql;    // quad slot of the second stage: quantity c, wave v
-    const u32 c = slot2 / nwv, v = slot2 - c * nwv;
-    if (wave < 2) {
-      q28::set_inf(S);
-      q28::set_inf(T);
-      if (c < 6) {
-        if (c == 1)
-          T = sh[v][1][tid & 3u];
-        else
-          S = sh[v][c][tid & 3u];
-      }
-      group_bits_and_sum(S, T, nwv);
-      if (c == 0) {
-        if (v == nwv - 1) emit(S, z == 1 ? bit0 : z);
-      } else if (z == 1 && c < 6) {
-        if (c == 1) {
-          if (v == 0) {
-            if (lv.last) q28::set_inf(T);
-            emit(T, 1);
-          } else if ((v & (v - 1)) == 0) {
-            emit(T, bit0 + 1 + 4 + (31 - __clz((int)v)));
-          }
-        } else if (v == nwv - 1) {
-          emit(S, bit0 + 1 + (c - 2));
-        }
-      }
-    }
-  }
-  // the bit slots this block's window does not fill hold infinity (z = 1's block owns them)
-  const u32 made = 1 + lg1 + lgw;  // new bits of this level
-  if (z == 1 && q >= bit0 + made && q < lv.P_out) {
-    q28::set_inf(S);
-    emit(S, q);
-  }
-}
-
-// Window sums from the group partials.  A window owns nseg / G consecutive
-// partials.  Wide windows (many partials): one 64-quad block per (window, MSM)
-// with an LDS tree.  A call whose windows all have <= 4 partials (batches of small
-// MSMs): one lane per window, so tens of thousands of windows fill the chip.
-// With the host combine (single MSMs, small batches) the window sums are written in
-// gnark form (canonical XYZZ coordinates); a large batch keeps them in internal form
-// for k_combine.
-// The quad's own coordinate of a window sum: gnark form for the host combine, internal form
-// for k_combine.
-__device__ __forceinline__ void write_window_sum_quad(const F28& c, G1XYZZ* winsums, X28* winsums28, const MsmPlan& p,
-                                                      u32 j, u32 lw) {
-  const u32 nw = p.win_end - p.win_begin;
-  if (!p.gpu_combine) {
-    u32 w12[12];
-    d28::to_gnark_msm(w12, c, q28::role());
-    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<u32*>(&winsums[(size_t)j * nw + lw]) + 12u * q28::role());
-#pragma unroll
-    for (int i = 0; i < 3; i++) dst[i] = make_uint4(w12[4 * i], w12[4 * i + 1], w12[4 * i + 2], w12[4 * i + 3]);
-  } else {
-    q28::store(&winsums28[(size_t)j * nw + lw], c);
-  }
-}
-
-__global__ void __launch_bounds__(kBlock, 2)
-    k_window_sum_wide_quad(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28,
-                           MsmPlan p) {
-  __shared__ F28 sh[4][4];
-  const u32 lw = blockIdx.x, j = blockIdx.y;
-  const u32 w = p.win_begin + lw;
-  const u32 tid = threadIdx.x;
-  const u32 lt = tid >> 2;  // logical lane 0..63
-  const u32 np = p.nbkt[w] / p.seg / p.G;
-  const X28* pw = partials + ((size_t)j * p.NS + p.base[w] / p.seg) / p.G;
-  F28 acc, b;
-  q28::set_inf(acc);
-  for (u32 k = lt; k < np; k += 64) {
-    q28::load(b, &pw[k]);
-    q28::add(acc, b);
-  }
-  group_sum_quad(acc, 64, sh);
-  if (tid < 4) write_window_sum_quad(acc, winsums, winsums28, p, j, lw);
-}
-
-__global__ void __launch_bounds__(kBlock, 2)
-    k_window_sum_flat(const X28* __restrict__ partials, G1XYZZ* __restrict__ winsums, X28* __restrict__ winsums28,
-                      MsmPlan p) {
-  // one quad per window (an addition is 4 product steps against a single lane's 14)
-  const u32 nw = p.win_end - p.win_begin;
-  const u32 gw = (blockIdx.x * kBlock + threadIdx.x) >> 2;
-  if (gw >= p.kr * nw) return;  // whole quads leave together
-  const u32 j = gw / nw, lw = gw - j * nw;
-  const u32 w = p.win_begin + lw;
-  const u32 np = p.nbkt[w] / p.seg / p.G;
-  const X28* pw = partials + ((size_t)j * p.NS + p.base[w] / p.seg) / p.G;
-  F28 acc, b;
-  q28::load(acc, &pw[0]);
-  for (u32 k = 1; k < np; k++) {
-    q28::load(b, &pw[k]);
-    q28::add(acc, b);
-  }
-  write_window_sum_quad(acc, winsums, winsums28, p, j, lw);
-}
-
-// Batched calls: one quad per MSM runs the Horner pass over its window sums (what the host
-// does for a single MSM) and the 2^shift scaling of a partial: ~255 doublings + one
-// addition per window, 3 and 4 product steps each (quad28.h); with hundreds of MSMs in
-// flight the serial chain is amortised over the batch.  The results leave as XYZZ in gnark
-// form; the host normalises the whole batch with ONE shared inversion
-// (curdle_host_batch_to_affine) -- a Fermat inversion here would be another 570-product
-// serial chain per MSM (round 1: 3.7 ms for this kernel, 1.2 ms of it the inversion).
-__global__ void __launch_bounds__(kBlock, 2)
-    k_combine(const X28* __restrict__ winsums28, G1XYZZ* __restrict__ results, MsmPlan p) {
-  const u32 j = blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2);
-  if (j >= p.kr) return;  // whole quads leave together
-  const u32 nw = p.win_end - p.win_begin;
-  F28 acc, b;
-  q28::set_inf(acc);
-  for (int lw = (int)nw - 1; lw >= 0; lw--) {
-    q28::load(b, &winsums28[(size_t)j * nw + lw]);
-    q28::add(acc, b);
-    const int dbls = lw > 0 ? p.bits[p.win_begin + lw - 1] : p.shift[p.win_begin];
-    if (!q28::is_inf(acc))
-      for (int q = 0; q < dbls; q++) q28::dbl(acc);
-  }
-  u32 w12[12];
-  d28::to_gnark_msm(w12, acc, q28::role());  // this lane's coordinate; ZZ = 0 (infinity) stays 0
-  u32* dst = reinterpret_cast<u32*>(&results[j]) + 12u * q28::role();
-#pragma unroll
-  for (int i = 0; i < 12; i++) dst[i] = w12[i];
-}
-
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
-static inline u32 cdiv(u64 a, u32 b) { return (u32)((a + b - 1) / b); }
-
 // LDS beyond the default 64 KiB needs an opt-in per kernel -- and per DEVICE (a process may drive
 // several: curdle_init_devices), so it is made once for every device a launch comes from.
 static hipError_t sort_lds_optin() {
@@ -1925,7 +1055,7 @@ static hipError_t sort_lds_optin() {
 
 // Layout of ws.ccur (two-level plans): [nw * 256] coarse cursors | [kCoarseReps][nw * 256] coarse counts (16-byte
 // aligned: k_coarse_scan reads them four at a time) | [nw * 256 + 1] packed bin starts + sentinel.  The counts must be
-// zero when k_digits starts and are zero again when it ends (msm_api.hip clears them when the buffer is made and after a
+// zero when k_digits starts and are zero again when it ends (msm_enqueue.hip clears them when the buffer is made and after a
 // failed call).
 static inline CoarseOut coarse_out(const MsmPlan& p, const MsmWorkspace& ws) {
   const size_t nw = (size_t)(p.win_end - p.win_begin);
@@ -2119,324 +1249,6 @@ hipError_t launch_convert_points_raw(const void* d_points, uint32_t n, void* d_o
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_convert_points, dim3(cdiv(n, kCvtBlock)), dim3(kCvtBlock), 0, stream,
                      reinterpret_cast<const uint4*>(d_points), n, reinterpret_cast<A28*>(d_out28), prio);
-  return hipGetLastError();
-}
-
-hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  const u32 nw = p.win_end - p.win_begin;
-  const u32 nb = p.k * p.NB;
-  const u32 nlanes = cdiv((u64)nw * p.n, p.L);
-  // two waves per SIMD (203 VGPRs, no spills): a three-wave build (168 VGPRs) spilled 26
-  // registers and was slower
-  hipLaunchKernelGGL(k_accumulate<2>, dim3(cdiv(nlanes, kBlock), p.sets), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const A28*>(ws.points28), ws.sorted, ws.starts, ws.foff,
-                     reinterpret_cast<X28*>(ws.frags), nb, p.L, p.n, p.frag_stride, p.acc_prio);
-  return hipGetLastError();
-}
-
-hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, bool wide) {
-  // One wave per chunk of 32 to 256 fragments; more chunks than waves go round.  The launch is almost always empty
-  // (uniform scalars queue nothing) and every block of it has to find room beside the next accumulation before it can
-  // read the empty queue and leave: a synchronous call, which has the chip to itself, takes up to 768 blocks = three
-  // 165-register waves on every SIMD; a pipelined one 256 (768 empty blocks cost its step 0.02 ms of 2.53:
-  // profiles/r06_pipeline_phase_costs.txt).
-  const u32 nw = p.win_end - p.win_begin;
-  const u64 nlanes = ((u64)nw * p.n + p.L - 1) / p.L;  // fragments <= bucket slots + lanes
-  const u64 chunks = (u64)p.max_large + ((u64)p.k * p.NB + nlanes) / 32u;
-  const u32 cap = wide ? 768u : 256u;
-  const u32 blocks = (u32)(chunks / 4u + 1u < cap ? chunks / 4u + 1u : cap);
-  hipLaunchKernelGGL(k_merge_large, dim3(blocks, p.sets), dim3(kBlock), 0, stream, ws.large, ws.nlarge, ws.foff, ws.fragcnt,
-                     reinterpret_cast<X28*>(ws.frags), ws.mdone, p.max_large, p.frag_stride, p.reduce_prio);
-  return hipGetLastError();
-}
-
-hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, const FragSources* extra) {
-  const u64 lanes = (u64)p.kr * p.NS;  // quads
-  FragSources src;
-  memset(&src, 0, sizeof(src));
-  if (extra) src = *extra;  // the earlier chunks first (any order gives the same bucket sums)
-  if (src.n >= (u32)kMaxFragSources) return hipErrorInvalidValue;
-  src.frags[src.n] = ws.frags;
-  src.foff[src.n] = ws.foff;
-  src.fragcnt[src.n] = ws.fragcnt;
-  src.n++;
-  hipLaunchKernelGGL(k_bucket_reduce_quad, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream, src,
-                     reinterpret_cast<X28*>(ws.partials), p);
-  return hipGetLastError();
-}
-
-hipError_t launch_reduce_segments(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, const FragSources* extra) {
-  // operand shapes the kernels assume: whole groups of <= 16 quads, every window a whole number of groups
-  if (!p.reduce_bits || p.G < 1 || p.G > 16 || (p.G & (p.G - 1)) || (1u << p.lgG) != p.G || (1u << p.lg_seg) != p.seg ||
-      p.NS != p.NB / p.seg || p.NG * p.G != p.NS)
-    return hipErrorInvalidValue;
-  for (int w = p.win_begin; w < p.win_end; w++)
-    if (p.nbkt[w] % (p.seg * p.G) || p.base[w] % (p.seg * p.G)) return hipErrorInvalidValue;
-  const u64 lanes = (u64)p.kr * p.NS;  // quads
-  FragSources src;
-  memset(&src, 0, sizeof(src));
-  if (extra) src = *extra;
-  if (src.n >= (u32)kMaxFragSources) return hipErrorInvalidValue;
-  src.frags[src.n] = ws.frags;
-  src.foff[src.n] = ws.foff;
-  src.fragcnt[src.n] = ws.fragcnt;
-  src.n++;
-  hipLaunchKernelGGL(k_reduce_segments, dim3(cdiv(lanes, kBlock / 4)), dim3(kBlock), 0, stream, src,
-                     reinterpret_cast<X28*>(ws.partials), p);
-  return hipGetLastError();
-}
-
-hipError_t launch_fold_fragments(const MsmPlan& p, const MsmWorkspace& ws, void* sums, void* meta, bool first, hipStream_t stream) {
-  if (p.k != 1 || p.sets != 1) return hipErrorInvalidValue;  // one MSM, one base set: the chunks of a host-buffer call
-  const u32 nb = p.NB;
-  hipLaunchKernelGGL(k_fold_fragments, dim3(cdiv(nb, kBlock / 4)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const X28*>(ws.frags), ws.foff, ws.fragcnt, reinterpret_cast<X28*>(sums),
-                     reinterpret_cast<u32*>(meta), nb, p.max_small, first ? 1u : 0u, p.aux_prio);
-  return hipGetLastError();
-}
-
-hipError_t launch_reduce_groups(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  const u32 nw = p.win_end - p.win_begin;
-  if (!p.reduce_bits || !p.NG) return hipErrorInvalidValue;
-  // levels of up to 128 groups per block until every window is one record; records ping-pong between
-  // the two halves of ws.partials (the first half holds k_reduce_segments' output)
-  const u32 per = p.seg * p.G;
-  X28* bufs[2] = {reinterpret_cast<X28*>(ws.partials), reinterpret_cast<X28*>(ws.partials) + (size_t)p.kr * p.NG * (2 + p.lgG) + 1};
-  ReduceLevel lv;
-  lv.ng_shift = 0;
-  lv.P_in = 2 + p.lgG;
-  lv.in_stride = p.NG;
-  for (int pass = 0;; pass++) {
-    u32 ng_max = 1, in_recs = 0, out_recs = 0;
-    for (int w = p.win_begin; w < p.win_end; w++) {
-      u32 g = (p.nbkt[w] / per) >> lv.ng_shift;
-      if (g == 0) g = 1;
-      if (g > ng_max) ng_max = g;
-      in_recs += g;
-      out_recs += g <= 128u ? 1u : g / 128u;
-    }
-    if (in_recs != lv.in_stride) return hipErrorInvalidValue;
-    const u32 B = ng_max < 128u ? ng_max : 128u;
-    u32 lgB = 0;
-    while ((1u << lgB) < B) lgB++;
-    lv.last = ng_max <= 128u ? 1u : 0u;
-    lv.P_out = lv.P_in + lgB;
-    lv.nblk_max = ng_max <= 128u ? 1u : ng_max / 128u;
-    lv.out_stride = out_recs;
-    if (lv.last && lv.P_out != p.nout) return hipErrorInvalidValue;
-    if (lv.P_out > 64u) return hipErrorInvalidValue;  // the filler takes one quad per slot
-    hipLaunchKernelGGL(k_reduce_level, dim3(nw, p.kr * lv.nblk_max, lv.P_in), dim3(kBlock), 0, stream, bufs[pass & 1],
-                       bufs[(pass + 1) & 1], ws.winsums, p, lv);
-    if (lv.last) break;
-    lv.ng_shift += 7;
-    lv.P_in = lv.P_out;
-    lv.in_stride = out_recs;
-    if (pass > 4) return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  const u32 nw = p.win_end - p.win_begin;
-  if (p.max_nbkt / p.seg / p.G > 4)
-    hipLaunchKernelGGL(k_window_sum_wide_quad, dim3(nw, p.kr), dim3(kBlock), 0, stream,
-                       reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
-  else
-    hipLaunchKernelGGL(k_window_sum_flat, dim3(cdiv((u64)p.kr * nw, kBlock / 4)), dim3(kBlock), 0, stream,
-                       reinterpret_cast<const X28*>(ws.partials), ws.winsums, reinterpret_cast<X28*>(ws.winsums28), p);
-  return hipGetLastError();
-}
-
-hipError_t launch_combine(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream) {
-  hipLaunchKernelGGL(k_combine, dim3(cdiv(p.kr, kBlock / 4)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const X28*>(ws.winsums28), ws.results, p);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// Synthetic bases of SURVEY.md section 8(d): P_i = P_0 + i*Q, affine, gnark
-// layout.  table[j] = 2^j * Q (affine).  One lane per point: <= 27 mixed adds,
-// then one Fermat inversion of ZZ*ZZZ to normalise.
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock, 2)
-    k_synth_walk(const G1Affine* __restrict__ table, G1Affine p0, u32 n, uint4* __restrict__ out) {
-  u32 i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  X28 acc;
-  if (g1_affine_is_inf(p0)) {
-    d28::set_inf(acc);
-  } else {
-    d28::from_gnark(acc.x, p0.x.l);
-    d28::from_gnark(acc.y, p0.y.l);
-    d28::set_one(acc.zz);
-    d28::set_one(acc.zzz);
-  }
-  for (int j = 0; j < 27; j++) {
-    if ((i >> j) & 1u) {
-      G1Affine t = table[j];
-      F28 x, y;
-      d28::from_gnark(x, t.x.l);
-      d28::from_gnark(y, t.y.l);
-      d28::madd(acc, x, y);
-    }
-  }
-  u32 w[24];
-  if (d28::is_inf(acc)) {
-    for (int k = 0; k < 24; k++) w[k] = 0;
-  } else {
-    F28 t, inv, izz, izzz, x, y;
-    d28::mul(t, acc.zz, acc.zzz);
-    d28::set_one(inv);
-    for (int b = 383; b >= 0; b--) {
-      d28::sqr(inv, inv);
-      if ((kPminus2[b >> 5] >> (b & 31)) & 1u) d28::mul(inv, inv, t);
-    }
-    d28::mul(izz, inv, acc.zzz);
-    d28::mul(izzz, inv, acc.zz);
-    d28::mul(x, acc.x, izz);
-    d28::mul(y, acc.y, izzz);
-    d28::to_gnark(w, x);
-    d28::to_gnark(w + 12, y);
-  }
-  d28::store_words<24>(out + (size_t)i * 6, w);
-}
-
-hipError_t launch_synth_walk(const G1Affine* d_table, const G1Affine& p0, uint32_t n, void* d_out,
-                             hipStream_t stream) {
-  hipLaunchKernelGGL(k_synth_walk, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, d_table, p0, n,
-                     reinterpret_cast<uint4*>(d_out));
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// Primitive self-test (curdle_selftest_op)
-// ---------------------------------------------------------------------------
-// All operands and results cross this kernel in gnark form; the operation itself
-// runs in the internal radix-2^28 form the MSM kernels use.
-// The widths come from kSelftestTable (msm_kernels.h) as arguments; a branch whose own layout does
-// not match them returns without touching memory, and so does an unknown op.
-__global__ void __launch_bounds__(kBlock, 2)
-    k_selftest(int op, const u32* __restrict__ in, size_t n, u32* __restrict__ out, u32 in_w, u32 out_w) {
-  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (op >= 8 && op <= 10) {  // lane-distributed point operations (quad28.h): four lanes per element
-    if (in_w != 96 || out_w != 48) return;
-    i >>= 2;
-    if (i >= n) return;  // whole quads leave together
-    G1XYZZ ga, gb;
-    const u32* src = in + i * in_w;
-    u32* a32 = reinterpret_cast<u32*>(&ga);
-    u32* b32 = reinterpret_cast<u32*>(&gb);
-    for (int k = 0; k < 48; k++) {
-      a32[k] = src[k];
-      b32[k] = src[48 + k];
-    }
-    X28 pa, pb;
-    d28::from_gnark(pa, ga);
-    d28::from_gnark(pb, gb);
-    F28 ca, cb;
-    q28::from_x28(ca, pa);
-    q28::from_x28(cb, pb);
-    if (op == 8) q28::add(ca, cb);
-    else if (op == 9) q28::dbl(ca);
-    else q28::mul_small(ca, cb, (u32)(i * 2654435761u) >> 12, 19);  // op 10: k * b, k = 20 bits of a hash of i
-    q28::to_x28(pa, ca);
-    if (threadIdx.x & 3u) return;
-    G1XYZZ o;
-    d28::to_gnark(o, pa);
-    const u32* o32 = reinterpret_cast<const u32*>(&o);
-    for (int k = 0; k < 48; k++) out[i * out_w + k] = o32[k];
-    return;
-  }
-  if (i >= n) return;
-  if (op == 11) {  // the GLV split exactly as k_digits runs it
-    if (in_w != 8 || out_w != 10) return;
-    Fr k;
-    for (int j = 0; j < 8; j++) k.l[j] = in[i * in_w + j];
-    u32 a[4], b[4], sa, sb;
-    glv_split(k, a, b, sa, sb);
-    for (int j = 0; j < 4; j++) {
-      out[i * out_w + j] = a[j];
-      out[i * out_w + 4 + j] = b[j];
-    }
-    out[i * out_w + 8] = sa;
-    out[i * out_w + 9] = sb;
-  } else if (op == 12) {  // the conversion k_convert_points runs and the exit product of the MSM kernels
-    if (in_w != 24 || out_w != 26) return;
-    u32 w[24];
-    for (int k = 0; k < 24; k++) w[k] = in[i * in_w + k];
-    F28 x, y;
-    d28::from_gnark_iso_x(x, w);
-    d28::from_gnark_iso_y(y, w + 12);
-    u32 o[24];
-    d28::to_gnark_msm(o, x, 0);
-    d28::to_gnark_msm(o + 12, y, 1);
-    for (int k = 0; k < 24; k++) out[i * out_w + k] = o[k];
-    // what madd asks of an affine operand: normalised limbs, value below 2p
-    F28 x2 = x, y2 = y;
-    d28::cond_sub_pshl<1>(x2);
-    d28::cond_sub_pshl<1>(y2);
-    bool same_x = true, same_y = true;
-    for (int k = 0; k < d28::N; k++) {
-      same_x = same_x && x2.l[k] == x.l[k] && x.l[k] <= d28::MASK;
-      same_y = same_y && y2.l[k] == y.l[k] && y.l[k] <= d28::MASK;
-    }
-    out[i * out_w + 24] = same_x;
-    out[i * out_w + 25] = same_y;
-  } else if (op >= 0 && op <= 3) {
-    if (in_w != 24 || out_w != 12) return;
-    u32 w[24];
-    for (int k = 0; k < 24; k++) w[k] = in[i * in_w + k];
-    F28 a, b, r;
-    d28::from_gnark(a, w);
-    d28::from_gnark(b, w + 12);
-    if (op == 0) d28::mul(r, a, b);
-    else if (op == 1) d28::add(r, a, b);
-    else if (op == 2) d28::sub<4>(r, a, b);
-    else d28::sqr(r, a);
-    u32 o[12];
-    d28::to_gnark(o, r);
-    for (int k = 0; k < 12; k++) out[i * out_w + k] = o[k];
-  } else if (op == 4) {
-    if (in_w != 16 || out_w != 8) return;
-    Fr a, r;
-    for (int k = 0; k < 8; k++) a.l[k] = in[i * in_w + k];
-    f_from_mont<FrParams>(r, a);
-    for (int k = 0; k < 8; k++) out[i * out_w + k] = r.l[k];
-  } else if (op >= 5 && op <= 7) {
-    if (in_w != 96 || out_w != 48) return;
-    G1XYZZ ga, gb;
-    const u32* src = in + i * in_w;
-    u32* a32 = reinterpret_cast<u32*>(&ga);
-    u32* b32 = reinterpret_cast<u32*>(&gb);
-    for (int k = 0; k < 48; k++) {
-      a32[k] = src[k];
-      b32[k] = src[48 + k];
-    }
-    X28 acc, b;
-    d28::from_gnark(acc, ga);
-    d28::from_gnark(b, gb);
-    // gnark-form infinity is ZZ = 0 (X = Y = one): from_gnark maps 0 -> 0
-    if (op == 5) {
-      if (!(f_is_zero(gb.x) && f_is_zero(gb.y))) d28::madd(acc, b.x, b.y);
-    } else if (op == 6) {
-      d28::add(acc, b);
-    } else {
-      d28::dbl(acc);
-    }
-    G1XYZZ o;
-    d28::to_gnark(o, acc);
-    const u32* o32 = reinterpret_cast<const u32*>(&o);
-    for (int k = 0; k < 48; k++) out[i * out_w + k] = o32[k];
-  }
-}
-
-hipError_t launch_selftest(int op, const uint32_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream) {
-  if (op < 0 || op >= kSelftestOps || !d_in || !d_out) return hipErrorInvalidValue;
-  if (n == 0) return hipSuccess;
-  const SelftestOp& t = kSelftestTable[op];
-  const size_t lanes = (size_t)t.lanes * n;
-  hipLaunchKernelGGL(k_selftest, dim3(cdiv(lanes, kBlock)), dim3(kBlock), 0, stream, op, d_in, n, d_out, t.in_words,
-                     t.out_words);
   return hipGetLastError();
 }
 

@@ -18,10 +18,10 @@ using namespace curdle;
 using alg::Point;
 using alg::Scalar;
 
-// defined in msm_api.hip
+// defined in csrc/msm_context.hip
 extern "C" int curdle_set_last_error(int code, const char* msg);
 
-struct curdle_rand {  // same layout as in msm_api.hip
+struct curdle_rand {  // same layout as in csrc/misc_api.hip
   common::Rand r;
   explicit curdle_rand(uint64_t seed) : r(seed) {}
 };

@@ -359,7 +359,7 @@ static int BatchSlots(size_t ell) {
 // contexts and counts the device-entry-point calls each one sees.  The k proofs are sharded over
 // the contexts (host/proto_api.cpp ShardOverDevices), every thread of a shard selects its device
 // first, and the accept bits are those of the single-device run.
-struct curdle_rand {  // same layout as in msm_api.hip / proto_api.cpp
+struct curdle_rand {  // same layout as in misc_api.hip / proto_api.cpp
   common::Rand r;
   explicit curdle_rand(uint64_t seed) : r(seed) {}
 };

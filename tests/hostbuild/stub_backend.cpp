@@ -184,7 +184,7 @@ static void decode_all(const uint8_t* in, size_t n, int subgroup_check, uint64_t
 extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgroup_check, uint64_t* out_affine,
                                           uint8_t* status) {
   // the device's one-shot decoding takes a workspace slot whenever the batch is beyond the
-  // two-kernel size (msm_api.hip: kTwoKernelMax) or every decode context is taken
+  // two-kernel size (decode_api.hip: two_kernel_max) or every decode context is taken
   stub_count_call();
   const char* tk = getenv("CURDLE_TWO_KERNEL_MAX");
   const bool needs_slot = tk && (size_t)atoll(tk) < n;

@@ -88,7 +88,7 @@ def test_device_selection_and_multi_device_entry_points_check_their_arguments(cm
 
 
 def glv_split(k, R):
-    """Host restatement of the kernels' split (msm_kernels.hip glv_split): k = s * (k1 + k2 *
+    """Host restatement of the kernels' split (bls12_381.h glv_split): k = s * (k1 + k2 *
     lambda) mod r with s = -1 for k > (r - 1) / 2, k2 = round(k' / lambda) >= 0 and k1 in
     [-lambda / 2, lambda / 2).  Returns the two signed halves."""
     s = -1 if k > (R - 1) // 2 else 1
@@ -116,7 +116,7 @@ def test_knobs_are_read_once_and_changed_only_through_the_hook(cm):
     assert cm.window_bits(n) == 12
     cm.plan_override("WINDOW_BITS", None)
     assert cm.window_bits(n) == 16
-    for bad in ("NO_SUCH_KNOB", "", "CURDLE_TWO_ROUNDS", "CURDLE_SYNC_STREAMS"):   # closed experiments are gone
+    for bad in ("NO_SUCH_KNOB", "", "CURDLE_TWO_ROUNDS", "CURDLE_SYNC_STREAMS", "SCAN", "FRONT", "HOST_GRADED", "PIPE_LANES"):   # closed experiments are gone
         with pytest.raises(cm.CurdleError):
             cm.plan_override(bad, 1)
     import subprocess, sys
@@ -190,7 +190,7 @@ def test_submit_refuses_a_window_width_outside_the_plan_before_it_touches_anythi
 
 
 def recode(s, widths):
-    """Host restatement of the kernels' recoding of ONE half of the split (msm_kernels.hip
+    """Host restatement of the kernels' recoding of ONE half of the split (msm_sort_kernels.hip
     for_each_digit): sign taken out, signed digits below the top window, unsigned top window.
     Returns [(digit, shift)]."""
     sign = -1 if s < 0 else 1

@@ -357,7 +357,7 @@ def test_chunked_host_call_folds_fragments_also_for_skewed_scalars(gpu, oracle, 
 
 def test_scalars_at_the_boundaries_of_the_split(gpu, oracle, coracle):
     """k_digits splits every scalar as k = +-(k1 + k2 lambda) with a Barrett division
-    (msm_kernels.hip glv_split): the scalars where its branches flip -- around (r - 1) / 2,
+    (bls12_381.h glv_split): the scalars where its branches flip -- around (r - 1) / 2,
     multiples of lambda and lambda / 2 either side (remainder 0, rounding boundary, the
     quotient's correction steps), 0, 1, r - 1, powers of two -- each on its own point and all
     together, against the C oracle."""
@@ -477,7 +477,7 @@ def test_linearity_at_full_size(gpu, oracle):
 
 def test_two_pass_scatter_with_skewed_scalars(gpu, oracle, coracle):
     """Single MSMs from ~200,000 pairs on sort their terms in two passes (coarse bins of 128
-    buckets, then buckets: msm_kernels.hip k_scatter_coarse / k_scatter_fine).  Uniform scalars
+    buckets, then buckets: msm_sort_kernels.hip k_scatter_coarse / k_scatter_fine).  Uniform scalars
     fill every bin evenly; these do not: all-equal scalars (one bucket per window holds every
     term), scalars below 300 (one window, a few bins), a hot top window, 1 % infinity bases, and
     an odd size -- each against the closed form of the known-discrete-log inputs, for the window

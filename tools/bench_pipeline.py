@@ -21,6 +21,9 @@ def child(logn, depth, steps, wb, we):
     import curdlemsm as cm
     from bench import uniform_scalars
     cm.init(0)
+    if os.environ.get("CURDLE_DEBUG_SKIP"):      # experiment build only (tools/exp/build_alt.sh -DCURDLE_EXP_SKIP msm_enqueue)
+        import ctypes
+        ctypes.CDLL(cm.LIB_PATH).curdle_debug_skip(ctypes.c_uint(int(os.environ["CURDLE_DEBUG_SKIP"])))
     n = 1 << logn
     d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
     cm.synth_points_walk_device(12345, 6789, n, d_pts.data_ptr())

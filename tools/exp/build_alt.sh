@@ -1,7 +1,7 @@
 #!/bin/bash
 # Experiment builds of the library, never the product: build_alt/libcurdlemsm_alt.so = the product's objects with the
 # named translation units recompiled under extra flags.  Usage: tools/exp/build_alt.sh "<flags>" unit [unit ...]
-#   tools/exp/build_alt.sh -DCURDLE_EXP_SKIP msm_api       (the phase-skip experiment, profiles/r06_pipeline_phase_costs.txt)
+#   tools/exp/build_alt.sh -DCURDLE_EXP_SKIP msm_enqueue       (the phase-skip experiment, profiles/r06_pipeline_phase_costs.txt)
 set -e
 cd "$(dirname "$0")/../../go-curdleproofs_amd"
 make -j8 >/dev/null

@@ -1,5 +1,5 @@
 #!/bin/bash
-# What each phase costs a PIPELINED caller, priced by leaving it out (experiment build: tools/exp/build_alt.sh -DCURDLE_EXP_SKIP msm_api).
+# What each phase costs a PIPELINED caller, priced by leaving it out (experiment build: tools/exp/build_alt.sh -DCURDLE_EXP_SKIP msm_enqueue).
 # Run on a GPU box from the repo root; writes the table to $1.
 O=$1
 export CURDLE_MSM_LIB=$PWD/build_alt/libcurdlemsm_alt.so

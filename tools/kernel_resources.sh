@@ -1,6 +1,6 @@
 #!/bin/bash
 # Register / scratch / LDS usage of every kernel of one HIP source (compile-time report).
-#   tools/kernel_resources.sh go-curdleproofs_amd/csrc/msm_kernels.hip
+#   tools/kernel_resources.sh go-curdleproofs_amd/csrc/msm_reduce_kernels.hip
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics \
   -Rpass-analysis=kernel-resource-usage -c "$1" -o /dev/null 2>&1 | python3 -c "
 import sys,re
