@@ -104,6 +104,41 @@ func BenchmarkMultiExp(b *testing.B) {
 	}
 }
 
+// BenchmarkCrossover is what a maintainer runs to SET curdlemsm.MinGPUPairs (32 as shipped: an estimate from this
+// repository's CPU port, never measured against gnark -- INTEGRATION.md section 3.1): the protocol's small MultiExp sizes
+// (m = 6..9 in the IPA / SameMSM verifiers, innerproductargument.go:238-280; 4 at curdleproof.go:76) on gnark's CPU path
+// and on the GPU with the threshold off.  MinGPUPairs = the smallest size from which gpu/ beats cpu/ for good.
+//
+//	go test -run xxx -bench Crossover ./bench
+func BenchmarkCrossover(b *testing.B) {
+	if err := curdlemsm.Init(0); err != nil {
+		b.Skipf("no MI355X: %v", err)
+	}
+	saved := curdlemsm.MinGPUPairs
+	curdlemsm.MinGPUPairs = 0
+	defer func() { curdlemsm.MinGPUPairs = saved }()
+	for _, n := range []int{4, 8, 16, 32, 64, 128, 256, 512, 1024} {
+		points, scalars := inputs(n)
+		cfg := ecc.MultiExpConfig{NbTasks: runtime.NumCPU()} // common.MultiExpConf (common/util.go:14)
+		b.Run(fmt.Sprintf("cpu/N=%d", n), func(b *testing.B) {
+			var dst bls12381.G1Jac
+			for i := 0; i < b.N; i++ {
+				if _, err := dst.MultiExp(points, scalars, cfg); err != nil {
+					b.Fatal(err)
+				}
+			}
+		})
+		b.Run(fmt.Sprintf("gpu/N=%d", n), func(b *testing.B) {
+			var dst bls12381.G1Jac
+			for i := 0; i < b.N; i++ {
+				if _, err := curdlemsm.MultiExp(&dst, points, scalars, cfg); err != nil {
+					b.Fatal(err)
+				}
+			}
+		})
+	}
+}
+
 func TestParity(t *testing.T) {
 	if err := curdlemsm.Init(0); err != nil {
 		t.Skipf("no MI355X: %v", err)
