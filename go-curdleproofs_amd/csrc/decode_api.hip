@@ -49,24 +49,11 @@ extern "C" int curdle_g1_decompress_batch(const uint8_t* in, size_t n, int subgr
     memcpy(S.h_stage[0], in, n * 48);
     uint8_t* h_out = static_cast<uint8_t*>(S.h_stage[1]);
     HIP_TRY(hipMemcpyAsync(S.scalars.p, S.h_stage[0], n * 48, hipMemcpyHostToDevice, S.stream));
-    const bool timed = cx.profile != 0;  // curdle_profile_totals: the decoding kernel's own duration
-    if (timed && !S.ev_made) {
-      for (auto& e : S.ev) HIP_TRY(hipEventCreate(&e));
-      S.ev_made = true;
-    }
-    if (timed) HIP_TRY(hipEventRecord(S.ev[0], S.stream));
     HIP_TRY(launch_g1_decompress((const uint8_t*)S.scalars.p, (uint32_t)n, subgroup_check, (uint32_t*)S.points.p,
                                  (uint8_t*)S.counts.p, S.stream));
-    if (timed) HIP_TRY(hipEventRecord(S.ev[1], S.stream));
     HIP_TRY(hipMemcpyAsync(h_out, S.points.p, n * 96, hipMemcpyDeviceToHost, S.stream));
     HIP_TRY(hipMemcpyAsync(h_out + n * 96, S.counts.p, n, hipMemcpyDeviceToHost, S.stream));
     HIP_TRY(hipStreamSynchronize(S.stream));
-    if (timed) {
-      float ms = 0.0f;
-      (void)hipEventElapsedTime(&ms, S.ev[0], S.ev[1]);
-      cx.prof_total_us.fetch_add((unsigned long long)(ms * 1000.0f), std::memory_order_relaxed);
-      cx.prof_calls.fetch_add(1, std::memory_order_relaxed);
-    }
     memcpy(out_affine, h_out, n * 96);
     memcpy(status, h_out + n * 96, n);
     return CURDLE_OK;
@@ -181,22 +168,14 @@ extern "C" int curdle_g1_decompress_start(const uint8_t* in, size_t n, int* tick
     memcpy(D.h_in, in, n * 48);
     HIP_TRY(hipMemcpyAsync(D.in.p, D.h_in, n * 48, hipMemcpyHostToDevice, D.stream));
     HIP_TRY(hipEventRecord(D.uploaded, D.stream));
-    D.timed = cx.profile != 0;  // curdle_profile_totals: both kernels' own durations, read at the finish
-    if (D.timed)
-      for (auto& e : D.t)
-        if (!e) HIP_TRY(hipEventCreate(&e));
-    if (D.timed) HIP_TRY(hipEventRecord(D.t[0], D.stream));
     HIP_TRY(launch_g1_decompress((const uint8_t*)D.in.p, (uint32_t)n, 0, (uint32_t*)D.out.p, (uint8_t*)D.status.p,
                                  D.stream));
-    if (D.timed) HIP_TRY(hipEventRecord(D.t[1], D.stream));
     HIP_TRY(hipEventRecord(D.decoded, D.stream));
     // The subgroup test does not wait for the square roots: it works on a twisted model of the
     // curve that needs only x (decode_kernels.hip), on its own stream, beside the decoding
     // kernel -- the two ~0.5 ms chains per point overlap instead of adding up.
     HIP_TRY(hipStreamWaitEvent(D.sub_stream, D.uploaded, 0));
-    if (D.timed) HIP_TRY(hipEventRecord(D.t[2], D.sub_stream));
     HIP_TRY(launch_g1_subgroup_from_bytes((const uint8_t*)D.in.p, (uint32_t)n, (uint8_t*)D.sub.p, D.sub_stream));
-    if (D.timed) HIP_TRY(hipEventRecord(D.t[3], D.sub_stream));
     return CURDLE_OK;
   };
   int rc = body();
@@ -292,14 +271,6 @@ extern "C" int curdle_g1_decompress_finish(int ticket, uint8_t* status) {
   if (he == hipSuccess) he = hipStreamSynchronize(D.stream);
   if (he == hipSuccess) he = hipStreamSynchronize(D.sub_stream);
   if (he != hipSuccess) rc = fail(CURDLE_EHIP, "decompress finish: %s", hipGetErrorString(he));
-  if (rc == CURDLE_OK && D.timed && n) {
-    float a = 0.0f, b = 0.0f;
-    (void)hipEventElapsedTime(&a, D.t[0], D.t[1]);
-    (void)hipEventElapsedTime(&b, D.t[2], D.t[3]);
-    cx.prof_total_us.fetch_add((unsigned long long)((a + b) * 1000.0f), std::memory_order_relaxed);
-    cx.prof_calls.fetch_add(1, std::memory_order_relaxed);
-  }
-  D.timed = false;
   if (rc == CURDLE_OK && n && status)  // a decoded point outside the subgroup: the one verdict the points came without
     for (size_t i = 0; i < n; i++)
       status[i] = (h[i] == CURDLE_DECODE_OK && !h[n + i]) ? (uint8_t)CURDLE_DECODE_NOT_IN_SUBGROUP : h[i];

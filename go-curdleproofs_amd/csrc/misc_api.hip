@@ -41,18 +41,7 @@ extern "C" int curdle_synth_points_walk_device(const uint64_t k[4], const uint64
 extern "C" int curdle_profile_enable(int on) {
   Ctx& cx = cur();
   std::lock_guard<std::mutex> g(cx.mu);
-  cx.profile = on < 0 || on > 3 ? 1 : on;
-  return CURDLE_OK;
-}
-
-extern "C" int curdle_profile_totals(double* kernel_ms, unsigned long long* calls, int reset) {
-  Ctx& cx = cur();
-  if (kernel_ms) *kernel_ms = (double)cx.prof_total_us.load(std::memory_order_relaxed) / 1000.0;
-  if (calls) *calls = cx.prof_calls.load(std::memory_order_relaxed);
-  if (reset) {
-    cx.prof_total_us.store(0, std::memory_order_relaxed);
-    cx.prof_calls.store(0, std::memory_order_relaxed);
-  }
+  cx.profile = on < 0 || on > 2 ? 1 : on;
   return CURDLE_OK;
 }
 

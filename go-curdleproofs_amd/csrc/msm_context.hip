@@ -214,10 +214,6 @@ void teardown_locked(Ctx& C) {
     d.copy_stream = nullptr;
     if (d.decoded) (void)hipEventDestroy(d.decoded);
     d.decoded = nullptr;
-    for (auto& e : d.t) {
-      if (e) (void)hipEventDestroy(e);
-      e = nullptr;
-    }
   }
   for (Slot& S : C.slots) {
     if (S.stream) (void)hipStreamSynchronize(S.stream);

@@ -335,14 +335,10 @@ int finish_slot(Ctx& cx, Slot& S, uint64_t* out) {
     std::lock_guard<std::mutex> g(cx.mu);
     curdle_profile& L = cx.last;
     L.n_kernels = S.prof_n;
-    float sum_ms = 0.0f;
     for (int i = 0; i < S.prof_n; i++) {
       L.name[i] = S.prof_name[i];
       (void)hipEventElapsedTime(&L.ms[i], S.ev[i], S.ev[i + 1]);
-      if (L.name[i][0] != '(') sum_ms += L.ms[i];  // "(queue)" is a wait, not a kernel
     }
-    cx.prof_total_us.fetch_add((unsigned long long)(sum_ms * 1000.0f), std::memory_order_relaxed);
-    cx.prof_calls.fetch_add(1, std::memory_order_relaxed);
     L.window_bits = p.c;
     L.num_windows = p.W;
     L.entries = L.fragments = 0;

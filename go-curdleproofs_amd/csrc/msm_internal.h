@@ -134,8 +134,6 @@ struct DSlot {
   bool claimed = false;
   uint32_t gen = 0;
   uint32_t n = 0;
-  hipEvent_t t[4] = {nullptr, nullptr, nullptr, nullptr};  // profiling only: around the decoding kernel and the subgroup test
-  bool timed = false;
 };
 
 struct DevWorker;
@@ -188,11 +186,7 @@ struct Ctx {
   uint64_t bstamp = 0;
   unsigned epoch = 0;  // bumped by curdle_shutdown: resident base sets of a closed context are refused
   int pending_uploads = 0;  // resident base sets being copied + converted on util_stream right now (outside cx.mu): curdle_shutdown waits for none
-  int profile = 0;  // 0 off, 1 every phase, 2 the dominant kernel only, 3 every phase without the diagnostic reads (totals)
-  // sums over every profiled call since the last reset (curdle_profile_totals): what `gpu_busy_frac` of the host-bound
-  // bench lines is made of -- MSM phases (finish_slot) and point-decoding kernels (decode_api.hip), microseconds
-  std::atomic<unsigned long long> prof_total_us{0};
-  std::atomic<unsigned long long> prof_calls{0};
+  int profile = 0;  // 0 off, 1 every phase, 2 the dominant kernel only
   curdle_profile last = {};
 };
 
@@ -311,7 +305,7 @@ struct Prof {
       for (auto& e : s.ev) (void)hipEventCreate(&e);
       s.ev_made = true;
     }
-    if (mode == 1 || mode == 3) (void)hipEventRecord(s.ev[0], st);
+    if (mode == 1) (void)hipEventRecord(s.ev[0], st);
   }
   void mark(const char* name) {
     if (!mode || s.prof_n >= CURDLE_PROF_MAX_KERNELS) return;

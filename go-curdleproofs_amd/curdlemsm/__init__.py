@@ -55,7 +55,7 @@ SYMBOLS = [
     "curdle_acc_new", "curdle_acc_free", "curdle_acc_accumulate_check", "curdle_acc_accumulate_check_deferred",
     "curdle_acc_verify",
     "curdle_acc_get_A_c", "curdle_acc_num_bases", "curdle_acc_export",
-    "curdle_profile_enable", "curdle_profile_last", "curdle_profile_totals", "curdle_selftest_op", "curdle_selftest_shape", "curdle_msm_free_slots",
+    "curdle_profile_enable", "curdle_profile_last", "curdle_selftest_op", "curdle_selftest_shape", "curdle_msm_free_slots",
     "curdle_synth_points_walk_device",
     "curdle_crs_generate", "curdle_crs_free", "curdle_crs_size", "curdle_shuffle_permute_commit",
     "curdle_prove", "curdle_verify", "curdle_proof_from_bytes", "curdle_proof_free", "curdle_verify_proof",
@@ -139,7 +139,6 @@ _acc_num_bases = _sig("curdle_acc_num_bases", C.c_size_t, _vp)
 _acc_export = _sig("curdle_acc_export", C.c_int, _vp, _vp, _vp)
 _profile_enable = _sig("curdle_profile_enable", C.c_int, C.c_int)
 _profile_last = _sig("curdle_profile_last", C.c_int, C.POINTER(_Profile))
-_profile_totals = _sig("curdle_profile_totals", C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), C.c_int)
 _synth_walk = _sig("curdle_synth_points_walk_device", C.c_int, _vp, _vp, C.c_size_t, _vp)
 _dbases_create = _sig("curdle_dbases_create", C.c_int, _vp, C.c_size_t, C.POINTER(C.c_void_p))
 _dbases_free = _sig("curdle_dbases_free", None, _vp)
@@ -534,15 +533,8 @@ class MsmAccumulator:
 
 
 def profile_enable(on=True) -> None:
-    """True / 1: HIP events around every kernel; 2: around the dominant kernel only; 3: every kernel, totals only; False / 0: off."""
+    """True / 1: HIP events around every kernel; 2: around the dominant kernel only; False / 0: off."""
     _check(_profile_enable(int(on)))
-
-
-def profile_totals(reset: bool = False):
-    """(kernel milliseconds, calls) summed over every profiled call since the last reset (curdle_profile_totals)."""
-    ms, calls = C.c_double(0.0), C.c_ulonglong(0)
-    _check(_profile_totals(C.byref(ms), C.byref(calls), 1 if reset else 0))
-    return float(ms.value), int(calls.value)
 
 
 def profile_last() -> dict:

@@ -554,16 +554,9 @@ typedef struct {
 /* on = 1: every MSM call brackets each kernel with hipEvents on the stream it launches on
  * and keeps the durations of the last call.  on = 2: only the dominant kernel (the bucket
  * accumulation) is bracketed -- two events instead of ten, which a pipelined caller does
- * not notice.  on = 3: every kernel like 1, without the two diagnostic 4-byte reads per call (entries /
- * fragments stay 0): for callers that only want the totals below.  on = 0: off. */
+ * not notice.  on = 0: off. */
 int curdle_profile_enable(int on);
 int curdle_profile_last(curdle_profile* out);
-/* Sums over every profiled call on the calling thread's context since the last reset: the kernels' own
- * durations (HIP events on the streams they run on) of the MSM phases and of the point-decoding kernels,
- * in milliseconds, and the number of calls that contributed.  Kernels of different calls that overlap on
- * the GPU are each counted in full, so kernel_ms / wall time is an UPPER bound on how busy the GPU was --
- * what bench.py prints as gpu_busy_frac beside the host-bound batch figures.  reset != 0 clears the sums. */
-int curdle_profile_totals(double* kernel_ms, unsigned long long* calls, int reset);
 
 /* Synthetic MSM bases of SURVEY.md section 8(d), generated on the GPU into
  * device memory: P_i = (k + i*q) * G for i < n, gnark G1Affine layout.  k and
