@@ -666,12 +666,13 @@ hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStrea
   // One wave per chunk of 32 to 256 fragments; more chunks than waves go round.  The launch is almost always empty
   // (uniform scalars queue nothing) and every block of it has to find room beside the next accumulation before it can
   // read the empty queue and leave: a synchronous call, which has the chip to itself, takes up to 768 blocks = three
-  // 165-register waves on every SIMD; a pipelined one 256 (768 empty blocks cost its step 0.02 ms of 2.53:
-  // profiles/r06_pipeline_phase_costs.txt).
+  // 165-register waves on every SIMD; a pipelined one 64 (768 empty blocks cost its step 0.02 ms of 2.53, 256 still 0.01
+  // of an 8-way rank's 0.43: profiles/r06_pipeline_phase_costs.txt; 64 against 256 on one lease: 2.452 against 2.478 ms
+  // per whole MSM, profiles/r06_merge_grid_ab.txt -- a skewed pipelined call goes round a few times, behind other work).
   const u32 nw = p.win_end - p.win_begin;
   const u64 nlanes = ((u64)nw * p.n + p.L - 1) / p.L;  // fragments <= bucket slots + lanes
   const u64 chunks = (u64)p.max_large + ((u64)p.k * p.NB + nlanes) / 32u;
-  const u32 cap = wide ? 768u : 256u;
+  const u32 cap = wide ? 768u : 64u;
   const u32 blocks = (u32)(chunks / 4u + 1u < cap ? chunks / 4u + 1u : cap);
   hipLaunchKernelGGL(k_merge_large, dim3(blocks, p.sets), dim3(kBlock), 0, stream, ws.large, ws.nlarge, ws.foff, ws.fragcnt,
                      reinterpret_cast<X28*>(ws.frags), ws.mdone, p.max_large, p.frag_stride, p.reduce_prio);
