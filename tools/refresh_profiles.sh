@@ -38,12 +38,14 @@ cut -c1-400 $O/bench_default.json
 fi
 if [[ $PART == *b* ]]; then
 timeout -k 10 400 python3 $R/tools/sweep.py > $O/sweep.log 2>/dev/null
+timeout -k 10 400 python3 $R/tools/sweep_adversarial.py --out gpurun_out/refresh/adversarial.json > /dev/null 2> $O/adversarial_rows.jsonl
 timeout -k 10 400 python3 $R/bench.py --sweep > $O/sweep.json 2> $O/sweep_rows.jsonl
 timeout -k 10 300 python3 $R/bench.py --mode whisk-batch --steps 5 --warmup 1 > $O/whisk_batch.json 2> /dev/null
 timeout -k 10 300 python3 $R/bench.py --mode verify --steps 200 --warmup 20 > $O/verify_line.json 2> /dev/null
 rm -f $O/multi_gpu_emulation.jsonl
+# (round 6: a window-split rank keeps its converted bases by DEFAULT -- what bench.py --gpus N runs; --convert-per-call is the gnark-layout-per-call figure)
 for w in 2 4 8; do timeout -k 10 200 python3 $R/bench.py --emulate-world $w --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl; done
-for w in 2 4 8; do timeout -k 10 200 python3 $R/bench.py --emulate-world $w --bases-unchanged --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl; done
+for w in 2 4 8; do timeout -k 10 200 python3 $R/bench.py --emulate-world $w --convert-per-call --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl; done
 for w in 2 4 8; do timeout -k 10 200 python3 $R/bench.py --emulate-world $w --resident-bases --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl; done
 timeout -k 10 200 python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 >> $O/multi_gpu_emulation.jsonl
 for lg in 22 24; do timeout -k 10 300 python3 $R/bench.py --logn $lg --steps 10 --warmup 2 --no-cpu-baseline --no-verify 2>/dev/null | tail -1 > $O/bench_2p$lg.json; done
