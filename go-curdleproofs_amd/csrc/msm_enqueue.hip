@@ -249,7 +249,10 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
     stream = tail;
     prof.st = tail;
   }
-  if (!EXP_SKIP(4)) HIP_TRY(launch_merge_large(p, ws, stream, latency_mode && !join));
+  // (wide: a synchronous call with the chip to itself -- also the one-chunk host-buffer call, whose join only splits its own
+  // enqueue in two; the chunks of a chunked call run beside each other's accumulations, like pipelined calls)
+  const bool alone = !join || (!join->accumulate_only && !join->fold_home && join->earlier.empty());
+  if (!EXP_SKIP(4)) HIP_TRY(launch_merge_large(p, ws, stream, latency_mode && alone));
   prof.mark("merge_large");
   if (join && join->accumulate_only) {
     if (join->fold_home) {
