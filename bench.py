@@ -136,6 +136,9 @@ def main():
                     help="diagnostic: a window-split rank (N > 1 or --emulate-world) converts its gnark-layout bases on EVERY "
                          "call instead of passing CURDLE_MSM_BASES_UNCHANGED (the default there since round 6: the inputs "
                          "are resident and unchanged between steps, which is the flag's contract)")
+    ap.add_argument("--exchange-batch", type=int, default=8,
+                    help="N > 1: partials of this many steps travel in one all_gather (144 x k bytes per rank); 1 = one collective "
+                         "per step.  Every step's result is gathered and summed inside the timed region either way")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: on ONE GPU, run only the share rank 0 of an N-rank job would run "
                          "(no collective); prints the per-rank step time, not a bench line")
@@ -264,26 +267,48 @@ def main():
     exchange = PartialExchange(device=dev if dist.get_backend() == "nccl" else None) if dist is not None else None
     exchanging = []     # (N > 1) the all_gather of the step before, finished one step later
 
+    batch_k = max(1, args.exchange_batch)
+    gathered = []       # this rank's partials waiting for the next all_gather
+
+    def sum_batch(allp, k_):
+        """uint64[world, k_ * 18] -> the k_ full results, one host sum each"""
+        per = allp.reshape(allp.shape[0], k_, 18)
+        return [cm.g1_sum(np.ascontiguousarray(per[:, j, :])) for j in range(k_)]
+
     def collect(ticket):
         """Result of one step on every rank: wait for this rank's share, then (N > 1)
-        all-gather the 144-byte partials over RCCL and add them.  The exchange of step i is
-        started here and finished when step i + 1 is collected (or by flush()), so that the
-        collective's wait for a free wave slot beside the accumulation is not in every step."""
+        all-gather the 144-byte partials over RCCL and add them.  Partials of --exchange-batch
+        steps travel in ONE all_gather (144 x k bytes per rank: fewer, larger collectives --
+        the collective's kernel and its two small copies cost a step 0.1 ms of GPU time beside
+        an accumulation that fills the chip, whatever they carry), and the exchange started
+        here is finished when the next one is started (or by flush()), so that its wait for a
+        free wave slot is not in every step.  Every step's result is still gathered to every
+        rank and summed inside the timed region."""
         t_ = time.perf_counter()
         part = cm.msm_wait(ticket)
         host_t["wait"] += time.perf_counter() - t_
         if dist is None:
             return part
         t_ = time.perf_counter()
-        exchanging.append(exchange.start(part))
-        res = cm.g1_sum(exchange.finish(exchanging.pop(0))) if len(exchanging) > 1 else None
+        res = None
+        gathered.append(part)
+        if len(gathered) == batch_k:
+            exchanging.append((exchange.start(np.concatenate(gathered)), len(gathered)))
+            gathered.clear()
+            if len(exchanging) > 1:
+                h, k_ = exchanging.pop(0)
+                res = sum_batch(exchange.finish(h), k_)[-1]
         host_t["exchange"] = host_t.get("exchange", 0.0) + time.perf_counter() - t_
         return res
 
     def flush():
         res = None
+        if gathered:
+            exchanging.append((exchange.start(np.concatenate(gathered)), len(gathered)))
+            gathered.clear()
         while exchanging:
-            res = cm.g1_sum(exchange.finish(exchanging.pop(0)))
+            h, k_ = exchanging.pop(0)
+            res = sum_batch(exchange.finish(h), k_)[-1]
         return res
 
     def run_steps(count, on_step=None):
@@ -372,7 +397,7 @@ def main():
     # (barrier, every rank's synchronous window-range call, all_gather, sum; MAX over ranks), the exchange alone, and the
     # SAME contract at one rank (the whole MSM with the flag on this rank's own GPU: the baseline a speed-up is a ratio to).
     multi = None
-    if dist is not None:
+    if dist is not None and not args.emulate_world:   # (--emulate-world with --force-dist: one rank's share WITH the exchange, at world size 1)
         from curdlemsm.distributed import msm_g1_distributed
         on_gpu = dist.get_backend() == "nccl"
 
@@ -415,7 +440,7 @@ def main():
                 raise SystemExit("bench.py: the one-rank baseline and the distributed result differ")
         if result is not None and not (r_d == result).all():
             raise SystemExit("bench.py: a synchronous distributed call and the pipelined steps differ")
-        multi = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+        multi = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "exchange_batch": batch_k,
                  "bases_unchanged": keep_bases,
                  "rank_step_ms": round(ms_per_step, 4),
                  "rank_single_call_ms": round(single_call_ms, 4),
@@ -426,8 +451,8 @@ def main():
                              + ("CURDLE_MSM_BASES_UNCHANGED" if keep_bases else "bases converted per call")
                              + ", run by every rank on its own GPU right after the timed region (MAX over ranks)",
                      "ms_per_step": round(base_ms, 4), "pairs_per_s": round(n / base_ms * 1e3, 1)},
-                 "note": "`value` is pipelined throughput (in_flight window-range calls per rank, the exchange of step i "
-                         "finished during step i + 1); ONE synchronous call scales as whole_single_call_ms against "
+                 "note": "`value` is pipelined throughput (in_flight window-range calls per rank; the partials of exchange_batch "
+                         "steps travel in one all_gather, finished while the next steps run); ONE synchronous call scales as whole_single_call_ms against "
                          "config.single_call.ms_per_call of the N = 1 line.  No scaling curve was measured by the builder "
                          "(one-GPU leases): the driver computes efficiency from its own runs."}
         assert multi["rccl_ranks"] == args.gpus == world, (multi["rccl_ranks"], args.gpus, world)

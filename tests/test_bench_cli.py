@@ -70,6 +70,7 @@ def _check_multi_gpu_keys(line, world, backend):
     mg = line["config"]["multi_gpu"]
     assert mg["rccl_ranks"] == world == line["n_gpus"] and mg["backend"] == backend
     assert mg["bases_unchanged"] is (world > 1) and line["config"]["bases_unchanged_flag"] is (world > 1)
+    assert mg["exchange_batch"] >= 1
     for key in ("rank_step_ms", "rank_single_call_ms", "whole_single_call_ms", "exchange_ms"):
         assert mg[key] > 0, key
     assert mg["whole_single_call_ms"] >= 0.9 * mg["rank_single_call_ms"]
