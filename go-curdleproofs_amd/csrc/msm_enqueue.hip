@@ -136,7 +136,7 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   ws.winsums28 = S.winsums28.p;
   // Round 5: what the host's Horner pass reads leaves the GPU by the kernels' own stores into the slot's pinned buffer
   // (device-visible like all pinned memory here) -- a hundred points or so, 16 bytes per store -- instead of through a
-  // device array and a copy command behind the last kernel (~10 us of every synchronous call; knob DIRECT_RESULTS=0: the copy).
+  // device array and a copy command behind the last kernel (~10 us of every synchronous call).
   const size_t win_bytes = kr * (size_t)nw * wpts * sizeof(G1XYZZ);
   const bool direct = !p.gpu_combine && win_bytes <= ((size_t)256 << 10);
   ws.winsums = direct ? (G1XYZZ*)S.h_buf : (G1XYZZ*)S.winsums.p;

@@ -25,7 +25,7 @@ static constexpr int kBlock = 256;
 // s_getreg_b32 operands: (size - 1) << 11 | offset << 6 | register id.  HW_ID (4): wave slot 3:0, SIMD 5:4, CU 11:8,
 // SH 12, SE 15:13; XCC_ID (20): the XCD in 3:0.
 static constexpr int kGetregHwId = ((32 - 1) << 11) | 4;
-static constexpr int kGetregXccId = ((32 - 1) << 11) | 20;
+[[maybe_unused]] static constexpr int kGetregXccId = ((32 - 1) << 11) | 20;  // (the wave-trace experiment build only)
 // s_setprio takes an immediate
 __device__ __forceinline__ void set_wave_prio(u32 v) {
   if (v == 1) __builtin_amdgcn_s_setprio(1);

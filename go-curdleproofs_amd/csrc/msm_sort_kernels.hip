@@ -661,7 +661,7 @@ __device__ __forceinline__ u32 block_exclusive_scan_shfl(u32 v, u32* sh /* [16] 
   return before + inc - v;
 }
 // Thread t owns slots [t per, (t + 1) per), per a multiple of 4: every load is issued before anything is
-// added (k_scan_fused walks its slots one dependent 4-byte load after the other, twice), two block scans in all.
+// added (the round-2 single-block form walked its slots one dependent 4-byte load after the other, twice), two block scans in all.
 __global__ void __launch_bounds__(kScanThreads)
     k_scan_one(const u32* __restrict__ counts, u32 nb, u32* __restrict__ starts, u32* __restrict__ cursor,
                u32* __restrict__ fragcnt, u32* __restrict__ foff, u32* __restrict__ large, u32* __restrict__ nlarge, u32 L,
