@@ -54,7 +54,8 @@ def _run_forced_dist(extra, timeout=600):
 
 @pytest.mark.gpu
 def test_the_nccl_path_of_the_bench_runs_at_world_size_one(gpu):
-    line = _run_forced_dist(["--steps", "6", "--warmup", "2", "--logn", "16", "--no-verify"])
+    # (--exchange-batch 3 with 6 steps: two full batches through the lagged finish, and the flush at the end)
+    line = _run_forced_dist(["--steps", "6", "--warmup", "2", "--logn", "16", "--no-verify", "--exchange-batch", "3"])
     assert line["n_gpus"] == 1 and line["value"] and line["value"] > 0
     assert "over nccl" in line["config"]["parallelism"]            # the partials went through RCCL's all_gather
     assert "exchange" in line["config"]["host_ms_per_step"]
@@ -91,7 +92,8 @@ def test_two_ranks_over_gloo_print_the_multi_gpu_keys(gpu):
     env = dict(os.environ, CURDLE_DIST_BACKEND="gloo")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
-                        "--warmup", "2", "--logn", "16", "--no-verify"], env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "2", "--logn", "16", "--no-verify", "--exchange-batch", "4"], env=env, capture_output=True, text=True,
+                       timeout=600)      # (4 of 6 steps in one all_gather, the other two by the flush)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-1500:]
