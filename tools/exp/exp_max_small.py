@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Experiment (round 6): the fragment count beyond which a bucket goes through k_merge_large (MsmPlan::max_small),
-on uniform inputs over the size table and on the adversarial families at 2^12 / 2^16."""
+on uniform inputs over the size table and on the adversarial families at 2^12 / 2^16.  Ran against a build that had an
+experiment knob MAX_SMALL (profiles/r06_max_small.txt); the knob was removed with the decision (16; 8 up to 4,096 pairs),
+so this script is the record of how the table was made, not something the product build can replay."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
