@@ -1087,8 +1087,9 @@ def compact_adversarial(cm, torch, d_pts, k, q, uniform):
             rows.append(row)
     return {"bar": "every family within 1.25x of uniform at the same N and entry point", "worst_ratio": worst,
             "note": "2^12: a bucket that holds a whole window's terms is ~2,000 fragments at 4 positions per lane, and summing "
-                    "them (k_merge_large: a chain of ~14 dependent additions) shows on a 0.3 ms call; from 2^16 on every family "
-                    "is inside the bar", "rows": rows}
+                    "them (k_merge_large: a chain of ~14 dependent additions) shows on a 0.3 ms call; from 2^16 on these families "
+                    "are inside the bar (a few hundred distinct values at 2^14..2^16 are not: 1.3-1.38x, "
+                    "profiles/r06_adversarial.json)", "rows": rows}
 
 
 def cpu_baseline(cm, k, q, n, sc, gpu_result, d_pts):

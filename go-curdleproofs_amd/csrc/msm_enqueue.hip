@@ -64,6 +64,12 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
   if (p.fuse_scan == 2 && (join || !latency_mode)) p.fuse_scan = 3;  // k_scan_chain: four 60-register waves (L >= 2 holds: make_plan)
   // a chunk of a host-buffer call sorts (and folds) beside the chunks before it: raised like a pipelined call's sort
   if (join && knobs::get(knobs::AUX_PRIO) < 0) p.aux_prio = 3;
+  // ... and ONE merge limit for every chunk of an MSM, in both of its enqueue steps, whatever the sizes of the chunks say: the
+  // reduction reads all their fragment lists under the last chunk's plan, and a bucket merged under one limit and read under
+  // another would count twice.  8, what the size rule gives every input large enough to be chunked: a bucket just under the limit
+  // is walked fragment by fragment by the fold and by the reduction (limits of 16 and 32 made 256..1,024 distinct scalar values
+  // from host slices 1.3-1.6x a uniform call: profiles/r06_adversarial_distinct_k.txt).
+  if (join && join->chunked) p.max_small = 8;
   // the kernels work on the GLV split's terms, two per pair (records and digits 2 i, 2 i + 1)
   const size_t n = 2 * n_pairs;
   const size_t kr = k * sets;
@@ -249,10 +255,12 @@ int enqueue_slot_impl(Ctx& cx, Slot& S, const void* d_points, const void* d_scal
     stream = tail;
     prof.st = tail;
   }
-  // (wide: a synchronous call with the chip to itself -- also the one-chunk host-buffer call, whose join only splits its own
-  // enqueue in two; the chunks of a chunked call run beside each other's accumulations, like pipelined calls)
-  const bool alone = !join || (!join->accumulate_only && !join->fold_home && join->earlier.empty());
-  if (!EXP_SKIP(4)) HIP_TRY(launch_merge_large(p, ws, stream, latency_mode && alone));
+  // The merge launch's grid: a synchronous call has the chip to itself (768 blocks; also the one-chunk host-buffer call, whose join
+  // only splits its own enqueue in two); a chunk of a chunked call runs beside the next chunk's accumulation (256); a pipelined call
+  // pays for every empty block (64: msm_reduce_kernels.hip launch_merge_large).
+  const bool alone = !join || !join->chunked;
+  const uint32_t merge_blocks = latency_mode && alone ? 768u : (join && join->chunked ? 256u : 64u);
+  if (!EXP_SKIP(4)) HIP_TRY(launch_merge_large(p, ws, stream, merge_blocks));
   prof.mark("merge_large");
   if (join && join->accumulate_only) {
     if (join->fold_home) {

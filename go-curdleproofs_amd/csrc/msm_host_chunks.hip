@@ -90,6 +90,7 @@ int run_host_chunked(const uint64_t* points, const uint64_t* scalars, size_t n, 
       // with three or four fragment lists per bucket the reduction's chain is fragments, not
       // running sums: half as many buckets per quad (N = 2^20, four chunks: 5.30 -> 5.02 ms)
       pt.join.seg = nchunks >= 3 ? 8 : 0;
+      pt.join.chunked = true;
       parts.push_back(pt);
     }
     int r;

@@ -324,6 +324,8 @@ struct Prof {
 // says when), the last one waits for the earlier chunks' events and folds their fragment lists
 // into its own bucket reduction (FragSources, msm_kernels.h).
 struct ChunkJoin {
+  bool chunked = false;               // one of SEVERAL chunks of a host-buffer MSM (set for every chunk, in both of its enqueue steps): the plan rules that differ
+                                      // for chunks -- bucket-merge limit, merge grid -- must be the same in the sort step and in the accumulate step
   bool accumulate_only = false;       // an earlier chunk: no reduce, no window sums, no D2H
   std::vector<Slot*> earlier;         // the last chunk: the slots of the chunks before it
   uint32_t seg = 0;                   // buckets per reduce segment, the same for every chunk (0: the plan's rule)

@@ -139,7 +139,7 @@ hipError_t launch_hist(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t str
 hipError_t launch_scan(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_scatter(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
 hipError_t launch_accumulate(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);
-hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, bool wide);
+hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, uint32_t max_blocks);
 // extra: fragment lists of earlier chunks (same plan) to fold in besides ws's own; may be null
 hipError_t launch_bucket_reduce(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, const FragSources* extra = nullptr);
 hipError_t launch_window_sum(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream);

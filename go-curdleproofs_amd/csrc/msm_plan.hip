@@ -223,7 +223,24 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   // and buy back 0.15 ms only where a few dozen buckets hold exactly that many (64 distinct scalar values at 2^12 pairs).
   // Up to 4,096 pairs 8 costs uniform inputs nothing (same file: 1,268 and 4,096 pairs equal to the microsecond) and takes
   // 0.15 ms off a call whose occupied buckets hold exactly 9..16 (0.54 -> 0.39 ms at 4,096 pairs).
-  p.max_small = n_total <= 8192 && k * sets == 1 ? 8 : 16;
+  // ... and beyond that: what an evenly loaded bucket of the narrowest window comes to plus four standard deviations of its
+  // (Poisson) load, between 8 and 16 -- 16 at 8,192 pairs (8 + 1 fragments, sigma 1.4), 12 at 2^16 (6.4 + 1, sigma 0.8), 8 from
+  // 2^18 on (1.8 + 1 at L = 36; 1.5 at N = 2^20, L = 128): uniform inputs still queue nothing, and a bucket just UNDER the limit,
+  // which the reduction walks fragment by fragment on its chain, is shorter.  Eight such buckets in one segment made the reduction
+  // of a synchronous 2^20 call 0.74 ms where it takes 0.25 (600 distinct scalar values: 13-16 fragments in every occupied bucket;
+  // profiles/r06_adversarial_distinct_k.txt).
+  p.max_small = 16;
+  if (k * sets == 1) {
+    if (n_total <= 8192) {
+      p.max_small = 8;
+    } else if (min_nbkt) {
+      const uint64_t load = (n_max + min_nbkt - 1) / min_nbkt;
+      uint64_t sd = 0;
+      while ((sd + 1) * (sd + 1) <= load) sd++;  // floor(sqrt(load))
+      const uint64_t lim = (load + 4 * (sd + 1) + p.L - 1) / p.L + 2;  // ceil((load + 4 sigma) / L) + 1 for the straddled lane + 1
+      p.max_small = (uint32_t)(lim < 8 ? 8 : lim > 16 ? 16 : lim);
+    }
+  }
   // a bucket with more than max_small fragments holds more than (max_small - 1) * L entries
   uint64_t ml = entries / ((uint64_t)(p.max_small - 1) * p.L) + 1;
   p.max_large = (uint32_t)(ml < nbk ? ml : nbk);

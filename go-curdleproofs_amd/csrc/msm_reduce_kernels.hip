@@ -55,6 +55,10 @@ __device__ __forceinline__ void group_sum_quad(F28& acc, u32 G, F28 (*wave_parti
 // balanced: a chain of 4 + 4 + 2 + 4 quad additions for 2,048 fragments, 8 + 4 + 4 + 4 for 8,192, instead of
 // 32 + 9 whole ones.
 static constexpr u32 kMergeTile = 1024;  // queue entries per pass over the queue
+// Buckets of at most this many fragments do not take a wave each: FOUR of them share one, a quarter wave (4 quads) per bucket --
+// a quad adds <= 4 fragments, two shuffle levels, no counter.  Thousands of 9..16-fragment buckets (a few hundred distinct scalar
+// values) are the case: a wave each is 9 of 16 quads at work for five steps.
+static constexpr u32 kMergeSmall = 16;
 __host__ __device__ inline u32 merge_chunk_shift(u32 m) {  // log2 of the chunk a bucket of m fragments is cut into
   return m <= 1024u ? 5u : m <= 4096u ? 6u : m <= 16384u ? 7u : 8u;
 }
@@ -62,7 +66,7 @@ __global__ void __launch_bounds__(kBlock, 2)
     k_merge_large(const u32* __restrict__ large, const u32* __restrict__ nlarge, const u32* __restrict__ foff,
                   const u32* __restrict__ fragcnt, X28* __restrict__ frags, u32* __restrict__ done, u32 max_large,
                   u32 frag_stride, u32 prio) {
-  __shared__ u32 pre[kMergeTile], gq[kMergeTile], mq[kMergeTile];
+  __shared__ u32 pre[kMergeTile], spre[kMergeTile], gq[kMergeTile], mq[kMergeTile];
   __shared__ u32 sh_scan[kBlock / 64];
   const u32 nl = min(*nlarge, max_large);
   if (nl == 0) return;  // the usual case
@@ -71,7 +75,15 @@ __global__ void __launch_bounds__(kBlock, 2)
   const u32 lane = tid & 63u, qd = lane >> 2;  // quad inside the wave
   frags += (size_t)blockIdx.y * frag_stride;
   done += (size_t)blockIdx.y * max_large;
-  const u32 nwaves = gridDim.x * (kBlock / 64), mywave = blockIdx.x * (kBlock / 64) + (tid >> 6);
+  // The queue is worked on in passes of kMergeTile entries (the tables are LDS), and the launch's blocks are dealt to the passes
+  // round robin, so that all passes run at once: pass t belongs to blocks t, t + T, t + 2 T, ... (one pass: all blocks; more
+  // passes than blocks: a block takes several, one after the other).  With every block walking every pass in turn, 16 passes of
+  // 1,024 nine-fragment buckets kept a quarter of the waves busy sixteen times over: 1.07 ms where this takes 0.1.
+  const u32 T = (nl + kMergeTile - 1) / kMergeTile;
+  const u32 tile = (nl + T - 1) / T;  // passes of equal length (1,280 entries: two of 640, not 1,024 + 256 behind equal teams)
+  const u32 team = gridDim.x >= T ? (gridDim.x - (blockIdx.x % T) + T - 1) / T : 1u;  // blocks on my pass
+  const u32 nwaves = team * (kBlock / 64);
+  const u32 mywave = (gridDim.x >= T ? blockIdx.x / T : 0u) * (kBlock / 64) + (tid >> 6);
   // More chunks than the launch has waves (hundreds of buckets of a hundred fragments each: 64 distinct scalar values)
   // would go round several times at the small buckets' chunk size: every bucket's chunks are doubled (up to 256
   // fragments) until one round takes them all -- 5,120 chunks of 32 on 1,024 waves took 0.30 ms, 2,560 of 64 on 3,072 take 0.1.
@@ -80,38 +92,68 @@ __global__ void __launch_bounds__(kBlock, 2)
     u32 mine = 0;
     for (u32 x = tid; x < nl; x += kBlock) {
       const u32 m = fragcnt[large[x]], sh = merge_chunk_shift(m);
-      mine += (m + (1u << sh) - 1u) >> sh;
+      if (m > kMergeSmall) mine += (m + (1u << sh) - 1u) >> sh;
     }
     u32 total0;
     (void)block_exclusive_scan_256(mine, sh_scan, total0);
-    while (bump < 3u && (total0 >> bump) > nwaves) bump++;
+    while (bump < 3u && (total0 >> bump) > gridDim.x * (kBlock / 64)) bump++;
   }
   auto chunk_shift = [&](u32 m) { return min(merge_chunk_shift(m) + bump, 8u); };
-  for (u32 t0 = 0; t0 < nl; t0 += kMergeTile) {  // block-uniform trip count
-    const u32 cnt = min(kMergeTile, nl - t0);
+  for (u32 t0 = (blockIdx.x % T) * tile; t0 < nl; t0 += gridDim.x * tile) {  // block-uniform trip count
+    const u32 cnt = min(tile, nl - t0);
     __syncthreads();  // the pass before is done with the tables
-    u32 nch[kMergeTile / kBlock], sum = 0;
+    u32 nch[kMergeTile / kBlock], nsm[kMergeTile / kBlock], sum = 0, ssum = 0;
 #pragma unroll
     for (u32 k = 0; k < kMergeTile / kBlock; k++) {
       const u32 idx = tid * (kMergeTile / kBlock) + k;
-      nch[k] = 0;
+      nch[k] = nsm[k] = 0;
       if (idx < cnt) {
         const u32 g = large[t0 + idx], m = fragcnt[g];
         gq[idx] = g;
         mq[idx] = m;
-        const u32 sh = chunk_shift(m);
-        nch[k] = (m + (1u << sh) - 1u) >> sh;
+        if (m <= kMergeSmall) {
+          nsm[k] = 1;
+        } else {
+          const u32 sh = chunk_shift(m);
+          nch[k] = (m + (1u << sh) - 1u) >> sh;
+        }
       }
       sum += nch[k];
+      ssum += nsm[k];
     }
-    u32 total;
+    u32 total, stotal;
     u32 ex = block_exclusive_scan_256(sum, sh_scan, total);
+    u32 sex = block_exclusive_scan_256(ssum, sh_scan, stotal);
 #pragma unroll
     for (u32 k = 0; k < kMergeTile / kBlock; k++) {
       pre[tid * (kMergeTile / kBlock) + k] = ex;
+      spre[tid * (kMergeTile / kBlock) + k] = sex;
       ex += nch[k];
+      sex += nsm[k];
     }
     __syncthreads();
+    // the small buckets of this pass, four to a wave: quarter `lane >> 4` takes the (4 c + quarter)-th of them
+    for (u32 c = mywave; 4u * c < stotal; c += nwaves) {  // wave-uniform trip count
+      const u32 si = 4u * c + (lane >> 4);
+      const bool have = si < stotal;
+      u32 lo = 0, hi = cnt;  // the last entry whose count of small ones before it is <= si: the si-th small one
+      while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (spre[mid] > si) hi = mid;
+        else lo = mid + 1;
+      }
+      const u32 e = have ? lo - 1 : 0u;
+      const u32 m = have ? mq[e] : 0u;
+      X28* f = frags + foff[gq[e]];
+      F28 acc, b;
+      q28::set_inf(acc);
+      for (u32 i = qd & 3u; i < m; i += 4) {  // quad-uniform; at most four
+        q28::load(b, &f[i]);
+        q28::add(acc, b);
+      }
+      group_sum_quad(acc, 4u, nullptr);  // every lane of the wave shuffles; sums meet in each quarter's first quad
+      if (have && (qd & 3u) == 0) q28::store(&f[0], acc);
+    }
     for (u32 c = mywave; c < total; c += nwaves) {  // wave-uniform from here on
       u32 lo = 0, hi = cnt;  // the queue entry of chunk c: the last one whose first chunk is <= c
       while (lo < hi) {
@@ -119,7 +161,8 @@ __global__ void __launch_bounds__(kBlock, 2)
         if (pre[mid] > c) hi = mid;
         else lo = mid + 1;
       }
-      const u32 e = lo - 1;
+      u32 e = lo - 1;
+      while (mq[e] <= kMergeSmall) e--;  // small entries own no chunk (they share the prefix of the big one before them)
       const u32 m = mq[e], sh = chunk_shift(m), base = (c - pre[e]) << sh;
       const u32 nchunks = (m + (1u << sh) - 1u) >> sh;
       X28* f = frags + foff[gq[e]];
@@ -662,7 +705,7 @@ __global__ void __launch_bounds__(kBlock, 2)
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
-hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, bool wide) {
+hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStream_t stream, uint32_t max_blocks) {
   // One wave per chunk of 32 to 256 fragments; more chunks than waves go round.  The launch is almost always empty
   // (uniform scalars queue nothing) and every block of it has to find room beside the next accumulation before it can
   // read the empty queue and leave: a synchronous call, which has the chip to itself, takes up to 768 blocks = three
@@ -672,7 +715,7 @@ hipError_t launch_merge_large(const MsmPlan& p, const MsmWorkspace& ws, hipStrea
   const u32 nw = p.win_end - p.win_begin;
   const u64 nlanes = ((u64)nw * p.n + p.L - 1) / p.L;  // fragments <= bucket slots + lanes
   const u64 chunks = (u64)p.max_large + ((u64)p.k * p.NB + nlanes) / 32u;
-  const u32 cap = wide ? 768u : 64u;
+  const u32 cap = max_blocks < 1u ? 1u : max_blocks > 768u ? 768u : max_blocks;
   const u32 blocks = (u32)(chunks / 4u + 1u < cap ? chunks / 4u + 1u : cap);
   hipLaunchKernelGGL(k_merge_large, dim3(blocks, p.sets), dim3(kBlock), 0, stream, ws.large, ws.nlarge, ws.foff, ws.fragcnt,
                      reinterpret_cast<X28*>(ws.frags), ws.mdone, p.max_large, p.frag_stride, p.reduce_prio);

@@ -884,6 +884,27 @@ __global__ void __launch_bounds__(kChainThreads)
   const u32 pre1 = sh_pre[1];
   run = pre0 + first;
   u32 frun = pre1 + ffirst;
+  // The queue of large buckets: ONE atomic per wave reserves the places of all its lanes' large buckets (round 6: one per
+  // bucket was 8,000 same-address atomics at ~80 ns each when a few hundred distinct scalar values make every occupied
+  // bucket a large one -- the scan took 0.051 ms against 0.018).
+  u32 qat;
+  {
+    u32 nlg = 0;
+#pragma unroll
+    for (int k = 0; k < kChainPer; k++) nlg += f[k] > max_small ? 1u : 0u;
+    const u32 lane = tid & 63u;
+    u32 inc = nlg;
+#pragma unroll
+    for (u32 off = 1; off < 64; off <<= 1) {
+      const u32 t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    const u32 wtot = __shfl(inc, 63, 64);
+    u32 wbase = 0;
+    if (lane == 63 && wtot) wbase = atomicAdd(nlarge, wtot);
+    wbase = __shfl(wbase, 63, 64);
+    qat = wbase + inc - nlg;
+  }
 #pragma unroll
   for (int g = 0; g < kChainPer / 4; g++) {
     const u32 at = lo + 4 * g;
@@ -895,8 +916,8 @@ __global__ void __launch_bounds__(kChainThreads)
       run += v[4 * g + k];
       frun += f[4 * g + k];
       if (f[4 * g + k] > max_small) {
-        const u32 q = atomicAdd(nlarge, 1u);
-        if (q < max_large) large[q] = at + k;
+        if (qat < max_large) large[qat] = at + k;
+        qat++;
       }
     }
     if (at < nb) {

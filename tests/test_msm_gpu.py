@@ -556,6 +556,24 @@ def test_merge_of_large_buckets_in_every_form(gpu, oracle, coracle):
         assert (gpu.msm_wait(t) == exp).all()
         m = 1 << 14
         assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), m) == _walk_expected(oracle, coracle, k, q, sc[:m])).all()
+        # (b') a few hundred distinct values: every occupied bucket holds 9..16 fragments -- over the plan's merge limit at this
+        # size (8), under the chunks' (16: a chunk of a host-buffer call keeps its mid-size buckets for the fold).  The limit
+        # must be the same in a chunk's sort step and in its accumulate step, with two chunks as with four: a bucket merged
+        # under one limit and read under the other would count twice.
+        table = rand_scalars(rng, 700, oracle)
+        sc = table[rng.integers(0, 700, n)]
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        exp = _walk_expected(oracle, coracle, k, q, sc)
+        assert (gpu.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n) == exp).all()
+        pts_h = d_pts.cpu().numpy().view(np.uint64)
+        for chunks in (None, 2, 3):
+            gpu.plan_override("HOST_CHUNKS", chunks)
+            assert (gpu.msm_g1(pts_h, sc) == exp).all(), chunks
+        gpu.plan_override("HOST_CHUNKS", None)
+        gpu.plan_override("HOST_FOLD", 0)
+        assert (gpu.msm_g1(pts_h, sc) == exp).all()
+        gpu.plan_override("HOST_FOLD", None)
+        sc = np.tile(beta, (n, 1))
         # (c) three base sets, one scalar vector, buckets of several chunks
         m = 40000
         sets = [coracle.points_walk(k + 5 * j, q, m) for j in range(3)]
@@ -563,7 +581,8 @@ def test_merge_of_large_buckets_in_every_form(gpu, oracle, coracle):
         for j in range(3):
             assert (out[j] == coracle.msm_pippenger(sets[j], np.ascontiguousarray(sc[:m]), threads=8)).all(), j
     finally:
-        gpu.plan_override("SEG_LEN", None)
+        for knob in ("SEG_LEN", "HOST_CHUNKS", "HOST_FOLD"):
+            gpu.plan_override(knob, None)
 
 
 # ------------------------------------------------------------- window partition ---

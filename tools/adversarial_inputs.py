@@ -17,7 +17,7 @@ import numpy as np
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 R_INV = pow(1 << 256, -1, R_MOD)
 LAMBDA = 0xAC45A4010001A40200000000FFFFFFFF          # z^2 - 1: phi(P) = lambda P (csrc/bls12_381.h glv_split)
-FAMILIES = ("uniform", "all_equal", "small_9bit", "infinity_1pct", "distinct_64", "hot_window", "half_equal")
+FAMILIES = ("uniform", "all_equal", "small_9bit", "infinity_1pct", "distinct_64", "distinct_600", "distinct_1024", "hot_window", "half_equal")
 
 
 def to_mont(v: int) -> np.ndarray:
@@ -68,9 +68,10 @@ def make_family(name: str, n: int, uniform: np.ndarray, window_bits: int = 16, s
         return table[rng.integers(0, 512, n)], None
     if name == "infinity_1pct":        # curdleproof.go:281,285 pads with zero points; here 1 % of all bases
         return uniform[:n], rng.choice(n, max(1, n // 100), replace=False)
-    if name == "distinct_64":
-        table = np.stack([to_mont(int.from_bytes(rng.bytes(32), "little") % R_MOD) for _ in range(64)])
-        return table[rng.integers(0, 64, n)], None
+    if name.startswith("distinct_"):   # K distinct scalar values: K..2K occupied buckets per window
+        kk = int(name.split("_")[1])
+        table = np.stack([to_mont(int.from_bytes(rng.bytes(32), "little") % R_MOD) for _ in range(kk)])
+        return table[rng.integers(0, kk, n)], None
     if name == "half_equal":           # every other term shares every digit; the rest uniform
         sc = uniform[:n].copy()
         sc[::2] = to_mont((7 << 250) % R_MOD)
