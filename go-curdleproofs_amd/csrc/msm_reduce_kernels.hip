@@ -44,16 +44,17 @@ __device__ __forceinline__ void group_sum_quad(F28& acc, u32 G, F28 (*wave_parti
 // (fragcnt itself stays as scanned: base sets of a shared-scalar call share it).
 // Round 6.  Until now: one block per queued bucket, every thread a chain of m / 256 whole-point additions (14 product
 // steps each) and a 9-level tree behind it -- all-equal scalars at N = 2^20 queue 16 buckets of 8,192 fragments: 64
-// waves on a chip of 1,024 SIMDs for 0.9 ms, a third of the accumulation (profiles/r06_adversarial.json, "before").
-// Now the unit of work is a CHUNK of 16 S consecutive fragments of one bucket, taken by one wave as 16 quads
-// (quad28.h: an addition is 4 product steps): a quad adds S fragments, the wave's 16 sums meet by shuffles, and the
-// chunk's sum replaces the chunk's first fragment.  Chunks of all queued buckets are numbered through (a prefix sum
-// over the queue, redone by every block in LDS: the queue is short) and dealt to the launch's waves round robin, so
-// 16 buckets of 8,192 fragments are 1,024 waves at once.  The wave that finishes a bucket's LAST chunk (a counter per
-// queue entry, left at zero for the next call) adds the chunk sums the same way into slot 0.  S grows with the
-// bucket (2 up to 1,024 fragments, 4 up to 4,096, 8 up to 16,384, 16 beyond) so that the two serial parts stay
-// balanced: a chain of 4 + 4 + 2 + 4 quad additions for 2,048 fragments, 8 + 4 + 4 + 4 for 8,192, instead of
-// 32 + 9 whole ones.
+// waves on a chip of 1,024 SIMDs for 0.9 ms, a third of the accumulation (profiles/r06_adversarial_before.json).
+// Now everything queued is worked on at once, on quads (quad28.h: an addition is 4 product steps):
+//   * a bucket of more than 16 fragments is cut into CHUNKS of 16 S consecutive fragments, one wave each: a quad adds S
+//     fragments, the wave's 16 sums meet by shuffles, the chunk's sum replaces the chunk's first fragment; the wave that
+//     finishes a bucket's LAST chunk (a counter per queue entry, left at zero for the next call) adds the chunk sums the
+//     same way into slot 0.  S grows with the bucket (2 up to 1,024 fragments, 4 up to 4,096, 8 up to 16,384, 16 beyond)
+//     so that the two serial parts stay balanced -- 4 + 4 + 2 + 4 quad additions for 2,048 fragments, 8 + 4 + 4 + 4 for
+//     8,192, instead of 32 + 9 whole ones -- and doubles while there are more chunks than waves;
+//   * buckets of at most 16 fragments go FOUR to a wave, a quarter wave each (kMergeSmall below);
+//   * the queue is numbered through by prefix sums in LDS, kMergeTile entries per pass, and the launch's blocks are dealt
+//     to the passes round robin, so all passes run at once.
 static constexpr u32 kMergeTile = 1024;  // queue entries per pass over the queue
 // Buckets of at most this many fragments do not take a wave each: FOUR of them share one, a quarter wave (4 quads) per bucket --
 // a quad adds <= 4 fragments, two shuffle levels, no counter.  Thousands of 9..16-fragment buckets (a few hundred distinct scalar

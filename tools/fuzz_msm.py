@@ -44,6 +44,9 @@ def scalars(n):
             v[:, 0] &= np.uint64(511)
         elif kind == 2:
             v[:] = v[0]
+        elif kind == 4:                                                           # K distinct values: buckets around the merge limit (round 6)
+            kk = int(rng.integers(16, 5000))
+            v = v[:kk][rng.integers(0, kk, size=n)]
         return v                                                                  # any 4 limbs < r are a valid Montgomery element
     if kind == 0:
         v = [int.from_bytes(rng.bytes(32), "little") % R for _ in range(n)]
