@@ -1,0 +1,23 @@
+import os, sys, time
+sys.path[:0] = ["/root/repo/go-curdleproofs_amd", "/root/repo/oracle/py", "/root/repo", "/root/repo/tools"]
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import numpy as np, torch, curdlemsm as cm, adversarial_inputs as adv, coracle as co
+from bench import uniform_scalars
+cm.init(0)
+for n in (252, 512, 1268, 2548):
+    d_pts = torch.empty((n, 12), dtype=torch.int64, device="cuda:0")
+    cm.synth_points_walk_device(12345, 6789, n, d_pts.data_ptr())
+    uni = uniform_scalars(np.random.default_rng(2), n)
+    pts = d_pts.cpu().numpy().view(np.uint64)
+    base = None
+    for fam in ("uniform", "all_equal", "small_9bit", "distinct_64"):
+        sc, _ = adv.make_family(fam, n, uni, window_bits=cm.window_bits(n))
+        sc = np.ascontiguousarray(sc)
+        d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        exp = co.msm_pippenger(pts, sc, threads=4)
+        for _ in range(5): r = cm.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n)
+        lat = []
+        for _ in range(60):
+            torch.cuda.synchronize(); t = time.perf_counter(); cm.msm_g1_device(d_pts.data_ptr(), d_sc.data_ptr(), n); lat.append((time.perf_counter() - t) * 1e3)
+        m = float(np.median(lat)); base = base or m
+        print(n, fam.ljust(12), round(m, 4), round(m / base, 3), bool((r == exp).all()), flush=True)
