@@ -1,5 +1,9 @@
+"""Round 6: the reference's own adversarial inputs (all-equal scalars, <= 9-bit scalars) and 64 distinct values at the
+reference's own sizes (ell = 252 / 512 pairs; 1,268 / 2,548 = the verifier's merged MSM), one synchronous resident call each,
+against the C oracle (profiles/r06_adversarial_protocol_sizes.txt)."""
 import os, sys, time
-sys.path[:0] = ["/root/repo/go-curdleproofs_amd", "/root/repo/oracle/py", "/root/repo", "/root/repo/tools"]
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(R, "go-curdleproofs_amd"), os.path.join(R, "oracle", "py"), R, os.path.join(R, "tools")]
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np, torch, curdlemsm as cm, adversarial_inputs as adv, coracle as co
 from bench import uniform_scalars
