@@ -525,6 +525,30 @@ def main():
                           "single_call_ms": single_call_ms, "in_flight": depth, "host_ms_per_step": host_ms,
                           "kernel_ms_alone": {k_: round(float(np.mean(v)), 4) for k_, v in solo_ms.items()}}))
         return
+    # north_star's size table on an N > 1 line too (so that the driver's 2 / 4 / 8-GPU runs fill the "N in {2^10 .. 2^20} at
+    # 1 / 2 / 4 / 8 GPUs" table by themselves): every size through ONE synchronous distributed call on ALL ranks (window
+    # ranges under the line's contract; barrier, call, MAX over the ranks; median of 7); rank 0 adds the CPU port below.
+    dsweep = None
+    if dist is not None and not args.emulate_world and args.logn == 20 and not args.no_cpu_baseline and args.split == "windows":
+        from curdlemsm.distributed import msm_g1_distributed
+        on_gpu = dist.get_backend() == "nccl"
+        dsweep = []
+        for lg in range(10, 21, 2):
+            m = 1 << lg
+            call = lambda: msm_g1_distributed(d_pts.data_ptr(), d_sc.data_ptr(), m, device=dev if on_gpu else None, split="windows",
+                                              flags=msm_flags)
+            for _ in range(3):
+                r_m = call()
+            lat = []
+            for _ in range(7):
+                barrier()
+                t1 = time.perf_counter()
+                call()
+                t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev if on_gpu else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                lat.append(float(t.item()) * 1e3)
+            dsweep.append((lg, float(np.median(lat)), r_m))
+        cm.msm_forget_bases(d_pts.data_ptr())      # (the prefixes' kept copies; the whole array's is made again on its next use)
     ok = True
     if rank == 0:
         # dominant kernel: bucket accumulation.  One launch covers this rank's windows over
@@ -627,7 +651,26 @@ def main():
             # barrier below -- seconds, far inside the collective's timeout
             out["cpu_baseline"] = cpu_baseline(cm, k, q, n, sc, result, d_pts)
             ok = out["cpu_baseline"]["gpu_matches_cpu"] and out["cpu_baseline"]["gpu_full_size_verified"]
-            if world == 1 and args.logn == 20 and not args.emulate_world:
+            if dsweep is not None:
+                sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+                import coracle as co
+                pts_h = d_pts.cpu().numpy().view(np.uint64)
+                native = os.path.exists(os.path.join(ROOT, "oracle", "libcurdle_cpufast_native.so"))
+                threads = min(host_cores(), 256)
+                rows = []
+                for lg, wall, r_m in dsweep:
+                    m = 1 << lg
+                    t1 = time.perf_counter()
+                    ref = co.msm_fast(pts_h[:m], sc[:m], threads=threads if m >= 4096 else 1, native=native)
+                    dt = time.perf_counter() - t1
+                    rows.append({"logn": lg, "wall_ms": round(wall, 4), "pairs_per_s": round(m / wall * 1e3, 1),
+                                 "hbm_frac_whole_call": round(BYTES_PER_PAIR * m / (wall * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 6),
+                                 "cpu_port_pairs_per_s": round(m / dt, 1), "gpu_matches_cpu": bool((r_m == ref).all())})
+                out["sweep"] = rows
+                out["sweep_what"] = (f"one synchronous msm_g1_distributed call per size on all {world} ranks (window ranges, all_gather of the "
+                                     "144 B partials, sum), MAX over ranks, median of 7; hbm_frac_whole_call against world x 8 TB/s; CPU port on rank 0")
+                ok = ok and all(r_["gpu_matches_cpu"] for r_ in rows)
+            if world == 1 and dist is None and args.logn == 20 and not args.emulate_world:
                 out["sweep"] = compact_sweep(cm, torch, d_pts, sc, d_sc)
                 ok = ok and all(r_["gpu_matches_cpu"] for r_ in out["sweep"])
                 out["adversarial"] = compact_adversarial(cm, torch, d_pts, k, q, sc)

@@ -104,6 +104,19 @@ def test_two_ranks_over_gloo_print_the_multi_gpu_keys(gpu):
 
 
 @pytest.mark.gpu
+def test_a_distributed_line_carries_the_size_table_too(gpu):
+    """north_star wants N in {2^10 .. 2^20} at 1 / 2 / 4 / 8 GPUs: an N > 1 line (here: the N > 1 path at world size 1
+    over nccl) carries the table itself -- one synchronous distributed call per size on all ranks, the CPU port beside
+    it on rank 0, bit-compared -- so that the driver's multi-GPU runs fill it without another command."""
+    line = _run_forced_dist(["--steps", "3", "--warmup", "1", "--no-verify"])
+    rows = line["sweep"]
+    assert [r["logn"] for r in rows] == [10, 12, 14, 16, 18, 20] and "msm_g1_distributed" in line["sweep_what"]
+    assert all(r["gpu_matches_cpu"] and r["wall_ms"] > 0 and r["cpu_port_pairs_per_s"] > 0 for r in rows)
+    assert rows[-1]["pairs_per_s"] > rows[0]["pairs_per_s"]
+    _check_multi_gpu_keys(line, 1, "nccl")
+
+
+@pytest.mark.gpu
 def test_the_accept_bit_exchange_of_config_5_runs_over_nccl(gpu):
     line = _run_forced_dist(["--mode", "whisk-batch", "--proofs", "96", "--steps", "1", "--warmup", "1"])
     assert line["accept_bits_exact"] is True and line["value"] and line["value"] > 0
