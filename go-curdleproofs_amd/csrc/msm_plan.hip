@@ -117,7 +117,7 @@ int make_plan(MsmPlan& p, size_t n_total, size_t k, size_t n_max, int c, int win
   if (latency_mode) {
     // (round 4: a whole round, 131,072 lanes, since the reduction lost its per-segment scalar multiple: shorter
     // segments now cost a quad almost nothing extra -- 131,072 pairs 0.93 -> 0.89 ms, 2^20 3.45 -> 3.41)
-    const uint64_t lanes = 131072;
+    const uint64_t lanes = 196608;  // (round 6: k_reduce_segments runs three waves per SIMD; 131,072 = two until then)
     uint32_t seg = 1;
     while (nbk / seg * 4 > lanes && seg < 32) seg *= 2;
     p.seg = nbk / seg * 4 <= lanes ? seg : 16;

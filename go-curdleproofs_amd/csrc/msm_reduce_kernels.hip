@@ -353,7 +353,10 @@ __global__ void __launch_bounds__(kBlock, 2)
 // fragment a step adds was loaded during the step before it, and a bucket's bookkeeping one bucket
 // ahead (source 0): the loads are off the chain.  Output per group of G quads: 2 + log2(G) points,
 // [sum S | total T | X_0 .. X_(lgG-1)].
-__global__ void __launch_bounds__(kBlock, 2)
+// (round 6: three waves per SIMD -- 168 registers, 8 of them spilled -- so that a synchronous mid-size call fits one bucket per quad
+// into ONE round of the chip, 196,608 lanes: 2^16 / 2^17 / 2^18 pairs 0.588 / 0.795 / 1.124 -> 0.578 / 0.775 / 1.110 ms, pipelined calls
+// equal: profiles/r06_reduce_three_waves_ab.txt)
+__global__ void __launch_bounds__(kBlock, 3)
     k_reduce_segments(FragSources src, X28* __restrict__ groups, MsmPlan p) {
   set_wave_prio(p.reduce_prio);
   const u32 tid = threadIdx.x;
